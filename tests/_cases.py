@@ -1,0 +1,81 @@
+"""Seeded calibration-activation generators shared by the golden-vector generator
+(tests/golden/gen_golden.py, which runs the *reference* on them in the build container)
+and by the parity tests (which run the oracle and the HIP path on the same data).
+
+Nothing here touches /root/reference.  Determinism relies on numpy's PCG64 stream, which is
+identical here and on the GPU box (same image, numpy 2.2.x); every fixture additionally stores
+a checksum of the regenerated data so a stream change would be detected rather than mis-compared.
+"""
+import zlib
+
+import numpy as np
+
+KINDS = ("normal", "relu", "laplace", "uniform", "zeros", "spike", "edges", "neg_only", "tiny")
+SIZES = (1000, 2048, 25088, 150528, 802816)
+
+
+def make_tensor(kind, n, seed):
+    """One fp32 activation tensor of `n` elements, flat.  `kind` picks the distribution."""
+    rng = np.random.default_rng([0xD1900, seed, n])
+    if kind == "normal":
+        x = rng.standard_normal(n, dtype=np.float32) * np.float32(1.0 + 0.1 * (seed % 17))
+    elif kind == "relu":  # ~50 % exact zeros: worst case for bin-0 contention
+        x = np.maximum(rng.standard_normal(n, dtype=np.float32) * np.float32(2.5), np.float32(0))
+    elif kind == "laplace":
+        x = rng.laplace(0.0, 0.7, n).astype(np.float32)
+    elif kind == "uniform":
+        x = rng.uniform(-3.0, 5.0, n).astype(np.float32)
+    elif kind == "zeros":
+        x = np.zeros(n, np.float32)
+    elif kind == "spike":  # one huge outlier, the rest tiny: nearly everything lands in bin 0
+        x = rng.standard_normal(n, dtype=np.float32) * np.float32(1e-3)
+        x[n // 3] = np.float32(1234.5)
+    elif kind == "edges":  # values exactly on fp32 bin edges and their fp32 neighbours
+        dmax = np.float32(7.3125 + seed)
+        bins = 2048 if seed % 2 == 0 else 1000
+        step = np.float32(dmax / np.float32(bins))
+        i = rng.integers(0, bins + 1, n).astype(np.float32)
+        e = i * step
+        e[i == bins] = dmax
+        jitter = rng.integers(-1, 2, n)
+        x = np.where(jitter < 0, np.nextafter(e, np.float32(-np.inf)),
+                     np.where(jitter > 0, np.nextafter(e, np.float32(np.inf)), e)).astype(np.float32)
+        x = np.clip(x, 0, dmax)
+        x[0] = dmax  # make sure the range maximum itself is present
+        x = x * rng.choice(np.array([-1, 1], np.float32), n)
+    elif kind == "neg_only":
+        x = -np.abs(rng.standard_normal(n, dtype=np.float32)) - np.float32(0.25)
+    elif kind == "tiny":  # data_min within 1e-6 of zero (dynamic_sym trigger), small magnitudes
+        x = np.abs(rng.standard_normal(n, dtype=np.float32)) * np.float32(1e-2)
+        x[1] = np.float32(3e-7)
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(x, dtype=np.float32)
+
+
+def checksum(x):
+    return int(zlib.crc32(np.ascontiguousarray(x).view(np.uint8)))
+
+
+# ---- a miniature "network": names, sizes and distributions of the tensors one image yields ----
+MINI_NET = (
+    # name, elements, kind
+    ("input", 3 * 32 * 32, "normal"),
+    ("conv1", 8192, "normal"),
+    ("relu1", 8192, "relu"),
+    ("pool1", 2048, "relu"),
+    ("fc", 1000, "laplace"),
+    ("dead", 512, "zeros"),
+)
+
+
+def mini_net_activations(image_idx):
+    """OrderedDict-like list [(name, fp32 array)] for calibration image `image_idx`."""
+    out = []
+    for t, (name, n, kind) in enumerate(MINI_NET):
+        x = make_tensor(kind, n, 1000 * t + image_idx)
+        if name == "dead" and image_idx == 5:
+            # one image wakes the dead tensor up so its OCTAV mean mixes NaN and finite values
+            x = make_tensor("relu", n, 77)
+        out.append((name, x))
+    return out

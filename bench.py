@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Benchmark of the calibration hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of B synthetic calibration images' activations
+(ResNet-50 tensor multiset: 123 tensors, 26,598,376 fp32 elements = 106.39 MB per image), already
+resident in HBM:
+    -A hist  (default, BASELINE configs[1]): range pass (k_minmax) + histogram pass (k_abs_hist) over the
+             batch = both reads the algorithm inherently needs (212.79 MB / image algorithmic);
+    -A minmax: range pass only (106.39 MB / image);   -A mse: OCTAV (106.39 MB / image credited).
+Default: B = 16, 64 steps = one whole N = 1024 calibration set.
+
+Prints ONE JSON line (rank 0).  `value` is whole-job images/s; `roofline` is for the dominant kernel
+(k_abs_hist for hist), its duration measured with HIP events on the launch stream inside the timed
+region; `cpu_baseline` times the CPU oracle (numpy port of the reference arithmetic) on a bounded
+sample of the same activations on the host cores of this box.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU): images are sharded across ranks with
+no data-path collective (weak scaling: every rank runs K steps of B images); the one real exchange of
+the algorithm — all-reduce MIN/MAX of the ranges and SUM of the histograms over RCCL — runs once,
+inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=64)
+    p.add_argument("--warmup", type=int, default=4)
+    p.add_argument("--batch", type=int, default=16, help="calibration images per step and per GPU")
+    p.add_argument("--algo", choices=["hist", "minmax", "mse"], default="hist")
+    p.add_argument("--bins", type=int, default=2048)
+    p.add_argument("--pool", type=int, default=2, help="distinct resident batches cycled through")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
+    p.add_argument("--chunk", type=int, default=0, help="work-item elements (0 = auto)")
+    return p.parse_args()
+
+
+def cpu_baseline(algo, bins, tensors, budget_s):
+    """Time the oracle (numpy restatement of forward_net.py:192-342) image by image until the budget is
+    spent.  Checker code is being MEASURED here as the CPU side of the comparison, never shipped."""
+    import warnings
+
+    import numpy as np
+
+    from oracle import np_oracle as O
+    B = tensors[0].shape[0]
+    done = 0
+    t_used = 0.0
+    for b in range(B):
+        xs = [t[b].cpu().numpy() for t in tensors]
+        t0 = time.perf_counter()
+        if algo in ("hist", "minmax"):
+            mm = [O.minmax(x) for x in xs]
+            if algo == "hist":
+                for x, (lo, hi) in zip(xs, mm):
+                    O.abs_hist(x, bins, O.hist_dmax(lo, hi))
+        else:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for x in xs:
+                    O.minmax(x)
+                    O.octav_scale(x, 1)
+        t_used += time.perf_counter() - t0
+        done += 1
+        if t_used >= budget_s:
+            break
+    return {"value": done / t_used, "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{done} image(s) of the same ResNet-50-shaped activations, -A {algo}, numpy oracle, "
+                      f"single thread, {t_used:.1f} s; host has {os.cpu_count()} cores"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        dist.init_process_group("nccl")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from dipoorlet_amd import _hip, ops
+    from dipoorlet_amd.synthetic import resnet50_tensors, synth_activations
+    st, devname, cus, mem = _hip.device_info()
+    spec = resnet50_tensors()
+    elems = [e for _, e, _ in spec]
+    T, E = len(elems), sum(elems)
+    B = a.batch
+    pool = [synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j) for j in range(max(1, a.pool))]
+    plan = ops.TensorSetPlan(elems, B, dev, chunk_elems=a.chunk or None)
+    acc = ops.CalibAccumulators(T, dev, a.bins)
+    acc_rng = ops.CalibAccumulators(T, dev, a.bins)  # timed range pass writes here; `acc` keeps the global ranges
+
+    # global ranges over everything this rank will see (pass 1 of the real algorithm), merged over ranks
+    for tset in pool:
+        acc.minmax_accumulate(plan, tset)
+    gmin, gmax = acc.finalize_minmax()
+    if world > 1:
+        dist.all_reduce(gmin, op=dist.ReduceOp.MIN)
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+        acc.set_minmax(gmin.clone(), gmax.clone())
+    acc.hist_prepare()
+    states = None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def step(i, timed):
+        ta = pool[i % len(pool)]
+        tb = pool[(i + 1) % len(pool)]
+        if a.algo == "minmax":
+            if timed:
+                ev[i][0].record()
+            acc_rng.minmax_accumulate(plan, ta)
+            if timed:
+                ev[i][1].record()
+        elif a.algo == "hist":
+            acc_rng.minmax_accumulate(plan, ta)  # pass 1 work for this batch
+            if timed:
+                ev[i][0].record()
+            acc.abs_hist_accumulate(plan, tb)  # pass 2 work (a different resident batch: no cache reuse)
+            if timed:
+                ev[i][1].record()
+        else:
+            if timed:
+                ev[i][0].record()
+            ops.octav_batch(plan, ta, False, states)
+            if timed:
+                ev[i][1].record()
+
+    if a.algo == "mse":
+        import ctypes
+        states = torch.empty(plan.n_pairs * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
+    for i in range(a.warmup):
+        step(i, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i, True)
+    if world > 1 and a.algo != "mse":  # the algorithm's one exchange step
+        mn, mx = acc_rng.finalize_minmax()
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        if a.algo == "hist":
+            dist.all_reduce(acc.hist, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    kern_ms = sum(s.elapsed_time(e) for s, e in ev) / max(1, a.steps)
+    bytes_per_img = {"hist": 8 * E, "minmax": 4 * E, "mse": 4 * E}[a.algo]
+    kernel_bytes = 4 * E * B  # the dominant kernel reads the batch once
+    achieved = kernel_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "traffic_latest.json"))
+    if os.path.exists(tj):
+        try:
+            with open(tj) as f:
+                tr = json.load(f)
+            if tr.get("algo") == a.algo and tr.get("batch") == B:
+                traffic = tr.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    images = a.steps * B * world
+    out = {
+        "metric": "calibration images/sec (whole node), ResNet-50 activation shapes, -A %s" % a.algo,
+        "value": images / dt, "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ResNet-50 ONNX activation set (T={T} tensors, {E} fp32 elems/img), -A {a.algo}"
+                               f" --bins {a.bins}, N={a.steps * B} images per GPU in batches of {B}",
+                   "batch": B, "bins": a.bins, "algo": a.algo, "work_items": plan.n_items,
+                   "chunk_elems": plan.chunk, "device": devname},
+        "algorithmic_GBps_job": bytes_per_img * images / dt / 1e9,
+        "roofline": {"bound": "hbm", "kernel": {"hist": "k_abs_hist", "minmax": "k_minmax",
+                                               "mse": "k_octav_pass (all rounds)"}[a.algo],
+                     "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                     "traffic": traffic, "bytes_per_launch": kernel_bytes, "avg_kernel_ms": kern_ms},
+    }
+    if rank == 0:
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(a.algo, a.bins, pool[0], a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

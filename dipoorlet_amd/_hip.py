@@ -1,0 +1,112 @@
+"""ctypes binding of the C ABI (include/dipoorlet_hip.h) exported by csrc/libdipoorlet_hip.so.
+
+There is NO CPU fallback: if the library is missing or a call fails this raises.  PyTorch only
+supplies device memory and streams; the signatures carry raw pointers and sizes.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
+
+ABI_VERSION = 1
+MAX_BINS = 16384
+
+
+class Span(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("count", C.c_uint64), ("seg", C.c_uint32), ("slot", C.c_uint32)]
+
+
+class WorkItem(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("count", C.c_uint32), ("seg", C.c_uint32), ("slot", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class HistRange(C.Structure):
+    _fields_ = [("first", C.c_float), ("last", C.c_float), ("step", C.c_float), ("inv", C.c_float),
+                ("zero_bin", C.c_uint32), ("status", C.c_uint32), ("dmax", C.c_float), ("exact_div", C.c_uint32)]
+
+
+class OctavState(C.Structure):
+    _fields_ = [("sum", C.c_double), ("cnt_gt", C.c_uint64), ("cnt_le", C.c_uint64), ("min_enc", C.c_uint32),
+                ("max_enc", C.c_uint32), ("nan_seen", C.c_uint32), ("done", C.c_uint32), ("s", C.c_float),
+                ("unsigned_div", C.c_float), ("iters", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 56
+
+_P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
+
+# name -> (restype, argtypes); mirrors include/dipoorlet_hip.h one to one
+SIGNATURES = {
+    "dpl_abi_version": (C.c_int, []),
+    "dpl_last_error": (C.c_char_p, []),
+    "dpl_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "dpl_build_work_items": (_I64, [_P, _I64, _U64, _P, _I64]),
+    "dpl_minmax_init": (C.c_int, [_P, _P, _P, _I64, _P]),
+    "dpl_minmax_accumulate": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "dpl_minmax_finalize": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
+    "dpl_minmax_encode": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
+    "dpl_hist_prepare": (C.c_int, [_P, _P, _I64, C.c_int, _P, _P]),
+    "dpl_abs_hist_accumulate": (C.c_int, [_P, _I64, _P, _P, C.c_int, _P, _P]),
+    "dpl_hist_percentile": (C.c_int, [_P, _P, _P, _I64, C.c_int, _DBL, _P, _P]),
+    "dpl_octav_init": (C.c_int, [_P, _I64, _P]),
+    "dpl_octav_run": (C.c_int, [_P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
+    "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
+    "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
+    "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
+}
+
+_lib = None
+
+
+class DipoorletHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library (cached).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DipoorletHipError(
+                f"{LIB_PATH} is missing: build it with `python -m dipoorlet_amd.csrc.build` "
+                "(or __graft_entry__.build()).  dipoorlet_amd has no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if l.dpl_abi_version() != ABI_VERSION:
+            raise DipoorletHipError(f"ABI mismatch: library {l.dpl_abi_version()} != binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise DipoorletHipError(f"{what} failed ({status}): {lib().dpl_last_error().decode()}")
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cus = C.c_int(0)
+    mem = C.c_uint64(0)
+    st = lib().dpl_device_info(name, 256, C.byref(cus), C.byref(mem))
+    return st, name.value.decode(), cus.value, mem.value
+
+
+def build_work_items(spans, chunk_elems):
+    """HOST: spans = iterable of (seg, offset, count, slot) -> ctypes array of WorkItem."""
+    spans = list(spans)
+    arr = (Span * max(len(spans), 1))()
+    for i, (seg, off, cnt, slot) in enumerate(spans):
+        arr[i] = Span(off, cnt, seg, slot)
+    n = lib().dpl_build_work_items(C.addressof(arr), len(spans), chunk_elems, None, 0)
+    if n < 0:
+        check(int(n), "dpl_build_work_items")
+    out = (WorkItem * max(n, 1))()
+    n2 = lib().dpl_build_work_items(C.addressof(arr), len(spans), chunk_elems, C.addressof(out), n)
+    assert n2 == n
+    return out, int(n)

@@ -1,0 +1,818 @@
+// MI355X (gfx950 / CDNA4) activation-calibration kernels + C ABI (include/dipoorlet_hip.h).
+//
+// Everything here is an HBM-bound streaming reduction / scatter-add: no MFMA.  Design rules
+// (guides: cdna_hip_programming.md G2/G11/G12/G13, MI355X_MICROARCH.md §LDS/§HBM):
+//   * 16 B per lane coalesced loads (global_load_dwordx4), several independent loads in flight,
+//     one workgroup per work item (a contiguous chunk of ONE tensor), >> 256 workgroups per launch;
+//   * wave64 reductions with DPP/ds_bpermute shuffles, then a tiny LDS combine per workgroup;
+//   * histograms privatised in LDS (ds_add_u32), exact zeros counted in registers (ReLU outputs are
+//     ~50 % zeros and would otherwise serialise on one LDS address), one flush per workgroup;
+//   * order-encoded integer atomics for fp32 min/max, so accumulators persist across launches.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+#include <math.h>
+
+#include "../../include/dipoorlet_hip.h"
+
+namespace {
+
+constexpr int kBlock = 256;   // 4 waves of 64
+constexpr int kUnroll = 4;    // float4 loads in flight per lane
+constexpr int kWave = 64;
+using f4 = __attribute__((ext_vector_type(4))) float;  // native vector: nontemporal builtins need it
+
+thread_local char g_err[512] = "";
+
+int fail(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return -1;
+}
+int fail_msg(const char* what) {
+    snprintf(g_err, sizeof(g_err), "%s", what);
+    return -2;
+}
+#define DPL_LAUNCH_CHECK(name)                              \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return fail(name, e__);      \
+    } while (0)
+
+// ---------------------------------------------------------------- fp32 <-> order-preserving u32
+__host__ __device__ inline uint32_t enc_f32(float f) {
+    uint32_t b;
+    memcpy(&b, &f, 4);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__host__ __device__ inline float dec_f32(uint32_t u) {
+    uint32_t b = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    float f;
+    memcpy(&f, &b, 4);
+    return f;
+}
+
+// ---------------------------------------------------------------- wave / block reductions
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
+    return v;
+}
+
+// ---------------------------------------------------------------- the streaming skeleton
+// Applies op(float) to every element of p[0..n).  Scalar head up to 16-B alignment, float4 body with
+// kUnroll independent loads per lane (each wave instruction covers 1 KiB contiguous), scalar tail.
+// Pointers fetched from the segment table are generic to the compiler; casting to address space 1
+// makes the loads global_load_dwordx4 (flat loads would also tick the LDS counter and stall ds ops).
+typedef const __attribute__((address_space(1))) f4* gptr_f4;
+typedef const __attribute__((address_space(1))) float* gptr_f32;
+
+template <class Op>
+__device__ __forceinline__ void stream_span(const float* __restrict__ p_generic, uint32_t n, Op& op) {
+    const uint32_t tid = threadIdx.x;
+    gptr_f32 p = (gptr_f32)p_generic;
+    uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)p_generic & 15u)) & 15u) >> 2);
+    if (head > n) head = n;
+    if (tid < head) op(p[tid]);
+    p += head;
+    n -= head;
+    const uint32_t nvec = n >> 2;
+    gptr_f4 pv = (gptr_f4)p;
+    uint32_t i = tid;
+    for (; i + (kUnroll - 1) * kBlock < nvec; i += kUnroll * kBlock) {
+        f4 v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(pv + i + u * kBlock);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            op(v[u].x);
+            op(v[u].y);
+            op(v[u].z);
+            op(v[u].w);
+        }
+    }
+    for (; i < nvec; i += kBlock) {
+        f4 v = __builtin_nontemporal_load(pv + i);
+        op(v.x);
+        op(v.y);
+        op(v.z);
+        op(v.w);
+    }
+    const uint32_t t = (nvec << 2) + tid;
+    if (t < n) op(p[t]);
+}
+
+// ================================================================ K1: running min / max
+struct MinMaxOp {
+    float mn, mx;
+    uint32_t nan;
+    __device__ __forceinline__ void operator()(float x) {
+        mn = fminf(mn, x);
+        mx = fmaxf(mx, x);
+        nan |= (x != x);
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void k_minmax(const dpl_work_item* __restrict__ items,
+                                                    const float* const* __restrict__ segs,
+                                                    uint32_t* __restrict__ min_enc, uint32_t* __restrict__ max_enc,
+                                                    uint32_t* __restrict__ nan_flag) {
+    __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    __shared__ uint32_t s_nan[kBlock / kWave];
+    const dpl_work_item it = items[blockIdx.x];
+    MinMaxOp op{INFINITY, -INFINITY, 0u};
+    stream_span(segs[it.seg] + it.offset, it.count, op);
+    float mn = wave_min(op.mn), mx = wave_max(op.mx);
+    uint32_t nn = __any(op.nan) ? 1u : 0u;
+    const int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        s_mn[w] = mn;
+        s_mx[w] = mx;
+        s_nan[w] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < kBlock / kWave; ++k) {
+            mn = fminf(mn, s_mn[k]);
+            mx = fmaxf(mx, s_mx[k]);
+            nn |= s_nan[k];
+        }
+        if (mn <= mx) {  // false only when the chunk held nothing but NaN
+            atomicMin(min_enc + it.slot, enc_f32(mn));
+            atomicMax(max_enc + it.slot, enc_f32(mx));
+        }
+        if (nn) atomicOr(nan_flag + it.slot, 1u);
+    }
+}
+
+__global__ void k_minmax_init(uint32_t* mn, uint32_t* mx, uint32_t* nan, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        mn[i] = 0xFFFFFFFFu;
+        mx[i] = 0u;
+        nan[i] = 0u;
+    }
+}
+
+__global__ void k_minmax_finalize(const uint32_t* mn, const uint32_t* mx, const uint32_t* nan, int64_t n,
+                                  float* omn, float* omx) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const bool bad = nan[i] != 0u || mn[i] == 0xFFFFFFFFu;
+        omn[i] = bad ? NAN : dec_f32(mn[i]);
+        omx[i] = bad ? NAN : dec_f32(mx[i]);
+    }
+}
+
+__global__ void k_minmax_encode(const float* mn, const float* mx, int64_t n, uint32_t* emn, uint32_t* emx,
+                                uint32_t* nan) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const bool bad = (mn[i] != mn[i]) || (mx[i] != mx[i]);
+        emn[i] = bad ? 0xFFFFFFFFu : enc_f32(mn[i]);
+        emx[i] = bad ? 0u : enc_f32(mx[i]);
+        nan[i] = bad ? 1u : 0u;
+    }
+}
+
+// ================================================================ K2: |x| histogram, numpy-exact
+// numpy's uniform-bin fast path lands every kept value a in the unique bin i with
+// edge[i] <= a < edge[i+1] (last bin closed), edge[i] = fl32(fl32(i*step) + first): an index
+// estimate followed by one decrement test and one increment test against those edges.  Any estimate
+// within +-1 of the true bin gives the same answer, so the estimate here is a multiply by the
+// reciprocal (error << 1 bin) unless the range is so small that the reciprocal is not finite.
+__device__ __forceinline__ float hist_edge(int i, float step, float first) {
+    return __fadd_rn(__fmul_rn((float)i, step), first);  // no FMA contraction: numpy rounds twice
+}
+
+template <bool kExactDiv>
+struct HistOp {
+    uint32_t* lds;
+    float first, last, step, inv, denom;
+    int last_bin;  // bins - 1
+    float fbins;
+    uint32_t zeros;
+    __device__ __forceinline__ void operator()(float x) {
+        // branch-free up to the single predicated ds_add: exact zeros are counted in a register (added to
+        // their bin once per wave), out-of-range values and NaN (a <= last is false) are dropped;
+        // a >= first always holds since first <= 0 <= a.
+        const float a = fabsf(x);
+        zeros += (a == 0.0f);
+        float t;
+        if (kExactDiv)
+            t = __fmul_rn(__fdiv_rn(__fsub_rn(a, first), denom), fbins);
+        else
+            t = __fmul_rn(__fsub_rn(a, first), inv);
+        int i = (int)t;  // v_cvt_i32_f32 saturates and maps NaN to 0
+        i = i > last_bin ? last_bin : i;
+        i = i < 0 ? 0 : i;
+        i -= (a < hist_edge(i, step, first)) ? 1 : 0;
+        i += (i != last_bin && a >= hist_edge(i + 1, step, first)) ? 1 : 0;
+        if (a <= last && a != 0.0f) atomicAdd(lds + i, 1u);  // ds_add_u32 (no return)
+    }
+};
+
+template <bool kExactDiv>
+__device__ __forceinline__ void hist_body(const dpl_work_item& it, const float* const* __restrict__ segs,
+                                          const dpl_hist_range& r, int bins, uint64_t* __restrict__ hist,
+                                          uint32_t* lds) {
+    HistOp<kExactDiv> op;
+    op.lds = lds;
+    op.first = r.first;
+    op.last = r.last;
+    op.step = r.step;
+    op.inv = r.inv;
+    op.denom = __fsub_rn(r.last, r.first);
+    op.last_bin = bins - 1;
+    op.fbins = (float)bins;
+    op.zeros = 0u;
+    stream_span(segs[it.seg] + it.offset, it.count, op);
+    const uint32_t z = wave_sum(op.zeros);
+    // |0| is kept iff first <= 0 <= last, which always holds for a finite range
+    if ((threadIdx.x & (kWave - 1)) == 0 && z) atomicAdd(lds + r.zero_bin, z);
+    __syncthreads();
+    uint64_t* __restrict__ out = hist + (uint64_t)it.slot * (uint64_t)bins;
+    for (int b = threadIdx.x; b < bins; b += kBlock) {
+        const uint32_t c = lds[b];
+        if (c) atomicAdd(reinterpret_cast<unsigned long long*>(out + b), (unsigned long long)c);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_abs_hist(const dpl_work_item* __restrict__ items,
+                                                      const float* const* __restrict__ segs,
+                                                      const dpl_hist_range* __restrict__ ranges, int bins,
+                                                      uint64_t* __restrict__ hist) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const dpl_work_item it = items[blockIdx.x];
+    const dpl_hist_range r = ranges[it.slot];
+    if (r.status != 0u) return;  // reference raises for this tensor; host reports it
+    for (int b = threadIdx.x; b < bins; b += kBlock) lds[b] = 0u;
+    __syncthreads();
+    if (r.exact_div)
+        hist_body<true>(it, segs, r, bins, hist, lds);
+    else
+        hist_body<false>(it, segs, r, bins, hist, lds);
+}
+
+__device__ __forceinline__ float py_max(float a, float b) { return (b > a) ? b : a; }  // python max(a, b)
+__device__ __forceinline__ float py_min(float a, float b) { return (b < a) ? b : a; }  // python min(a, b)
+
+__global__ void k_hist_prepare(const float* __restrict__ gmin, const float* __restrict__ gmax, int64_t n, int bins,
+                               dpl_hist_range* __restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dpl_hist_range r;
+    // forward_net.py:266 — data_max = max(np.max(maxlist), -np.min(minlist))
+    const float dmax = py_max(gmax[i], -gmin[i]);
+    float first = 0.0f, last = dmax;
+    r.dmax = dmax;
+    r.status = 0u;
+    if (!(fabsf(last) <= 3.402823466e+38f) || last < first) r.status = 1u;  // NaN, inf (or negative) range
+    if (first == last) {  // numpy _get_outer_edges: expand an empty range
+        first = -0.5f;
+        last = 0.5f;
+    }
+    const float delta = __fsub_rn(last, first);
+    const float fb = (float)bins;
+    r.first = first;
+    r.last = last;
+    r.step = __fdiv_rn(delta, fb);
+    r.inv = __fdiv_rn(fb, delta);
+    // linspace must give strictly increasing fp32 edges, else numpy raises "Too many bins"
+    if (r.status == 0u) {
+        const float e1 = hist_edge(1, r.step, first);
+        const float el = hist_edge(bins - 1, r.step, first);
+        const float el2 = hist_edge(bins - 2 > 0 ? bins - 2 : 0, r.step, first);
+        if (!(r.step > 0.0f) || !(e1 > first) || !(last > el) || (bins > 2 && !(el > el2))) r.status = 2u;
+    }
+    r.exact_div = (!(fabsf(r.inv) <= 3.402823466e+38f) || r.step < 1.0e-30f) ? 1u : 0u;
+    // bin of |x| == 0
+    {
+        const float a = 0.0f;
+        float t = __fmul_rn(__fdiv_rn(__fsub_rn(a, first), delta), fb);
+        int b = (int)t;
+        b = b > bins - 1 ? bins - 1 : b;
+        b = b < 0 ? 0 : b;
+        if (a < hist_edge(b, r.step, first)) --b;
+        if (b != bins - 1 && a >= hist_edge(b + 1, r.step, first)) ++b;
+        r.zero_bin = (uint32_t)(b < 0 ? 0 : b);
+    }
+    out[i] = r;
+}
+
+// ================================================================ K4: percentile clip (basic_algorithm.py:40-53)
+// One wave per slot.  The cumulative sum is a SEQUENTIAL fp64 accumulation in bin order (the >=
+// threshold test is order sensitive), so lanes load 64 bins at a time and the wave walks them in order.
+__global__ __launch_bounds__(kWave) void k_hist_percentile(const uint64_t* __restrict__ hist,
+                                                            const float* __restrict__ gmin_a,
+                                                            const float* __restrict__ gmax_a, int bins,
+                                                            double threshold, float* __restrict__ clip) {
+    const int slot = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint64_t* h = hist + (uint64_t)slot * bins;
+    unsigned long long tot = 0;
+    for (int b = lane; b < bins; b += kWave) tot += h[b];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, kWave);
+    const double total = (double)(long long)tot;  // int64 -> float64
+    const float gmin = gmin_a[slot], gmax = gmax_a[slot];
+    double accum = 0.0;
+    int found = -1;
+    for (int base = 0; base < bins && found < 0; base += kWave) {
+        const int b = base + lane;
+        // hist.astype(float32) / hist.sum()  -> float64(float32(count)) / float64(total)
+        const double hv = (b < bins) ? (double)(float)(long long)h[b] / total : 0.0;
+        const int lim = (bins - base) < kWave ? (bins - base) : kWave;
+        for (int j = 0; j < lim; ++j) {
+            accum += __shfl(hv, j, kWave);
+            if (accum >= threshold) {
+                found = base + j;
+                break;
+            }
+        }
+    }
+    if (lane == 0) {
+        float lo = gmin, hi = gmax;
+        if (found >= 0) {
+            const float dmax = py_max(-gmin, gmax);  // basic_algorithm.py:42
+            const float cv = __fmul_rn((float)found + 0.5f, __fdiv_rn(dmax, (float)bins));
+            lo = py_max(-cv, gmin);
+            hi = py_min(cv, gmax);
+        }
+        clip[2 * slot] = lo;
+        clip[2 * slot + 1] = hi;
+    }
+}
+
+// ================================================================ K3: OCTAV (forward_net.py:315-330)
+struct OctavFirstOp {
+    float mn, mx;
+    uint32_t nan, nz;
+    double sum;
+    __device__ __forceinline__ void operator()(float x) {
+        mn = fminf(mn, x);
+        mx = fmaxf(mx, x);
+        nan |= (x != x);
+        const float a = fabsf(x);
+        nz += (a > 0.0f);
+        sum += (double)a;
+    }
+};
+struct OctavIterOp {
+    float s;
+    uint32_t gt, le;
+    double sum;
+    __device__ __forceinline__ void operator()(float x) {
+        const float a = fabsf(x);
+        const bool g = a > s;
+        gt += g;
+        le += (a <= s);
+        sum += g ? (double)a : 0.0;
+    }
+};
+
+template <bool kFirst>
+__global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __restrict__ items,
+                                                        const float* const* __restrict__ segs,
+                                                        dpl_octav_state* __restrict__ st) {
+    __shared__ double s_sum[kBlock / kWave];
+    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave], s_c[kBlock / kWave];
+    __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    const dpl_work_item it = items[blockIdx.x];
+    dpl_octav_state* me = st + it.slot;
+    const int w = threadIdx.x / kWave;
+    const bool lead = (threadIdx.x & (kWave - 1)) == 0;
+    const float* p = segs[it.seg] + it.offset;
+    if (kFirst) {
+        OctavFirstOp op{INFINITY, -INFINITY, 0u, 0u, 0.0};
+        stream_span(p, it.count, op);
+        const float mn = wave_min(op.mn), mx = wave_max(op.mx);
+        const uint32_t nz = wave_sum(op.nz);
+        const double sum = wave_sum(op.sum);
+        const uint32_t nn = __any(op.nan) ? 1u : 0u;
+        if (lead) {
+            s_sum[w] = sum;
+            s_a[w] = nz;
+            s_b[w] = nn;
+            s_mn[w] = mn;
+            s_mx[w] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tsum = 0.0;
+            uint32_t tnz = 0, tnn = 0;
+            float tmn = INFINITY, tmx = -INFINITY;
+            for (int k = 0; k < kBlock / kWave; ++k) {
+                tsum += s_sum[k];
+                tnz += s_a[k];
+                tnn |= s_b[k];
+                tmn = fminf(tmn, s_mn[k]);
+                tmx = fmaxf(tmx, s_mx[k]);
+            }
+            atomicAdd(&me->sum, tsum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+            if (tmn <= tmx) {
+                atomicMin(&me->min_enc, enc_f32(tmn));
+                atomicMax(&me->max_enc, enc_f32(tmx));
+            }
+            if (tnn) atomicOr(&me->nan_seen, 1u);
+        }
+    } else {
+        if (me->done) return;  // uniform per workgroup
+        OctavIterOp op{me->s, 0u, 0u, 0.0};
+        stream_span(p, it.count, op);
+        const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
+        const double sum = wave_sum(op.sum);
+        if (lead) {
+            s_sum[w] = sum;
+            s_a[w] = gt;
+            s_b[w] = le;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tsum = 0.0;
+            uint32_t tgt = 0, tle = 0;
+            for (int k = 0; k < kBlock / kWave; ++k) {
+                tsum += s_sum[k];
+                tgt += s_a[k];
+                tle += s_b[k];
+            }
+            if (tgt) {
+                atomicAdd(&me->sum, tsum);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tgt);
+            }
+            if (tle) atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_le), (unsigned long long)tle);
+        }
+    }
+}
+
+template <bool kFirst>
+__global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int dynamic_sym, int max_iters) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dpl_octav_state* me = st + i;
+    if (kFirst) {
+        const float mn = dec_f32(me->min_enc);
+        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+        me->unsigned_div = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
+        // forward_net.py:324 — s_n = abs_x.sum() / abs_x[abs_x > 0].size   (float32 / int)
+        const float s0 = __fdiv_rn((float)me->sum, (float)(long long)me->cnt_gt);
+        me->s = s0;
+        me->iters = 0u;
+        me->done = (s0 != s0 || max_iters <= 0) ? 1u : 0u;  // NaN is a fixed point of the iteration
+    } else {
+        if (me->done) return;
+        // forward_net.py:326-327 — python-float denominator, cast to float32 for the divide (NEP 50)
+        const double c = 1.0 / 65536.0 / 3.0 / (double)me->unsigned_div;
+        const double denom = c * (double)(long long)me->cnt_le + (double)(long long)me->cnt_gt;
+        const float s1 = __fdiv_rn((float)me->sum, (float)denom);
+        const float s = me->s;
+        if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
+            me->done = 1u;  // break: keeps the PREVIOUS iterate
+        } else {
+            me->s = s1;
+            me->iters += 1u;
+            if ((int)me->iters >= max_iters || s1 != s1) me->done = 1u;
+        }
+    }
+    me->sum = 0.0;
+    me->cnt_gt = 0ull;
+    me->cnt_le = 0ull;
+}
+
+__global__ void k_octav_init(dpl_octav_state* st, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    dpl_octav_state z;
+    z.sum = 0.0;
+    z.cnt_gt = 0;
+    z.cnt_le = 0;
+    z.min_enc = 0xFFFFFFFFu;
+    z.max_enc = 0u;
+    z.nan_seen = 0u;
+    z.done = 0u;
+    z.s = 0.0f;
+    z.unsigned_div = 1.0f;
+    z.iters = 0u;
+    z.reserved = 0u;
+    st[i] = z;
+}
+
+__global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool bad = st[i].nan_seen != 0u || st[i].min_enc == 0xFFFFFFFFu;
+    out[3 * i + 0] = st[i].s;
+    out[3 * i + 1] = bad ? NAN : dec_f32(st[i].min_enc);
+    out[3 * i + 2] = bad ? NAN : dec_f32(st[i].max_enc);
+}
+
+// ================================================================ K5: per-row min / max of a [rows, cols] matrix
+__global__ __launch_bounds__(kBlock) void k_rowwise_minmax(const float* __restrict__ w, int64_t cols,
+                                                            float* __restrict__ omn, float* __restrict__ omx) {
+    __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    __shared__ uint32_t s_nan[kBlock / kWave];
+    const float* p = w + (int64_t)blockIdx.x * cols;
+    MinMaxOp op{INFINITY, -INFINITY, 0u};
+    // rows can be longer than 2^32 only in theory; weights are at most a few 10^7 elements
+    stream_span(p, (uint32_t)cols, op);
+    float mn = wave_min(op.mn), mx = wave_max(op.mx);
+    uint32_t nn = __any(op.nan) ? 1u : 0u;
+    const int wv = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        s_mn[wv] = mn;
+        s_mx[wv] = mx;
+        s_nan[wv] = nn;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < kBlock / kWave; ++k) {
+            mn = fminf(mn, s_mn[k]);
+            mx = fmaxf(mx, s_mx[k]);
+            nn |= s_nan[k];
+        }
+        omn[blockIdx.x] = nn ? NAN : mn;
+        omx[blockIdx.x] = nn ? NAN : mx;
+    }
+}
+
+// ================================================================ K6: fused quantize -> dequantize
+__device__ __forceinline__ float fq_one(float x, float scale, float zp, float qlo, float qhi) {
+    float q = __fadd_rn(rintf(__fdiv_rn(x, scale)), zp);  // round half to even, then zero point
+    q = fminf(fmaxf(q, qlo), qhi);                        // saturate
+    return __fmul_rn(__fsub_rn(q, zp), scale);
+}
+
+__global__ __launch_bounds__(kBlock) void k_fake_quant_tensor(const float* __restrict__ x, float* __restrict__ y,
+                                                               int64_t n, const float* __restrict__ scale_p,
+                                                               const int32_t* __restrict__ zp_p, float qlo,
+                                                               float qhi) {
+    const float scale = scale_p[0];
+    const float zp = (float)zp_p[0];
+    const int64_t nvec = n >> 2;
+    const f4* xv = reinterpret_cast<const f4*>(x);
+    f4* yv = reinterpret_cast<f4*>(y);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+        f4 v = __builtin_nontemporal_load(xv + i);
+        v.x = fq_one(v.x, scale, zp, qlo, qhi);
+        v.y = fq_one(v.y, scale, zp, qlo, qhi);
+        v.z = fq_one(v.z, scale, zp, qlo, qhi);
+        v.w = fq_one(v.w, scale, zp, qlo, qhi);
+        __builtin_nontemporal_store(v, yv + i);
+    }
+    const int64_t t = (nvec << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) y[t] = fq_one(x[t], scale, zp, qlo, qhi);
+}
+
+__global__ __launch_bounds__(kBlock) void k_fake_quant_channel(const float* __restrict__ x, float* __restrict__ y,
+                                                                int64_t n, const float* __restrict__ scale_p,
+                                                                const int32_t* __restrict__ zp_p, int64_t n_channels,
+                                                                int64_t inner, float qlo, float qhi) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const int64_t c = (i / inner) % n_channels;
+        y[i] = fq_one(x[i], scale_p[c], (float)zp_p[c], qlo, qhi);
+    }
+}
+
+// ================================================================ N1: cosine-similarity partial sums
+__global__ __launch_bounds__(kBlock) void k_cos_acc(const float* __restrict__ a, const float* __restrict__ b,
+                                                     int64_t n, double* __restrict__ acc) {
+    __shared__ double s_r[3][kBlock / kWave];
+    double ab = 0.0, aa = 0.0, bb = 0.0;
+    const int64_t nvec = n >> 2;
+    const f4* av = reinterpret_cast<const f4*>(a);
+    const f4* bv = reinterpret_cast<const f4*>(b);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+        const f4 p = __builtin_nontemporal_load(av + i);
+        const f4 q = __builtin_nontemporal_load(bv + i);
+        ab += (double)p.x * q.x + (double)p.y * q.y + (double)p.z * q.z + (double)p.w * q.w;
+        aa += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z + (double)p.w * p.w;
+        bb += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+    }
+    const int64_t t = (nvec << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (t < n) {
+        ab += (double)a[t] * b[t];
+        aa += (double)a[t] * a[t];
+        bb += (double)b[t] * b[t];
+    }
+    ab = wave_sum(ab);
+    aa = wave_sum(aa);
+    bb = wave_sum(bb);
+    const int w = threadIdx.x / kWave;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        s_r[0][w] = ab;
+        s_r[1][w] = aa;
+        s_r[2][w] = bb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double v = 0.0;
+        for (int k = 0; k < kBlock / kWave; ++k) v += s_r[threadIdx.x][k];
+        atomicAdd(acc + threadIdx.x, v);
+    }
+}
+
+inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+int dpl_abi_version(void) { return DPL_ABI_VERSION; }
+const char* dpl_last_error(void) { return g_err; }
+
+int dpl_device_info(char* name, int name_cap, int* compute_units, uint64_t* hbm_bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail("hipGetDevice", e);
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) return fail("hipGetDeviceProperties", e);
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s (%s)", p.name, p.gcnArchName);
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)p.totalGlobalMem;
+    if (strncmp(p.gcnArchName, "gfx950", 6) != 0) return fail_msg("current HIP device is not gfx950");
+    return 0;
+}
+
+int64_t dpl_build_work_items(const dpl_span* spans, int64_t n_spans, uint64_t chunk_elems, dpl_work_item* out,
+                             int64_t cap) {
+    if (!spans || n_spans < 0 || chunk_elems == 0 || (chunk_elems % 1024) != 0 || chunk_elems > 0xFFFFFC00ull)
+        return fail_msg("dpl_build_work_items: chunk_elems must be a non-zero multiple of 1024 below 2^32");
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_spans; ++i) {
+        uint64_t off = spans[i].offset, left = spans[i].count;
+        while (left) {
+            const uint64_t c = left < chunk_elems ? left : chunk_elems;
+            if (out && n < cap) {
+                out[n].offset = off;
+                out[n].count = (uint32_t)c;
+                out[n].seg = spans[i].seg;
+                out[n].slot = spans[i].slot;
+                out[n].reserved = 0;
+            }
+            ++n;
+            off += c;
+            left -= c;
+        }
+    }
+    return n;
+}
+
+int dpl_minmax_init(uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, int64_t n_slots, dpl_stream_t s) {
+    if (n_slots <= 0) return 0;
+    hipLaunchKernelGGL(k_minmax_init, dim3(grid_for(n_slots, 256)), dim3(256), 0, (hipStream_t)s, d_min_enc,
+                       d_max_enc, d_nan, n_slots);
+    DPL_LAUNCH_CHECK("k_minmax_init");
+    return 0;
+}
+
+int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
+                          uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s) {
+    if (n_items <= 0) return 0;
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)n_items), dim3(kBlock), 0, (hipStream_t)s, d_items, d_seg_ptrs,
+                       d_min_enc, d_max_enc, d_nan);
+    DPL_LAUNCH_CHECK("k_minmax");
+    return 0;
+}
+
+int dpl_minmax_finalize(const uint32_t* d_min_enc, const uint32_t* d_max_enc, const uint32_t* d_nan,
+                        int64_t n_slots, float* d_min, float* d_max, dpl_stream_t s) {
+    if (n_slots <= 0) return 0;
+    hipLaunchKernelGGL(k_minmax_finalize, dim3(grid_for(n_slots, 256)), dim3(256), 0, (hipStream_t)s, d_min_enc,
+                       d_max_enc, d_nan, n_slots, d_min, d_max);
+    DPL_LAUNCH_CHECK("k_minmax_finalize");
+    return 0;
+}
+
+int dpl_minmax_encode(const float* d_min, const float* d_max, int64_t n_slots, uint32_t* d_min_enc,
+                      uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s) {
+    if (n_slots <= 0) return 0;
+    hipLaunchKernelGGL(k_minmax_encode, dim3(grid_for(n_slots, 256)), dim3(256), 0, (hipStream_t)s, d_min, d_max,
+                       n_slots, d_min_enc, d_max_enc, d_nan);
+    DPL_LAUNCH_CHECK("k_minmax_encode");
+    return 0;
+}
+
+int dpl_hist_prepare(const float* d_min, const float* d_max, int64_t n_slots, int bins, dpl_hist_range* d_ranges,
+                     dpl_stream_t s) {
+    if (bins < 1 || bins > DPL_MAX_BINS) return fail_msg("dpl_hist_prepare: bins must be in [1, 16384]");
+    if (n_slots <= 0) return 0;
+    hipLaunchKernelGGL(k_hist_prepare, dim3(grid_for(n_slots, 64)), dim3(64), 0, (hipStream_t)s, d_min, d_max,
+                       n_slots, bins, d_ranges);
+    DPL_LAUNCH_CHECK("k_hist_prepare");
+    return 0;
+}
+
+int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
+                            const dpl_hist_range* d_ranges, int bins, uint64_t* d_hist, dpl_stream_t s) {
+    if (bins < 1 || bins > DPL_MAX_BINS) return fail_msg("dpl_abs_hist_accumulate: bins must be in [1, 16384]");
+    if (n_items <= 0) return 0;
+    hipLaunchKernelGGL(k_abs_hist, dim3((unsigned)n_items), dim3(kBlock), (size_t)bins * sizeof(uint32_t),
+                       (hipStream_t)s, d_items, d_seg_ptrs, d_ranges, bins, d_hist);
+    DPL_LAUNCH_CHECK("k_abs_hist");
+    return 0;
+}
+
+int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float* d_max, int64_t n_slots, int bins,
+                        double threshold, float* d_clip, dpl_stream_t s) {
+    if (n_slots <= 0) return 0;
+    hipLaunchKernelGGL(k_hist_percentile, dim3((unsigned)n_slots), dim3(kWave), 0, (hipStream_t)s, d_hist, d_min,
+                       d_max, bins, threshold, d_clip);
+    DPL_LAUNCH_CHECK("k_hist_percentile");
+    return 0;
+}
+
+int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s) {
+    if (n_pairs <= 0) return 0;
+    hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs);
+    DPL_LAUNCH_CHECK("k_octav_init");
+    return 0;
+}
+
+int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
+                  dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_items <= 0 || n_pairs <= 0) return 0;
+    hipStream_t st = (hipStream_t)s;
+    const dim3 ug(grid_for(n_pairs, 256)), ub(256);
+    hipLaunchKernelGGL(k_octav_pass<true>, dim3((unsigned)n_items), dim3(kBlock), 0, st, d_items, d_seg_ptrs,
+                       d_states);
+    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+    for (int k = 0; k < max_iters; ++k) {
+        hipLaunchKernelGGL(k_octav_pass<false>, dim3((unsigned)n_items), dim3(kBlock), 0, st, d_items, d_seg_ptrs,
+                           d_states);
+        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+    }
+    DPL_LAUNCH_CHECK("k_octav");
+    return 0;
+}
+
+int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s) {
+    if (n_pairs <= 0) return 0;
+    hipLaunchKernelGGL(k_octav_finalize, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)s, d_states,
+                       n_pairs, d_out);
+    DPL_LAUNCH_CHECK("k_octav_finalize");
+    return 0;
+}
+
+int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_min, float* d_max, dpl_stream_t s) {
+    if (rows <= 0) return 0;
+    if (cols <= 0 || cols > 0xFFFFFFFFll) return fail_msg("dpl_rowwise_minmax: cols out of range");
+    hipLaunchKernelGGL(k_rowwise_minmax, dim3((unsigned)rows), dim3(kBlock), 0, (hipStream_t)s, d_w, cols, d_min,
+                       d_max);
+    DPL_LAUNCH_CHECK("k_rowwise_minmax");
+    return 0;
+}
+
+int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
+                   int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s) {
+    if (n <= 0) return 0;
+    if (n_channels < 1 || inner < 1) return fail_msg("dpl_fake_quant: n_channels and inner must be >= 1");
+    int64_t blocks = (n / 4 + kBlock - 1) / kBlock;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (n_channels == 1) {
+        if (((uintptr_t)d_x | (uintptr_t)d_y) & 15u) return fail_msg("dpl_fake_quant: buffers must be 16-B aligned");
+        hipLaunchKernelGGL(k_fake_quant_tensor, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y, n,
+                           d_scale, d_zp, (float)qlo, (float)qhi);
+    } else {
+        hipLaunchKernelGGL(k_fake_quant_channel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y,
+                           n, d_scale, d_zp, n_channels, inner, (float)qlo, (float)qhi);
+    }
+    DPL_LAUNCH_CHECK("k_fake_quant");
+    return 0;
+}
+
+int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_acc, int64_t slot, dpl_stream_t s) {
+    if (n <= 0) return 0;
+    if (((uintptr_t)d_a | (uintptr_t)d_b) & 15u) return fail_msg("dpl_cos_accumulate: buffers must be 16-B aligned");
+    int64_t blocks = (n / 4 + kBlock * 8 - 1) / (kBlock * 8);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_cos_acc, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_a, d_b, n,
+                       d_acc + 3 * slot);
+    DPL_LAUNCH_CHECK("k_cos_acc");
+    return 0;
+}
+
+}  // extern "C"

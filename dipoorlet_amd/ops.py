@@ -1,0 +1,264 @@
+"""Torch-facing operators over the C ABI: device memory and streams come from PyTorch-ROCm, the
+arithmetic runs in the hand-written gfx950 kernels (csrc/calib_kernels.hip).
+
+Vocabulary: a *tensor set* is the list of activation tensors one forward of the network yields for a
+batch of B calibration images (each tensor is [B, ...] contiguous fp32).  A `TensorSetPlan` cuts the
+set into work items once; `CalibAccumulators` holds the persistent device-side statistics
+(running min/max, uint64 histograms, OCTAV states) that replace the reference's per-image Python
+lists (forward_net.py:204-235, 252-280, 297-340).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _hip
+
+_SEG_CACHE_MAX = 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _require_cuda(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _hip.DipoorletHipError(f"{name} must be a ROCm device tensor; dipoorlet_amd has no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _hip.DipoorletHipError(f"{name} must be contiguous float32")
+
+
+def _upload_struct_array(arr, n, device):
+    """ctypes struct array -> device uint8 tensor (one-off, synchronous)."""
+    nbytes = C.sizeof(arr._type_) * max(n, 1)
+    host = torch.frombuffer(bytearray(C.string_at(C.addressof(arr), nbytes)), dtype=torch.uint8)
+    return host.to(device)
+
+
+def default_chunk_elems(total_elems, target_items=1792, lo=16 * 1024, hi=4 * 1024 * 1024):
+    """Work-item size: about `target_items` workgroups per launch (<= 8 resident per CU on 256 CUs, so the
+    whole grid is co-resident and finishes together), never below 64 KiB so the per-workgroup flush
+    (bins atomics) stays amortised."""
+    c = (total_elems + target_items - 1) // target_items
+    c = max(lo, min(hi, c))
+    return ((c + 1023) // 1024) * 1024
+
+
+class TensorSetPlan:
+    """Static decomposition of a tensor set into work items.
+
+    elems_per_image[t] = elements of tensor t for ONE image; batch = images stacked along dim 0.
+    `items` feeds the per-tensor statistics (slot = t); `pair_items` feeds OCTAV (slot = b * T + t).
+    """
+
+    def __init__(self, elems_per_image, batch, device, chunk_elems=None):
+        self.elems = [int(e) for e in elems_per_image]
+        self.batch = int(batch)
+        self.T = len(self.elems)
+        self.device = torch.device(device)
+        self.total = sum(self.elems) * self.batch
+        self.chunk = int(chunk_elems) if chunk_elems else default_chunk_elems(self.total)
+        spans = [(t, 0, e * self.batch, t) for t, e in enumerate(self.elems)]
+        arr, self.n_items = _hip.build_work_items(spans, self.chunk)
+        self.items = _upload_struct_array(arr, self.n_items, self.device)
+        self._pair = None
+        self._seg_cache = {}
+
+    @property
+    def n_pairs(self):
+        return self.batch * self.T
+
+    def pair_items(self):
+        if self._pair is None:
+            spans = [(t, b * e, e, b * self.T + t) for b in range(self.batch) for t, e in enumerate(self.elems)]
+            arr, n = _hip.build_work_items(spans, self.chunk)
+            self._pair = (_upload_struct_array(arr, n, self.device), n)
+        return self._pair
+
+    def seg_table(self, tensors):
+        """Device table of base pointers for this launch (cached per pointer tuple)."""
+        if len(tensors) != self.T:
+            raise _hip.DipoorletHipError(f"expected {self.T} tensors, got {len(tensors)}")
+        for t, (x, e) in enumerate(zip(tensors, self.elems)):
+            _require_cuda(x, f"tensor {t}")
+            if x.numel() != e * self.batch:
+                raise _hip.DipoorletHipError(f"tensor {t}: {x.numel()} elements, plan expects {e * self.batch}")
+        key = tuple(x.data_ptr() for x in tensors)
+        tab = self._seg_cache.get(key)
+        if tab is None:
+            if len(self._seg_cache) >= _SEG_CACHE_MAX:
+                self._seg_cache.clear()
+            host = torch.tensor(key, dtype=torch.int64).pin_memory()
+            tab = host.to(self.device, non_blocking=True)
+            self._seg_cache[key] = (tab, host)  # keep the pinned source alive until the copy has run
+            return tab
+        return tab[0]
+
+
+class CalibAccumulators:
+    """Persistent per-tensor statistics on the device."""
+
+    def __init__(self, n_slots, device, bins=2048):
+        self.n = int(n_slots)
+        self.device = torch.device(device)
+        self.bins = int(bins)
+        if not (1 <= self.bins <= _hip.MAX_BINS):
+            raise _hip.DipoorletHipError(f"bins must be in [1, {_hip.MAX_BINS}]")
+        self.min_enc = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.max_enc = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.nan = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.gmin = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        self.gmax = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        self.hist = None
+        self.ranges = None
+        self.reset_minmax()
+
+    def reset_minmax(self):
+        _hip.check(_hip.lib().dpl_minmax_init(_ptr(self.min_enc), _ptr(self.max_enc), _ptr(self.nan), self.n,
+                                              _stream()), "dpl_minmax_init")
+
+    # ---- pass 1
+    def minmax_accumulate(self, plan, tensors):
+        tab = plan.seg_table(tensors)
+        _hip.check(_hip.lib().dpl_minmax_accumulate(_ptr(plan.items), plan.n_items, _ptr(tab), _ptr(self.min_enc),
+                                                    _ptr(self.max_enc), _ptr(self.nan), _stream()),
+                   "dpl_minmax_accumulate")
+
+    def finalize_minmax(self):
+        """-> (gmin, gmax) fp32 device tensors [n_slots]."""
+        _hip.check(_hip.lib().dpl_minmax_finalize(_ptr(self.min_enc), _ptr(self.max_enc), _ptr(self.nan), self.n,
+                                                  _ptr(self.gmin), _ptr(self.gmax), _stream()),
+                   "dpl_minmax_finalize")
+        return self.gmin, self.gmax
+
+    def set_minmax(self, gmin, gmax):
+        """Install merged ranges (e.g. after an all-reduce across ranks)."""
+        self.gmin.copy_(gmin)
+        self.gmax.copy_(gmax)
+        _hip.check(_hip.lib().dpl_minmax_encode(_ptr(self.gmin), _ptr(self.gmax), self.n, _ptr(self.min_enc),
+                                                _ptr(self.max_enc), _ptr(self.nan), _stream()), "dpl_minmax_encode")
+
+    # ---- pass 2
+    def hist_prepare(self):
+        """Derive per-tensor histogram ranges from gmin/gmax (call after finalize_minmax / set_minmax)."""
+        if self.hist is None:
+            self.hist = torch.zeros(self.n, self.bins, dtype=torch.int64, device=self.device)
+            self.ranges = torch.empty(self.n * C.sizeof(_hip.HistRange), dtype=torch.uint8, device=self.device)
+        else:
+            self.hist.zero_()
+        _hip.check(_hip.lib().dpl_hist_prepare(_ptr(self.gmin), _ptr(self.gmax), self.n, self.bins,
+                                               _ptr(self.ranges), _stream()), "dpl_hist_prepare")
+
+    def abs_hist_accumulate(self, plan, tensors):
+        tab = plan.seg_table(tensors)
+        _hip.check(_hip.lib().dpl_abs_hist_accumulate(_ptr(plan.items), plan.n_items, _ptr(tab), _ptr(self.ranges),
+                                                      self.bins, _ptr(self.hist), _stream()),
+                   "dpl_abs_hist_accumulate")
+
+    def range_status(self):
+        """HOST (synchronises): per-slot status from dpl_hist_prepare: 0 ok, 1 not finite, 2 too many bins."""
+        raw = self.ranges.cpu().numpy().view(np.dtype([("first", "<f4"), ("last", "<f4"), ("step", "<f4"),
+                                                       ("inv", "<f4"), ("zero_bin", "<u4"), ("status", "<u4"),
+                                                       ("dmax", "<f4"), ("exact_div", "<u4")]))
+        return raw
+
+    def hist_percentile(self, threshold):
+        clip = torch.empty(self.n, 2, dtype=torch.float32, device=self.device)
+        _hip.check(_hip.lib().dpl_hist_percentile(_ptr(self.hist), _ptr(self.gmin), _ptr(self.gmax), self.n,
+                                                  self.bins, float(threshold), _ptr(clip), _stream()),
+                   "dpl_hist_percentile")
+        return clip
+
+
+_OCTAV_MAX_ITERS = 20  # forward_net.py:325
+
+
+def octav_batch(plan, tensors, dynamic_sym, states=None):
+    """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max)."""
+    items, n_items = plan.pair_items()
+    n_pairs = plan.n_pairs
+    if states is None or states.numel() < n_pairs * C.sizeof(_hip.OctavState):
+        states = torch.empty(n_pairs * C.sizeof(_hip.OctavState), dtype=torch.uint8, device=plan.device)
+    tab = plan.seg_table(tensors)
+    L = _hip.lib()
+    _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, _stream()), "dpl_octav_init")
+    _hip.check(L.dpl_octav_run(_ptr(items), n_items, _ptr(tab), _ptr(states), n_pairs, 1 if dynamic_sym else 0,
+                               _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run")
+    out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+    _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
+    return out
+
+
+# ------------------------------------------------------------------------------- single-tensor conveniences
+def minmax(x):
+    """(min, max) of one device tensor as a fp32 device tensor [2] (NaN if x holds a NaN)."""
+    _require_cuda(x)
+    plan = TensorSetPlan([x.numel()], 1, x.device)
+    acc = CalibAccumulators(1, x.device)
+    acc.minmax_accumulate(plan, [x])
+    lo, hi = acc.finalize_minmax()
+    return torch.stack([lo[0], hi[0]])
+
+
+def abs_hist(x, bins, gmin, gmax):
+    """np.histogram(|x|, bins, (0, max(gmax, -gmin)))[0] as an int64 device tensor [bins]."""
+    _require_cuda(x)
+    plan = TensorSetPlan([x.numel()], 1, x.device)
+    acc = CalibAccumulators(1, x.device, bins)
+    acc.set_minmax(torch.tensor([gmin], dtype=torch.float32, device=x.device),
+                   torch.tensor([gmax], dtype=torch.float32, device=x.device))
+    acc.hist_prepare()
+    acc.abs_hist_accumulate(plan, [x])
+    return acc.hist[0], acc
+
+
+def rowwise_minmax(w2d):
+    """Per-row (min, max) of a [rows, cols] fp32 device matrix (basic_algorithm.py:88-90)."""
+    _require_cuda(w2d, "w2d")
+    rows, cols = w2d.shape
+    lo = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    hi = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    _hip.check(_hip.lib().dpl_rowwise_minmax(_ptr(w2d), rows, cols, _ptr(lo), _ptr(hi), _stream()),
+               "dpl_rowwise_minmax")
+    return lo, hi
+
+
+def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None):
+    """Fused QuantizeLinear -> DequantizeLinear (quantize.py:197-239) on the device.
+
+    scale: fp32 device tensor [1] or [C]; zero_point: int32 device tensor of the same length;
+    axis: channel axis when len(scale) > 1.  y = (clamp(rint(x/scale)+zp, qlo, qhi) - zp) * scale.
+    """
+    _require_cuda(x, "x")
+    scale = scale.to(device=x.device, dtype=torch.float32).contiguous().reshape(-1)
+    zero_point = zero_point.to(device=x.device, dtype=torch.int32).contiguous().reshape(-1)
+    nch = scale.numel()
+    if zero_point.numel() != nch:
+        raise _hip.DipoorletHipError("scale and zero_point lengths differ")
+    inner = 1
+    if nch > 1:
+        if axis is None:
+            raise _hip.DipoorletHipError("per-channel fake_quant needs an axis")
+        if x.shape[axis] != nch:
+            raise _hip.DipoorletHipError(f"axis {axis} has {x.shape[axis]} channels, scale has {nch}")
+        for d in x.shape[axis + 1:]:
+            inner *= int(d)
+    y = torch.empty_like(x) if out is None else out
+    _hip.check(_hip.lib().dpl_fake_quant(_ptr(x), _ptr(y), x.numel(), _ptr(scale), _ptr(zero_point), nch, inner,
+                                         int(qlo), int(qhi), _stream()), "dpl_fake_quant")
+    return y
+
+
+def cos_accumulate(a, b, acc, slot=0):
+    """acc[slot] += (sum a*b, sum a*a, sum b*b) in fp64 (utils.py:273-278 partial sums)."""
+    _require_cuda(a, "a")
+    _require_cuda(b, "b")
+    if a.numel() != b.numel():
+        raise _hip.DipoorletHipError("cos_accumulate: size mismatch")
+    _hip.check(_hip.lib().dpl_cos_accumulate(_ptr(a), _ptr(b), a.numel(), _ptr(acc), slot, _stream()),
+               "dpl_cos_accumulate")
+    return acc

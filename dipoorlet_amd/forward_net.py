@@ -1,0 +1,223 @@
+"""Calibration statistics over the calibration set — the GPU-resident replacement of
+dipoorlet/forward_net.py:192-342 (forward_get_minmax / forward_get_hist / forward_net_octav) and its
+.bin loader (:459-464).
+
+Reference flow per image: ORT forward with every node output exposed -> copy all activations to the
+host -> numpy reductions appended to Python lists.  Here: B images per forward, activations stay in
+HBM, one batched HIP launch per statistic over the whole tensor set, persistent device accumulators.
+The functions keep the reference's names, arguments and return shapes (dict keyed by tensor name) so
+tensor_cali and tests read the same; where the reference returns one entry per image and only their
+min / max / sum is ever consumed (ranges, histograms), the list holds the already-reduced value unless
+`per_image=True` asks for the full lists.
+
+`onnx_graph` is anything offering the reference ONNXGraph's calibration-facing surface:
+    .network_inputs            list of input names
+    .get_tensor_shape(name)    model input shape (batch dim 1)
+    .make_session(args)        -> ActivationSession  (replaces ort.InferenceSession(...all outputs...))
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .dist_helper import shard_range
+from .platform_settings import platform_setting_table
+from .utils import logger
+
+DEFAULT_BATCH = 16
+
+
+class ActivationSession:
+    """What a graph executor must provide: one forward of a batch -> every calibration tensor.
+
+    tensor_names     network inputs first, then every node output in graph order (forward_net.py:220-235)
+    elems_per_image  elements of each tensor for ONE image
+    run(inputs)      inputs: {name: device tensor [B, ...]} -> list of contiguous fp32 device tensors
+                     [B, ...] aligned with tensor_names (the inputs themselves included)
+    """
+    tensor_names = ()
+    elems_per_image = ()
+
+    def run(self, inputs):
+        raise NotImplementedError
+
+
+def input_data_generator(input_dir, input_name_list, data_st_idx, data_ed_idx):
+    """forward_net.py:459-464 — one dict {input_name: flat fp32 array} per calibration image, read from
+    `{input_dir}/{input_name}/{idx}.bin` (raw little-endian fp32)."""
+    for idx in range(data_st_idx, data_ed_idx):
+        yield {n: np.fromfile(f"{input_dir}/{n}/{idx}.bin", "float32") for n in input_name_list}
+
+
+def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
+    """Images [idx0, idx1) of every network input as device tensors [B, *shape[1:]]: files are read
+    into one pinned staging buffer per input and copied with a single async H2D transfer."""
+    out = {}
+    b = idx1 - idx0
+    for n in input_names:
+        shape = tuple(int(d) for d in shapes[n])
+        per = int(np.prod(shape))
+        stage = torch.empty((b, per), dtype=torch.float32, pin_memory=device.type == "cuda")
+        sv = stage.numpy()
+        for j, idx in enumerate(range(idx0, idx1)):
+            a = np.fromfile(f"{input_dir}/{n}/{idx}.bin", "float32")
+            if a.size != per:
+                raise ValueError(f"{input_dir}/{n}/{idx}.bin holds {a.size} fp32 values, model input needs {per}")
+            sv[j] = a
+        lead = shape[0] if len(shape) > 0 else 1
+        full = (b * lead,) + shape[1:] if len(shape) > 1 else (b * per,)
+        out[n] = stage.to(device, non_blocking=True).reshape(full)
+    return out
+
+
+class CalibrationRun:
+    """One rank's sweep(s) over its shard of the calibration set."""
+
+    def __init__(self, onnx_graph, args):
+        self.graph = onnx_graph
+        self.args = args
+        self.session = onnx_graph.make_session(args)
+        self.names = list(self.session.tensor_names)
+        self.elems = [int(e) for e in self.session.elems_per_image]
+        self.T = len(self.names)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.batch = int(getattr(args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
+        self.st, self.ed = shard_range(args.data_num, args.rank, args.world_size)
+        self._plans = {}
+        budget_gb = float(getattr(args, "resident_gb", 160.0))
+        self._budget = int(budget_gb * 2**30)
+        self._resident = []  # tensor sets kept in HBM between pass 1 and pass 2
+        self._resident_ok = True
+        self._resident_bytes = 0
+
+    def plan(self, b):
+        p = self._plans.get(b)
+        if p is None:
+            p = self._plans[b] = ops.TensorSetPlan(self.elems, b, self.device)
+        return p
+
+    def n_images(self):
+        return self.ed - self.st
+
+    def batches(self):
+        i = self.st
+        while i < self.ed:
+            j = min(i + self.batch, self.ed)
+            yield i, j
+            i = j
+
+    def forward(self, keep=False):
+        """Yields (b, tensors) per batch.  With keep=True the tensor sets stay resident in HBM (up to
+        args.resident_gb) so a second pass re-reads them instead of re-running the network."""
+        shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
+        for i, j in self.batches():
+            inputs = load_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, self.device)
+            tensors = self.session.run(inputs)
+            if keep and self._resident_ok:
+                nbytes = sum(t.numel() * 4 for t in tensors)
+                if self._resident_bytes + nbytes <= self._budget:
+                    self._resident.append((j - i, tensors))
+                    self._resident_bytes += nbytes
+                else:
+                    self._resident_ok = False
+                    self._resident = []
+                    self._resident_bytes = 0
+            yield j - i, tensors
+
+    def second_pass(self):
+        if self._resident_ok and self._resident:
+            yield from self._resident
+        else:
+            yield from self.forward()
+
+    def release(self):
+        self._resident = []
+        self._resident_bytes = 0
+
+
+def _np32(t):
+    return t.detach().cpu().numpy().astype(np.float32, copy=False)
+
+
+def _run_of(onnx_graph, args, run):
+    return run if run is not None else CalibrationRun(onnx_graph, args)
+
+
+def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_resident=False):
+    """forward_net.py:192-237 — {name: {'max': [...], 'min': [...]}} over this rank's shard."""
+    run = _run_of(onnx_graph, args, run)
+    if per_image:
+        rows = []
+        for b, tensors in run.forward(keep=keep_resident):
+            plan = run.plan(b)
+            acc = ops.CalibAccumulators(plan.n_pairs, run.device)
+            acc.minmax_accumulate(plan, tensors, per_image=True)
+            lo, hi = acc.finalize_minmax()
+            rows.append(torch.stack([lo.reshape(b, run.T), hi.reshape(b, run.T)], -1).clone())
+        allr = _np32(torch.cat(rows)) if rows else np.zeros((0, run.T, 2), np.float32)
+        return {n: {"max": list(allr[:, t, 1]), "min": list(allr[:, t, 0])} for t, n in enumerate(run.names)}
+    acc = ops.CalibAccumulators(run.T, run.device, int(getattr(args, "bins", 2048)))
+    for b, tensors in run.forward(keep=keep_resident):
+        acc.minmax_accumulate(run.plan(b), tensors)
+    gmin, gmax = acc.finalize_minmax()
+    run.acc = acc
+    lo, hi = _np32(gmin), _np32(gmax)
+    return {n: {"max": [hi[t]], "min": [lo[t]]} for t, n in enumerate(run.names)}
+
+
+def _ranges_from_stats(stats_min_max, names, device):
+    gmin = np.array([np.min(stats_min_max[n]["min"]) for n in names], np.float32)
+    gmax = np.array([np.max(stats_min_max[n]["max"]) for n in names], np.float32)
+    return torch.from_numpy(gmin).to(device), torch.from_numpy(gmax).to(device)
+
+
+def forward_get_hist(onnx_graph, stats_min_max, args, run=None):
+    """forward_net.py:240-281 — {name: [int64[bins]]}: the |x| histogram over (0, max(max, -min)) of the
+    shard, already summed over images (the reference returns one per image and sums them later,
+    basic_algorithm.py:37-38)."""
+    run = _run_of(onnx_graph, args, run)
+    gmin, gmax = _ranges_from_stats(stats_min_max, run.names, run.device)
+    acc = hist_pass(run, gmin, gmax, int(args.bins))
+    h = acc.hist.cpu().numpy()
+    return {n: [h[t]] for t, n in enumerate(run.names)}
+
+
+def hist_pass(run, gmin, gmax, bins):
+    """Device side of forward_get_hist: install the ranges, sweep the shard, leave the uint64 histograms
+    in run.acc.hist.  Raises like np.histogram for a non-finite or degenerate range."""
+    acc = getattr(run, "acc", None)
+    if acc is None or acc.bins != bins:
+        acc = run.acc = ops.CalibAccumulators(run.T, run.device, bins)
+    acc.set_minmax(gmin, gmax)
+    acc.hist_prepare()
+    for b, tensors in run.second_pass():
+        acc.abs_hist_accumulate(run.plan(b), tensors)
+    run.release()
+    status = acc.range_status()["status"]
+    for t, n in enumerate(run.names):
+        if status[t] == 1:
+            raise ValueError(f"supplied range of [0, {gmax[t].item()}] is not finite (tensor {n})")
+        if status[t] == 2:
+            raise ValueError(f"Too many bins for data range. Cannot create {bins} finite-sized bins. (tensor {n})")
+    return acc
+
+
+def forward_net_octav(onnx_graph, args, run=None):
+    """forward_net.py:284-342 — {name: {'optimal_s': [...], 'min': [...], 'max': [...]}}, one entry per
+    image of the shard."""
+    run = _run_of(onnx_graph, args, run)
+    dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
+    rows = []
+    for b, tensors in run.forward():
+        rows.append(ops.octav_batch(run.plan(b), tensors, dynamic_sym).clone())
+    run.octav_rows = torch.cat(rows) if rows else torch.zeros(0, run.T, 3, device=run.device)
+    r = _np32(run.octav_rows)
+    return {n: {"optimal_s": list(r[:, t, 0]), "min": list(r[:, t, 1]), "max": list(r[:, t, 2])}
+            for t, n in enumerate(run.names)}
+
+
+def log_forward_time(seconds):
+    logger.info("Forward time: {:.2f} seconds".format(seconds))
+
+
+__all__ = ["ActivationSession", "CalibrationRun", "input_data_generator", "load_input_batch", "forward_get_minmax",
+           "forward_get_hist", "forward_net_octav", "DEFAULT_BATCH"]

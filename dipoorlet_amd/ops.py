@@ -122,9 +122,14 @@ class CalibAccumulators:
                                               _stream()), "dpl_minmax_init")
 
     # ---- pass 1
-    def minmax_accumulate(self, plan, tensors):
+    def minmax_accumulate(self, plan, tensors, per_image=False):
+        """per_image=False: slot = tensor (n_slots = T).  per_image=True: slot = image * T + tensor
+        (n_slots = B * T), the reference's one-entry-per-image lists."""
         tab = plan.seg_table(tensors)
-        _hip.check(_hip.lib().dpl_minmax_accumulate(_ptr(plan.items), plan.n_items, _ptr(tab), _ptr(self.min_enc),
+        items, n_items = plan.pair_items() if per_image else (plan.items, plan.n_items)
+        if self.n < (plan.n_pairs if per_image else plan.T):
+            raise _hip.DipoorletHipError("accumulator has fewer slots than the plan addresses")
+        _hip.check(_hip.lib().dpl_minmax_accumulate(_ptr(items), n_items, _ptr(tab), _ptr(self.min_enc),
                                                     _ptr(self.max_enc), _ptr(self.nan), _stream()),
                    "dpl_minmax_accumulate")
 

@@ -1,0 +1,156 @@
+"""CPU: host-side mirror of the reference interfaces — dispatcher, clip JSON exchange (byte-compatible
+with the reference's files), scale/zero-point derivation, sharding, and the world_size-2 merge over gloo."""
+import json
+import os
+import types
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from _cases import MINI_NET, mini_net_activations
+from oracle import np_oracle as O
+
+
+def _args(**kw):
+    a = types.SimpleNamespace(rank=0, world_size=1, deploy="trt", act_quant="hist", output_dir=None)
+    a.__dict__.update(kw)
+    return a
+
+
+def test_dispatcher_semantics():
+    from dipoorlet_amd.utils import dispatch_functool
+
+    calls = []
+
+    @dispatch_functool
+    def disp(*a, **k):
+        calls.append(("default", a, k))
+
+    @disp.register("x")
+    def fx(g, args, **k):
+        return ("x", g, args, k)
+
+    assert disp("x", 1, 2, store_stats=3) == ("x", 1, 2, {"store_stats": 3})
+    assert disp("nope", 1, 2) is None and calls == [("default", (1, 2), {})]  # unknown key -> default
+    assert disp.dispatch("x") is fx and "x" in disp.registry
+
+
+def test_registry_keys_match_reference():
+    from dipoorlet_amd.tensor_cali import tensor_cali_dispatcher
+    assert set(tensor_cali_dispatcher.registry) == {"minmax", "hist", "mse"}
+    assert tensor_cali_dispatcher("kl", None, None) is None  # "Calibration Algorithm Not Found!"
+
+
+def test_clip_json_roundtrip_is_byte_compatible(golden_dir, tmp_path):
+    """save -> per-rank files -> reduce -> load reproduces the reference's merged act_clip_val.json text."""
+    from dipoorlet_amd.utils import load_clip_val, reduce_clip_val, save_clip_val
+    with open(os.path.join(golden_dir, "pipeline_level.json")) as f:
+        pl = json.load(f)
+    for run in pl["runs"]:
+        od = tmp_path / f"{run['algo']}_{run['deploy']}_{run['world_size']}_{run['bins']}"
+        od.mkdir()
+        a = _args(output_dir=str(od), act_quant=run["algo"], deploy=run["deploy"])
+        for r, clips in enumerate(run["ranks"]):
+            act = {k: [np.float32(v[0]), np.float32(v[1])] for k, v in clips.items()}
+            save_clip_val(act, {}, a, act_fname=f"act_clip_val.json.rank{r}", weight_fname=f"weight_clip_val.json.rank{r}")
+        reduce_clip_val(run["world_size"], a)
+        assert (od / "act_clip_val.json").read_text() == run["merged_json_text"]
+        act, wt = load_clip_val(a)
+        for k, v in run["merged"].items():
+            assert isinstance(act[k][0], np.float64) and act[k][0] == v[0] and act[k][1] == v[1]
+
+
+def test_get_qnode_by_param_all_platforms(golden_dir):
+    from dipoorlet_amd.platform_settings import platform_setting_table
+    from dipoorlet_amd.quantize import get_qnode_by_param
+    with open(os.path.join(golden_dir, "qparam_level.json")) as f:
+        q = json.load(f)
+    for row in q["rows"]:
+        param = platform_setting_table[row["platform"]][row["param"]]
+        if row["per_channel_in"]:
+            rng = [np.array(row["lo"]), np.array(row["hi"])]
+        else:
+            rng = [np.float64(row["lo"][0]), np.float64(row["hi"][0])]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            node, qmin, qmax = get_qnode_by_param(param, "t", [5, 3], rng)
+        assert np.array_equal(node.scale.view(np.uint32), np.array(row["scale"], np.float32).view(np.uint32)), row
+        assert node.zero_point.astype(np.int64).tolist() == row["zp"], row
+        assert [int(v) for v in np.ravel(qmin)] == [int(v) for v in row["qmin"]], row
+        assert [int(v) for v in np.ravel(qmax)] == [int(v) for v in row["qmax"]], row
+        assert node.symmetric == row["symmetric"] and node.per_channel == row["per_channel"]
+        assert node.output == "t_dq" and node.q_name == "t_QuantizeLinear" and node.scale_name == "t_scale"
+    # the documented latent wrap: snpe, range [-3, 1] -> zp 191 stored as int8 -65, read back as uint8 191
+    node, qmin, qmax = get_qnode_by_param(platform_setting_table["snpe"]["qi_params"], "t", [1],
+                                          [np.float64(-3.0), np.float64(1.0)])
+    assert node.zero_point.tolist() == [-65] and node.zero_point_as_stored().tolist() == [191]
+    assert (qmin, qmax) == ([-191], [64]) and node.saturation() == (0, 255)
+
+
+def test_shard_range_matches_reference_split():
+    from dipoorlet_amd.dist_helper import shard_range, slurm_master_addr
+    for n in (8, 10, 1024, 7):
+        for w in (1, 2, 3, 8):
+            got = [shard_range(n, r, w) for r in range(w)]
+            assert got == [O.shard_range(n, r, w) for r in range(w)]
+            assert got[-1][1] == (n // w) * w  # the remainder images are dropped, as in the reference
+    assert slurm_master_addr("SH-IDC1-10-5-30-[12-15]") == "10.5.30.12"
+
+
+# ------------------------------------------------------------------ world_size 2 over gloo (CPU)
+def _worker(rank, world, port, tmp, golden_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from dipoorlet_amd import dist_helper as dh
+    dh.init_default()
+    assert dist.get_backend() == "gloo"
+    N, bins = 8, 2048
+    names = [n for n, _, _ in MINI_NET]
+    st, ed = dh.shard_range(N, rank, world)
+    acts = [dict(mini_net_activations(i)) for i in range(st, ed)]
+    # this rank's statistics (oracle stands in for the kernels: no GPU in this container)
+    gmin = torch.tensor([min(O.minmax(a[k])[0] for a in acts) for k in names])
+    gmax = torch.tensor([max(O.minmax(a[k])[1] for a in acts) for k in names])
+    dh.merge_ranges(gmin, gmax, world)
+    hist = torch.from_numpy(np.stack([
+        sum(O.abs_hist(a[k], bins, O.hist_dmax(gmin[t].numpy(), gmax[t].numpy())) for a in acts)
+        for t, k in enumerate(names)]))
+    dh.merge_hist(hist, world)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rows = torch.tensor([[[float(O.octav_scale(a[k], 1)), float(O.minmax(a[k])[0]), float(O.minmax(a[k])[1])]
+                              for k in names] for a in acts], dtype=torch.float32)
+    rows = dh.gather_rows(rows, world)
+    torch.save({"gmin": gmin, "gmax": gmax, "hist": hist, "rows": rows}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_merge_equals_world1_reference(golden_dir, tmp_path):
+    world = 2
+    port = 29600 + os.getpid() % 300
+    mp.spawn(_worker, args=(world, port, str(tmp_path), golden_dir), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    for k in ("gmin", "gmax", "hist", "rows"):
+        assert torch.equal(r0[k], r1[k]) or (k == "rows" and torch.allclose(r0[k], r1[k], equal_nan=True))
+    # equals the reference's own world_size = 1 answer over all 8 images
+    with open(os.path.join(golden_dir, "pipeline_level.json")) as f:
+        pl = json.load(f)
+    st = np.load(os.path.join(golden_dir, "pipeline_stats.npz"))
+    names = [n for n, _, _ in MINI_NET]
+    ref = {(r["algo"], r["deploy"], r["bins"], r["world_size"]): r for r in pl["runs"]}
+    mm = ref[("minmax", "trt", 2048, 1)]["ranks"][0]
+    hh = ref[("hist", "trt", 2048, 1)]["ranks"][0]
+    oo = ref[("mse", "trt", 2048, 1)]["ranks"][0]
+    for t, k in enumerate(names):
+        assert [r0["gmin"][t].item(), r0["gmax"][t].item()] == mm[k]
+        assert np.array_equal(r0["hist"][t].numpy(), st[f"{k}/hist"].sum(0))
+        clip = O.hist_percentile(r0["hist"][t].numpy(), r0["gmin"][t].numpy(), r0["gmax"][t].numpy(), 2048, 0.99999)
+        assert [float(clip[0]), float(clip[1])] == hh[k]
+        rows = r0["rows"][:, t].numpy()
+        clip = O.octav_clip(rows[:, 0], rows[:, 1], rows[:, 2])
+        assert [float(clip[0]), float(clip[1])] == oo[k]

@@ -193,7 +193,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"ResNet-50 ONNX activation set (T={T} tensors, {E} fp32 elems/img), -A {a.algo}"
                                f" --bins {a.bins}, N={a.steps * B} images per GPU in batches of {B}",
-                   "batch": B, "bins": a.bins, "algo": a.algo, "work_items": plan.n_items,
+                   "batch": B, "bins": a.bins, "algo": a.algo, "workgroups": plan.work("minmax" if a.algo == "minmax" else ("octav" if a.algo == "mse" else "hist"),
+                                                     a.algo == "mse").n_blocks,
                    "chunk_elems": plan.chunk, "device": devname},
         "algorithmic_GBps_job": bytes_per_img * images / dt / 1e9,
         "roofline": {"bound": "hbm", "kernel": {"hist": "k_abs_hist", "minmax": "k_minmax",

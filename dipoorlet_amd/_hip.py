@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_BINS = 16384
 
 
@@ -48,15 +48,16 @@ SIGNATURES = {
     "dpl_last_error": (C.c_char_p, []),
     "dpl_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
     "dpl_build_work_items": (_I64, [_P, _I64, _U64, _P, _I64]),
+    "dpl_build_balanced_items": (_I64, [_P, _I64, _I64, _P, _I64, _P]),
     "dpl_minmax_init": (C.c_int, [_P, _P, _P, _I64, _P]),
-    "dpl_minmax_accumulate": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P]),
+    "dpl_minmax_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "dpl_minmax_finalize": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "dpl_minmax_encode": (C.c_int, [_P, _P, _I64, _P, _P, _P, _P]),
     "dpl_hist_prepare": (C.c_int, [_P, _P, _I64, C.c_int, _P, _P]),
-    "dpl_abs_hist_accumulate": (C.c_int, [_P, _I64, _P, _P, C.c_int, _P, _P]),
+    "dpl_abs_hist_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, C.c_int, _P, _P]),
     "dpl_hist_percentile": (C.c_int, [_P, _P, _P, _I64, C.c_int, _DBL, _P, _P]),
     "dpl_octav_init": (C.c_int, [_P, _I64, _P]),
-    "dpl_octav_run": (C.c_int, [_P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
+    "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
@@ -100,6 +101,28 @@ def device_info():
     mem = C.c_uint64(0)
     st = lib().dpl_device_info(name, 256, C.byref(cus), C.byref(mem))
     return st, name.value.decode(), cus.value, mem.value
+
+
+def _span_array(spans):
+    spans = list(spans)
+    arr = (Span * max(len(spans), 1))()
+    for i, (seg, off, cnt, slot) in enumerate(spans):
+        arr[i] = Span(off, cnt, seg, slot)
+    return arr, len(spans)
+
+
+def build_balanced_items(spans, n_blocks):
+    """HOST: spans = iterable of (seg, offset, count, slot) -> (WorkItem array, n_items, block_begin array):
+    n_blocks contiguous equal shares of the concatenated element stream."""
+    arr, ns = _span_array(spans)
+    n = lib().dpl_build_balanced_items(C.addressof(arr), ns, n_blocks, None, 0, None)
+    if n < 0:
+        check(int(n), "dpl_build_balanced_items")
+    out = (WorkItem * max(n, 1))()
+    bb = (C.c_uint32 * (n_blocks + 1))()
+    n2 = lib().dpl_build_balanced_items(C.addressof(arr), ns, n_blocks, C.addressof(out), n, C.addressof(bb))
+    assert n2 == n
+    return out, int(n), bb
 
 
 def build_work_items(spans, chunk_elems):

@@ -13,6 +13,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/dipoorlet_hip.h"
 
@@ -99,18 +100,44 @@ __device__ __forceinline__ void stream_span(const float* __restrict__ p_generic,
     const uint32_t nvec = n >> 2;
     gptr_f4 pv = (gptr_f4)p;
     uint32_t i = tid;
-    for (; i + (kUnroll - 1) * kBlock < nvec; i += kUnroll * kBlock) {
-        f4 v[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = __builtin_nontemporal_load(pv + i + u * kBlock);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            op(v[u].x);
-            op(v[u].y);
-            op(v[u].z);
-            op(v[u].w);
+    constexpr uint32_t kStride = kUnroll * kBlock;
+    // software pipeline: the next kUnroll loads are issued before the current ones are consumed, so a wave
+    // always has 4-8 KiB in flight and few waves per SIMD suffice (fewer, larger work items stream
+    // measurably faster from HBM than many small ones)
+    // (ping-pong register sets A/B, loop unrolled by two: a register copy nxt -> cur would make the compiler
+    // wait for the loads it just issued)
+#define DPL_LOAD(buf, base)                                                                       \
+    _Pragma("unroll") for (int u = 0; u < kUnroll; ++u) buf[u] = __builtin_nontemporal_load(pv + (base) + u * kBlock)
+#define DPL_EAT(buf)                                 \
+    _Pragma("unroll") for (int u = 0; u < kUnroll; ++u) { \
+        op(buf[u].x);                                \
+        op(buf[u].y);                                \
+        op(buf[u].z);                                \
+        op(buf[u].w);                                \
+    }
+    if (i + (kUnroll - 1) * kBlock < nvec) {
+        f4 A[kUnroll], B[kUnroll];
+        DPL_LOAD(A, i);
+        i += kStride;
+        for (;;) {
+            if (!(i + (kUnroll - 1) * kBlock < nvec)) {
+                DPL_EAT(A);
+                break;
+            }
+            DPL_LOAD(B, i);
+            i += kStride;
+            DPL_EAT(A);
+            if (!(i + (kUnroll - 1) * kBlock < nvec)) {
+                DPL_EAT(B);
+                break;
+            }
+            DPL_LOAD(A, i);
+            i += kStride;
+            DPL_EAT(B);
         }
     }
+#undef DPL_LOAD
+#undef DPL_EAT
     for (; i < nvec; i += kBlock) {
         f4 v = __builtin_nontemporal_load(pv + i);
         op(v.x);
@@ -133,36 +160,54 @@ struct MinMaxOp {
     }
 };
 
+// Work distribution shared by the streaming kernels: block b owns items [bb[b], bb[b+1]) (a balanced,
+// contiguous share of the launch's elements, dpl_build_balanced_items) or, when bb is null, item b alone.
+__device__ __forceinline__ void block_items(const uint32_t* __restrict__ bb, uint32_t& k0, uint32_t& k1) {
+    if (bb) {
+        k0 = bb[blockIdx.x];
+        k1 = bb[blockIdx.x + 1];
+    } else {
+        k0 = blockIdx.x;
+        k1 = k0 + 1;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_minmax(const dpl_work_item* __restrict__ items,
+                                                    const uint32_t* __restrict__ bb,
                                                     const float* const* __restrict__ segs,
                                                     uint32_t* __restrict__ min_enc, uint32_t* __restrict__ max_enc,
                                                     uint32_t* __restrict__ nan_flag) {
     __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
     __shared__ uint32_t s_nan[kBlock / kWave];
-    const dpl_work_item it = items[blockIdx.x];
-    MinMaxOp op{INFINITY, -INFINITY, 0u};
-    stream_span(segs[it.seg] + it.offset, it.count, op);
-    float mn = wave_min(op.mn), mx = wave_max(op.mx);
-    uint32_t nn = __any(op.nan) ? 1u : 0u;
-    const int w = threadIdx.x / kWave;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        s_mn[w] = mn;
-        s_mx[w] = mx;
-        s_nan[w] = nn;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        MinMaxOp op{INFINITY, -INFINITY, 0u};
+        stream_span(segs[it.seg] + it.offset, it.count, op);
+        float mn = wave_min(op.mn), mx = wave_max(op.mx);
+        uint32_t nn = __any(op.nan) ? 1u : 0u;
+        const int w = threadIdx.x / kWave;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            s_mn[w] = mn;
+            s_mx[w] = mx;
+            s_nan[w] = nn;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 1; k < kBlock / kWave; ++k) {
-            mn = fminf(mn, s_mn[k]);
-            mx = fmaxf(mx, s_mx[k]);
-            nn |= s_nan[k];
+            for (int j = 1; j < kBlock / kWave; ++j) {
+                mn = fminf(mn, s_mn[j]);
+                mx = fmaxf(mx, s_mx[j]);
+                nn |= s_nan[j];
+            }
+            if (mn <= mx) {  // false only when the chunk held nothing but NaN
+                atomicMin(min_enc + it.slot, enc_f32(mn));
+                atomicMax(max_enc + it.slot, enc_f32(mx));
+            }
+            if (nn) atomicOr(nan_flag + it.slot, 1u);
         }
-        if (mn <= mx) {  // false only when the chunk held nothing but NaN
-            atomicMin(min_enc + it.slot, enc_f32(mn));
-            atomicMax(max_enc + it.slot, enc_f32(mx));
-        }
-        if (nn) atomicOr(nan_flag + it.slot, 1u);
+        __syncthreads();
     }
 }
 
@@ -206,38 +251,58 @@ __device__ __forceinline__ float hist_edge(int i, float step, float first) {
     return __fadd_rn(__fmul_rn((float)i, step), first);  // no FMA contraction: numpy rounds twice
 }
 
-template <bool kExactDiv>
+// Two bin paths:
+//   kFast  (first == 0, reciprocal finite — every non-degenerate range): `inv` carries a +1e-6 relative
+//          bias (k_hist_prepare), which dominates the ~3e-7 of accumulated fp32 rounding in the estimate
+//          and in the edges, so floor(a*inv) is the true bin or the one above it, never below: ONE
+//          decrement test against edge(i) = fl32(i*step) settles it (the bias is < 0.02 bin at 16384 bins).
+//   exact  (degenerate (-0.5, 0.5) range of an all-zero tensor, or a range so small that the reciprocal
+//          overflows): numpy's own sequence — correctly rounded divide, decrement test, increment test.
+// Variant (tuning knob, DPL_HIST_VARIANT): 0 predicated ds_add; 1 unconditional ds_add with per-lane dummy
+// slots for dropped / zero values; 2 and 3 are timing ablations (no flush / no LDS atomics) with WRONG results.
+template <bool kFast, int kVariant>
 struct HistOp {
     uint32_t* lds;
     float first, last, step, inv, denom;
     int last_bin;  // bins - 1
     float fbins;
-    uint32_t zeros;
+    uint32_t nonzero;  // count of a != 0 (NaN included); exact zeros = elements - nonzero
+    uint32_t dummy;    // kVariant 1: LDS index of this lane's dummy slot
     __device__ __forceinline__ void operator()(float x) {
-        // branch-free up to the single predicated ds_add: exact zeros are counted in a register (added to
-        // their bin once per wave), out-of-range values and NaN (a <= last is false) are dropped;
-        // a >= first always holds since first <= 0 <= a.
         const float a = fabsf(x);
-        zeros += (a == 0.0f);
-        float t;
-        if (kExactDiv)
-            t = __fmul_rn(__fdiv_rn(__fsub_rn(a, first), denom), fbins);
-        else
-            t = __fmul_rn(__fsub_rn(a, first), inv);
-        int i = (int)t;  // v_cvt_i32_f32 saturates and maps NaN to 0
-        i = i > last_bin ? last_bin : i;
-        i = i < 0 ? 0 : i;
-        i -= (a < hist_edge(i, step, first)) ? 1 : 0;
-        i += (i != last_bin && a >= hist_edge(i + 1, step, first)) ? 1 : 0;
-        if (a <= last && a != 0.0f) atomicAdd(lds + i, 1u);  // ds_add_u32 (no return)
+        const bool nz = (a != 0.0f);
+        nonzero += nz;
+        int i;
+        if (kFast) {
+            i = (int)__fmul_rn(a, inv);  // v_cvt_i32_f32 saturates and maps NaN to 0
+            i = i > last_bin ? last_bin : i;
+            i -= (a < __fmul_rn((float)i, step)) ? 1 : 0;
+        } else {
+            i = (int)__fmul_rn(__fdiv_rn(__fsub_rn(a, first), denom), fbins);
+            i = i > last_bin ? last_bin : i;
+            i = i < 0 ? 0 : i;
+            i -= (a < hist_edge(i, step, first)) ? 1 : 0;
+            i += (i != last_bin && a >= hist_edge(i + 1, step, first)) ? 1 : 0;
+        }
+        // exact zeros are counted in a register and added to their bin once per wave (ReLU outputs are ~50 %
+        // zeros: they would serialise on one LDS address); out-of-range values and NaN (a <= last false) drop;
+        // a >= first always holds since first <= 0 <= a.
+        const bool keep = nz && (a <= last);
+        if (kVariant == 1) {
+            atomicAdd(lds + (keep ? (uint32_t)i : dummy), 1u);
+        } else if (kVariant == 3) {
+            asm volatile("" ::"v"(keep ? i : -1));
+        } else {
+            if (keep) atomicAdd(lds + i, 1u);  // ds_add_u32 (no return)
+        }
     }
 };
 
-template <bool kExactDiv>
+template <bool kFast, int kVariant>
 __device__ __forceinline__ void hist_body(const dpl_work_item& it, const float* const* __restrict__ segs,
                                           const dpl_hist_range& r, int bins, uint64_t* __restrict__ hist,
-                                          uint32_t* lds) {
-    HistOp<kExactDiv> op;
+                                          uint32_t* lds, uint32_t* s_nz) {
+    HistOp<kFast, kVariant> op;
     op.lds = lds;
     op.first = r.first;
     op.last = r.last;
@@ -246,12 +311,21 @@ __device__ __forceinline__ void hist_body(const dpl_work_item& it, const float* 
     op.denom = __fsub_rn(r.last, r.first);
     op.last_bin = bins - 1;
     op.fbins = (float)bins;
-    op.zeros = 0u;
+    op.nonzero = 0u;
+    op.dummy = (uint32_t)bins + (threadIdx.x & (kWave - 1));
     stream_span(segs[it.seg] + it.offset, it.count, op);
-    const uint32_t z = wave_sum(op.zeros);
-    // |0| is kept iff first <= 0 <= last, which always holds for a finite range
-    if ((threadIdx.x & (kWave - 1)) == 0 && z) atomicAdd(lds + r.zero_bin, z);
+    const uint32_t nzw = wave_sum(op.nonzero);
+    if ((threadIdx.x & (kWave - 1)) == 0) s_nz[threadIdx.x / kWave] = nzw;
     __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t nzb = 0;
+        for (int k = 0; k < kBlock / kWave; ++k) nzb += s_nz[k];
+        // |0| is kept iff first <= 0 <= last, which always holds for a finite range
+        const uint32_t z = it.count - nzb;
+        if (z) atomicAdd(lds + r.zero_bin, z);
+    }
+    __syncthreads();
+    if (kVariant == 2) return;
     uint64_t* __restrict__ out = hist + (uint64_t)it.slot * (uint64_t)bins;
     for (int b = threadIdx.x; b < bins; b += kBlock) {
         const uint32_t c = lds[b];
@@ -259,20 +333,28 @@ __device__ __forceinline__ void hist_body(const dpl_work_item& it, const float* 
     }
 }
 
+template <int kVariant>
 __global__ __launch_bounds__(kBlock) void k_abs_hist(const dpl_work_item* __restrict__ items,
+                                                      const uint32_t* __restrict__ bb,
                                                       const float* const* __restrict__ segs,
                                                       const dpl_hist_range* __restrict__ ranges, int bins,
                                                       uint64_t* __restrict__ hist) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const dpl_work_item it = items[blockIdx.x];
-    const dpl_hist_range r = ranges[it.slot];
-    if (r.status != 0u) return;  // reference raises for this tensor; host reports it
-    for (int b = threadIdx.x; b < bins; b += kBlock) lds[b] = 0u;
-    __syncthreads();
-    if (r.exact_div)
-        hist_body<true>(it, segs, r, bins, hist, lds);
-    else
-        hist_body<false>(it, segs, r, bins, hist, lds);
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];  // bins counters + kWave dummy slots + 4
+    uint32_t* s_nz = lds + bins + kWave;
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        const dpl_hist_range r = ranges[it.slot];
+        if (r.status != 0u) continue;  // reference raises for this tensor; host reports it (uniform branch)
+        for (int b = threadIdx.x; b < bins + kWave; b += kBlock) lds[b] = 0u;
+        __syncthreads();
+        if (r.exact_div)
+            hist_body<false, kVariant>(it, segs, r, bins, hist, lds, s_nz);
+        else
+            hist_body<true, kVariant>(it, segs, r, bins, hist, lds, s_nz);
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ float py_max(float a, float b) { return (b > a) ? b : a; }  // python max(a, b)
@@ -298,7 +380,9 @@ __global__ void k_hist_prepare(const float* __restrict__ gmin, const float* __re
     r.first = first;
     r.last = last;
     r.step = __fdiv_rn(delta, fb);
-    r.inv = __fdiv_rn(fb, delta);
+    // +1e-6 relative bias: see HistOp (kFast).  1.000001f = 1 + 8*2^-23 exactly representable enough:
+    // the product is rounded once more, still >= (1 + 9e-7) * bins/delta.
+    r.inv = __fmul_rn(__fdiv_rn(fb, delta), 1.000001f);
     // linspace must give strictly increasing fp32 edges, else numpy raises "Too many bins"
     if (r.status == 0u) {
         const float e1 = hist_edge(1, r.step, first);
@@ -306,7 +390,7 @@ __global__ void k_hist_prepare(const float* __restrict__ gmin, const float* __re
         const float el2 = hist_edge(bins - 2 > 0 ? bins - 2 : 0, r.step, first);
         if (!(r.step > 0.0f) || !(e1 > first) || !(last > el) || (bins > 2 && !(el > el2))) r.status = 2u;
     }
-    r.exact_div = (!(fabsf(r.inv) <= 3.402823466e+38f) || r.step < 1.0e-30f) ? 1u : 0u;
+    r.exact_div = (first != 0.0f || !(fabsf(r.inv) <= 3.402823466e+38f) || r.step < 1.0e-30f) ? 1u : 0u;
     // bin of |x| == 0
     {
         const float a = 0.0f;
@@ -394,76 +478,82 @@ struct OctavIterOp {
 
 template <bool kFirst>
 __global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __restrict__ items,
+                                                        const uint32_t* __restrict__ bb,
                                                         const float* const* __restrict__ segs,
                                                         dpl_octav_state* __restrict__ st) {
     __shared__ double s_sum[kBlock / kWave];
-    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave], s_c[kBlock / kWave];
+    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
     __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
-    const dpl_work_item it = items[blockIdx.x];
-    dpl_octav_state* me = st + it.slot;
     const int w = threadIdx.x / kWave;
     const bool lead = (threadIdx.x & (kWave - 1)) == 0;
-    const float* p = segs[it.seg] + it.offset;
-    if (kFirst) {
-        OctavFirstOp op{INFINITY, -INFINITY, 0u, 0u, 0.0};
-        stream_span(p, it.count, op);
-        const float mn = wave_min(op.mn), mx = wave_max(op.mx);
-        const uint32_t nz = wave_sum(op.nz);
-        const double sum = wave_sum(op.sum);
-        const uint32_t nn = __any(op.nan) ? 1u : 0u;
-        if (lead) {
-            s_sum[w] = sum;
-            s_a[w] = nz;
-            s_b[w] = nn;
-            s_mn[w] = mn;
-            s_mx[w] = mx;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tsum = 0.0;
-            uint32_t tnz = 0, tnn = 0;
-            float tmn = INFINITY, tmx = -INFINITY;
-            for (int k = 0; k < kBlock / kWave; ++k) {
-                tsum += s_sum[k];
-                tnz += s_a[k];
-                tnn |= s_b[k];
-                tmn = fminf(tmn, s_mn[k]);
-                tmx = fmaxf(tmx, s_mx[k]);
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        dpl_octav_state* me = st + it.slot;
+        const float* p = segs[it.seg] + it.offset;
+        if (kFirst) {
+            OctavFirstOp op{INFINITY, -INFINITY, 0u, 0u, 0.0};
+            stream_span(p, it.count, op);
+            const float mn = wave_min(op.mn), mx = wave_max(op.mx);
+            const uint32_t nz = wave_sum(op.nz);
+            const double sum = wave_sum(op.sum);
+            const uint32_t nn = __any(op.nan) ? 1u : 0u;
+            if (lead) {
+                s_sum[w] = sum;
+                s_a[w] = nz;
+                s_b[w] = nn;
+                s_mn[w] = mn;
+                s_mx[w] = mx;
             }
-            atomicAdd(&me->sum, tsum);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
-            if (tmn <= tmx) {
-                atomicMin(&me->min_enc, enc_f32(tmn));
-                atomicMax(&me->max_enc, enc_f32(tmx));
-            }
-            if (tnn) atomicOr(&me->nan_seen, 1u);
-        }
-    } else {
-        if (me->done) return;  // uniform per workgroup
-        OctavIterOp op{me->s, 0u, 0u, 0.0};
-        stream_span(p, it.count, op);
-        const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
-        const double sum = wave_sum(op.sum);
-        if (lead) {
-            s_sum[w] = sum;
-            s_a[w] = gt;
-            s_b[w] = le;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tsum = 0.0;
-            uint32_t tgt = 0, tle = 0;
-            for (int k = 0; k < kBlock / kWave; ++k) {
-                tsum += s_sum[k];
-                tgt += s_a[k];
-                tle += s_b[k];
-            }
-            if (tgt) {
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tsum = 0.0;
+                uint32_t tnz = 0, tnn = 0;
+                float tmn = INFINITY, tmx = -INFINITY;
+                for (int j = 0; j < kBlock / kWave; ++j) {
+                    tsum += s_sum[j];
+                    tnz += s_a[j];
+                    tnn |= s_b[j];
+                    tmn = fminf(tmn, s_mn[j]);
+                    tmx = fmaxf(tmx, s_mx[j]);
+                }
                 atomicAdd(&me->sum, tsum);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tgt);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+                if (tmn <= tmx) {
+                    atomicMin(&me->min_enc, enc_f32(tmn));
+                    atomicMax(&me->max_enc, enc_f32(tmx));
+                }
+                if (tnn) atomicOr(&me->nan_seen, 1u);
             }
-            if (tle) atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_le), (unsigned long long)tle);
+        } else {
+            if (me->done) continue;  // uniform per workgroup
+            OctavIterOp op{me->s, 0u, 0u, 0.0};
+            stream_span(p, it.count, op);
+            const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
+            const double sum = wave_sum(op.sum);
+            if (lead) {
+                s_sum[w] = sum;
+                s_a[w] = gt;
+                s_b[w] = le;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double tsum = 0.0;
+                uint32_t tgt = 0, tle = 0;
+                for (int j = 0; j < kBlock / kWave; ++j) {
+                    tsum += s_sum[j];
+                    tgt += s_a[j];
+                    tle += s_b[j];
+                }
+                if (tgt) {
+                    atomicAdd(&me->sum, tsum);
+                    atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tgt);
+                }
+                if (tle) atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_le), (unsigned long long)tle);
+            }
         }
+        __syncthreads();
     }
 }
 
@@ -692,11 +782,81 @@ int dpl_minmax_init(uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, i
     return 0;
 }
 
-int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
-                          uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s) {
+int64_t dpl_build_balanced_items(const dpl_span* spans, int64_t n_spans, int64_t n_blocks, dpl_work_item* out,
+                                 int64_t cap, uint32_t* block_begin) {
+    if (!spans || n_spans < 0 || n_blocks < 1) return fail_msg("dpl_build_balanced_items: bad arguments");
+    unsigned __int128 total = 0;
+    for (int64_t i = 0; i < n_spans; ++i) total += spans[i].count;
+    int64_t n = 0;
+    int64_t si = 0;
+    uint64_t lo = 0;       // offset inside span si
+    unsigned __int128 g = 0;  // global position of the cursor in the concatenated element stream
+    for (int64_t b = 0; b < n_blocks; ++b) {
+        if (block_begin) block_begin[b] = (uint32_t)n;
+        const unsigned __int128 target = (b + 1 == n_blocks) ? total : (total * (unsigned __int128)(b + 1)) / (unsigned __int128)n_blocks;
+        while (si < n_spans && g < target) {
+            const uint64_t remaining = spans[si].count - lo;
+            if (remaining == 0) {
+                ++si;
+                lo = 0;
+                continue;
+            }
+            const unsigned __int128 want = target - g;
+            uint64_t take;
+            bool span_done;
+            if (want >= remaining) {
+                take = remaining;
+                span_done = true;
+            } else {
+                take = ((uint64_t)want / 1024u) * 1024u;  // cut points stay 4 KiB-aligned inside a span
+                span_done = false;
+                if (take == 0) break;  // less than one aligned piece left for this block: next block takes it
+            }
+            uint64_t off = spans[si].offset + lo, left = take;
+            while (left) {  // a share larger than 2^32-1024 elements is emitted as several items
+                const uint64_t c = left < 0xFFFFFC00ull ? left : 0xFFFFFC00ull;
+                if (out && n < cap) {
+                    out[n].offset = off;
+                    out[n].count = (uint32_t)c;
+                    out[n].seg = spans[si].seg;
+                    out[n].slot = spans[si].slot;
+                    out[n].reserved = 0;
+                }
+                ++n;
+                off += c;
+                left -= c;
+            }
+            g += take;
+            lo += take;
+            if (span_done) {
+                ++si;
+                lo = 0;
+            } else {
+                break;
+            }
+        }
+    }
+    if (block_begin) block_begin[n_blocks] = (uint32_t)n;
+    return n;
+}
+
+// n_blocks = number of workgroups; d_block_begin (n_blocks + 1 entries) may be null, then n_blocks must equal
+// n_items and workgroup b processes item b.
+static int check_blocks(const char* who, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks) {
+    if (n_blocks <= 0 || n_blocks > 0x7FFFFFFFll || (!d_block_begin && n_blocks != n_items)) {
+        snprintf(g_err, sizeof(g_err), "%s: n_blocks must be positive and equal n_items when d_block_begin is null", who);
+        return -2;
+    }
+    return 0;
+}
+
+int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, uint32_t* d_min_enc,
+                          uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s) {
     if (n_items <= 0) return 0;
-    hipLaunchKernelGGL(k_minmax, dim3((unsigned)n_items), dim3(kBlock), 0, (hipStream_t)s, d_items, d_seg_ptrs,
-                       d_min_enc, d_max_enc, d_nan);
+    if (int e = check_blocks("dpl_minmax_accumulate", n_items, d_block_begin, n_blocks)) return e;
+    hipLaunchKernelGGL(k_minmax, dim3((unsigned)n_blocks), dim3(kBlock), 0, (hipStream_t)s, d_items, d_block_begin,
+                       d_seg_ptrs, d_min_enc, d_max_enc, d_nan);
     DPL_LAUNCH_CHECK("k_minmax");
     return 0;
 }
@@ -729,12 +889,25 @@ int dpl_hist_prepare(const float* d_min, const float* d_max, int64_t n_slots, in
     return 0;
 }
 
-int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
-                            const dpl_hist_range* d_ranges, int bins, uint64_t* d_hist, dpl_stream_t s) {
+int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                            int64_t n_blocks, const float* const* d_seg_ptrs, const dpl_hist_range* d_ranges,
+                            int bins, uint64_t* d_hist, dpl_stream_t s) {
     if (bins < 1 || bins > DPL_MAX_BINS) return fail_msg("dpl_abs_hist_accumulate: bins must be in [1, 16384]");
     if (n_items <= 0) return 0;
-    hipLaunchKernelGGL(k_abs_hist, dim3((unsigned)n_items), dim3(kBlock), (size_t)bins * sizeof(uint32_t),
-                       (hipStream_t)s, d_items, d_seg_ptrs, d_ranges, bins, d_hist);
+    if (int e = check_blocks("dpl_abs_hist_accumulate", n_items, d_block_begin, n_blocks)) return e;
+    static const int variant = getenv("DPL_HIST_VARIANT") ? atoi(getenv("DPL_HIST_VARIANT")) : 0;
+    const dim3 g((unsigned)n_blocks), b(kBlock);
+    const size_t sh = ((size_t)bins + kWave + kBlock / kWave) * sizeof(uint32_t);
+    hipStream_t st = (hipStream_t)s;
+#define DPL_HIST_LAUNCH(V) \
+    hipLaunchKernelGGL(k_abs_hist<V>, g, b, sh, st, d_items, d_block_begin, d_seg_ptrs, d_ranges, bins, d_hist)
+    switch (variant) {
+        case 1: DPL_HIST_LAUNCH(1); break;
+        case 2: DPL_HIST_LAUNCH(2); break;
+        case 3: DPL_HIST_LAUNCH(3); break;
+        default: DPL_HIST_LAUNCH(0);
+    }
+#undef DPL_HIST_LAUNCH
     DPL_LAUNCH_CHECK("k_abs_hist");
     return 0;
 }
@@ -755,17 +928,17 @@ int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s) {
     return 0;
 }
 
-int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
-                  dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym, int max_iters, dpl_stream_t s) {
+int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                  const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym,
+                  int max_iters, dpl_stream_t s) {
     if (n_items <= 0 || n_pairs <= 0) return 0;
+    if (int e = check_blocks("dpl_octav_run", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
-    const dim3 ug(grid_for(n_pairs, 256)), ub(256);
-    hipLaunchKernelGGL(k_octav_pass<true>, dim3((unsigned)n_items), dim3(kBlock), 0, st, d_items, d_seg_ptrs,
-                       d_states);
+    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock);
+    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
     hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
     for (int k = 0; k < max_iters; ++k) {
-        hipLaunchKernelGGL(k_octav_pass<false>, dim3((unsigned)n_items), dim3(kBlock), 0, st, d_items, d_seg_ptrs,
-                           d_states);
+        hipLaunchKernelGGL(k_octav_pass<false>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
         hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
     }
     DPL_LAUNCH_CHECK("k_octav");

@@ -8,6 +8,7 @@ set into work items once; `CalibAccumulators` holds the persistent device-side s
 lists (forward_net.py:204-235, 252-280, 297-340).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -39,20 +40,35 @@ def _upload_struct_array(arr, n, device):
     return host.to(device)
 
 
-def default_chunk_elems(total_elems, target_items=1792, lo=16 * 1024, hi=4 * 1024 * 1024):
-    """Work-item size: about `target_items` workgroups per launch (<= 8 resident per CU on 256 CUs, so the
-    whole grid is co-resident and finishes together), never below 64 KiB so the per-workgroup flush
-    (bins atomics) stays amortised."""
-    c = (total_elems + target_items - 1) // target_items
-    c = max(lo, min(hi, c))
-    return ((c + 1023) // 1024) * 1024
+# Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
+# faster from HBM than many small items; the histogram wants a little more latency hiding).
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 512}
+
+
+def _blocks_for(kind):
+    v = os.environ.get("DPL_BLOCKS_" + kind.upper())
+    return int(v) if v else DEFAULT_BLOCKS[kind]
+
+
+class WorkSet:
+    """Device-resident work decomposition of one launch: items (+ block_begin for the balanced form)."""
+
+    def __init__(self, items, n_items, block_begin, n_blocks):
+        self.items, self.n_items, self.block_begin, self.n_blocks = items, n_items, block_begin, n_blocks
+
+    def args(self):
+        """(d_items, n_items, d_block_begin, n_blocks) as the C ABI takes them."""
+        bb = _ptr(self.block_begin) if self.block_begin is not None else C.c_void_p(0)
+        return _ptr(self.items), self.n_items, bb, self.n_blocks
 
 
 class TensorSetPlan:
-    """Static decomposition of a tensor set into work items.
+    """Static decomposition of a tensor set into work.
 
     elems_per_image[t] = elements of tensor t for ONE image; batch = images stacked along dim 0.
-    `items` feeds the per-tensor statistics (slot = t); `pair_items` feeds OCTAV (slot = b * T + t).
+    Slots: tensor index t (per_image=False: images of a batch merge for free) or b * T + t (per image).
+    Default form: the balanced partition (dpl_build_balanced_items) with a per-kernel workgroup count.
+    chunk_elems forces the one-item-per-workgroup form (dpl_build_work_items) instead.
     """
 
     def __init__(self, elems_per_image, batch, device, chunk_elems=None):
@@ -61,23 +77,35 @@ class TensorSetPlan:
         self.T = len(self.elems)
         self.device = torch.device(device)
         self.total = sum(self.elems) * self.batch
-        self.chunk = int(chunk_elems) if chunk_elems else default_chunk_elems(self.total)
-        spans = [(t, 0, e * self.batch, t) for t, e in enumerate(self.elems)]
-        arr, self.n_items = _hip.build_work_items(spans, self.chunk)
-        self.items = _upload_struct_array(arr, self.n_items, self.device)
-        self._pair = None
+        self.chunk = int(chunk_elems) if chunk_elems else None
+        self._work = {}
         self._seg_cache = {}
 
     @property
     def n_pairs(self):
         return self.batch * self.T
 
-    def pair_items(self):
-        if self._pair is None:
-            spans = [(t, b * e, e, b * self.T + t) for b in range(self.batch) for t, e in enumerate(self.elems)]
-            arr, n = _hip.build_work_items(spans, self.chunk)
-            self._pair = (_upload_struct_array(arr, n, self.device), n)
-        return self._pair
+    def _spans(self, per_image):
+        if per_image:
+            return [(t, b * e, e, b * self.T + t) for b in range(self.batch) for t, e in enumerate(self.elems)]
+        return [(t, 0, e * self.batch, t) for t, e in enumerate(self.elems)]
+
+    def work(self, kind, per_image=False):
+        """WorkSet for kernel family `kind` in {'minmax', 'hist', 'octav'}."""
+        nb = None if self.chunk else max(1, min(_blocks_for(kind), (self.total + 4095) // 4096))
+        key = (per_image, nb)
+        w = self._work.get(key)
+        if w is None:
+            spans = self._spans(per_image)
+            if self.chunk:
+                arr, n = _hip.build_work_items(spans, self.chunk)
+                w = WorkSet(_upload_struct_array(arr, n, self.device), n, None, n)
+            else:
+                arr, n, bb = _hip.build_balanced_items(spans, nb)
+                bbt = torch.frombuffer(bytearray(bytes(bb)), dtype=torch.int32).to(self.device)
+                w = WorkSet(_upload_struct_array(arr, n, self.device), n, bbt, nb)
+            self._work[key] = w
+        return w
 
     def seg_table(self, tensors):
         """Device table of base pointers for this launch (cached per pointer tuple)."""
@@ -126,12 +154,11 @@ class CalibAccumulators:
         """per_image=False: slot = tensor (n_slots = T).  per_image=True: slot = image * T + tensor
         (n_slots = B * T), the reference's one-entry-per-image lists."""
         tab = plan.seg_table(tensors)
-        items, n_items = plan.pair_items() if per_image else (plan.items, plan.n_items)
+        w = plan.work("minmax", per_image)
         if self.n < (plan.n_pairs if per_image else plan.T):
             raise _hip.DipoorletHipError("accumulator has fewer slots than the plan addresses")
-        _hip.check(_hip.lib().dpl_minmax_accumulate(_ptr(items), n_items, _ptr(tab), _ptr(self.min_enc),
-                                                    _ptr(self.max_enc), _ptr(self.nan), _stream()),
-                   "dpl_minmax_accumulate")
+        _hip.check(_hip.lib().dpl_minmax_accumulate(*w.args(), _ptr(tab), _ptr(self.min_enc), _ptr(self.max_enc),
+                                                    _ptr(self.nan), _stream()), "dpl_minmax_accumulate")
 
     def finalize_minmax(self):
         """-> (gmin, gmax) fp32 device tensors [n_slots]."""
@@ -160,9 +187,9 @@ class CalibAccumulators:
 
     def abs_hist_accumulate(self, plan, tensors):
         tab = plan.seg_table(tensors)
-        _hip.check(_hip.lib().dpl_abs_hist_accumulate(_ptr(plan.items), plan.n_items, _ptr(tab), _ptr(self.ranges),
-                                                      self.bins, _ptr(self.hist), _stream()),
-                   "dpl_abs_hist_accumulate")
+        w = plan.work("hist")
+        _hip.check(_hip.lib().dpl_abs_hist_accumulate(*w.args(), _ptr(tab), _ptr(self.ranges), self.bins,
+                                                      _ptr(self.hist), _stream()), "dpl_abs_hist_accumulate")
 
     def range_status(self):
         """HOST (synchronises): per-slot status from dpl_hist_prepare: 0 ok, 1 not finite, 2 too many bins."""
@@ -184,14 +211,14 @@ _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 def octav_batch(plan, tensors, dynamic_sym, states=None):
     """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max)."""
-    items, n_items = plan.pair_items()
+    w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
     if states is None or states.numel() < n_pairs * C.sizeof(_hip.OctavState):
         states = torch.empty(n_pairs * C.sizeof(_hip.OctavState), dtype=torch.uint8, device=plan.device)
     tab = plan.seg_table(tensors)
     L = _hip.lib()
     _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, _stream()), "dpl_octav_init")
-    _hip.check(L.dpl_octav_run(_ptr(items), n_items, _ptr(tab), _ptr(states), n_pairs, 1 if dynamic_sym else 0,
+    _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, 1 if dynamic_sym else 0,
                                _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run")
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 1
+#define DPL_ABI_VERSION 2
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -78,12 +78,20 @@ int dpl_device_info(char* name, int name_cap, int* compute_units, uint64_t* hbm_
  * Returns the number of items (may exceed cap: call again with a larger buffer), <0 on error. */
 int64_t dpl_build_work_items(const dpl_span* spans, int64_t n_spans, uint64_t chunk_elems,
                              dpl_work_item* out, int64_t cap);
+/* HOST-only: split the concatenated element stream of `spans` into n_blocks contiguous, equal shares
+ * (cuts 4 KiB-aligned inside a span).  Writes the items in stream order and block_begin[0..n_blocks]
+ * (workgroup b owns items [block_begin[b], block_begin[b+1])).  Returns the item count (call with
+ * out = NULL to size the buffer).  Few large, equal shares stream faster from HBM than many small items. */
+int64_t dpl_build_balanced_items(const dpl_span* spans, int64_t n_spans, int64_t n_blocks, dpl_work_item* out,
+                                 int64_t cap, uint32_t* block_begin);
 
 /* ---- running min / max: replaces ort_outs[i].max()/.min() per tensor per image
  *      (forward_net.py:220-235) and np.min/np.max over the per-image lists (basic_algorithm.py:21). */
 int dpl_minmax_init(uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, int64_t n_slots, dpl_stream_t s);
-int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
-                          uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s);
+/* d_block_begin: device copy of block_begin (n_blocks + 1 entries), or NULL with n_blocks == n_items. */
+int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, uint32_t* d_min_enc,
+                          uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s);
 /* decode to fp32; a slot that saw a NaN yields NaN for both (numpy max/min propagate NaN). */
 int dpl_minmax_finalize(const uint32_t* d_min_enc, const uint32_t* d_max_enc, const uint32_t* d_nan,
                         int64_t n_slots, float* d_min, float* d_max, dpl_stream_t s);
@@ -96,8 +104,9 @@ int dpl_minmax_encode(const float* d_min, const float* d_max, int64_t n_slots, u
  *      Counts are bit-exact with numpy; d_hist is uint64 [n_slots, bins], accumulated in place. */
 int dpl_hist_prepare(const float* d_min, const float* d_max, int64_t n_slots, int bins,
                      dpl_hist_range* d_ranges, dpl_stream_t s);
-int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
-                            const dpl_hist_range* d_ranges, int bins, uint64_t* d_hist, dpl_stream_t s);
+int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                            int64_t n_blocks, const float* const* d_seg_ptrs, const dpl_hist_range* d_ranges,
+                            int bins, uint64_t* d_hist, dpl_stream_t s);
 /* ---- percentile clip: replaces the python loop of basic_algorithm.py:40-53. d_clip: fp32 [n_slots,2]. */
 int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float* d_max, int64_t n_slots,
                         int bins, double threshold, float* d_clip, dpl_stream_t s);
@@ -105,8 +114,9 @@ int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float*
 /* ---- OCTAV ("mse"): replaces forward_net.py:315-330 per (image,tensor) pair (slot = pair).
  *      dpl_octav_run enqueues the first pass plus 20 (pass, update) rounds; converged pairs exit early. */
 int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
-int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const float* const* d_seg_ptrs,
-                  dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym, int max_iters, dpl_stream_t s);
+int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                  const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym,
+                  int max_iters, dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
 

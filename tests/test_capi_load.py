@@ -54,6 +54,36 @@ def test_build_work_items_host(lib):
         _hip.build_work_items(spans, 1000)  # not a multiple of 1024
 
 
+def test_build_balanced_items_host(lib):
+    import random
+    rnd = random.Random(4)
+    for trial in range(30):
+        spans = [(i, rnd.choice([0, 16, 4096]), rnd.choice([0, 1, 1000, 2048, 25088, 401408, 802816 * 16]), 100 + i)
+                 for i in range(rnd.randint(1, 12))]
+        nb = rnd.choice([1, 2, 7, 64, 512])
+        arr, n, bb = _hip.build_balanced_items(spans, nb)
+        items = [(arr[i].seg, arr[i].offset, arr[i].count, arr[i].slot) for i in range(n)]
+        assert bb[0] == 0 and bb[nb] == n and all(bb[i] <= bb[i + 1] for i in range(nb))
+        # every element of every span exactly once, in order, slots preserved
+        for seg, off, cnt, slot in spans:
+            pos = off
+            for s_, o, c, sl in items:
+                if s_ == seg:
+                    assert o == pos and sl == slot and c > 0
+                    pos += c
+            assert pos == off + cnt
+        # shares are balanced to within one aligned piece per span boundary
+        total = sum(c for _, _, c, _ in spans)
+        share = [sum(items[k][2] for k in range(bb[b], bb[b + 1])) for b in range(nb)]
+        assert sum(share) == total
+        if total >= nb * 8192:
+            assert max(share) <= total / nb + 1024 * (len(spans) + 1)
+        # cuts inside a span are 4 KiB aligned relative to the span start
+        for s_, o, c, sl in items:
+            base = [sp for sp in spans if sp[0] == s_][0][1]
+            assert (o - base) % 1024 == 0
+
+
 def test_ops_refuse_cpu_tensors(lib):
     import torch
     from dipoorlet_amd import ops

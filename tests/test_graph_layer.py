@@ -1,0 +1,141 @@
+"""CPU: the graph layer that stands in for onnx / onnxruntime on the calibration path — wire-format
+reader/writer, ONNXGraph surface, torch executor (all node outputs, batched)."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from dipoorlet_amd import models, onnx_io
+from dipoorlet_amd.executor import GraphSession
+from dipoorlet_amd.graph import ONNXGraph
+
+
+def _torch_export(model, x, path):
+    """Real ONNX bytes from torch's C++ serializer (TorchScript exporter internals; the public entry point
+    insists on the absent `onnx` package only for a post-processing step that is a no-op here)."""
+    try:
+        from torch.onnx._internal.torchscript_exporter import onnx_proto_utils as P
+        from torch.onnx._internal.torchscript_exporter import utils as U
+    except Exception as e:  # pragma: no cover
+        pytest.skip(f"torch internal exporter unavailable: {e}")
+    P._add_onnxscript_fn = lambda proto, custom_opsets: proto
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        U._export(model, (x,), path, opset_version=13, input_names=["input"], output_names=["out"])
+
+
+class SmallCNN(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.bn = torch.nn.BatchNorm2d(8)
+        self.c2 = torch.nn.Conv2d(8, 8, 3, stride=2, padding=1, groups=2)
+        self.fc = torch.nn.Linear(8 * 8 * 8, 10)
+
+    def forward(self, x):
+        y = torch.relu(self.bn(self.c1(x)))
+        z = torch.nn.functional.max_pool2d(y, 3, 2, 1)
+        y = torch.nn.functional.avg_pool2d(torch.sigmoid(self.c2(y)), 1) + z
+        return self.fc(y.flatten(1))
+
+
+class SmallMLP(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.l1 = torch.nn.Linear(16, 32)
+        self.ln = torch.nn.LayerNorm(32)
+        self.l2 = torch.nn.Linear(32, 8)
+
+    def forward(self, x):
+        y = torch.nn.functional.gelu(self.ln(self.l1(x)))
+        return torch.softmax(self.l2(y), -1)
+
+
+@pytest.mark.parametrize("mk,shape", [(SmallCNN, (1, 3, 16, 16)), (SmallMLP, (1, 5, 16))])
+def test_reader_and_executor_on_torch_exported_onnx(tmp_path, mk, shape):
+    torch.manual_seed(0)
+    model = mk().eval()
+    for p in model.parameters():
+        p.data.normal_(0, 0.3)
+    x = torch.randn(*shape)
+    path = str(tmp_path / "m.onnx")
+    _torch_export(model, x, path)
+    g = ONNXGraph.load(path)
+    assert g.network_inputs == ["input"] and g.network_outputs == ["out"]
+    assert g.get_tensor_shape("input") == list(shape)
+    s = GraphSession(g, device="cpu")
+    assert s.tensor_names[0] == "input" and "out" in s.tensor_names
+    # single image
+    got = dict(zip(s.tensor_names, s.run({"input": x})))
+    ref = model(x)
+    assert torch.allclose(got["out"], ref, rtol=1e-4, atol=1e-5)
+    # batch of 3 stacked on dim 0 == three single runs
+    xb = torch.randn(3 * shape[0], *shape[1:])
+    gb = dict(zip(s.tensor_names, s.run({"input": xb})))
+    assert torch.allclose(gb["out"].reshape(3, -1), model(xb).reshape(3, -1), rtol=1e-4, atol=1e-5)
+    for n, e in zip(s.tensor_names, s.elems_per_image):
+        assert gb[n].shape[0] == 3 and gb[n].numel() == 3 * e and gb[n].is_contiguous()
+    # every node output is exposed, network inputs first (forward_net.py:193-198, 220-235)
+    outs = [o for n in g.graph.node for o in n.output]
+    assert s.tensor_names == ["input"] + outs
+
+
+def test_writer_roundtrip_and_reference_graph_surface(tmp_path):
+    g = models.resnet18(seed=3)
+    g.output_dir = str(tmp_path)
+    path = g.save_onnx_model("r18")
+    assert os.path.getsize(path) > 40e6
+    g2 = ONNXGraph.load(path)
+    assert [(n.op_type, n.name, n.input, n.output, n.attrs) for n in g2.graph.node] == \
+           [(n.op_type, n.name, n.input, n.output, n.attrs) for n in g.graph.node]
+    assert set(g2.initializer) == set(g.initializer)
+    assert all(np.array_equal(g2.initializer[k], v) for k, v in g.initializer.items())
+    assert g2.network_inputs == ["input"] and g2.network_outputs == ["output"]
+    conv1 = g2.graph.node[0]
+    assert g2.get_tensor_producer("input") == "INPUT_TOKEN" and g2.get_tensor_producer("conv1_out") is conv1
+    assert g2.get_tensor_consumer("output") == ["OUTPUT_TOKEN"]
+    assert [n.op_type for n in g2.get_tensor_consumer("maxpool_out")] == ["Conv", "Add"]
+    assert g2.get_initializer("conv1.weight").shape == (64, 3, 7, 7) and g2.index(conv1) == 0
+    assert g2.get_tensor_shape("conv1.weight") == [64, 3, 7, 7]
+
+
+def test_baseline_network_tensor_sets_match_survey():
+    s18 = GraphSession(models.resnet18(), device="cpu")
+    s50 = GraphSession(models.resnet50(), device="cpu")
+    assert (len(s18.tensor_names), sum(s18.elems_per_image)) == (50, 5897704)
+    assert (len(s50.tensor_names), sum(s50.elems_per_image)) == (123, 26598376)
+    from dipoorlet_amd.synthetic import resnet50_tensors
+    assert sorted(s50.elems_per_image) == sorted(e for _, e, _ in resnet50_tensors())
+
+
+def test_vit_batch_axis_normalisation():
+    s = GraphSession(models.vit(depth=1, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10), device="cpu")
+    torch.manual_seed(1)
+    x = torch.randn(3, 3, 32, 32)
+    a = s.run({"input": x})
+    b = s.run({"input": x[2:3]})
+    for n, u, v in zip(s.tensor_names, a, b):
+        assert u.shape[0] == 3 and tuple(u.shape[1:]) == tuple(v.shape[1:]) or u[2].numel() == v.numel(), n
+        assert torch.allclose(u[2].reshape(-1), v.reshape(-1), rtol=1e-4, atol=1e-5), n
+
+
+def test_wire_format_scalar_and_attr_types(tmp_path):
+    m = onnx_io.Model()
+    m.nodes = [onnx_io.Node("Foo", ["a", ""], ["b"], name="n0",
+                            attrs={"f": 1.5, "i": -3, "s": "txt", "ints": [1, -2, 3], "floats": [0.5, 2.0],
+                                   "t": np.arange(6, dtype=np.int64).reshape(2, 3), "strs": ["x", "y"]})]
+    m.initializers = {"w": np.float32(3.25).reshape(()), "h": np.arange(4, dtype=np.float16), "u": np.array([1, 255], np.uint8)}
+    m.inputs = [("a", onnx_io.FLOAT, [1, 0, 3])]
+    m.outputs = [("b", onnx_io.FLOAT, None)]
+    p = str(tmp_path / "x.onnx")
+    onnx_io.save_model(m, p)
+    r = onnx_io.load_model(p)
+    n = r.nodes[0]
+    assert (n.op_type, n.input, n.output, n.name) == ("Foo", ["a", ""], ["b"], "n0")
+    assert n.attrs["f"] == 1.5 and n.attrs["i"] == -3 and n.attrs["s"] == "txt" and n.attrs["ints"] == [1, -2, 3]
+    assert n.attrs["floats"] == [0.5, 2.0] and n.attrs["strs"] == ["x", "y"] and np.array_equal(n.attrs["t"], m.nodes[0].attrs["t"])
+    assert r.initializers["w"].shape == () and r.initializers["w"] == np.float32(3.25)
+    assert r.initializers["h"].dtype == np.float16 and r.initializers["u"].tolist() == [1, 255]
+    assert r.inputs == [("a", 1, [1, 0, 3])]

@@ -1,0 +1,112 @@
+"""`python -m dipoorlet_amd -M model.onnx -I calib_dir -N 1024 -A hist -D trt` — the reference's CLI
+(dipoorlet/__main__.py:23-161) over the MI355X calibration core.
+
+Same flags; same phases where they are in scope: load model -> tensor calibration (sharded over ranks)
+-> per-rank clip JSON -> rank-0 reduce -> load -> profiling (cosine similarity of the fake-quantised
+model, optional) -> platform deploy file.  Flags of the out-of-scope fine-tuning phases (--adaround,
+--brecq, --drop, --sparse, --we, --update_bn) are accepted and rejected with a clear message.
+Extra flags: --calib_batch, --resident_gb, --merge {allreduce,reference}, --skip_profiling.
+"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+import torch.distributed as dist
+
+from . import dist_helper
+from .deploy import to_deploy
+from .graph import ONNXGraph
+from .tensor_cali import tensor_calibration
+from .utils import load_clip_val, logger, reduce_clip_val, save_clip_val, setup_logger
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="dipoorlet_amd")
+    p.add_argument("-M", "--model", help="onnx model")
+    p.add_argument("-I", "--input_dir", help="calibration data", required=True)
+    p.add_argument("-O", "--output_dir", help="output data path")
+    p.add_argument("-N", "--data_num", help="num of calibration pics", type=int, required=True)
+    for flag in ("--we", "--bc", "--update_bn", "--adaround", "--brecq", "--drop", "--savefp", "--stpu_wg",
+                 "--skip_prof_layer", "--slurm", "--mpirun", "--sparse", "--optim_transformer"):
+        p.add_argument(flag, default=False, action="store_true")
+    p.add_argument("-A", "--act_quant", choices=["minmax", "hist", "mse"], default="mse")
+    p.add_argument("-D", "--deploy", choices=["trt", "stpu", "magicmind", "rv", "atlas", "snpe", "ti", "imx"],
+                   required=True)
+    p.add_argument("--bins", default=2048, type=int)  # the reference omits type= and crashes on a CLI value
+    p.add_argument("--threshold", default=0.99999, type=float)
+    p.add_argument("--ada_bs", type=int, default=64)
+    p.add_argument("--ada_epoch", type=int, default=5000)
+    p.add_argument("--skip_layers", default=[], type=str, nargs="+")
+    p.add_argument("--sparse_rate", type=float, default=0.5)
+    p.add_argument("--pattern", choices=["unstruction", "nv24"], default="unstruction")
+    p.add_argument("--model_type", choices=["unet"], default=None)
+    p.add_argument("--quant_format", default="QDQ", type=str, choices=["QOP", "QDQ"])
+    # MI355X-side knobs
+    p.add_argument("--calib_batch", type=int, default=16, help="calibration images per forward")
+    p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
+    p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
+    p.add_argument("--skip_profiling", default=False, action="store_true")
+    return p
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    for flag in ("we", "update_bn", "adaround", "brecq", "drop", "sparse"):
+        if getattr(args, flag):
+            sys.exit(f"--{flag} belongs to the fine-tuning phases that are out of this package's scope "
+                     "(activation calibration hot path); run it with the reference after calibration.")
+    if args.slurm:
+        dist_helper.init_from_slurm()
+    elif args.mpirun:
+        dist_helper.init_from_mpi()
+    else:
+        dist_helper.init_default()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if args.output_dir is None:
+        args.output_dir = os.path.join(os.path.abspath(os.path.dirname(args.model)), "results")
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        setup_logger(args)
+    dist.barrier()
+    start = time.time()
+    onnx_graph = ONNXGraph.load(args.model, args.output_dir, args.deploy, args.model_type)
+    args.rank, args.world_size = rank, world
+    args.local_rank = rank % max(1, __import__("torch").cuda.device_count())
+    if rank == 0:
+        logger.info("Do tensor calibration...")
+    act_clip_val, weight_clip_val = tensor_calibration(onnx_graph, args)
+    tensor_range = copy.deepcopy(act_clip_val)
+    save_clip_val(act_clip_val, weight_clip_val, args, act_fname=f"act_clip_val.json.rank{rank}",
+                  weight_fname=f"weight_clip_val.json.rank{rank}")
+    dist.barrier()
+    if rank == 0:
+        reduce_clip_val(world, args)
+    dist.barrier()
+    act_clip_val, weight_clip_val = load_clip_val(args)
+    if args.bc:
+        from .weight_transform import bias_correction
+        if rank == 0:
+            logger.info("Bias correction...")
+        onnx_graph = bias_correction(onnx_graph, act_clip_val, weight_clip_val, args)
+        dist.barrier()
+    if not args.skip_profiling:
+        from .profiling import quantize_profiling_multipass, show_model_profiling_res
+        if rank == 0:
+            logger.info("Profiling...")
+        layer_cos, model_cos, qnodes = quantize_profiling_multipass(onnx_graph, onnx_graph, act_clip_val,
+                                                                    weight_clip_val, args)
+        if rank == 0:
+            show_model_profiling_res(onnx_graph, layer_cos, model_cos, qnodes, args)
+    if rank == 0:
+        logger.info("Deploy to " + args.deploy + "...")
+        to_deploy(onnx_graph, act_clip_val, weight_clip_val, args)
+        logger.info("Total time cost: {} seconds.".format(int(time.time() - start)))
+    dist.barrier()
+    _ = tensor_range
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -62,6 +62,7 @@ SIGNATURES = {
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
+    "dpl_cos_items_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),
 }
 
 _lib = None

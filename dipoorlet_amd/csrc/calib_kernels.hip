@@ -726,6 +726,63 @@ __global__ __launch_bounds__(kBlock) void k_cos_acc(const float* __restrict__ a,
     }
 }
 
+// Per-slot cosine partial sums over work items: slot = (image, tensor) pair for the profiling flow
+// (profiling.py:57-64: one cosine per image per quantised layer output).  a and b come from two segment
+// tables with identical geometry (fp model vs fake-quantised model).
+__global__ __launch_bounds__(kBlock) void k_cos_items(const dpl_work_item* __restrict__ items,
+                                                       const uint32_t* __restrict__ bb,
+                                                       const float* const* __restrict__ segs_a,
+                                                       const float* const* __restrict__ segs_b,
+                                                       double* __restrict__ acc) {
+    __shared__ double s_r[3][kBlock / kWave];
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        gptr_f32 a = (gptr_f32)(segs_a[it.seg] + it.offset);
+        gptr_f32 b = (gptr_f32)(segs_b[it.seg] + it.offset);
+        const uint32_t n = it.count;
+        double ab = 0.0, aa = 0.0, bbs = 0.0;
+        const bool vec = ((((uintptr_t)(segs_a[it.seg] + it.offset)) | ((uintptr_t)(segs_b[it.seg] + it.offset))) & 15u) == 0;
+        uint32_t done = 0;
+        if (vec) {
+            const uint32_t nvec = n >> 2;
+            gptr_f4 av = (gptr_f4)a;
+            gptr_f4 bv = (gptr_f4)b;
+            for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) {
+                const f4 p = __builtin_nontemporal_load(av + i);
+                const f4 q = __builtin_nontemporal_load(bv + i);
+                ab += (double)p.x * q.x + (double)p.y * q.y + (double)p.z * q.z + (double)p.w * q.w;
+                aa += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z + (double)p.w * p.w;
+                bbs += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+            }
+            done = nvec << 2;
+        }
+        for (uint32_t i = done + threadIdx.x; i < n; i += kBlock) {
+            const float p = a[i], q = b[i];
+            ab += (double)p * q;
+            aa += (double)p * p;
+            bbs += (double)q * q;
+        }
+        ab = wave_sum(ab);
+        aa = wave_sum(aa);
+        bbs = wave_sum(bbs);
+        const int w = threadIdx.x / kWave;
+        if ((threadIdx.x & (kWave - 1)) == 0) {
+            s_r[0][w] = ab;
+            s_r[1][w] = aa;
+            s_r[2][w] = bbs;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            double v = 0.0;
+            for (int j = 0; j < kBlock / kWave; ++j) v += s_r[threadIdx.x][j];
+            atomicAdd(acc + 3 * (uint64_t)it.slot + threadIdx.x, v);
+        }
+        __syncthreads();
+    }
+}
+
 inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
 
 }  // namespace
@@ -990,6 +1047,17 @@ int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_
     hipLaunchKernelGGL(k_cos_acc, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_a, d_b, n,
                        d_acc + 3 * slot);
     DPL_LAUNCH_CHECK("k_cos_acc");
+    return 0;
+}
+
+int dpl_cos_items_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                             int64_t n_blocks, const float* const* d_seg_a, const float* const* d_seg_b,
+                             double* d_acc, dpl_stream_t s) {
+    if (n_items <= 0) return 0;
+    if (int e = check_blocks("dpl_cos_items_accumulate", n_items, d_block_begin, n_blocks)) return e;
+    hipLaunchKernelGGL(k_cos_items, dim3((unsigned)n_blocks), dim3(kBlock), 0, (hipStream_t)s, d_items,
+                       d_block_begin, d_seg_a, d_seg_b, d_acc);
+    DPL_LAUNCH_CHECK("k_cos_items");
     return 0;
 }
 

@@ -431,6 +431,13 @@ class GraphSession(ActivationSession):
             raise NotImplementedError(f"executor: unsupported ONNX ops {missing}")
         self.expose_fake_quant = expose_fake_quant
         self.input_names = list(graph.network_inputs)
+        # fake-quantised WEIGHTS are constants: quantise them once here instead of on every forward
+        self._folded = set()
+        for node in graph.graph.node:
+            if node.op_type == "FakeQuant" and node.input[0] in self.consts:
+                w = self.consts[node.input[0]]
+                self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, w) if w.is_cuda else w
+                self._folded.add(node.name)
         self._infer()
 
     def _infer(self):
@@ -445,7 +452,7 @@ class GraphSession(ActivationSession):
             elems.append(env[n].numel())
             self.shape1[n] = tuple(env[n].shape)
         for node in self.graph.graph.node:
-            if node.op_type == "FakeQuant" and not self.expose_fake_quant:
+            if (node.op_type == "FakeQuant" and not self.expose_fake_quant) or node.name in self._folded:
                 continue
             for o in node.output:
                 if o == "" or o in names:
@@ -466,6 +473,8 @@ class GraphSession(ActivationSession):
         env = dict(self.consts)
         env.update(feeds)
         for node in self.graph.graph.node:
+            if node.name in self._folded:
+                continue
             args = [env[i] if i != "" else None for i in node.input]
             while args and args[-1] is None:
                 args.pop()

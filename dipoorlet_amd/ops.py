@@ -294,3 +294,15 @@ def cos_accumulate(a, b, acc, slot=0):
     _hip.check(_hip.lib().dpl_cos_accumulate(_ptr(a), _ptr(b), a.numel(), _ptr(acc), slot, _stream()),
                "dpl_cos_accumulate")
     return acc
+
+
+def cos_per_image(plan, tensors_a, tensors_b):
+    """Cosine partial sums for every (image, tensor) pair of two tensor sets with the same geometry ->
+    fp64 device tensor [B, T, 3] = (sum a*b, sum a*a, sum b*b)."""
+    w = plan.work("minmax", per_image=True)
+    ta = plan.seg_table(tensors_a)
+    tb = plan.seg_table(tensors_b)
+    acc = torch.zeros(plan.batch, plan.T, 3, dtype=torch.float64, device=plan.device)
+    _hip.check(_hip.lib().dpl_cos_items_accumulate(*w.args(), _ptr(ta), _ptr(tb), _ptr(acc), _stream()),
+               "dpl_cos_items_accumulate")
+    return acc

@@ -129,3 +129,84 @@ def quant_acti(x, scale, q_min, q_max, prob=1.0):
     if prob < 1.0:
         y = torch.where(torch.rand_like(x) < prob, y, x)
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# Which tensors get fake-quantised: the reference's graph surgery (quantize.py:20-108) on this package's
+# ONNXGraph.  Each inserted pair is one fused FakeQuant node (graph.insert_qnodes_purely).
+def quant_graph(onnx_graph, clip_val, args):
+    """quantize.py:20-37 — copy the graph, fake-quantise the inputs of every node whose op type is in the
+    platform's quant_nodes (minus --skip_layers), optionally the network outputs."""
+    from .graph import ONNXGraph
+    from .platform_settings import platform_setting_table
+    graph_q = ONNXGraph()
+    graph_q.copy_from(onnx_graph)
+    skip = getattr(args, "skip_layers", []) or []
+    plat = platform_setting_table[args.deploy]
+    quant_node_list = [n for n in graph_q.graph.node if n.name not in skip and n.op_type in plat["quant_nodes"]]
+    act_quantized = []
+    for node in quant_node_list:
+        insert_fake_quant_node(graph_q, node, act_quantized, clip_val, args)
+    if plat["quantize_network_output"]:
+        insert_fake_quant_node_output(graph_q, clip_val, args)
+    graph_q.update_model()
+    return graph_q, quant_node_list
+
+
+def insert_fake_quant_node(graph, node, act_quantized, data_range_list, args):
+    """quantize.py:40-95 — per input of `node`: first initializer input of a weighted layer -> qw_params,
+    later initializers -> qb_params if the platform has them, activations -> qi_params; a ReLU-type node
+    directly behind Conv/Gemm/Eltwise/Add is left alone ("merge relu"); for TensorRT the first Conv-fed
+    branch of an Add is left alone; a tensor already quantised is only re-wired."""
+    from .platform_settings import LAYER_HAS_WEIGHT, platform_setting_table
+    param = platform_setting_table[args.deploy]
+    find_weight = False
+    trt_merge_add = False
+    for idx, in_tensor in enumerate(list(node.input)):
+        if in_tensor == "":
+            continue
+        need_transpose = False
+        shape = graph.tensor_name_shape_map.get(in_tensor)
+        if node.op_type in RELU_TYPE:
+            prev = graph.get_tensor_producer(node.input[0])
+            if isinstance(prev, str):
+                continue
+            if len(node.input) == 1 and prev.op_type in MERGE_RELU:
+                continue
+        q_nodes = None
+        if in_tensor in graph.initializer and node.op_type in LAYER_HAS_WEIGHT:
+            if not find_weight:
+                find_weight = True
+                need_transpose = node.op_type == "ConvTranspose"
+                q_nodes, _, _ = get_qnode_by_param(param["qw_params"], in_tensor, shape, data_range_list[in_tensor],
+                                                   need_transpose)
+            elif "qb_params" in param:
+                q_nodes, _, _ = get_qnode_by_param(param["qb_params"], in_tensor, shape, data_range_list[in_tensor],
+                                                   need_transpose)
+        if in_tensor in graph.network_inputs or in_tensor not in graph.input:
+            if args.deploy == "trt" and node.op_type == "Add" and not trt_merge_add:
+                prev = graph.get_tensor_producer(in_tensor)
+                if not isinstance(prev, str) and prev.op_type == "Conv":
+                    trt_merge_add = True
+                    continue
+            q_nodes, _, _ = get_qnode_by_param(param["qi_params"], in_tensor, shape, data_range_list[in_tensor])
+        if q_nodes is not None:
+            node.input[idx] = q_nodes.output
+            if in_tensor in act_quantized:
+                continue
+            graph.insert_qnodes_purely(q_nodes=q_nodes, node=node)
+            act_quantized.append(in_tensor)
+    graph.topologize_graph()
+
+
+def insert_fake_quant_node_output(graph, clip_val, args):
+    """quantize.py:98-108 — fake-quantise every network output and make `<out>_dq` the new output."""
+    from .platform_settings import platform_setting_table
+    param = platform_setting_table[args.deploy]
+    for out_tensor in list(graph.network_outputs):
+        q_nodes, _, _ = get_qnode_by_param(param["qi_params"], out_tensor, graph.tensor_name_shape_map.get(out_tensor),
+                                           clip_val[out_tensor])
+        graph.insert_qnodes_purely(q_nodes=q_nodes, idx=graph.index(graph.get_tensor_producer(out_tensor)) + 1)
+        graph.del_network_output(out_tensor)
+        graph.add_network_output(q_nodes.output)
+    graph.topologize_graph()

@@ -135,6 +135,12 @@ int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale
  *      sum(b*b) in fp64. */
 int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_acc, int64_t slot, dpl_stream_t s);
 
+/* Same sums per work-item slot (slot = (image, tensor) pair in the profiling flow, profiling.py:57-64):
+ * d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a), sum(b*b); a from d_seg_a, b from d_seg_b (same geometry). */
+int dpl_cos_items_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                             int64_t n_blocks, const float* const* d_seg_a, const float* const* d_seg_b,
+                             double* d_acc, dpl_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

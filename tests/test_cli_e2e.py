@@ -1,0 +1,160 @@
+"""GPU: the CLI end to end from a real .onnx file and a .bin calibration directory (BASELINE configs[0]
+shape: ResNet-18, minmax / hist / mse), checked against the CPU oracle applied to the very activations
+the executor produced."""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+N, BATCH, IMG = 8, 4, 64
+
+
+@pytest.fixture(scope="module")
+def workdir(tmp_path_factory):
+    from dipoorlet_amd import models
+    d = tmp_path_factory.mktemp("cli")
+    g = models.resnet18(seed=11, image=IMG)
+    g.output_dir = str(d)
+    g.save_onnx_model("model")
+    os.makedirs(d / "calib" / "input")
+    rng = np.random.default_rng(5)
+    for i in range(N):
+        rng.standard_normal(3 * IMG * IMG).astype(np.float32).tofile(d / "calib" / "input" / f"{i}.bin")
+    return d
+
+
+@pytest.fixture(scope="module")
+def activations(workdir):
+    """All calibration tensors of all images, produced with the same batch composition the CLI uses."""
+    from dipoorlet_amd.forward_net import load_input_batch
+    from dipoorlet_amd.graph import ONNXGraph
+    g = ONNXGraph.load(str(workdir / "model.onnx"))
+    s = g.make_session()
+    acts = {n: [] for n in s.tensor_names}
+    for i in range(0, N, BATCH):
+        inp = load_input_batch(str(workdir / "calib"), g.network_inputs, {"input": g.get_tensor_shape("input")}, i,
+                               i + BATCH, torch.device("cuda:0"))
+        for n, t in zip(s.tensor_names, s.run(inp)):
+            acts[n] += [x.reshape(-1) for x in t.cpu().numpy()]
+    return g, acts
+
+
+def _run(workdir, algo, deploy, extra=()):
+    """Runs the CLI in-process and records, on the host, exactly the activations its calibration forward
+    produced (convolution algorithms are not bit-reproducible from one session to the next, and a
+    percentile clip moves by a whole bin if a value crosses an edge)."""
+    from dipoorlet_amd.__main__ import main
+    from dipoorlet_amd.executor import GraphSession
+    out = workdir / f"out_{algo}_{deploy}"
+    rec = {}
+    orig = GraphSession.run
+
+    def spy(self, inputs):
+        res = orig(self, inputs)
+        for n, t in zip(self.tensor_names, res):
+            rec.setdefault(n, []).extend(x.reshape(-1) for x in t.cpu().numpy())
+        return res
+    GraphSession.run = spy
+    try:
+        rc = main(["-M", str(workdir / "model.onnx"), "-I", str(workdir / "calib"), "-N", str(N), "-A", algo, "-D",
+                   deploy, "-O", str(out), "--calib_batch", str(BATCH), *extra])
+    finally:
+        GraphSession.run = orig
+    assert rc == 0
+    assert all(len(v) == N for v in rec.values()), "one calibration forward per image expected"
+    return out, rec
+
+
+def test_cli_hist_trt(workdir, activations):
+    g, _ = activations
+    out, acts = _run(workdir, "hist", "trt")
+    act = json.load(open(out / "act_clip_val.json"))
+    wt = json.load(open(out / "weight_clip_val.json"))
+    trt = json.load(open(out / "trt_clip_val.json"))["blob_range"]
+    assert set(act) == set(acts) and len(act) == 50
+    for name, per_img in acts.items():
+        lo = min(O.minmax(x)[0] for x in per_img)
+        hi = max(O.minmax(x)[1] for x in per_img)
+        h = sum(O.abs_hist(x, 2048, O.hist_dmax(lo, hi)) for x in per_img)
+        clip = O.hist_percentile(h, lo, hi, 2048, 0.99999)
+        assert act[name] == [float(clip[0]), float(clip[1])], name
+        assert trt[name] == max(-float(clip[0]), float(clip[1]))
+    for name, arr in g.initializer.items():   # per-output-channel weight ranges (every Conv/Gemm initializer)
+        a2 = arr.reshape(arr.shape[0], -1)
+        assert wt[name][0] == a2.min(-1).tolist() and wt[name][1] == a2.max(-1).tolist()
+    assert os.path.getsize(out / "quant_model.onnx") > 1e6  # profiling ran and saved the Q/DQ model
+    from dipoorlet_amd import onnx_io
+    qm = onnx_io.load_model(str(out / "quant_model.onnx"))
+    ops_ = [n.op_type for n in qm.nodes]
+    assert ops_.count("QuantizeLinear") == ops_.count("DequantizeLinear") > 20
+    assert "conv1.weight_scale" in qm.initializers and qm.initializers["conv1.weight_zero_point"].dtype == np.int8
+
+
+def test_cli_minmax_and_mse(workdir, activations):
+    g, _ = activations
+    out, acts = _run(workdir, "minmax", "snpe", ["--skip_profiling"])
+    act = json.load(open(out / "act_clip_val.json"))
+    enc = json.load(open(out / "snpe_encodings.json"))["activation_encodings"]
+    for name, per_img in acts.items():
+        lo = min(O.minmax(x)[0] for x in per_img)
+        hi = max(O.minmax(x)[1] for x in per_img)
+        assert act[name] == [float(lo), float(hi)], name
+    assert enc["input"][0]["bitwidth"] == 8 and "output" in enc
+    out, acts = _run(workdir, "mse", "ti", ["--skip_profiling"])
+    act = json.load(open(out / "act_clip_val.json"))
+    for name, per_img in acts.items():
+        mins = [O.minmax(x)[0] for x in per_img]
+        maxs = [O.minmax(x)[1] for x in per_img]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = [O.octav_scale(x, O.octav_unsigned(mn, True)) for x, mn in zip(per_img, mins)]
+            clip = O.octav_clip(s, mins, maxs)
+        assert np.allclose(act[name], [float(clip[0]), float(clip[1])], rtol=1e-5, atol=1e-5), (name, act[name], clip)
+
+
+def test_profiling_cosine_against_numpy(workdir, activations):
+    import types
+
+    from dipoorlet_amd import dist_helper
+    from dipoorlet_amd.profiling import quantize_profiling_multipass
+    from dipoorlet_amd.quantize import quant_graph
+    from dipoorlet_amd.tensor_cali import tensor_calibration
+    from dipoorlet_amd.utils import load_clip_val, save_clip_val
+    dist_helper.init_default()
+    g, acts = activations
+    out = workdir / "prof"
+    os.makedirs(out, exist_ok=True)
+    args = types.SimpleNamespace(input_dir=str(workdir / "calib"), data_num=N, rank=0, local_rank=0, world_size=1,
+                                 bins=2048, threshold=0.99999, deploy="trt", act_quant="minmax", calib_batch=BATCH,
+                                 output_dir=str(out), skip_layers=[], savefp=False)
+    a, w = tensor_calibration(g, args)
+    save_clip_val(a, w, args)
+    a, w = load_clip_val(args)
+    layer, model, qnodes = quantize_profiling_multipass(g, g, a, w, args)
+    assert len(layer) == sum(len(n.output) for n in qnodes)
+    assert all(0.9 < v <= 1.0 + 1e-9 for v in layer.values()), min(layer.values())
+    # independent check of two layers + the output: run the quantised graph, cosine with numpy
+    clip = dict(a)
+    clip.update(w)
+    gq, _ = quant_graph(g, clip, args)
+    sq = gq.make_session()
+    from dipoorlet_amd.forward_net import load_input_batch
+    names = ["conv1_out", "layer2.0.add_out", "output"]
+    cos = {n: [] for n in names}
+    for i in range(0, N, BATCH):
+        inp = load_input_batch(args.input_dir, g.network_inputs, {"input": g.get_tensor_shape("input")}, i, i + BATCH,
+                               torch.device("cuda:0"))
+        for n, t in zip(names, sq.run_named(inp, names)):
+            for r, x in enumerate(t.cpu().numpy()):
+                cos[n].append(float(O.cos_similarity(acts[n][i + r], x.reshape(-1))))
+    # (activations are regenerated here, so agreement is to conv-algorithm noise, not to the last bit)
+    for n in names[:2]:
+        assert abs(layer[n] - np.mean(cos[n])) < 1e-4, (n, layer[n], np.mean(cos[n]))
+    assert abs(model["output"][0] - np.mean(cos["output"])) < 1e-4 and abs(model["output"][1] - np.min(cos["output"])) < 1e-4

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BINS = 16384
 
 
@@ -35,10 +35,11 @@ class HistRange(C.Structure):
 class OctavState(C.Structure):
     _fields_ = [("sum", C.c_double), ("cnt_gt", C.c_uint64), ("cnt_le", C.c_uint64), ("min_enc", C.c_uint32),
                 ("max_enc", C.c_uint32), ("nan_seen", C.c_uint32), ("done", C.c_uint32), ("s", C.c_float),
-                ("unsigned_div", C.c_float), ("iters", C.c_uint32), ("reserved", C.c_uint32)]
+                ("unsigned_div", C.c_float), ("iters", C.c_uint32), ("mode", C.c_uint32), ("n_elems", C.c_uint64),
+                ("len0", C.c_uint32), ("len1", C.c_uint32), ("cur", C.c_uint32), ("reserved", C.c_uint32)]
 
 
-assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 56
+assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 80
 
 _P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
 
@@ -56,7 +57,8 @@ SIGNATURES = {
     "dpl_hist_prepare": (C.c_int, [_P, _P, _I64, C.c_int, _P, _P]),
     "dpl_abs_hist_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, C.c_int, _P, _P]),
     "dpl_hist_percentile": (C.c_int, [_P, _P, _P, _I64, C.c_int, _DBL, _P, _P]),
-    "dpl_octav_init": (C.c_int, [_P, _I64, _P]),
+    "dpl_octav_init": (C.c_int, [_P, _I64, C.c_int, _P]),
+    "dpl_octav_run_compact": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),

@@ -520,6 +520,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __re
                 }
                 atomicAdd(&me->sum, tsum);
                 atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)it.count);
                 if (tmn <= tmx) {
                     atomicMin(&me->min_enc, enc_f32(tmn));
                     atomicMax(&me->max_enc, enc_f32(tmx));
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __re
                 if (tnn) atomicOr(&me->nan_seen, 1u);
             }
         } else {
-            if (me->done) continue;  // uniform per workgroup
+            if (me->done || me->mode == 1u) continue;  // uniform per workgroup; list-mode pairs: k_octav_compact_*
             OctavIterOp op{me->s, 0u, 0u, 0.0};
             stream_span(p, it.count, op);
             const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
@@ -573,25 +574,217 @@ __global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int 
         me->done = (s0 != s0 || max_iters <= 0) ? 1u : 0u;  // NaN is a fixed point of the iteration
     } else {
         if (me->done) return;
+        // list mode evaluates only the tail: everything not above s is below or equal (no NaN: those pairs are done)
+        const unsigned long long cnt_le = me->mode == 1u ? me->n_elems - me->cnt_gt : me->cnt_le;
         // forward_net.py:326-327 — python-float denominator, cast to float32 for the divide (NEP 50)
         const double c = 1.0 / 65536.0 / 3.0 / (double)me->unsigned_div;
-        const double denom = c * (double)(long long)me->cnt_le + (double)(long long)me->cnt_gt;
+        const double denom = c * (double)(long long)cnt_le + (double)(long long)me->cnt_gt;
         const float s1 = __fdiv_rn((float)me->sum, (float)denom);
         const float s = me->s;
         if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
             me->done = 1u;  // break: keeps the PREVIOUS iterate
         } else {
+            // the list just written holds the values above s: it cannot answer for a smaller threshold
+            if (me->mode == 1u && !(s1 >= s)) me->mode = 0u;
             me->s = s1;
             me->iters += 1u;
             if ((int)me->iters >= max_iters || s1 != s1) me->done = 1u;
         }
+        if (me->mode == 1u) me->cur = (me->cur == 2u) ? 0u : 1u - me->cur;  // the freshly written list is the next source
     }
     me->sum = 0.0;
     me->cnt_gt = 0ull;
     me->cnt_le = 0ull;
 }
 
-__global__ void k_octav_init(dpl_octav_state* st, int64_t n) {
+// ---------------------------------------------------------------- OCTAV with tail compaction
+// The iterates climb (s_{k+1} >= s_k while below the fixed point), so evaluation k only needs the values
+// above s_{k-1}.  The first evaluation reads the full data once and writes the values above s_0; each later
+// one reads the previous list and writes the next, and the lists shrink ~2.5x per step.  Exactly the same
+// iterate sequence as the full-pass form; a pair whose iterate ever decreases drops back to full passes.
+constexpr int kStageCap = 2048;  // floats of LDS staging per wave
+
+struct TailAcc {
+    uint32_t gt;
+    double sum;
+};
+
+// One wave, one 1024-element tile in registers: survivors (|x| > s) go to the wave's LDS stage.
+template <class FlushFn>
+__device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stage, uint32_t& fill, TailAcc& acc,
+                                          FlushFn&& flush) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    float a[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        a[4 * u + 0] = fabsf(v[u].x);
+        a[4 * u + 1] = fabsf(v[u].y);
+        a[4 * u + 2] = fabsf(v[u].z);
+        a[4 * u + 3] = fabsf(v[u].w);
+    }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bool g = a[j] > s;
+        cnt += g;
+        acc.sum += g ? (double)a[j] : 0.0;
+    }
+    acc.gt += cnt;
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, kWave);
+        if (lane >= (uint32_t)o) inc += t;
+    }
+    const uint32_t total = __shfl(inc, kWave - 1, kWave);
+    if (total == 0) return;
+    if (fill + total > (uint32_t)kStageCap) flush();
+    uint32_t pos = fill + inc - cnt;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (a[j] > s) stage[pos++] = a[j];
+    fill += total;
+}
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ p_generic, uint32_t base, uint32_t n, bool aligned,
+                                          f4 (&v)[4]) {
+    gptr_f32 p = (gptr_f32)p_generic;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t idx = base + u * 256 + lane * 4;
+        if (aligned && idx + 3 < n) {
+            v[u] = __builtin_nontemporal_load((gptr_f4)(p + idx));
+        } else {  // zeros never survive (s >= 0)
+            v[u].x = idx + 0 < n ? p[idx + 0] : 0.0f;
+            v[u].y = idx + 1 < n ? p[idx + 1] : 0.0f;
+            v[u].z = idx + 2 < n ? p[idx + 2] : 0.0f;
+            v[u].w = idx + 3 < n ? p[idx + 3] : 0.0f;
+        }
+    }
+}
+
+// First evaluation: full data -> list 0, several workgroups per pair (global cursor + atomics).
+__global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_item* __restrict__ items,
+                                                                const uint32_t* __restrict__ bb,
+                                                                const float* const* __restrict__ segs,
+                                                                dpl_octav_state* __restrict__ st,
+                                                                const uint64_t* __restrict__ pair_base,
+                                                                float* __restrict__ list0) {
+    extern __shared__ __attribute__((aligned(16))) float stage_all[];
+    __shared__ double s_sum[kBlock / kWave];
+    __shared__ uint32_t s_gt[kBlock / kWave];
+    const int w = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    float* stage = stage_all + w * kStageCap;
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        dpl_octav_state* me = st + it.slot;
+        if (me->done || me->mode != 1u) continue;
+        const float s = me->s;
+        const float* p = segs[it.seg] + it.offset;
+        const bool aligned = (((uintptr_t)p) & 15u) == 0;
+        float* dst = list0 + pair_base[it.slot];
+        uint32_t fill = 0;
+        TailAcc acc{0u, 0.0};
+        auto flush = [&]() {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&me->len[0], fill);
+            base = __shfl(base, 0, kWave);
+            for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
+            fill = 0;
+        };
+        for (uint32_t tile = w * 1024; tile < it.count; tile += kBlock * 16) {
+            f4 v[4];
+            load_tile(p, tile, it.count, aligned, v);
+            tail_tile(v, s, stage, fill, acc, flush);
+        }
+        if (fill) flush();
+        const uint32_t gt = wave_sum(acc.gt);
+        const double sum = wave_sum(acc.sum);
+        if (lane == 0) {
+            s_gt[w] = gt;
+            s_sum[w] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tg = 0;
+            double ts = 0.0;
+            for (int j = 0; j < kBlock / kWave; ++j) {
+                tg += s_gt[j];
+                ts += s_sum[j];
+            }
+            if (tg) {
+                atomicAdd(&me->sum, ts);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tg);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Later evaluations: list[cur] -> list[1 - cur], one workgroup per pair (lists are short), LDS cursor.
+__global__ __launch_bounds__(kBlock) void k_octav_compact_list(dpl_octav_state* __restrict__ st, int64_t n_pairs,
+                                                                const uint64_t* __restrict__ pair_base,
+                                                                float* __restrict__ list0, float* __restrict__ list1) {
+    extern __shared__ __attribute__((aligned(16))) float stage_all[];
+    __shared__ double s_sum[kBlock / kWave];
+    __shared__ uint32_t s_gt[kBlock / kWave];
+    __shared__ uint32_t s_cursor;
+    const int w = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    float* stage = stage_all + w * kStageCap;
+    for (int64_t pr = blockIdx.x; pr < n_pairs; pr += gridDim.x) {
+        dpl_octav_state* me = st + pr;
+        if (me->done || me->mode != 1u || me->cur > 1u) continue;  // uniform per workgroup
+        const uint32_t cur = me->cur;
+        const uint32_t n = me->len[cur];
+        const float s = me->s;
+        const float* src = (cur == 0 ? list0 : list1) + pair_base[pr];
+        float* dst = (cur == 0 ? list1 : list0) + pair_base[pr];
+        if (threadIdx.x == 0) s_cursor = 0u;
+        __syncthreads();
+        uint32_t fill = 0;
+        TailAcc acc{0u, 0.0};
+        auto flush = [&]() {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&s_cursor, fill);
+            base = __shfl(base, 0, kWave);
+            for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
+            fill = 0;
+        };
+        const bool aligned = (((uintptr_t)src) & 15u) == 0;
+        for (uint32_t tile = w * 1024; tile < n; tile += kBlock * 16) {
+            f4 v[4];
+            load_tile(src, tile, n, aligned, v);
+            tail_tile(v, s, stage, fill, acc, flush);
+        }
+        if (fill) flush();
+        const uint32_t gt = wave_sum(acc.gt);
+        const double sum = wave_sum(acc.sum);
+        if (lane == 0) {
+            s_gt[w] = gt;
+            s_sum[w] = sum;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tg = 0;
+            double ts = 0.0;
+            for (int j = 0; j < kBlock / kWave; ++j) {
+                tg += s_gt[j];
+                ts += s_sum[j];
+            }
+            me->sum = ts;
+            me->cnt_gt = tg;
+            me->len[1u - cur] = s_cursor;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void k_octav_init(dpl_octav_state* st, int64_t n, uint32_t mode) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     dpl_octav_state z;
@@ -605,6 +798,11 @@ __global__ void k_octav_init(dpl_octav_state* st, int64_t n) {
     z.s = 0.0f;
     z.unsigned_div = 1.0f;
     z.iters = 0u;
+    z.mode = mode;
+    z.n_elems = 0ull;
+    z.len[0] = 0u;
+    z.len[1] = 0u;
+    z.cur = 2u;
     z.reserved = 0u;
     st[i] = z;
 }
@@ -978,9 +1176,10 @@ int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float*
     return 0;
 }
 
-int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s) {
+int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, int list_mode, dpl_stream_t s) {
     if (n_pairs <= 0) return 0;
-    hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs);
+    hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs,
+                       list_mode ? 1u : 0u);
     DPL_LAUNCH_CHECK("k_octav_init");
     return 0;
 }
@@ -999,6 +1198,32 @@ int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t*
         hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
     }
     DPL_LAUNCH_CHECK("k_octav");
+    return 0;
+}
+
+int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                          int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, float* d_list1,
+                          int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_items <= 0 || n_pairs <= 0) return 0;
+    if (int e = check_blocks("dpl_octav_run_compact", n_items, d_block_begin, n_blocks)) return e;
+    hipStream_t st = (hipStream_t)s;
+    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock);
+    const dim3 lg((unsigned)(n_pairs < 2048 ? n_pairs : 2048));
+    const size_t sh = (size_t)(kBlock / kWave) * kStageCap * sizeof(float);
+    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
+    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+    for (int k = 0; k < max_iters; ++k) {
+        if (k == 0)
+            hipLaunchKernelGGL(k_octav_compact_full, pg, pb, sh, st, d_items, d_block_begin, d_seg_ptrs, d_states,
+                               d_pair_base, d_list0);
+        else
+            hipLaunchKernelGGL(k_octav_compact_list, lg, pb, sh, st, d_states, n_pairs, d_pair_base, d_list0, d_list1);
+        // pairs that left list mode (a decreasing iterate) are evaluated on the full data
+        hipLaunchKernelGGL(k_octav_pass<false>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
+        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+    }
+    DPL_LAUNCH_CHECK("k_octav_compact");
     return 0;
 }
 

@@ -107,6 +107,19 @@ class TensorSetPlan:
             self._work[key] = w
         return w
 
+    def octav_scratch(self):
+        """(pair_base u64 [B*T], list0, list1): two tail lists of the batch's size, pair regions laid out in
+        pair order (4-element aligned so list reads can use 16-byte loads)."""
+        if getattr(self, "_octav_scratch", None) is None:
+            sizes = [((e + 3) // 4) * 4 for _ in range(self.batch) for e in self.elems]
+            base = np.zeros(len(sizes), np.int64)
+            base[1:] = np.cumsum(sizes)[:-1]
+            tot = int(sum(sizes))
+            self._octav_scratch = (torch.from_numpy(base).to(self.device),
+                                   torch.empty(tot, dtype=torch.float32, device=self.device),
+                                   torch.empty(tot, dtype=torch.float32, device=self.device))
+        return self._octav_scratch
+
     def seg_table(self, tensors):
         """Device table of base pointers for this launch (cached per pointer tuple)."""
         if len(tensors) != self.T:
@@ -209,17 +222,29 @@ class CalibAccumulators:
 _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 
-def octav_batch(plan, tensors, dynamic_sym, states=None):
-    """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max)."""
+def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None):
+    """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max).
+
+    compact=True (default unless DPL_OCTAV_COMPACT=0): tail-compaction form — two scratch lists of the batch's
+    size live in the plan; compact=False: every evaluation re-reads the full data."""
+    if compact is None:
+        compact = os.environ.get("DPL_OCTAV_COMPACT", "1") != "0"
     w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
-    if states is None or states.numel() < n_pairs * C.sizeof(_hip.OctavState):
-        states = torch.empty(n_pairs * C.sizeof(_hip.OctavState), dtype=torch.uint8, device=plan.device)
+    nbytes = n_pairs * C.sizeof(_hip.OctavState)
+    if states is None or states.numel() < nbytes:
+        states = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
     tab = plan.seg_table(tensors)
     L = _hip.lib()
-    _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, _stream()), "dpl_octav_init")
-    _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, 1 if dynamic_sym else 0,
-                               _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run")
+    _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, 1 if compact else 0, _stream()), "dpl_octav_init")
+    if compact:
+        base, l0, l1 = plan.octav_scratch()
+        _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(base), _ptr(l0), _ptr(l1),
+                                           1 if dynamic_sym else 0, _OCTAV_MAX_ITERS, _stream()),
+                   "dpl_octav_run_compact")
+    else:
+        _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, 1 if dynamic_sym else 0,
+                                   _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run")
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
     return out

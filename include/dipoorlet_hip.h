@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 2
+#define DPL_ABI_VERSION 3
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -66,6 +66,10 @@ typedef struct dpl_octav_state {
     float s;
     float unsigned_div; /* 1 or 4 */
     uint32_t iters;
+    uint32_t mode;      /* 0: every evaluation re-reads the full data; 1: tail lists (dpl_octav_run_compact) */
+    uint64_t n_elems;   /* elements of the pair (counted by the first pass) */
+    uint32_t len[2];    /* lengths of the two tail lists */
+    uint32_t cur;       /* list holding the values above the previous iterate: 0, 1, or 2 = none yet */
     uint32_t reserved;
 } dpl_octav_state;
 
@@ -113,10 +117,18 @@ int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float*
 
 /* ---- OCTAV ("mse"): replaces forward_net.py:315-330 per (image,tensor) pair (slot = pair).
  *      dpl_octav_run enqueues the first pass plus 20 (pass, update) rounds; converged pairs exit early. */
-int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
+int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, int list_mode, dpl_stream_t s);
 int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
                   const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym,
                   int max_iters, dpl_stream_t s);
+/* Same iterate sequence with tail compaction (init with list_mode = 1): the first evaluation reads the data
+ * once and writes the values above s_0 to d_list0; every later one reads the previous tail list and writes
+ * the next (they shrink ~2.5x per step).  d_pair_base[pair] = element offset of the pair's region in both
+ * lists (regions must hold the pair's element count).  Pairs whose iterate decreases fall back to full passes. */
+int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                          int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, float* d_list1,
+                          int dynamic_sym, int max_iters, dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
 

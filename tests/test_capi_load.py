@@ -33,7 +33,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_hip.Span) == 24
     assert C.sizeof(_hip.WorkItem) == 24
     assert C.sizeof(_hip.HistRange) == 32
-    assert C.sizeof(_hip.OctavState) == 56
+    assert C.sizeof(_hip.OctavState) == 80
 
 
 def test_build_work_items_host(lib):

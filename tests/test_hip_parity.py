@@ -114,7 +114,9 @@ def test_hist_prepare_flags_bad_ranges(dev):
     assert acc.range_status()["status"][0] == 2
 
 
-def test_octav_golden(dev, kl):
+@pytest.mark.parametrize("compact", [True, False])
+def test_octav_golden(dev, kl, compact):
+    """Both forms: tail compaction (default) and full re-reads; same iterate sequence, same answers."""
     from dipoorlet_amd import ops
     meta, g = kl
     for c in meta["cases"]:
@@ -122,9 +124,39 @@ def test_octav_golden(dev, kl):
         plan = ops.TensorSetPlan([c["n"]], 1, dev)
         for deploy, dyn in (("trt", False), ("ti", True)):
             ref = g[f"{c['key']}/octav_{deploy}"]
-            got = ops.octav_batch(plan, [x], dyn).cpu().numpy()[0, 0]
-            assert _close(got[0], ref[0]), (c["key"], deploy, got, ref)
+            got = ops.octav_batch(plan, [x], dyn, compact=compact).cpu().numpy()[0, 0]
+            assert _close(got[0], ref[0]), (c["key"], deploy, compact, got, ref)
             assert np.array_equal(got[1:], ref[1:], equal_nan=True), (c["key"], got, ref)
+
+
+def test_octav_non_monotone_pairs_fall_back_to_full_passes(dev):
+    """Degenerate tensors whose iterates oscillate (all non-zeros equal; two-level values) leave list mode;
+    batched with ordinary tensors and odd, unaligned sizes."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(8)
+    B = 3
+    sizes = [4099, 70001, 1000, 33]
+    tensors = []
+    for t, n in enumerate(sizes):
+        rows = []
+        for b in range(B):
+            if t == 0:
+                x = np.where(rng.random(n) < 0.5, np.float32(2.0), np.float32(0.0)).astype(np.float32)
+            elif t == 2:
+                x = np.where(rng.random(n) < 0.9, np.float32(0.5), np.float32(-7.0)).astype(np.float32)
+            else:
+                x = make_tensor("relu" if b % 2 else "normal", n, 31 * t + b)
+            rows.append(x)
+        tensors.append(torch.from_numpy(np.stack(rows)).to(dev))
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    a = ops.octav_batch(plan, tensors, False, compact=True).cpu().numpy()
+    f = ops.octav_batch(plan, tensors, False, compact=False).cpu().numpy()
+    for t in range(len(sizes)):
+        for b in range(B):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
+            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s), (t, b, a[b, t], f[b, t], s)
 
 
 def test_batched_tensor_set_vs_golden_pipeline_stats(dev, golden_dir):

@@ -145,7 +145,7 @@ def main():
 
     if a.algo == "mse":
         import ctypes
-        states = torch.empty(plan.n_pairs * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
+        states = torch.empty((plan.n_pairs + 1) * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
     for i in range(a.warmup):
         step(i, False)
     torch.cuda.synchronize()

@@ -480,7 +480,10 @@ template <bool kFirst>
 __global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __restrict__ items,
                                                         const uint32_t* __restrict__ bb,
                                                         const float* const* __restrict__ segs,
-                                                        dpl_octav_state* __restrict__ st) {
+                                                        dpl_octav_state* __restrict__ st,
+                                                        const dpl_octav_state* __restrict__ ctl) {
+    // ctl (the extra state slot behind the pairs) counts the pairs in full-pass mode: nothing to do when 0
+    if (!kFirst && ctl && ctl->cnt_gt == 0ull) return;
     __shared__ double s_sum[kBlock / kWave];
     __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
     __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
@@ -558,8 +561,32 @@ __global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __re
     }
 }
 
+// One fixed-point step (forward_net.py:326-330): s' = fl32(sum) / fl32(c/unsigned * cnt_le + cnt_gt) — the python-float
+// denominator is cast to float32 for the divide (NEP 50); |s' - s| < 1e-6 stops KEEPING the previous s.
+struct OctavStep {
+    float s;
+    uint32_t iters, done, decreased;
+};
+__device__ __forceinline__ OctavStep octav_step(double sum, unsigned long long cnt_gt, unsigned long long cnt_le,
+                                                float unsigned_div, float s, uint32_t iters, int max_iters) {
+    const double c = 1.0 / 65536.0 / 3.0 / (double)unsigned_div;
+    const double denom = c * (double)(long long)cnt_le + (double)(long long)cnt_gt;
+    const float s1 = __fdiv_rn((float)sum, (float)denom);
+    OctavStep r{s, iters, 0u, 0u};
+    if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
+        r.done = 1u;
+    } else {
+        r.decreased = !(s1 >= s) ? 1u : 0u;
+        r.s = s1;
+        r.iters = iters + 1u;
+        if ((int)r.iters >= max_iters || s1 != s1) r.done = 1u;
+    }
+    return r;
+}
+
 template <bool kFirst>
-__global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int dynamic_sym, int max_iters) {
+__global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int dynamic_sym, int max_iters,
+                               dpl_octav_state* __restrict__ ctl) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     dpl_octav_state* me = st + i;
@@ -576,21 +603,19 @@ __global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int 
         if (me->done) return;
         // list mode evaluates only the tail: everything not above s is below or equal (no NaN: those pairs are done)
         const unsigned long long cnt_le = me->mode == 1u ? me->n_elems - me->cnt_gt : me->cnt_le;
-        // forward_net.py:326-327 — python-float denominator, cast to float32 for the divide (NEP 50)
-        const double c = 1.0 / 65536.0 / 3.0 / (double)me->unsigned_div;
-        const double denom = c * (double)(long long)cnt_le + (double)(long long)me->cnt_gt;
-        const float s1 = __fdiv_rn((float)me->sum, (float)denom);
-        const float s = me->s;
-        if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
-            me->done = 1u;  // break: keeps the PREVIOUS iterate
-        } else {
-            // the list just written holds the values above s: it cannot answer for a smaller threshold
-            if (me->mode == 1u && !(s1 >= s)) me->mode = 0u;
-            me->s = s1;
-            me->iters += 1u;
-            if ((int)me->iters >= max_iters || s1 != s1) me->done = 1u;
+        const OctavStep r = octav_step(me->sum, me->cnt_gt, cnt_le, me->unsigned_div, me->s, me->iters, max_iters);
+        me->s = r.s;
+        me->iters = r.iters;
+        me->done = r.done;
+        // the list just written holds the values above the old s: it cannot answer for a smaller threshold
+        if (me->mode == 1u && r.decreased && !r.done) {
+            me->mode = 0u;
+            if (ctl) atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_gt), 1ull);
         }
-        if (me->mode == 1u) me->cur = (me->cur == 2u) ? 0u : 1u - me->cur;  // the freshly written list is the next source
+        if (me->mode == 1u) {
+            me->cur = (me->cur == 2u) ? 0u : 1u - me->cur;  // the freshly written list is the next source
+            me->len[1u - me->cur] = 0u;                       // ... and the other one the next destination
+        }
     }
     me->sum = 0.0;
     me->cnt_gt = 0ull;
@@ -610,7 +635,7 @@ struct TailAcc {
 };
 
 // One wave, one 1024-element tile in registers: survivors (|x| > s) go to the wave's LDS stage.
-template <class FlushFn>
+template <int kCap = kStageCap, class FlushFn>
 __device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stage, uint32_t& fill, TailAcc& acc,
                                           FlushFn&& flush) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
@@ -638,7 +663,7 @@ __device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stag
     }
     const uint32_t total = __shfl(inc, kWave - 1, kWave);
     if (total == 0) return;
-    if (fill + total > (uint32_t)kStageCap) flush();
+    if (fill + total > (uint32_t)kCap) flush();
     uint32_t pos = fill + inc - cnt;
 #pragma unroll
     for (int j = 0; j < 16; ++j)
@@ -696,10 +721,29 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
             for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
             fill = 0;
         };
-        for (uint32_t tile = w * 1024; tile < it.count; tile += kBlock * 16) {
-            f4 v[4];
-            load_tile(p, tile, it.count, aligned, v);
-            tail_tile(v, s, stage, fill, acc, flush);
+        // two register sets: the next tile is in flight while the current one is compacted
+        uint32_t tile = w * 1024;
+        if (tile < it.count) {
+            f4 va[4], vb[4];
+            load_tile(p, tile, it.count, aligned, va);
+            for (;;) {
+                uint32_t nxt = tile + kBlock * 16;
+                if (nxt >= it.count) {
+                    tail_tile(va, s, stage, fill, acc, flush);
+                    break;
+                }
+                load_tile(p, nxt, it.count, aligned, vb);
+                tail_tile(va, s, stage, fill, acc, flush);
+                tile = nxt;
+                nxt = tile + kBlock * 16;
+                if (nxt >= it.count) {
+                    tail_tile(vb, s, stage, fill, acc, flush);
+                    break;
+                }
+                load_tile(p, nxt, it.count, aligned, va);
+                tail_tile(vb, s, stage, fill, acc, flush);
+                tile = nxt;
+            }
         }
         if (fill) flush();
         const uint32_t gt = wave_sum(acc.gt);
@@ -725,41 +769,71 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
     }
 }
 
-// Later evaluations: list[cur] -> list[1 - cur], one workgroup per pair (lists are short), LDS cursor.
-__global__ __launch_bounds__(kBlock) void k_octav_compact_list(dpl_octav_state* __restrict__ st, int64_t n_pairs,
-                                                                const uint64_t* __restrict__ pair_base,
-                                                                float* __restrict__ list0, float* __restrict__ list1) {
+// Later evaluations: ONE persistent workgroup per pair walks the remaining iterations by itself — evaluate
+// at s over list[cur], compact the survivors into list[1 - cur], take the fixed-point step, swap — with no
+// kernel boundary in between (the lists shrink ~2.5x per step and stay in this XCD's L2).
+constexpr int kIterBlock = 1024;     // 16 waves: a single workgroup must pull a ~1 MB first list quickly
+constexpr int kIterStageCap = 1024;  // floats of LDS staging per wave (one full tile)
+
+__global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_state* __restrict__ st,
+                                                                     dpl_octav_state* __restrict__ ctl,
+                                                                     const uint64_t* __restrict__ pair_base,
+                                                                     float* __restrict__ list0,
+                                                                     float* __restrict__ list1, int max_iters) {
     extern __shared__ __attribute__((aligned(16))) float stage_all[];
-    __shared__ double s_sum[kBlock / kWave];
-    __shared__ uint32_t s_gt[kBlock / kWave];
+    constexpr int kWaves = kIterBlock / kWave;
+    __shared__ double s_sum[kWaves];
+    __shared__ uint32_t s_gt[kWaves];
     __shared__ uint32_t s_cursor;
+    __shared__ OctavStep s_step;
+    dpl_octav_state* me = st + blockIdx.x;
+    if (me->done || me->mode != 1u || me->cur > 1u) return;  // uniform per workgroup
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* stage = stage_all + w * kStageCap;
-    for (int64_t pr = blockIdx.x; pr < n_pairs; pr += gridDim.x) {
-        dpl_octav_state* me = st + pr;
-        if (me->done || me->mode != 1u || me->cur > 1u) continue;  // uniform per workgroup
-        const uint32_t cur = me->cur;
-        const uint32_t n = me->len[cur];
-        const float s = me->s;
-        const float* src = (cur == 0 ? list0 : list1) + pair_base[pr];
-        float* dst = (cur == 0 ? list1 : list0) + pair_base[pr];
+    float* stage = stage_all + w * kIterStageCap;
+    const uint64_t base_off = pair_base[blockIdx.x];
+    const unsigned long long n_elems = me->n_elems;
+    const float unsigned_div = me->unsigned_div;
+    float s = me->s;
+    uint32_t iters = me->iters, cur = me->cur, n = me->len[cur];
+    uint32_t done = 0u, decreased = 0u;
+    while (!done && !decreased) {
+        const float* src = (cur == 0 ? list0 : list1) + base_off;
+        float* dst = (cur == 0 ? list1 : list0) + base_off;
         if (threadIdx.x == 0) s_cursor = 0u;
         __syncthreads();
         uint32_t fill = 0;
         TailAcc acc{0u, 0.0};
         auto flush = [&]() {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&s_cursor, fill);
-            base = __shfl(base, 0, kWave);
-            for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
+            uint32_t b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&s_cursor, fill);
+            b0 = __shfl(b0, 0, kWave);
+            for (uint32_t j = lane; j < fill; j += kWave) dst[b0 + j] = stage[j];
             fill = 0;
         };
         const bool aligned = (((uintptr_t)src) & 15u) == 0;
-        for (uint32_t tile = w * 1024; tile < n; tile += kBlock * 16) {
-            f4 v[4];
-            load_tile(src, tile, n, aligned, v);
-            tail_tile(v, s, stage, fill, acc, flush);
+        uint32_t tile = w * 1024;
+        if (tile < n) {
+            f4 va[4], vb[4];
+            load_tile(src, tile, n, aligned, va);
+            for (;;) {
+                uint32_t nxt = tile + kIterBlock * 16;
+                if (nxt >= n) {
+                    tail_tile<kIterStageCap>(va, s, stage, fill, acc, flush);
+                    break;
+                }
+                load_tile(src, nxt, n, aligned, vb);
+                tail_tile<kIterStageCap>(va, s, stage, fill, acc, flush);
+                tile = nxt;
+                nxt = tile + kIterBlock * 16;
+                if (nxt >= n) {
+                    tail_tile<kIterStageCap>(vb, s, stage, fill, acc, flush);
+                    break;
+                }
+                load_tile(src, nxt, n, aligned, va);
+                tail_tile<kIterStageCap>(vb, s, stage, fill, acc, flush);
+                tile = nxt;
+            }
         }
         if (fill) flush();
         const uint32_t gt = wave_sum(acc.gt);
@@ -768,25 +842,101 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_list(dpl_octav_state* 
             s_gt[w] = gt;
             s_sum[w] = sum;
         }
-        __syncthreads();
+        __syncthreads();  // also orders every wave's dst stores before the next round reads them
         if (threadIdx.x == 0) {
-            uint32_t tg = 0;
+            unsigned long long tg = 0;
             double ts = 0.0;
-            for (int j = 0; j < kBlock / kWave; ++j) {
+            for (int j = 0; j < kWaves; ++j) {
                 tg += s_gt[j];
                 ts += s_sum[j];
             }
-            me->sum = ts;
-            me->cnt_gt = tg;
-            me->len[1u - cur] = s_cursor;
+            s_step = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const OctavStep r = s_step;
+        n = s_cursor;
+        s = r.s;
+        iters = r.iters;
+        done = r.done;
+        decreased = r.decreased;
+        cur = 1u - cur;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        me->s = s;
+        me->iters = iters;
+        me->done = done;
+        me->cur = cur;
+        me->len[cur] = n;
+        me->len[1u - cur] = 0u;
+        me->sum = 0.0;
+        me->cnt_gt = 0ull;
+        me->cnt_le = 0ull;
+        if (!done && decreased) {  // the iterate went down: the tail list cannot answer; finish on the full data
+            me->mode = 0u;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_gt), 1ull);
+        }
+    }
+}
+
+// Fallback for the (degenerate) pairs that left list mode: one workgroup per pair finishes the iteration on
+// the pair's full data.  Returns at once when the control block counts no such pair.
+__global__ __launch_bounds__(kBlock) void k_octav_iterate_full(dpl_octav_state* __restrict__ st,
+                                                                const dpl_octav_state* __restrict__ ctl,
+                                                                const dpl_span* __restrict__ pair_spans,
+                                                                const float* const* __restrict__ segs, int max_iters) {
+    if (ctl->cnt_gt == 0ull) return;
+    __shared__ double s_sum[kBlock / kWave];
+    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
+    __shared__ OctavStep s_step;
+    dpl_octav_state* me = st + blockIdx.x;
+    if (me->done || me->mode != 0u) return;
+    const dpl_span sp = pair_spans[blockIdx.x];
+    const float* p = segs[sp.seg] + sp.offset;
+    const int w = threadIdx.x / kWave;
+    const bool lead = (threadIdx.x & (kWave - 1)) == 0;
+    float s = me->s;
+    uint32_t iters = me->iters, done = 0u;
+    const float unsigned_div = me->unsigned_div;
+    while (!done) {
+        OctavIterOp op{s, 0u, 0u, 0.0};
+        stream_span(p, (uint32_t)sp.count, op);
+        const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
+        const double sum = wave_sum(op.sum);
+        if (lead) {
+            s_sum[w] = sum;
+            s_a[w] = gt;
+            s_b[w] = le;
         }
         __syncthreads();
+        if (threadIdx.x == 0) {
+            double ts = 0.0;
+            unsigned long long tg = 0, tl = 0;
+            for (int j = 0; j < kBlock / kWave; ++j) {
+                ts += s_sum[j];
+                tg += s_a[j];
+                tl += s_b[j];
+            }
+            s_step = octav_step(ts, tg, tl, unsigned_div, s, iters, max_iters);
+        }
+        __syncthreads();
+        const OctavStep r = s_step;
+        s = r.s;
+        iters = r.iters;
+        done = r.done;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        me->s = s;
+        me->iters = iters;
+        me->done = 1u;
     }
 }
 
 __global__ void k_octav_init(dpl_octav_state* st, int64_t n, uint32_t mode) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i > n) return;  // slot n is the control block
     dpl_octav_state z;
     z.sum = 0.0;
     z.cnt_gt = 0;
@@ -804,6 +954,7 @@ __global__ void k_octav_init(dpl_octav_state* st, int64_t n, uint32_t mode) {
     z.len[1] = 0u;
     z.cur = 2u;
     z.reserved = 0u;
+    if (i == n) z.cnt_gt = mode ? 0ull : (unsigned long long)n;  // control block: pairs in full-pass mode
     st[i] = z;
 }
 
@@ -1178,8 +1329,8 @@ int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float*
 
 int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, int list_mode, dpl_stream_t s) {
     if (n_pairs <= 0) return 0;
-    hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs,
-                       list_mode ? 1u : 0u);
+    hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs + 1, 256)), dim3(256), 0, (hipStream_t)s, d_states,
+                       n_pairs, list_mode ? 1u : 0u);
     DPL_LAUNCH_CHECK("k_octav_init");
     return 0;
 }
@@ -1191,11 +1342,12 @@ int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t*
     if (int e = check_blocks("dpl_octav_run", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
     const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock);
-    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
-    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+    dpl_octav_state* ctl = d_states + n_pairs;
+    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states, ctl);
+    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
     for (int k = 0; k < max_iters; ++k) {
-        hipLaunchKernelGGL(k_octav_pass<false>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
-        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+        hipLaunchKernelGGL(k_octav_pass<false>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states, ctl);
+        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
     }
     DPL_LAUNCH_CHECK("k_octav");
     return 0;
@@ -1203,25 +1355,26 @@ int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t*
 
 int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
                           int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
-                          int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, float* d_list1,
-                          int dynamic_sym, int max_iters, dpl_stream_t s) {
+                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
     if (n_items <= 0 || n_pairs <= 0) return 0;
     if (int e = check_blocks("dpl_octav_run_compact", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
     const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock);
-    const dim3 lg((unsigned)(n_pairs < 2048 ? n_pairs : 2048));
-    const size_t sh = (size_t)(kBlock / kWave) * kStageCap * sizeof(float);
-    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
-    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
-    for (int k = 0; k < max_iters; ++k) {
-        if (k == 0)
-            hipLaunchKernelGGL(k_octav_compact_full, pg, pb, sh, st, d_items, d_block_begin, d_seg_ptrs, d_states,
-                               d_pair_base, d_list0);
-        else
-            hipLaunchKernelGGL(k_octav_compact_list, lg, pb, sh, st, d_states, n_pairs, d_pair_base, d_list0, d_list1);
-        // pairs that left list mode (a decreasing iterate) are evaluated on the full data
-        hipLaunchKernelGGL(k_octav_pass<false>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states);
-        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters);
+    dpl_octav_state* ctl = d_states + n_pairs;
+    // 1. statistics + s_0             2. evaluate at s_0 over the full data, keep the values above s_0
+    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states, ctl);
+    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
+    if (max_iters > 0) {
+        hipLaunchKernelGGL(k_octav_compact_full, pg, pb, (size_t)(kBlock / kWave) * kStageCap * sizeof(float), st,
+                           d_items, d_block_begin, d_seg_ptrs, d_states, d_pair_base, d_list0);
+        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
+        // 3. every remaining iteration of every pair inside one launch    4. degenerate pairs on the full data
+        hipLaunchKernelGGL(k_octav_iterate_lists, dim3((unsigned)n_pairs), dim3(kIterBlock),
+                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_base,
+                           d_list0, d_list1, max_iters);
+        hipLaunchKernelGGL(k_octav_iterate_full, dim3((unsigned)n_pairs), pb, 0, st, d_states, ctl, d_pair_spans,
+                           d_seg_ptrs, max_iters);
     }
     DPL_LAUNCH_CHECK("k_octav_compact");
     return 0;

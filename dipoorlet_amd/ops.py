@@ -42,7 +42,7 @@ def _upload_struct_array(arr, n, device):
 
 # Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
 # faster from HBM than many small items; the histogram wants a little more latency hiding).
-DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 512}
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024}
 
 
 def _blocks_for(kind):
@@ -108,14 +108,15 @@ class TensorSetPlan:
         return w
 
     def octav_scratch(self):
-        """(pair_base u64 [B*T], list0, list1): two tail lists of the batch's size, pair regions laid out in
-        pair order (4-element aligned so list reads can use 16-byte loads)."""
+        """(pair_spans, pair_base u64 [B*T], list0, list1): where each pair's data lives, and two tail lists of
+        the batch's size with the pair regions laid out in pair order (4-element aligned: 16-byte loads)."""
         if getattr(self, "_octav_scratch", None) is None:
             sizes = [((e + 3) // 4) * 4 for _ in range(self.batch) for e in self.elems]
             base = np.zeros(len(sizes), np.int64)
             base[1:] = np.cumsum(sizes)[:-1]
             tot = int(sum(sizes))
-            self._octav_scratch = (torch.from_numpy(base).to(self.device),
+            arr, ns = _hip._span_array(self._spans(True))
+            self._octav_scratch = (_upload_struct_array(arr, ns, self.device), torch.from_numpy(base).to(self.device),
                                    torch.empty(tot, dtype=torch.float32, device=self.device),
                                    torch.empty(tot, dtype=torch.float32, device=self.device))
         return self._octav_scratch
@@ -231,15 +232,16 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None):
         compact = os.environ.get("DPL_OCTAV_COMPACT", "1") != "0"
     w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
-    nbytes = n_pairs * C.sizeof(_hip.OctavState)
+    nbytes = (n_pairs + 1) * C.sizeof(_hip.OctavState)  # + control block
     if states is None or states.numel() < nbytes:
         states = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
     tab = plan.seg_table(tensors)
     L = _hip.lib()
     _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, 1 if compact else 0, _stream()), "dpl_octav_init")
     if compact:
-        base, l0, l1 = plan.octav_scratch()
-        _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(base), _ptr(l0), _ptr(l1),
+        spans, base, l0, l1 = plan.octav_scratch()
+        _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
+                                           _ptr(l0), _ptr(l1),
                                            1 if dynamic_sym else 0, _OCTAV_MAX_ITERS, _stream()),
                    "dpl_octav_run_compact")
     else:

@@ -58,7 +58,7 @@ SIGNATURES = {
     "dpl_abs_hist_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, C.c_int, _P, _P]),
     "dpl_hist_percentile": (C.c_int, [_P, _P, _P, _I64, C.c_int, _DBL, _P, _P]),
     "dpl_octav_init": (C.c_int, [_P, _I64, C.c_int, _P]),
-    "dpl_octav_run_compact": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dpl_octav_run_compact": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),

@@ -630,15 +630,19 @@ __global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int 
 constexpr int kStageCap = 2048;  // floats of LDS staging per wave
 
 struct TailAcc {
-    uint32_t gt;
-    double sum;
+    uint32_t gt;  // wave-uniform: survivors this wave has seen
+    double sum;   // per lane
 };
 
 // One wave, one 1024-element tile in registers: survivors (|x| > s) go to the wave's LDS stage.
+// Per element column j: the wave's ballot gives every surviving lane its slot (v_mbcnt) and the stage
+// cursor advances by the population count on the scalar unit — no cross-lane scan, conflict-free writes.
+// Values are summed in fp32 over the lane's 16 elements, then added to the fp64 accumulator (at least as
+// accurate as numpy's blocked fp32 pairwise sum).
 template <int kCap = kStageCap, class FlushFn>
 __device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stage, uint32_t& fill, TailAcc& acc,
                                           FlushFn&& flush) {
-    const uint32_t lane = threadIdx.x & (kWave - 1);
+    if (fill + 1024u > (uint32_t)kCap) flush();  // wave-uniform
     float a[16];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -647,28 +651,19 @@ __device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stag
         a[4 * u + 2] = fabsf(v[u].z);
         a[4 * u + 3] = fabsf(v[u].w);
     }
-    uint32_t cnt = 0;
+    float part = 0.0f;
+    const uint32_t fill0 = fill;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const bool g = a[j] > s;
-        cnt += g;
-        acc.sum += g ? (double)a[j] : 0.0;
+        const unsigned long long m = __ballot(g);
+        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (g) stage[fill + off] = a[j];
+        fill += (uint32_t)__popcll(m);
+        part += g ? a[j] : 0.0f;
     }
-    acc.gt += cnt;
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const uint32_t t = __shfl_up(inc, o, kWave);
-        if (lane >= (uint32_t)o) inc += t;
-    }
-    const uint32_t total = __shfl(inc, kWave - 1, kWave);
-    if (total == 0) return;
-    if (fill + total > (uint32_t)kCap) flush();
-    uint32_t pos = fill + inc - cnt;
-#pragma unroll
-    for (int j = 0; j < 16; ++j)
-        if (a[j] > s) stage[pos++] = a[j];
-    fill += total;
+    acc.gt += fill - fill0;
+    acc.sum += (double)part;
 }
 
 __device__ __forceinline__ void load_tile(const float* __restrict__ p_generic, uint32_t base, uint32_t n, bool aligned,
@@ -746,7 +741,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
             }
         }
         if (fill) flush();
-        const uint32_t gt = wave_sum(acc.gt);
+        const uint32_t gt = acc.gt;  // already wave-uniform
         const double sum = wave_sum(acc.sum);
         if (lane == 0) {
             s_gt[w] = gt;
@@ -772,11 +767,12 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
 // Later evaluations: ONE persistent workgroup per pair walks the remaining iterations by itself — evaluate
 // at s over list[cur], compact the survivors into list[1 - cur], take the fixed-point step, swap — with no
 // kernel boundary in between (the lists shrink ~2.5x per step and stay in this XCD's L2).
-constexpr int kIterBlock = 1024;     // 16 waves: a single workgroup must pull a ~1 MB first list quickly
-constexpr int kIterStageCap = 1024;  // floats of LDS staging per wave (one full tile)
+constexpr int kIterBlock = 512;      // 8 waves per pair; 64 KiB of LDS staging -> 2 workgroups per CU
+constexpr int kIterStageCap = 2048;  // floats of LDS staging per wave (two full tiles)
 
 __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_state* __restrict__ st,
                                                                      dpl_octav_state* __restrict__ ctl,
+                                                                     const uint32_t* __restrict__ pair_order,
                                                                      const uint64_t* __restrict__ pair_base,
                                                                      float* __restrict__ list0,
                                                                      float* __restrict__ list1, int max_iters) {
@@ -786,12 +782,15 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
     __shared__ uint32_t s_gt[kWaves];
     __shared__ uint32_t s_cursor;
     __shared__ OctavStep s_step;
-    dpl_octav_state* me = st + blockIdx.x;
+    // largest pairs first (pair_order is sorted by size): the long sequential chains start at once and the
+    // short ones fill the tail of the launch
+    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
+    dpl_octav_state* me = st + pair;
     if (me->done || me->mode != 1u || me->cur > 1u) return;  // uniform per workgroup
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float* stage = stage_all + w * kIterStageCap;
-    const uint64_t base_off = pair_base[blockIdx.x];
+    const uint64_t base_off = pair_base[pair];
     const unsigned long long n_elems = me->n_elems;
     const float unsigned_div = me->unsigned_div;
     float s = me->s;
@@ -800,6 +799,52 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
     while (!done && !decreased) {
         const float* src = (cur == 0 ? list0 : list1) + base_off;
         float* dst = (cur == 0 ? list1 : list0) + base_off;
+        if (n <= (uint32_t)(kIterBlock * 32)) {
+            // the tail now fits the workgroup's registers (32 values per lane): finish every remaining
+            // iteration without touching memory again — each one is a compare, a reduction and a step
+            gptr_f32 g = (gptr_f32)src;
+            float r[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const uint32_t idx = j * kIterBlock + threadIdx.x;
+                r[j] = idx < n ? g[idx] : 0.0f;  // zeros never exceed s >= 0
+            }
+            while (!done && !decreased) {
+                uint32_t c = 0;
+                float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 32; j += 2) {
+                    const bool g0 = r[j] > s, g1 = r[j + 1] > s;
+                    c += (uint32_t)g0 + (uint32_t)g1;
+                    p0 += g0 ? r[j] : 0.0f;
+                    p1 += g1 ? r[j + 1] : 0.0f;
+                }
+                c = wave_sum(c);
+                double sm = wave_sum((double)p0 + (double)p1);
+                if (lane == 0) {
+                    s_gt[w] = c;
+                    s_sum[w] = sm;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned long long tg = 0;
+                    double ts = 0.0;
+                    for (int j = 0; j < kWaves; ++j) {
+                        tg += s_gt[j];
+                        ts += s_sum[j];
+                    }
+                    s_step = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
+                }
+                __syncthreads();
+                const OctavStep st2 = s_step;
+                s = st2.s;
+                iters = st2.iters;
+                done = st2.done;
+                decreased = st2.decreased;
+                __syncthreads();
+            }
+            break;
+        }
         if (threadIdx.x == 0) s_cursor = 0u;
         __syncthreads();
         uint32_t fill = 0;
@@ -836,7 +881,7 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
             }
         }
         if (fill) flush();
-        const uint32_t gt = wave_sum(acc.gt);
+        const uint32_t gt = acc.gt;  // already wave-uniform
         const double sum = wave_sum(acc.sum);
         if (lane == 0) {
             s_gt[w] = gt;
@@ -1356,7 +1401,8 @@ int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t*
 int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
                           int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
-                          float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym,
+                          int max_iters, dpl_stream_t s) {
     if (n_items <= 0 || n_pairs <= 0) return 0;
     if (int e = check_blocks("dpl_octav_run_compact", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
@@ -1371,8 +1417,8 @@ int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const u
         hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
         // 3. every remaining iteration of every pair inside one launch    4. degenerate pairs on the full data
         hipLaunchKernelGGL(k_octav_iterate_lists, dim3((unsigned)n_pairs), dim3(kIterBlock),
-                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_base,
-                           d_list0, d_list1, max_iters);
+                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
+                           d_pair_base, d_list0, d_list1, max_iters);
         hipLaunchKernelGGL(k_octav_iterate_full, dim3((unsigned)n_pairs), pb, 0, st, d_states, ctl, d_pair_spans,
                            d_seg_ptrs, max_iters);
     }

@@ -108,7 +108,7 @@ class TensorSetPlan:
         return w
 
     def octav_scratch(self):
-        """(pair_spans, pair_base u64 [B*T], list0, list1): where each pair's data lives, and two tail lists of
+        """(pair_spans, pair_base u64 [B*T], pair_order, list0, list1): where each pair's data lives, and two tail lists of
         the batch's size with the pair regions laid out in pair order (4-element aligned: 16-byte loads)."""
         if getattr(self, "_octav_scratch", None) is None:
             sizes = [((e + 3) // 4) * 4 for _ in range(self.batch) for e in self.elems]
@@ -116,7 +116,9 @@ class TensorSetPlan:
             base[1:] = np.cumsum(sizes)[:-1]
             tot = int(sum(sizes))
             arr, ns = _hip._span_array(self._spans(True))
+            order = np.argsort(-np.array(sizes, np.int64), kind="stable").astype(np.int32)  # largest pairs first
             self._octav_scratch = (_upload_struct_array(arr, ns, self.device), torch.from_numpy(base).to(self.device),
+                                   torch.from_numpy(order).to(self.device),
                                    torch.empty(tot, dtype=torch.float32, device=self.device),
                                    torch.empty(tot, dtype=torch.float32, device=self.device))
         return self._octav_scratch
@@ -239,9 +241,9 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None):
     L = _hip.lib()
     _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, 1 if compact else 0, _stream()), "dpl_octav_init")
     if compact:
-        spans, base, l0, l1 = plan.octav_scratch()
+        spans, base, order, l0, l1 = plan.octav_scratch()
         _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
-                                           _ptr(l0), _ptr(l1),
+                                           _ptr(order), _ptr(l0), _ptr(l1),
                                            1 if dynamic_sym else 0, _OCTAV_MAX_ITERS, _stream()),
                    "dpl_octav_run_compact")
     else:

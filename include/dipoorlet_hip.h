@@ -126,12 +126,14 @@ int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t*
  * once and writes the values above s_0 to d_list0; then ONE launch walks all remaining iterations with a
  * persistent workgroup per pair over the shrinking tail lists (~2.5x smaller per step).
  * d_pair_spans[pair] = where the pair's data lives (seg, offset, count); d_pair_base[pair] = element offset of
- * the pair's region in both lists (a region holds the pair's element count).  Pairs whose iterate decreases
+ * the pair's region in both lists (a region holds the pair's element count); d_pair_order = pair indices,
+ * largest first (launch order of the per-pair workgroups), may be NULL.  Pairs whose iterate decreases
  * (degenerate data) finish on the full data. */
 int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
                           int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
-                          float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s);
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym,
+                          int max_iters, dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
 

@@ -85,23 +85,28 @@ def main(argv=None):
         reduce_clip_val(world, args)
     dist.barrier()
     act_clip_val, weight_clip_val = load_clip_val(args)
-    if args.bc:
+    graph_ori, graph_after_wt = onnx_graph, onnx_graph
+    if args.bc:  # weight_trans_base.py:21-29 — rank 0 corrects, everyone reloads, weight (bias) ranges refreshed
+        from .tensor_cali import find_clip_val_minmax_weight
         from .weight_transform import bias_correction
         if rank == 0:
-            logger.info("Bias correction...")
-        onnx_graph = bias_correction(onnx_graph, act_clip_val, weight_clip_val, args)
+            logger.info("Weight transform: bias correction...")
+            bias_correction(onnx_graph, act_clip_val, weight_clip_val, args)
         dist.barrier()
+        args.model = os.path.join(args.output_dir, "update_bias_model.onnx")
+        graph_after_wt = ONNXGraph.load(args.model, args.output_dir, args.deploy, args.model_type)
+        weight_clip_val = find_clip_val_minmax_weight(graph_after_wt, args)
     if not args.skip_profiling:
         from .profiling import quantize_profiling_multipass, show_model_profiling_res
         if rank == 0:
             logger.info("Profiling...")
-        layer_cos, model_cos, qnodes = quantize_profiling_multipass(onnx_graph, onnx_graph, act_clip_val,
+        layer_cos, model_cos, qnodes = quantize_profiling_multipass(graph_after_wt, graph_ori, act_clip_val,
                                                                     weight_clip_val, args)
         if rank == 0:
-            show_model_profiling_res(onnx_graph, layer_cos, model_cos, qnodes, args)
+            show_model_profiling_res(graph_after_wt, layer_cos, model_cos, qnodes, args)
     if rank == 0:
         logger.info("Deploy to " + args.deploy + "...")
-        to_deploy(onnx_graph, act_clip_val, weight_clip_val, args)
+        to_deploy(graph_after_wt, act_clip_val, weight_clip_val, args)
         logger.info("Total time cost: {} seconds.".format(int(time.time() - start)))
     dist.barrier()
     _ = tensor_range

@@ -39,6 +39,7 @@ def quantize_profiling_multipass(graph_after_wt, graph_ori, act_clip_val, weight
     graph_q, quant_node_list = quant_graph(graph_after_wt, clip_val, args)
     rank = dist.get_rank() if _world() > 1 or (dist.is_available() and dist.is_initialized()) else 0
     if rank == 0 and getattr(args, "output_dir", None):
+        graph_q.output_dir = args.output_dir
         graph_q.save_onnx_model(name="quant_model")
     dev = torch.device("cuda", torch.cuda.current_device())
     fp_sess = graph_ori.make_session(args)

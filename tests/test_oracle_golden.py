@@ -166,3 +166,24 @@ def test_weight_minmax_and_quant_acti(golden_dir):
     y = O.fake_quant_qdq(x, np.float32(0.05), 0, signed=True)
     ya = O.quant_acti(x, 0.05, -128, 127)
     assert np.array_equal(y, ya)  # values; Q/DQ yields +0.0 where quant_acti keeps -0.0
+
+
+def test_c_oracle_bit_exact_against_goldens(kl):
+    """The plain-C restatement (oracle/c_oracle.c) is held to the same reference-generated vectors."""
+    from oracle import c_oracle as CO
+    meta, g = kl
+    for c in meta["cases"]:
+        x = make_tensor(c["kind"], c["n"], c["seed"])
+        gmin0, gmax0 = g[c["key"] + "/minmax"]
+        assert np.array_equal(_bits(CO.minmax(x)), _bits([gmin0, gmax0])), c["key"]
+        for bins in (2048, 1000):
+            for scale in (1.0, 1.5):
+                gmin, gmax = np.float32(gmin0 * np.float32(scale)), np.float32(gmax0 * np.float32(scale))
+                assert np.array_equal(CO.abs_hist(x, bins, O.hist_dmax(gmin, gmax)), g[f"{c['key']}/hist_b{bins}_s{scale}"])
+        for deploy, dyn in (("trt", False), ("ti", True)):
+            ref = g[f"{c['key']}/octav_{deploy}"]
+            s = CO.octav_scale(x, O.octav_unsigned(ref[1], dyn))
+            assert np.array_equal(_bits(s), _bits(ref[0])) or (np.isnan(s) and np.isnan(ref[0])), (c["key"], s, ref[0])
+    xs = [make_tensor("relu", 50000, 1), make_tensor("normal", 7000, 2)]
+    used, mins, maxs, s, hist = CO.batch(xs, "hist", 2048, threads=2)
+    assert used >= 1 and np.array_equal(hist[0], O.abs_hist(xs[0], 2048, O.hist_dmax(mins[0], maxs[0])))

@@ -88,10 +88,18 @@ def cpu_baseline(algo, bins, tensors, budget_s):
                     O.octav_scale(x, 1)
         t_np += time.perf_counter() - t0
         n_np += 1
-    return {"value": done / t_used, "unit": "images/s", "cores": int(used), "kind": "port",
-            "sample": f"{done} images ({done // B} passes over {B} images' ResNet-50-shaped activations), -A {algo}, "
-                      f"C oracle with OpenMP over (image, tensor) arrays, {t_used:.1f} s; host has {os.cpu_count()} cores",
-            "numpy_single_thread_images_per_s": n_np / t_np}
+    c_rate, np_rate = done / t_used, n_np / t_np
+    out = {"unit": "images/s", "kind": "port", "c_openmp_images_per_s": c_rate, "c_openmp_threads": int(used),
+           "numpy_single_thread_images_per_s": np_rate}
+    if c_rate >= np_rate:
+        out.update(value=c_rate, cores=int(used),
+                   sample=f"{done} images ({done // B} passes over {B} images' ResNet-50-shaped activations), -A {algo}, "
+                          f"C oracle with OpenMP over (image, tensor) arrays, {t_used:.1f} s; host has {os.cpu_count()} cores")
+    else:  # (a streaming min/max is memory-bound: one numpy thread beats the OpenMP fan-out on this host)
+        out.update(value=np_rate, cores=1,
+                   sample=f"{n_np} images of the same ResNet-50-shaped activations, -A {algo}, numpy oracle on one "
+                          f"thread, {t_np:.1f} s; host has {os.cpu_count()} cores")
+    return out
 
 
 def main():
@@ -99,8 +107,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run (also with one rank: same code path)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group("nccl")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -122,7 +132,7 @@ def main():
     for tset in pool:
         acc.minmax_accumulate(plan, tset)
     gmin, gmax = acc.finalize_minmax()
-    if world > 1:
+    if use_dist:
         dist.all_reduce(gmin, op=dist.ReduceOp.MIN)
         dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
         acc.set_minmax(gmin.clone(), gmax.clone())
@@ -150,9 +160,11 @@ def main():
         else:
             if timed:
                 ev[i][0].record()
-            ops.octav_batch(plan, ta, False, states)
+            rows = ops.octav_batch(plan, ta, False, states)
             if timed:
                 ev[i][1].record()
+            return rows
+        return None
 
     if a.algo == "mse":
         import ctypes
@@ -160,24 +172,29 @@ def main():
     for i in range(a.warmup):
         step(i, False)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    octav_rows = None
     for i in range(a.steps):
-        step(i, True)
-    if world > 1 and a.algo != "mse":  # the algorithm's one exchange step
-        mn, mx = acc_rng.finalize_minmax()
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN)
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        if a.algo == "hist":
-            dist.all_reduce(acc.hist, op=dist.ReduceOp.SUM)
+        octav_rows = step(i, True)
+    if use_dist:  # the algorithm's one exchange step per run, inside the timed region
+        if a.algo == "mse":
+            from dipoorlet_amd.dist_helper import gather_rows
+            gather_rows(octav_rows, world)       # per-image (s, min, max) rows of the last batch as a stand-in
+        else:
+            mn, mx = acc_rng.finalize_minmax()
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            if a.algo == "hist":
+                dist.all_reduce(acc.hist, op=dist.ReduceOp.SUM)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -219,7 +236,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

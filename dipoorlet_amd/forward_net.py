@@ -215,9 +215,18 @@ def forward_net_octav(onnx_graph, args, run=None):
             for t, n in enumerate(run.names)}
 
 
+# forward_net.py:345-456 — the reference's "*_transformer" variants compute the same statistics, only walking
+# the graph node by node through its host-side ActivationCache to bound host memory.  Here every schedule is
+# the batched, HBM-resident one, so they are the same functions.
+forward_get_minmax_transformer = forward_get_minmax
+forward_get_hist_transformer = forward_get_hist
+forward_net_octav_transformer = forward_net_octav
+
+
 def log_forward_time(seconds):
     logger.info("Forward time: {:.2f} seconds".format(seconds))
 
 
 __all__ = ["ActivationSession", "CalibrationRun", "input_data_generator", "load_input_batch", "forward_get_minmax",
-           "forward_get_hist", "forward_net_octav", "DEFAULT_BATCH"]
+           "forward_get_hist", "forward_net_octav", "forward_get_minmax_transformer", "forward_get_hist_transformer",
+           "forward_net_octav_transformer", "hist_pass", "DEFAULT_BATCH"]

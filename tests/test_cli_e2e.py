@@ -205,3 +205,35 @@ def test_bias_correction_matches_sequential_definition(workdir):
         want = ref.get_initializer(bname)
         assert np.allclose(got, want, rtol=1e-3, atol=2e-4), (node.name, np.abs(got - want).max())
         assert np.abs(got - g.get_initializer(bname)).max() > 0  # something was corrected
+
+
+def test_vit_calibration_mse_and_cli_bc(tmp_path):
+    """BASELINE configs[4] in miniature: a ViT (decomposed LayerNorm / attention / erf-GELU), -A mse, --bc.
+    Per-image OCTAV needs batch-major tensors although the graph carries the batch on axis 1 in places."""
+    import types
+
+    from dipoorlet_amd import models
+    from dipoorlet_amd.__main__ import main
+    from dipoorlet_amd.forward_net import forward_net_octav
+    g = models.vit(seed=2, depth=2, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10)
+    g.output_dir = str(tmp_path)
+    g.save_onnx_model("vit")
+    os.makedirs(tmp_path / "calib" / "input")
+    rng = np.random.default_rng(9)
+    imgs = [rng.standard_normal(3 * 32 * 32).astype(np.float32) for _ in range(6)]
+    for i, x in enumerate(imgs):
+        x.tofile(tmp_path / "calib" / "input" / f"{i}.bin")
+    args = types.SimpleNamespace(input_dir=str(tmp_path / "calib"), data_num=6, rank=0, local_rank=0, world_size=1,
+                                 deploy="trt", calib_batch=4)
+    stats = forward_net_octav(g, args)
+    s1 = g.make_session()
+    for i, x in enumerate(imgs):  # image by image, batch 1: the reference's own schedule
+        outs = s1.run({"input": torch.from_numpy(x).reshape(1, 3, 32, 32).cuda()})
+        for n, t in zip(s1.tensor_names, outs):
+            ref_s = O.octav_scale(t.cpu().numpy(), 1)
+            assert np.isclose(stats[n]["optimal_s"][i], ref_s, rtol=2e-4, atol=1e-5), (n, i)
+            assert np.isclose(stats[n]["max"][i], t.max().item(), rtol=1e-4, atol=1e-5)
+    rc = main(["-M", str(tmp_path / "vit.onnx"), "-I", str(tmp_path / "calib"), "-N", "6", "-A", "mse", "-D", "trt", "-O",
+               str(tmp_path / "out"), "--calib_batch", "4", "--bc"])
+    assert rc == 0
+    assert os.path.exists(tmp_path / "out" / "update_bias_model.onnx") and os.path.exists(tmp_path / "out" / "trt_clip_val.json")

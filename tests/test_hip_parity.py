@@ -286,3 +286,60 @@ def test_full_size_properties_resnet50_shapes(dev):
             warnings.simplefilter("ignore")
             s = O.octav_scale(x, 1)
         assert _close(oc[b, t, 0], s), (b, t, oc[b, t], s)
+
+
+def test_abs_hist_edge_stress_all_bin_counts_and_magnitudes(dev):
+    """The one-sided bin search (biased reciprocal + single decrement test) must equal np.histogram for
+    values ON the fp32 bin edges and one ulp to either side, for any bin count up to the LDS limit and
+    ranges from 1e-30 to 1e30 (tiny ranges take the exact-divide path, checked too)."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(2024)
+    cases = [(2048, 6.1), (16384, 3.3e-3), (16384, 9.7e29), (1000, 1e-29), (777, 4.2e12), (3, 1.0), (1, 5.0),
+             (2047, 1.1754944e-38 * 4096), (4096, 1e-33), (1024, 2.5e-36)]
+    for _ in range(12):
+        cases.append((int(rng.integers(2, 16385)), float(10.0 ** rng.uniform(-25, 25))))
+    for bins, dm in cases:
+        dmax = np.float32(dm)
+        step = np.float32(dmax / np.float32(bins))
+        i = rng.integers(0, bins + 1, 60000).astype(np.float32)
+        e = (i * step).astype(np.float32)
+        e[i == bins] = dmax
+        lo = np.nextafter(e, np.float32(-np.inf))
+        hi = np.nextafter(e, np.float32(np.inf))
+        x = np.concatenate([e, lo, hi, rng.uniform(0, float(dmax), 60000).astype(np.float32),
+                            np.array([0.0, -0.0, float(dmax), -float(dmax)], np.float32)])
+        x = np.clip(x, 0, None).astype(np.float32) * rng.choice(np.array([-1, 1], np.float32), x.size)
+        try:
+            ref, _ = np.histogram(np.abs(x), bins, (0, dmax))
+        except ValueError:
+            _, acc = ops.abs_hist(torch.from_numpy(x).to(dev), bins, 0.0, float(dmax))
+            assert acc.range_status()["status"][0] != 0, (bins, dm)
+            continue
+        h, acc = ops.abs_hist(torch.from_numpy(x).to(dev), bins, 0.0, float(dmax))
+        assert acc.range_status()["status"][0] == 0, (bins, dm)
+        got = h.cpu().numpy()
+        assert np.array_equal(got, ref), (bins, dm, int(acc.range_status()["exact_div"][0]),
+                                          np.nonzero(got != ref)[0][:8], int(np.abs(got - ref).sum()))
+
+
+def test_empty_and_tiny_spans(dev):
+    from dipoorlet_amd import ops
+    plan = ops.TensorSetPlan([1, 3, 5], 2, dev)
+    xs = [torch.tensor([[1.5], [-2.5]], device=dev), torch.tensor([[0., 1., 2.], [3., -4., 0.]], device=dev),
+          torch.zeros(2, 5, device=dev)]
+    acc = ops.CalibAccumulators(3, dev, 64)
+    acc.minmax_accumulate(plan, xs)
+    lo, hi = acc.finalize_minmax()
+    assert lo.tolist() == [-2.5, -4.0, 0.0] and hi.tolist() == [1.5, 3.0, 0.0]
+    acc.hist_prepare()
+    acc.abs_hist_accumulate(plan, xs)
+    for t, x in enumerate(xs):
+        ref, _ = np.histogram(np.abs(x.cpu().numpy()), 64, (0, np.float32(max(hi[t].item(), -lo[t].item()))))
+        assert np.array_equal(acc.hist[t].cpu().numpy(), ref)
+    oc = ops.octav_batch(plan, xs, False).cpu().numpy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t, x in enumerate(xs):
+            for b in range(2):
+                s = O.octav_scale(x[b].cpu().numpy(), 1)
+                assert _close(oc[b, t, 0], s), (t, b, oc[b, t], s)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BINS = 16384
 
 
@@ -60,6 +60,8 @@ SIGNATURES = {
     "dpl_octav_init": (C.c_int, [_P, _I64, C.c_int, _P]),
     "dpl_octav_run_compact": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
+    "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
+                                        C.c_int, _P]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),

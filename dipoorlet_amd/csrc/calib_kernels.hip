@@ -589,7 +589,7 @@ __global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int 
         me->iters = 0u;
         me->done = (s0 != s0 || max_iters <= 0) ? 1u : 0u;  // NaN is a fixed point of the iteration
     } else {
-        if (me->done) return;
+        if (me->done || me->mode == 2u) return;
         // list mode evaluates only the tail: everything not above s is below or equal (no NaN: those pairs are done)
         const unsigned long long cnt_le = me->mode == 1u ? me->n_elems - me->cnt_gt : me->cnt_le;
         const OctavStep r = octav_step(me->sum, me->cnt_gt, cnt_le, me->unsigned_div, me->s, me->iters, max_iters);
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
                                                                 const uint32_t* __restrict__ bb,
                                                                 const float* const* __restrict__ segs,
                                                                 dpl_octav_state* __restrict__ st,
+                                                                const dpl_octav_state* __restrict__ ctl,
                                                                 const uint64_t* __restrict__ pair_base,
                                                                 float* __restrict__ list0) {
     extern __shared__ __attribute__((aligned(16))) float stage_all[];
@@ -686,6 +687,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
     float* stage = stage_all + w * kStageCap;
+    if (ctl && ctl->cnt_le == 0ull) return;  // no pair on the compaction route
     uint32_t k0, k1;
     block_items(bb, k0, k1);
     for (uint32_t k = k0; k < k1; ++k) {
@@ -773,6 +775,7 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
     __shared__ OctavStep s_step;
     // largest pairs first (pair_order is sorted by size): the long sequential chains start at once and the
     // short ones fill the tail of the launch
+    if (ctl->cnt_le == 0ull) return;  // no pair on the compaction route
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
     dpl_octav_state* me = st + pair;
     if (me->done || me->mode != 1u || me->cur > 1u) return;  // uniform per workgroup
@@ -988,7 +991,10 @@ __global__ void k_octav_init(dpl_octav_state* st, int64_t n, uint32_t mode) {
     z.len[1] = 0u;
     z.cur = 2u;
     z.reserved = 0u;
-    if (i == n) z.cnt_gt = mode ? 0ull : (unsigned long long)n;  // control block: pairs in full-pass mode
+    if (i == n) {  // control block: cnt_gt = pairs in full-pass mode, cnt_le = pairs on the compaction route
+        z.cnt_gt = mode == 0u ? (unsigned long long)n : 0ull;
+        z.cnt_le = mode == 1u ? (unsigned long long)n : 0ull;
+    }
     st[i] = z;
 }
 
@@ -999,6 +1005,446 @@ __global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* ou
     out[3 * i + 0] = st[i].s;
     out[3 * i + 1] = bad ? NAN : dec_f32(st[i].min_enc);
     out[3 * i + 2] = bad ? NAN : dec_f32(st[i].max_enc);
+}
+
+
+// ================================================================ K3c: OCTAV through a log-scale histogram
+// Goal: two reads of the data, no tail lists.  Pass 1 (with the statistics) bins |x| by its float bit
+// pattern — 64 sub-bins per octave over 2^-18 .. 2^14, i.e. bin = (bits >> 17) - key0 — keeping per bin an
+// exact count and an exact integer sum of mantissas (all values of a bin share the exponent, so
+// sum = (sum of 24-bit mantissas) * 2^(e-150): order-independent, deterministic).  F(s) is then exact at every
+// bin edge.  A small per-pair kernel walks the iteration in BRACKET form over the edges and marks the few
+// dozen bins the true iterates can fall into (3-8 % of the elements); pass 2 gathers just those elements; a
+// per-pair kernel then runs the reference's exact iteration from (exact bin totals above the current bin) +
+// (gathered elements of the current bin).  Every iterate is verified to land in a marked bin; a pair that
+// fails (or whose bracket explodes: flat / degenerate distributions) takes the compaction path instead.
+constexpr int kLogNB = 2048;
+constexpr int kLogShift = 17;                               // 23 - 6: six mantissa bits per bin
+constexpr uint32_t kLogKey0 = (uint32_t)(127 - 18) << 6;    // key of 2^-18
+constexpr int kLogWords = kLogNB / 32;
+constexpr int kLogMaxMarked = 256;
+constexpr uint32_t kSmallPair = 16384;                      // pairs this small are gathered whole
+
+__device__ __forceinline__ int log_bin(float a) {
+    const int b = (int)(__float_as_uint(a) >> kLogShift) - (int)kLogKey0;
+    return b < 0 ? 0 : (b > kLogNB - 1 ? kLogNB - 1 : b);
+}
+__device__ __forceinline__ double log_bin_scale(int b) {   // 2^(e - 150) for the exponent field e of bin b
+    const int e = (int)(((uint32_t)b + kLogKey0) >> 6);
+    return __longlong_as_double((long long)(e - 150 + 1023) << 52);
+}
+
+struct LogHistOp {
+    uint32_t* cnt;
+    unsigned long long* msum;
+    float mn, mx;
+    uint32_t nan, nz;
+    double sum;
+    __device__ __forceinline__ void operator()(float x) {
+        mn = fminf(mn, x);
+        mx = fmaxf(mx, x);
+        nan |= (x != x);
+        const float a = fabsf(x);
+        nz += (a > 0.0f);
+        sum += (double)a;
+        const uint32_t u = __float_as_uint(a);
+        const int b = log_bin(a);
+        if (b > 0) {  // bin 0 (zeros and |x| < 2^-18) is never needed: counts below come from n_elems
+            atomicAdd(cnt + b, 1u);
+            atomicAdd(msum + b, (unsigned long long)((u & 0x7FFFFFu) | 0x800000u));
+        }
+    }
+};
+
+__global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* __restrict__ items,
+                                                           const uint32_t* __restrict__ bb,
+                                                           const float* const* __restrict__ segs,
+                                                           dpl_octav_state* __restrict__ st,
+                                                           uint32_t* __restrict__ lh_cnt,
+                                                           unsigned long long* __restrict__ lh_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
+    unsigned long long* l_sum = lds64;                       // kLogNB u64
+    uint32_t* l_cnt = reinterpret_cast<uint32_t*>(lds64 + kLogNB);  // kLogNB u32
+    __shared__ double s_sum[kBlock / kWave];
+    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
+    __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
+    const int w = threadIdx.x / kWave;
+    const bool lead = (threadIdx.x & (kWave - 1)) == 0;
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        dpl_octav_state* me = st + it.slot;
+        for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
+            l_cnt[b] = 0u;
+            l_sum[b] = 0ull;
+        }
+        __syncthreads();
+        LogHistOp op{l_cnt, l_sum, INFINITY, -INFINITY, 0u, 0u, 0.0};
+        stream_span(segs[it.seg] + it.offset, it.count, op);
+        const float mn = wave_min(op.mn), mx = wave_max(op.mx);
+        const uint32_t nz = wave_sum(op.nz);
+        const double sum = wave_sum(op.sum);
+        const uint32_t nn = __any(op.nan) ? 1u : 0u;
+        if (lead) {
+            s_sum[w] = sum;
+            s_a[w] = nz;
+            s_b[w] = nn;
+            s_mn[w] = mn;
+            s_mx[w] = mx;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tsum = 0.0;
+            uint32_t tnz = 0, tnn = 0;
+            float tmn = INFINITY, tmx = -INFINITY;
+            for (int j = 0; j < kBlock / kWave; ++j) {
+                tsum += s_sum[j];
+                tnz += s_a[j];
+                tnn |= s_b[j];
+                tmn = fminf(tmn, s_mn[j]);
+                tmx = fmaxf(tmx, s_mx[j]);
+            }
+            atomicAdd(&me->sum, tsum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)it.count);
+            if (tmn <= tmx) {
+                atomicMin(&me->min_enc, enc_f32(tmn));
+                atomicMax(&me->max_enc, enc_f32(tmx));
+            }
+            if (tnn) atomicOr(&me->nan_seen, 1u);
+        }
+        uint32_t* gc = lh_cnt + (uint64_t)it.slot * kLogNB;
+        unsigned long long* gs = lh_sum + (uint64_t)it.slot * kLogNB;
+        for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
+            const uint32_t c = l_cnt[b];
+            if (c) {
+                atomicAdd(gc + b, c);
+                atomicAdd(gs + b, l_sum[b]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Shared by the bracket walk and the exact walk: suffix totals over the bins, S_ge[j] / N_ge[j] = everything
+// in bins >= j.  Built by one workgroup per pair into LDS (N as u32, S as fp64; j = 0 .. kLogNB).
+__device__ __forceinline__ void build_suffix(const uint32_t* __restrict__ gc, const unsigned long long* __restrict__ gs,
+                                             uint32_t* n_ge, double* s_ge, double* scratch_s, uint32_t* scratch_n) {
+    // each thread owns a run of consecutive bins (top bins first), then a serial combine of the per-thread totals
+    const int per = (kLogNB + (int)blockDim.x - 1) / (int)blockDim.x;
+    const int hi = kLogNB - 1 - (int)threadIdx.x * per;  // my highest bin
+    double ls = 0.0;
+    uint32_t ln = 0;
+    for (int q = 0; q < per; ++q) {
+        const int b = hi - q;
+        if (b >= 0) {
+            ln += gc[b];
+            ls += (double)gs[b] * log_bin_scale(b);
+        }
+    }
+    scratch_s[threadIdx.x] = ls;
+    scratch_n[threadIdx.x] = ln;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double as = 0.0;
+        uint32_t an = 0;
+        for (int t = 0; t < (int)blockDim.x; ++t) {  // exclusive prefix over threads (thread 0 holds the top bins)
+            const double ts = scratch_s[t];
+            const uint32_t tn = scratch_n[t];
+            scratch_s[t] = as;
+            scratch_n[t] = an;
+            as += ts;
+            an += tn;
+        }
+    }
+    __syncthreads();
+    double rs = scratch_s[threadIdx.x];
+    uint32_t rn = scratch_n[threadIdx.x];
+    for (int q = 0; q < per; ++q) {
+        const int b = hi - q;
+        if (b >= 0) {
+            rn += gc[b];
+            rs += (double)gs[b] * log_bin_scale(b);
+            n_ge[b] = rn;
+            s_ge[b] = rs;
+        }
+    }
+    if (threadIdx.x == 0) {
+        n_ge[kLogNB] = 0u;
+        s_ge[kLogNB] = 0.0;
+    }
+    __syncthreads();
+}
+
+// Per pair: s_0, then the bracket walk over the bin edges; marks the bins the iterates can visit.
+__global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __restrict__ st,
+                                                           dpl_octav_state* __restrict__ ctl,
+                                                           const uint32_t* __restrict__ lh_cnt,
+                                                           const unsigned long long* __restrict__ lh_sum,
+                                                           uint32_t* __restrict__ bitmap, int dynamic_sym, int max_iters) {
+    __shared__ uint32_t n_ge[kLogNB + 1];
+    __shared__ double s_ge[kLogNB + 1];
+    __shared__ double scr_s[kBlock];
+    __shared__ uint32_t scr_n[kBlock];
+    __shared__ uint32_t bm[kLogWords];
+    __shared__ uint32_t route;  // 0: done already, 2: bracket route, 1: compaction route
+    const int64_t pr = blockIdx.x;
+    dpl_octav_state* me = st + pr;
+    const uint32_t* gc = lh_cnt + pr * kLogNB;
+    const unsigned long long* gs = lh_sum + pr * kLogNB;
+    if (threadIdx.x < kLogWords) bm[threadIdx.x] = 0u;
+    build_suffix(gc, gs, n_ge, s_ge, scr_s, scr_n);
+    if (threadIdx.x == 0) {
+        const float mn = dec_f32(me->min_enc);
+        const float ud = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
+        const float s0 = __fdiv_rn((float)me->sum, (float)(long long)me->cnt_gt);
+        const unsigned long long n = me->n_elems;
+        me->unsigned_div = ud;
+        me->s = s0;
+        me->iters = 0u;
+        me->sum = 0.0;
+        me->cnt_gt = 0ull;
+        me->cnt_le = 0ull;
+        me->len[0] = 0u;
+        me->len[1] = 0u;
+        me->cur = 2u;
+        uint32_t r = 2u;
+        if (s0 != s0 || max_iters <= 0) {
+            me->done = 1u;  // NaN is a fixed point of the iteration
+            r = 0u;
+        } else if (n <= (unsigned long long)kSmallPair) {
+            for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair
+        } else if (n_ge[kLogNB - 1] != 0u) {
+            r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
+        } else {
+            const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
+            double lo = (double)s0, hi = (double)s0;
+            int marked = 0;
+            for (int itn = 0; itn < 20 && r == 2u; ++itn) {
+                const int jl = log_bin((float)lo), jh = log_bin((float)hi);
+                if (jl <= 1 || jh >= kLogNB - 2 || !(lo == lo) || !(hi == hi)) {
+                    r = 1u;
+                    break;
+                }
+                for (int j = jl - 1; j <= jh + 1; ++j) {
+                    const uint32_t bit = 1u << (j & 31);
+                    if (!(bm[j >> 5] & bit)) {
+                        bm[j >> 5] |= bit;
+                        ++marked;
+                    }
+                }
+                if (marked > kLogMaxMarked) {
+                    r = 1u;
+                    break;
+                }
+                double nlo = INFINITY, nhi = -INFINITY;
+                for (int j = jl; j <= jh + 1; ++j) {  // F with everything in bins >= j counted as "above"
+                    const double ng = (double)n_ge[j];
+                    const double f = s_ge[j] / (c * ((double)(long long)n - ng) + ng);
+                    nlo = fmin(nlo, f);
+                    nhi = fmax(nhi, f);
+                }
+                if (nlo == lo && nhi == hi) break;  // the bracket stopped moving
+                lo = nlo;
+                hi = nhi;
+            }
+        }
+        if (r == 1u) {  // compaction route (k_octav_compact_full and friends)
+            me->mode = 1u;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        } else {
+            me->mode = 2u;
+        }
+        route = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < kLogWords) bitmap[pr * kLogWords + threadIdx.x] = (route == 2u) ? bm[threadIdx.x] : 0u;
+}
+
+// Pass 2: collect the elements that fall in marked bins (|x| values) into the pair's list 0.
+__global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __restrict__ items,
+                                                          const uint32_t* __restrict__ bb,
+                                                          const float* const* __restrict__ segs,
+                                                          dpl_octav_state* __restrict__ st,
+                                                          const uint32_t* __restrict__ bitmap,
+                                                          const uint64_t* __restrict__ pair_base,
+                                                          float* __restrict__ list0) {
+    extern __shared__ __attribute__((aligned(16))) float stage_all[];
+    __shared__ uint32_t bm[kLogWords];
+    const int w = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    float* stage = stage_all + w * kStageCap;
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        dpl_octav_state* me = st + it.slot;
+        if (me->done || me->mode != 2u) continue;  // uniform per workgroup
+        __syncthreads();
+        if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)it.slot * kLogWords + threadIdx.x];
+        __syncthreads();
+        const float* p = segs[it.seg] + it.offset;
+        const bool aligned = (((uintptr_t)p) & 15u) == 0;
+        float* dst = list0 + pair_base[it.slot];
+        uint32_t fill = 0;
+        auto flush = [&]() {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&me->len[0], fill);
+            base = __shfl(base, 0, kWave);
+            for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
+            fill = 0;
+        };
+        auto eat = [&](const f4 (&v)[4], uint32_t tile_base) {
+            if (fill + 1024u > (uint32_t)kStageCap) flush();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a4[4] = {fabsf(v[u].x), fabsf(v[u].y), fabsf(v[u].z), fabsf(v[u].w)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t idx = tile_base + u * 256 + lane * 4 + q;
+                    const int b = log_bin(a4[q]);
+                    const bool g = idx < it.count && ((bm[b >> 5] >> (b & 31)) & 1u);
+                    const unsigned long long m = __ballot(g);
+                    const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (g) stage[fill + off] = a4[q];
+                    fill += (uint32_t)__popcll(m);
+                }
+            }
+        };
+        uint32_t tile = w * 1024;
+        if (tile < it.count) {
+            f4 va[4], vb[4];
+            load_tile(p, tile, it.count, aligned, va);
+            for (;;) {
+                uint32_t nxt = tile + kBlock * 16;
+                if (nxt >= it.count) {
+                    eat(va, tile);
+                    break;
+                }
+                load_tile(p, nxt, it.count, aligned, vb);
+                eat(va, tile);
+                tile = nxt;
+                nxt = tile + kBlock * 16;
+                if (nxt >= it.count) {
+                    eat(vb, tile);
+                    break;
+                }
+                load_tile(p, nxt, it.count, aligned, va);
+                eat(vb, tile);
+                tile = nxt;
+            }
+        }
+        if (fill) flush();
+    }
+}
+
+// Per pair: the reference's exact iteration from the exact bin totals + the gathered elements.
+constexpr int kExactBlock = 512;
+constexpr int kExactRegs = 32;  // gathered values held per lane (kExactBlock * kExactRegs = 16 K)
+
+__global__ __launch_bounds__(kExactBlock) void k_octav_exact(dpl_octav_state* __restrict__ st,
+                                                              dpl_octav_state* __restrict__ ctl,
+                                                              const uint32_t* __restrict__ pair_order,
+                                                              const uint32_t* __restrict__ lh_cnt,
+                                                              const unsigned long long* __restrict__ lh_sum,
+                                                              const uint32_t* __restrict__ bitmap,
+                                                              const uint64_t* __restrict__ pair_base,
+                                                              const float* __restrict__ list0, int max_iters) {
+    __shared__ uint32_t n_ge[kLogNB + 1];
+    __shared__ double s_ge[kLogNB + 1];
+    __shared__ double scr_s[kExactBlock];
+    __shared__ uint32_t scr_n[kExactBlock];
+    __shared__ uint32_t bm[kLogWords];
+    __shared__ OctavStep s_step;
+    constexpr int kWaves = kExactBlock / kWave;
+    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
+    dpl_octav_state* me = st + pair;
+    if (me->done || me->mode != 2u) return;  // uniform per workgroup
+    const int w = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)pair * kLogWords + threadIdx.x];
+    build_suffix(lh_cnt + (uint64_t)pair * kLogNB, lh_sum + (uint64_t)pair * kLogNB, n_ge, s_ge, scr_s, scr_n);
+    const uint32_t n_list = me->len[0];
+    const unsigned long long n_elems = me->n_elems;
+    const float unsigned_div = me->unsigned_div;
+    gptr_f32 lst = (gptr_f32)(list0 + pair_base[pair]);
+    const bool in_regs = n_list <= (uint32_t)(kExactBlock * kExactRegs);
+    float r[kExactRegs];
+    if (in_regs) {
+#pragma unroll
+        for (int j = 0; j < kExactRegs; ++j) {
+            const uint32_t idx = j * kExactBlock + threadIdx.x;
+            r[j] = idx < n_list ? lst[idx] : 0.0f;
+        }
+    }
+    float s = me->s;
+    uint32_t iters = me->iters, done = 0u, bad = 0u;
+    while (!done && !bad) {
+        const int jb = log_bin(s);
+        const bool marked = (bm[jb >> 5] >> (jb & 31)) & 1u;
+        if (!marked || jb <= 0 || jb >= kLogNB - 1) {  // the iterate left the gathered bins: cannot answer exactly
+            bad = 1u;
+            break;
+        }
+        // elements of bin jb above s (bins above jb are exact totals; bin jb is split by the gathered values)
+        uint32_t c = 0;
+        float p0 = 0.0f;
+        double pd = 0.0;
+        if (in_regs) {
+#pragma unroll
+            for (int j = 0; j < kExactRegs; ++j) {
+                const bool g = r[j] > s && log_bin(r[j]) == jb;
+                c += g;
+                p0 += g ? r[j] : 0.0f;
+            }
+            pd = (double)p0;
+        } else {
+            for (uint32_t i = threadIdx.x; i < n_list; i += kExactBlock) {
+                const float a = lst[i];
+                const bool g = a > s && log_bin(a) == jb;
+                c += g;
+                pd += g ? (double)a : 0.0;
+            }
+        }
+        c = wave_sum(c);
+        pd = wave_sum(pd);
+        if (lane == 0) {
+            scr_n[w] = c;
+            scr_s[w] = pd;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long tg = n_ge[jb + 1];
+            double ts = s_ge[jb + 1];
+            for (int j = 0; j < kWaves; ++j) {
+                tg += scr_n[j];
+                ts += scr_s[j];
+            }
+            s_step = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
+        }
+        __syncthreads();
+        const OctavStep q = s_step;
+        s = q.s;
+        iters = q.iters;
+        done = q.done;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (bad) {  // restart this pair on the compaction route from s_0 (state as k_octav_update<true> leaves it)
+            me->mode = 1u;
+            me->iters = 0u;
+            me->len[0] = 0u;
+            me->len[1] = 0u;
+            me->cur = 2u;
+            // (s_0 is still in me->s: this kernel only writes it back on success)
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        } else {
+            me->s = s;
+            me->iters = iters;
+            me->done = 1u;
+        }
+    }
 }
 
 // ================================================================ K5: per-row min / max of a [rows, cols] matrix
@@ -1353,8 +1799,9 @@ int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float*
 
 int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, int list_mode, dpl_stream_t s) {
     if (n_pairs <= 0) return 0;
+    if (list_mode < 0 || list_mode > 2) return fail_msg("dpl_octav_init: mode must be 0 (full), 1 (compaction) or 2 (bracket)");
     hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs + 1, 256)), dim3(256), 0, (hipStream_t)s, d_states,
-                       n_pairs, list_mode ? 1u : 0u);
+                       n_pairs, (uint32_t)list_mode);
     DPL_LAUNCH_CHECK("k_octav_init");
     return 0;
 }
@@ -1392,7 +1839,7 @@ int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const u
     hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
     if (max_iters > 0) {
         hipLaunchKernelGGL(k_octav_compact_full, pg, pb, (size_t)(kBlock / kWave) * kStageCap * sizeof(float), st,
-                           d_items, d_block_begin, d_seg_ptrs, d_states, d_pair_base, d_list0);
+                           d_items, d_block_begin, d_seg_ptrs, d_states, ctl, d_pair_base, d_list0);
         hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
         // 3. every remaining iteration of every pair inside one launch    4. degenerate pairs on the full data
         hipLaunchKernelGGL(k_octav_iterate_lists, dim3((unsigned)n_pairs), dim3(kIterBlock),
@@ -1402,6 +1849,44 @@ int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const u
                            d_seg_ptrs, max_iters);
     }
     DPL_LAUNCH_CHECK("k_octav_compact");
+    return 0;
+}
+
+int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
+                          uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_items <= 0 || n_pairs <= 0) return 0;
+    if (int e = check_blocks("dpl_octav_run_bracket", n_items, d_block_begin, n_blocks)) return e;
+    hipStream_t st = (hipStream_t)s;
+    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock), pairs((unsigned)n_pairs);
+    dpl_octav_state* ctl = d_states + n_pairs;
+    const size_t stage_bytes = (size_t)(kBlock / kWave) * kStageCap * sizeof(float);
+    hipError_t e1 = hipMemsetAsync(d_lh_cnt, 0, (size_t)n_pairs * kLogNB * sizeof(uint32_t), st);
+    hipError_t e2 = hipMemsetAsync(d_lh_sum, 0, (size_t)n_pairs * kLogNB * sizeof(uint64_t), st);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail("hipMemsetAsync", e1 != hipSuccess ? e1 : e2);
+    // 1. statistics + log-scale histogram   2. s_0 and the bracket walk   3. gather the marked bins   4. exact walk
+    hipLaunchKernelGGL(k_octav_loghist, pg, pb, (size_t)kLogNB * 12, st, d_items, d_block_begin, d_seg_ptrs, d_states,
+                       d_lh_cnt, reinterpret_cast<unsigned long long*>(d_lh_sum));
+    hipLaunchKernelGGL(k_octav_bracket, pairs, pb, 0, st, d_states, ctl, d_lh_cnt,
+                       reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);
+    if (max_iters > 0) {
+        hipLaunchKernelGGL(k_octav_gather, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
+                           d_bitmap, d_pair_base, d_list0);
+        hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock), 0, st, d_states, ctl, d_pair_order, d_lh_cnt,
+                           reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, d_pair_base, d_list0,
+                           max_iters);
+        // 5. pairs the bracket could not serve (flat / degenerate distributions, values >= 2^14): compaction route
+        hipLaunchKernelGGL(k_octav_compact_full, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
+                           ctl, d_pair_base, d_list0);
+        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
+        hipLaunchKernelGGL(k_octav_iterate_lists, pairs, dim3(kIterBlock),
+                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
+                           d_pair_base, d_list0, d_list1, max_iters);
+        hipLaunchKernelGGL(k_octav_iterate_full, pairs, pb, 0, st, d_states, ctl, d_pair_spans, d_seg_ptrs, max_iters);
+    }
+    DPL_LAUNCH_CHECK("k_octav_bracket");
     return 0;
 }
 

@@ -123,6 +123,15 @@ class TensorSetPlan:
                                    torch.empty(tot, dtype=torch.float32, device=self.device))
         return self._octav_scratch
 
+    def octav_loghist_scratch(self):
+        """(count u32 [B*T, 2048], mantissa-sum u64 [B*T, 2048], bitmap u32 [B*T, 64]) for the bracket form."""
+        if getattr(self, "_octav_lh", None) is None:
+            n = self.n_pairs
+            self._octav_lh = (torch.empty(n, 2048, dtype=torch.int32, device=self.device),
+                              torch.empty(n, 2048, dtype=torch.int64, device=self.device),
+                              torch.empty(n, 64, dtype=torch.int32, device=self.device))
+        return self._octav_lh
+
     def seg_table(self, tensors):
         """Device table of base pointers for this launch (cached per pointer tuple)."""
         if len(tensors) != self.T:
@@ -225,13 +234,21 @@ class CalibAccumulators:
 _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 
-def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None):
+_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2}
+
+
+def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):
     """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max).
 
-    compact=True (default unless DPL_OCTAV_COMPACT=0): tail-compaction form — two scratch lists of the batch's
-    size live in the plan; compact=False: every evaluation re-reads the full data."""
-    if compact is None:
-        compact = os.environ.get("DPL_OCTAV_COMPACT", "1") != "0"
+    Three forms computing the SAME iterate sequence (forward_net.py:323-330):
+      'bracket' (default)  two reads: statistics + exact log-scale histogram, bracket walk, gather of the marked
+                           bins, exact per-pair iteration; pairs it cannot serve finish on the compaction route
+      'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists
+      'full'               every evaluation re-reads the full data (21 passes)
+    `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default."""
+    if form is None:
+        form = ("compact" if compact else "full") if compact is not None else os.environ.get("DPL_OCTAV_FORM", "bracket")
+    mode = _OCTAV_MODE[form]
     w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
     nbytes = (n_pairs + 1) * C.sizeof(_hip.OctavState)  # + control block
@@ -239,16 +256,22 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None):
         states = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
     tab = plan.seg_table(tensors)
     L = _hip.lib()
-    _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, 1 if compact else 0, _stream()), "dpl_octav_init")
-    if compact:
-        spans, base, order, l0, l1 = plan.octav_scratch()
-        _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
-                                           _ptr(order), _ptr(l0), _ptr(l1),
-                                           1 if dynamic_sym else 0, _OCTAV_MAX_ITERS, _stream()),
-                   "dpl_octav_run_compact")
+    _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, mode, _stream()), "dpl_octav_init")
+    dyn = 1 if dynamic_sym else 0
+    if mode == 0:
+        _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, dyn, _OCTAV_MAX_ITERS, _stream()),
+                   "dpl_octav_run")
     else:
-        _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, 1 if dynamic_sym else 0,
-                                   _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run")
+        spans, base, order, l0, l1 = plan.octav_scratch()
+        if mode == 1:
+            _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
+                                               _ptr(order), _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
+                       "dpl_octav_run_compact")
+        else:
+            cnt, msum, bitmap = plan.octav_loghist_scratch()
+            _hip.check(L.dpl_octav_run_bracket(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
+                                               _ptr(order), _ptr(l0), _ptr(l1), _ptr(cnt), _ptr(msum), _ptr(bitmap),
+                                               dyn, _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run_bracket")
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
     return out

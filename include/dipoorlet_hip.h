@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 3
+#define DPL_ABI_VERSION 4
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -66,7 +66,8 @@ typedef struct dpl_octav_state {
     float s;
     float unsigned_div; /* 1 or 4 */
     uint32_t iters;
-    uint32_t mode;      /* 0: every evaluation re-reads the full data; 1: tail lists (dpl_octav_run_compact) */
+    uint32_t mode;      /* 0: every evaluation re-reads the full data; 1: tail lists (dpl_octav_run_compact);
+                           2: log-histogram bracket (dpl_octav_run_bracket) */
     uint64_t n_elems;   /* elements of the pair (counted by the first pass) */
     uint32_t len[2];    /* lengths of the two tail lists */
     uint32_t cur;       /* list holding the values above the previous iterate: 0, 1, or 2 = none yet */
@@ -134,6 +135,19 @@ int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const u
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym,
                           int max_iters, dpl_stream_t s);
+/* Same iterate sequence in TWO reads of the data and no tail lists (init with list_mode = 2): pass 1 takes the
+ * statistics and an exact log-scale histogram of |x| (64 bins per octave over 2^-18..2^14: per bin a count
+ * and an integer sum of mantissas); a per-pair bracket walk over the bin edges marks the few dozen bins the
+ * iterates can visit; pass 2 gathers only those elements (3-8 %) into d_list0; a per-pair kernel then runs the
+ * exact iteration from (exact totals of the bins above) + (gathered elements of the current bin), verifying
+ * that every iterate lands in a marked bin.  Pairs it cannot serve (bracket explodes on flat / degenerate
+ * distributions, values >= 2^14, failed verification) are finished by the compaction route above.
+ * d_lh_cnt: uint32 [n_pairs, 2048]; d_lh_sum: uint64 [n_pairs, 2048]; d_bitmap: uint32 [n_pairs, 64]. */
+int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
+                          uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
 

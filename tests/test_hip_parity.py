@@ -114,9 +114,9 @@ def test_hist_prepare_flags_bad_ranges(dev):
     assert acc.range_status()["status"][0] == 2
 
 
-@pytest.mark.parametrize("compact", [True, False])
-def test_octav_golden(dev, kl, compact):
-    """Both forms: tail compaction (default) and full re-reads; same iterate sequence, same answers."""
+@pytest.mark.parametrize("form", ["bracket", "compact", "full"])
+def test_octav_golden(dev, kl, form):
+    """All three forms (log-histogram bracket, tail compaction, full re-reads): same iterate sequence."""
     from dipoorlet_amd import ops
     meta, g = kl
     for c in meta["cases"]:
@@ -124,8 +124,8 @@ def test_octav_golden(dev, kl, compact):
         plan = ops.TensorSetPlan([c["n"]], 1, dev)
         for deploy, dyn in (("trt", False), ("ti", True)):
             ref = g[f"{c['key']}/octav_{deploy}"]
-            got = ops.octav_batch(plan, [x], dyn, compact=compact).cpu().numpy()[0, 0]
-            assert _close(got[0], ref[0]), (c["key"], deploy, compact, got, ref)
+            got = ops.octav_batch(plan, [x], dyn, form=form).cpu().numpy()[0, 0]
+            assert _close(got[0], ref[0]), (c["key"], deploy, form, got, ref)
             assert np.array_equal(got[1:], ref[1:], equal_nan=True), (c["key"], got, ref)
 
 
@@ -149,14 +149,15 @@ def test_octav_non_monotone_pairs_fall_back_to_full_passes(dev):
             rows.append(x)
         tensors.append(torch.from_numpy(np.stack(rows)).to(dev))
     plan = ops.TensorSetPlan(sizes, B, dev)
-    a = ops.octav_batch(plan, tensors, False, compact=True).cpu().numpy()
-    f = ops.octav_batch(plan, tensors, False, compact=False).cpu().numpy()
+    a = ops.octav_batch(plan, tensors, False, form="compact").cpu().numpy()
+    f = ops.octav_batch(plan, tensors, False, form="full").cpu().numpy()
+    k = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
     for t in range(len(sizes)):
         for b in range(B):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
-            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s), (t, b, a[b, t], f[b, t], s)
+            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s), (t, b, a[b, t], f[b, t], k[b, t], s)
 
 
 def test_batched_tensor_set_vs_golden_pipeline_stats(dev, golden_dir):
@@ -343,3 +344,26 @@ def test_empty_and_tiny_spans(dev):
             for b in range(2):
                 s = O.octav_scale(x[b].cpu().numpy(), 1)
                 assert _close(oc[b, t, 0], s), (t, b, oc[b, t], s)
+
+
+def test_octav_bracket_routes(dev):
+    """The bracket form on data that exercises each route: ordinary tensors (bracket), a flat distribution whose
+    bracket explodes, values beyond the 2^14 window, a huge dynamic range, all in one batched launch."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(17)
+    B, n = 2, 300000
+    mk = [lambda: rng.standard_normal(n).astype(np.float32) * 3,
+          lambda: rng.uniform(-3, 5, n).astype(np.float32),                       # flat: goes to the compaction route
+          lambda: (rng.standard_normal(n) * 9000).astype(np.float32),             # values >= 2^14
+          lambda: np.maximum(rng.standard_normal(n), 0).astype(np.float32) * 1e-3,
+          lambda: (rng.laplace(0, 1, n) * np.exp(rng.uniform(-6, 6, n))).astype(np.float32),
+          lambda: np.where(rng.random(n) < 0.999, 0, rng.standard_normal(n)).astype(np.float32)]
+    tensors = [torch.from_numpy(np.stack([f() for _ in range(B)])).to(dev) for f in mk]
+    plan = ops.TensorSetPlan([n] * len(mk), B, dev)
+    got = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
+    for t in range(len(mk)):
+        for b in range(B):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
+            assert _close(got[b, t, 0], s), (t, b, got[b, t], s)

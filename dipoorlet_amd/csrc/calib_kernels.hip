@@ -673,6 +673,51 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ p_generic, u
     }
 }
 
+// Tile walker for the compaction-style kernels: wave w of the workgroup takes the 1024-element tiles
+// w, w + waves, ... of p[0..n).  Full tiles of an aligned span go through a branch-free, software-pipelined
+// loop (two register sets; the next tile's four 16-byte loads are in flight while the current tile is
+// consumed); the ragged end (< one workgroup tile) or an unaligned span uses the bounds-checked loader, which
+// pads with zeros.  eat(v, tile_base, full): `full` tells the consumer that no element is padding.
+template <int kThreads, class Eat>
+__device__ __forceinline__ void for_each_tile(const float* __restrict__ p, uint32_t n, Eat&& eat) {
+    const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    constexpr uint32_t kStep = kThreads * 16;
+    const bool aligned = (((uintptr_t)p) & 15u) == 0;
+    const uint32_t n_main = aligned ? (n / kStep) * kStep : 0u;
+    gptr_f4 pv = (gptr_f4)p;
+#define DPL_TLOAD(buf, t0)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[u] = __builtin_nontemporal_load(pv + ((t0) >> 2) + u * 64 + lane)
+    uint32_t tile = w * 1024;
+    if (tile < n_main) {
+        f4 A[4], B[4];
+        DPL_TLOAD(A, tile);
+        for (;;) {
+            uint32_t nxt = tile + kStep;
+            if (nxt >= n_main) {
+                eat(A, tile, true);
+                break;
+            }
+            DPL_TLOAD(B, nxt);
+            eat(A, tile, true);
+            tile = nxt;
+            nxt = tile + kStep;
+            if (nxt >= n_main) {
+                eat(B, tile, true);
+                break;
+            }
+            DPL_TLOAD(A, nxt);
+            eat(B, tile, true);
+            tile = nxt;
+        }
+    }
+#undef DPL_TLOAD
+    for (uint32_t t2 = n_main + w * 1024; t2 < n; t2 += kStep) {
+        f4 v[4];
+        load_tile(p, t2, n, aligned, v);
+        eat(v, t2, false);
+    }
+}
+
 // First evaluation: full data -> list 0, several workgroups per pair (global cursor + atomics).
 __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_item* __restrict__ items,
                                                                 const uint32_t* __restrict__ bb,
@@ -696,7 +741,6 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
         if (me->done || me->mode != 1u) continue;
         const float s = me->s;
         const float* p = segs[it.seg] + it.offset;
-        const bool aligned = (((uintptr_t)p) & 15u) == 0;
         float* dst = list0 + pair_base[it.slot];
         uint32_t fill = 0;
         TailAcc acc{0u, 0.0};
@@ -707,30 +751,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_it
             for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
             fill = 0;
         };
-        // two register sets: the next tile is in flight while the current one is compacted
-        uint32_t tile = w * 1024;
-        if (tile < it.count) {
-            f4 va[4], vb[4];
-            load_tile(p, tile, it.count, aligned, va);
-            for (;;) {
-                uint32_t nxt = tile + kBlock * 16;
-                if (nxt >= it.count) {
-                    tail_tile(va, s, stage, fill, acc, flush);
-                    break;
-                }
-                load_tile(p, nxt, it.count, aligned, vb);
-                tail_tile(va, s, stage, fill, acc, flush);
-                tile = nxt;
-                nxt = tile + kBlock * 16;
-                if (nxt >= it.count) {
-                    tail_tile(vb, s, stage, fill, acc, flush);
-                    break;
-                }
-                load_tile(p, nxt, it.count, aligned, va);
-                tail_tile(vb, s, stage, fill, acc, flush);
-                tile = nxt;
-            }
-        }
+        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t, bool) { tail_tile(v, s, stage, fill, acc, flush); });
         if (fill) flush();
         const uint32_t gt = acc.gt;  // already wave-uniform
         const double sum = wave_sum(acc.sum);
@@ -848,30 +869,9 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
             for (uint32_t j = lane; j < fill; j += kWave) dst[b0 + j] = stage[j];
             fill = 0;
         };
-        const bool aligned = (((uintptr_t)src) & 15u) == 0;
-        uint32_t tile = w * 1024;
-        if (tile < n) {
-            f4 va[4], vb[4];
-            load_tile(src, tile, n, aligned, va);
-            for (;;) {
-                uint32_t nxt = tile + kIterBlock * 16;
-                if (nxt >= n) {
-                    tail_tile<kIterStageCap>(va, s, stage, fill, acc, flush);
-                    break;
-                }
-                load_tile(src, nxt, n, aligned, vb);
-                tail_tile<kIterStageCap>(va, s, stage, fill, acc, flush);
-                tile = nxt;
-                nxt = tile + kIterBlock * 16;
-                if (nxt >= n) {
-                    tail_tile<kIterStageCap>(vb, s, stage, fill, acc, flush);
-                    break;
-                }
-                load_tile(src, nxt, n, aligned, va);
-                tail_tile<kIterStageCap>(vb, s, stage, fill, acc, flush);
-                tile = nxt;
-            }
-        }
+        for_each_tile<kIterBlock>(src, n, [&](const f4 (&v)[4], uint32_t, bool) {
+            tail_tile<kIterStageCap>(v, s, stage, fill, acc, flush);
+        });
         if (fill) flush();
         const uint32_t gt = acc.gt;  // already wave-uniform
         const double sum = wave_sum(acc.sum);
@@ -1022,6 +1022,7 @@ constexpr int kLogNB = 2048;
 constexpr int kLogShift = 17;                               // 23 - 6: six mantissa bits per bin
 constexpr uint32_t kLogKey0 = (uint32_t)(127 - 18) << 6;    // key of 2^-18
 constexpr int kLogWords = kLogNB / 32;
+constexpr int kBitmapRow = kLogWords + 2;                   // + the gather range [lo, hi) as float bits
 constexpr int kLogMaxMarked = 256;
 constexpr uint32_t kSmallPair = 16384;                      // pairs this small are gathered whole
 
@@ -1131,43 +1132,50 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
 // in bins >= j.  Built by one workgroup per pair into LDS (N as u32, S as fp64; j = 0 .. kLogNB).
 __device__ __forceinline__ void build_suffix(const uint32_t* __restrict__ gc, const unsigned long long* __restrict__ gs,
                                              uint32_t* n_ge, double* s_ge, double* scratch_s, uint32_t* scratch_n) {
-    // each thread owns a run of consecutive bins (top bins first), then a serial combine of the per-thread totals
+    // each thread owns a run of consecutive bins (thread 0 the top ones); exclusive prefix over threads by a
+    // wave-level shuffle scan + a serial pass over the (<= 16) wave totals
     const int per = (kLogNB + (int)blockDim.x - 1) / (int)blockDim.x;
     const int hi = kLogNB - 1 - (int)threadIdx.x * per;  // my highest bin
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave, nw = (int)blockDim.x / kWave;
     double ls = 0.0;
     uint32_t ln = 0;
     for (int q = 0; q < per; ++q) {
-        const int b = hi - q;
-        if (b >= 0) {
-            ln += gc[b];
-            ls += (double)gs[b] * log_bin_scale(b);
+        const int bq = hi - q;
+        if (bq >= 0) {
+            ln += gc[bq];
+            ls += (double)gs[bq] * log_bin_scale(bq);
         }
     }
-    scratch_s[threadIdx.x] = ls;
-    scratch_n[threadIdx.x] = ln;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double as = 0.0;
-        uint32_t an = 0;
-        for (int t = 0; t < (int)blockDim.x; ++t) {  // exclusive prefix over threads (thread 0 holds the top bins)
-            const double ts = scratch_s[t];
-            const uint32_t tn = scratch_n[t];
-            scratch_s[t] = as;
-            scratch_n[t] = an;
-            as += ts;
-            an += tn;
+    double is = ls;
+    uint32_t in = ln;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double ts = __shfl_up(is, o, kWave);
+        const uint32_t tn = __shfl_up(in, o, kWave);
+        if (lane >= (uint32_t)o) {
+            is += ts;
+            in += tn;
         }
     }
+    if (lane == kWave - 1) {
+        scratch_s[w] = is;
+        scratch_n[w] = in;
+    }
     __syncthreads();
-    double rs = scratch_s[threadIdx.x];
-    uint32_t rn = scratch_n[threadIdx.x];
+    double rs = is - ls;  // exclusive within the wave
+    uint32_t rn = in - ln;
+    for (int q = 0; q < w && q < nw; ++q) {
+        rs += scratch_s[q];
+        rn += scratch_n[q];
+    }
     for (int q = 0; q < per; ++q) {
-        const int b = hi - q;
-        if (b >= 0) {
-            rn += gc[b];
-            rs += (double)gs[b] * log_bin_scale(b);
-            n_ge[b] = rn;
-            s_ge[b] = rs;
+        const int bq = hi - q;
+        if (bq >= 0) {
+            rn += gc[bq];
+            rs += (double)gs[bq] * log_bin_scale(bq);
+            n_ge[bq] = rn;
+            s_ge[bq] = rs;
         }
     }
     if (threadIdx.x == 0) {
@@ -1175,6 +1183,10 @@ __device__ __forceinline__ void build_suffix(const uint32_t* __restrict__ gc, co
         s_ge[kLogNB] = 0.0;
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ float log_edge(int b) {  // lower edge of bin b (bin 0 starts at 0)
+    return b <= 0 ? 0.0f : __uint_as_float(((uint32_t)b + kLogKey0) << kLogShift);
 }
 
 // Per pair: s_0, then the bracket walk over the bin edges; marks the bins the iterates can visit.
@@ -1189,6 +1201,11 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
     __shared__ uint32_t scr_n[kBlock];
     __shared__ uint32_t bm[kLogWords];
     __shared__ uint32_t route;  // 0: done already, 2: bracket route, 1: compaction route
+    __shared__ int jmin_s, jmax_s;
+    if (threadIdx.x == 0) {
+        jmin_s = kLogNB;
+        jmax_s = -1;
+    }
     const int64_t pr = blockIdx.x;
     dpl_octav_state* me = st + pr;
     const uint32_t* gc = lh_cnt + pr * kLogNB;
@@ -1215,12 +1232,16 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
             r = 0u;
         } else if (n <= (unsigned long long)kSmallPair) {
             for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair
+            jmin_s = 0;
+            jmax_s = kLogNB - 1;
         } else if (n_ge[kLogNB - 1] != 0u) {
             r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
         } else {
             const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
             double lo = (double)s0, hi = (double)s0;
             int marked = 0;
+            jmin_s = kLogNB;
+            jmax_s = -1;
             for (int itn = 0; itn < 20 && r == 2u; ++itn) {
                 const int jl = log_bin((float)lo), jh = log_bin((float)hi);
                 if (jl <= 1 || jh >= kLogNB - 2 || !(lo == lo) || !(hi == hi)) {
@@ -1234,6 +1255,8 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
                         ++marked;
                     }
                 }
+                jmin_s = jl - 1 < jmin_s ? jl - 1 : jmin_s;
+                jmax_s = jh + 1 > jmax_s ? jh + 1 : jmax_s;
                 if (marked > kLogMaxMarked) {
                     r = 1u;
                     break;
@@ -1259,10 +1282,23 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
         route = r;
     }
     __syncthreads();
-    if (threadIdx.x < kLogWords) bitmap[pr * kLogWords + threadIdx.x] = (route == 2u) ? bm[threadIdx.x] : 0u;
+    // bitmap row: kLogWords words of marks + [lowest marked edge, edge above the highest marked bin] as float bits
+    if (threadIdx.x < kLogWords) bitmap[pr * kBitmapRow + threadIdx.x] = (route == 2u) ? bm[threadIdx.x] : 0u;
+    if (threadIdx.x == 0) {
+        const int jmin = route == 2u ? jmin_s : kLogNB, jmax = route == 2u ? jmax_s : -1;
+        const float rlo = jmax < 0 ? INFINITY : log_edge(jmin);
+        const float rhi = jmax < 0 ? -INFINITY : (jmax >= kLogNB - 1 ? INFINITY : log_edge(jmax + 1));
+        bitmap[pr * kBitmapRow + kLogWords] = __float_as_uint(rlo);
+        bitmap[pr * kBitmapRow + kLogWords + 1] = __float_as_uint(rhi);
+    }
 }
 
-// Pass 2: collect the elements that fall in marked bins (|x| values) into the pair's list 0.
+// Pass 2: collect the elements that fall in marked bins (|x| values) into the pair's list 0.  Survivors are
+// rare (3-8 %), so each lane appends to a private LDS queue (no cross-lane work per element); a wave flushes
+// its queues behind one scan + one returning atomic when any queue is half full.
+constexpr int kQueueCap = 32;
+constexpr int kQueueStride = kQueueCap + 1;  // odd stride: lanes with equal fill hit different banks
+
 __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __restrict__ items,
                                                           const uint32_t* __restrict__ bb,
                                                           const float* const* __restrict__ segs,
@@ -1270,11 +1306,11 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
                                                           const uint32_t* __restrict__ bitmap,
                                                           const uint64_t* __restrict__ pair_base,
                                                           float* __restrict__ list0) {
-    extern __shared__ __attribute__((aligned(16))) float stage_all[];
-    __shared__ uint32_t bm[kLogWords];
+    extern __shared__ __attribute__((aligned(16))) float queues[];  // [waves][64][kQueueStride]
+    __shared__ uint32_t bm[kBitmapRow];
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* stage = stage_all + w * kStageCap;
+    float* q = queues + ((size_t)w * kWave + lane) * kQueueStride;
     uint32_t k0, k1;
     block_items(bb, k0, k1);
     for (uint32_t k = k0; k < k1; ++k) {
@@ -1282,132 +1318,183 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
         dpl_octav_state* me = st + it.slot;
         if (me->done || me->mode != 2u) continue;  // uniform per workgroup
         __syncthreads();
-        if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)it.slot * kLogWords + threadIdx.x];
+        if (threadIdx.x < kBitmapRow) bm[threadIdx.x] = bitmap[(uint64_t)it.slot * kBitmapRow + threadIdx.x];
         __syncthreads();
+        const float rlo = __uint_as_float(bm[kLogWords]), rhi = __uint_as_float(bm[kLogWords + 1]);
         const float* p = segs[it.seg] + it.offset;
-        const bool aligned = (((uintptr_t)p) & 15u) == 0;
         float* dst = list0 + pair_base[it.slot];
-        uint32_t fill = 0;
+        uint32_t cnt = 0;
         auto flush = [&]() {
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o, kWave);
+                if (lane >= (uint32_t)o) inc += t;
+            }
+            const uint32_t total = __shfl(inc, kWave - 1, kWave);
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&me->len[0], fill);
-            base = __shfl(base, 0, kWave);
-            for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
-            fill = 0;
+            if (lane == kWave - 1) base = atomicAdd(&me->len[0], total);
+            base = __shfl(base, kWave - 1, kWave) + inc - cnt;
+            for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j];
+            cnt = 0;
         };
-        auto eat = [&](const f4 (&v)[4], uint32_t tile_base) {
-            if (fill + 1024u > (uint32_t)kStageCap) flush();
+        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t tile_base, bool full) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float a4[4] = {fabsf(v[u].x), fabsf(v[u].y), fabsf(v[u].z), fabsf(v[u].w)};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t idx = tile_base + u * 256 + lane * 4 + q;
-                    const int b = log_bin(a4[q]);
-                    const bool g = idx < it.count && ((bm[b >> 5] >> (b & 31)) & 1u);
-                    const unsigned long long m = __ballot(g);
-                    const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (g) stage[fill + off] = a4[q];
-                    fill += (uint32_t)__popcll(m);
+                for (int e = 0; e < 4; ++e) {
+                    const float a = a4[e];
+                    const bool real = full || (tile_base + u * 256 + lane * 4 + e < it.count);  // padding zeros are not data
+                    if (a >= rlo && a < rhi && real) {  // inside the span of marked bins: consult the bitmap
+                        const int b = log_bin(a);
+                        if ((bm[b >> 5] >> (b & 31)) & 1u) q[cnt++] = a;
+                    }
                 }
             }
-        };
-        uint32_t tile = w * 1024;
-        if (tile < it.count) {
-            f4 va[4], vb[4];
-            load_tile(p, tile, it.count, aligned, va);
-            for (;;) {
-                uint32_t nxt = tile + kBlock * 16;
-                if (nxt >= it.count) {
-                    eat(va, tile);
-                    break;
-                }
-                load_tile(p, nxt, it.count, aligned, vb);
-                eat(va, tile);
-                tile = nxt;
-                nxt = tile + kBlock * 16;
-                if (nxt >= it.count) {
-                    eat(vb, tile);
-                    break;
-                }
-                load_tile(p, nxt, it.count, aligned, va);
-                eat(vb, tile);
-                tile = nxt;
-            }
-        }
-        if (fill) flush();
+            if (__any(cnt > (uint32_t)(kQueueCap - 16))) flush();
+        });
+        if (__any(cnt != 0u)) flush();
     }
 }
 
 // Per pair: the reference's exact iteration from the exact bin totals + the gathered elements.
-constexpr int kExactBlock = 512;
-constexpr int kExactRegs = 32;  // gathered values held per lane (kExactBlock * kExactRegs = 16 K)
+// For the iterate s in bin jb:  count(|x| > s) = (exact total of the bins above jb) + (gathered values v with
+// s < v < edge(jb+1)).  The iterates climb, so values not above s are dropped from the gathered list as it is
+// walked (the same tail compaction as k_octav_iterate_lists, list 0 -> list 1 -> ...), and the totals above the
+// current bin are updated incrementally.  An iterate that lands in an unmarked bin, or moves down, sends the
+// pair to the compaction route.
+constexpr int kExactBlock = 256;
+constexpr int kExactRegs = 32;  // gathered values held per lane once the list is short (256 * 32 = 8 K)
 
-__global__ __launch_bounds__(kExactBlock) void k_octav_exact(dpl_octav_state* __restrict__ st,
+__global__ __launch_bounds__(kExactBlock, 4) void k_octav_exact(dpl_octav_state* __restrict__ st,
                                                               dpl_octav_state* __restrict__ ctl,
                                                               const uint32_t* __restrict__ pair_order,
                                                               const uint32_t* __restrict__ lh_cnt,
                                                               const unsigned long long* __restrict__ lh_sum,
                                                               const uint32_t* __restrict__ bitmap,
                                                               const uint64_t* __restrict__ pair_base,
-                                                              const float* __restrict__ list0, int max_iters) {
-    __shared__ uint32_t n_ge[kLogNB + 1];
-    __shared__ double s_ge[kLogNB + 1];
-    __shared__ double scr_s[kExactBlock];
-    __shared__ uint32_t scr_n[kExactBlock];
-    __shared__ uint32_t bm[kLogWords];
-    __shared__ OctavStep s_step;
+                                                              float* __restrict__ list0, float* __restrict__ list1,
+                                                              int max_iters) {
+    extern __shared__ __attribute__((aligned(16))) float stage_all[];
     constexpr int kWaves = kExactBlock / kWave;
+    __shared__ double scr_s[kWaves];
+    __shared__ unsigned long long scr_n[kWaves];
+    __shared__ uint32_t bm[kLogWords];
+    __shared__ uint32_t s_cursor;
+    __shared__ OctavStep s_step;
+    __shared__ double s_above;             // exact totals of the bins above the current one
+    __shared__ unsigned long long n_above;
+    __shared__ int s_jb;
+    __shared__ uint32_t s_bad;
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
     dpl_octav_state* me = st + pair;
     if (me->done || me->mode != 2u) return;  // uniform per workgroup
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)pair * kLogWords + threadIdx.x];
-    build_suffix(lh_cnt + (uint64_t)pair * kLogNB, lh_sum + (uint64_t)pair * kLogNB, n_ge, s_ge, scr_s, scr_n);
-    const uint32_t n_list = me->len[0];
+    float* stage = stage_all + w * kIterStageCap;
+    const uint32_t* gc = lh_cnt + (uint64_t)pair * kLogNB;
+    const unsigned long long* gs = lh_sum + (uint64_t)pair * kLogNB;
+    if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)pair * kBitmapRow + threadIdx.x];
     const unsigned long long n_elems = me->n_elems;
     const float unsigned_div = me->unsigned_div;
-    gptr_f32 lst = (gptr_f32)(list0 + pair_base[pair]);
-    const bool in_regs = n_list <= (uint32_t)(kExactBlock * kExactRegs);
-    float r[kExactRegs];
-    if (in_regs) {
-#pragma unroll
-        for (int j = 0; j < kExactRegs; ++j) {
-            const uint32_t idx = j * kExactBlock + threadIdx.x;
-            r[j] = idx < n_list ? lst[idx] : 0.0f;
-        }
-    }
+    const uint64_t base_off = pair_base[pair];
     float s = me->s;
-    uint32_t iters = me->iters, done = 0u, bad = 0u;
-    while (!done && !bad) {
-        const int jb = log_bin(s);
-        const bool marked = (bm[jb >> 5] >> (jb & 31)) & 1u;
-        if (!marked || jb <= 0 || jb >= kLogNB - 1) {  // the iterate left the gathered bins: cannot answer exactly
-            bad = 1u;
-            break;
+    uint32_t iters = me->iters, n = me->len[0], cur = 0u;
+    // totals above the first iterate's bin: one block-wide reduction over the histogram
+    int jb = log_bin(s);
+    {
+        double ls = 0.0;
+        unsigned long long ln = 0;
+        for (int b2 = jb + 1 + (int)threadIdx.x; b2 < kLogNB; b2 += kExactBlock) {
+            ln += gc[b2];
+            ls += (double)gs[b2] * log_bin_scale(b2);
         }
-        // elements of bin jb above s (bins above jb are exact totals; bin jb is split by the gathered values)
+        ls = wave_sum(ls);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ln += __shfl_xor(ln, o, kWave);
+        if (lane == 0) {
+            scr_s[w] = ls;
+            scr_n[w] = ln;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double ts = 0.0;
+            unsigned long long tn = 0;
+            for (int j = 0; j < kWaves; ++j) {
+                ts += scr_s[j];
+                tn += scr_n[j];
+            }
+            s_above = ts;
+            n_above = tn;
+            s_jb = jb;
+            s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
+        }
+        __syncthreads();
+    }
+    uint32_t done = 0u, bad = s_bad;
+    bool in_regs = false;
+    float r[kExactRegs];
+    while (!done && !bad) {
+        const float e_hi = log_edge(jb + 1);
+        const float* src = (cur == 0 ? list0 : list1) + base_off;
+        float* dst = (cur == 0 ? list1 : list0) + base_off;
         uint32_t c = 0;
-        float p0 = 0.0f;
         double pd = 0.0;
-        if (in_regs) {
+        if (!in_regs && n <= (uint32_t)(kExactBlock * kExactRegs)) {
+            gptr_f32 g = (gptr_f32)src;
 #pragma unroll
             for (int j = 0; j < kExactRegs; ++j) {
-                const bool g = r[j] > s && log_bin(r[j]) == jb;
-                c += g;
-                p0 += g ? r[j] : 0.0f;
+                const uint32_t idx = j * kExactBlock + threadIdx.x;
+                r[j] = idx < n ? g[idx] : 0.0f;
+            }
+            in_regs = true;
+        }
+        if (in_regs) {
+            float p0 = 0.0f;
+#pragma unroll
+            for (int j = 0; j < kExactRegs; ++j) {
+                const bool gq = r[j] > s && r[j] < e_hi;
+                c += gq;
+                p0 += gq ? r[j] : 0.0f;
             }
             pd = (double)p0;
+            c = wave_sum(c);
         } else {
-            for (uint32_t i = threadIdx.x; i < n_list; i += kExactBlock) {
-                const float a = lst[i];
-                const bool g = a > s && log_bin(a) == jb;
-                c += g;
-                pd += g ? (double)a : 0.0;
-            }
+            if (threadIdx.x == 0) s_cursor = 0u;
+            __syncthreads();
+            uint32_t fill = 0;
+            auto flush = [&]() {
+                uint32_t b0 = 0;
+                if (lane == 0) b0 = atomicAdd(&s_cursor, fill);
+                b0 = __shfl(b0, 0, kWave);
+                for (uint32_t j = lane; j < fill; j += kWave) dst[b0 + j] = stage[j];
+                fill = 0;
+            };
+            for_each_tile<kExactBlock>(src, n, [&](const f4 (&v)[4], uint32_t, bool) {
+                if (fill + 1024u > (uint32_t)kIterStageCap) flush();
+                float part = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float a4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a = a4[e];
+                        const bool keep = a > s;                 // stays in the list for later iterates
+                        const bool cntit = keep && a < e_hi;     // belongs to the current bin
+                        const unsigned long long m = __ballot(keep);
+                        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        if (keep) stage[fill + off] = a;
+                        fill += (uint32_t)__popcll(m);
+                        c += cntit;
+                        part += cntit ? a : 0.0f;
+                    }
+                }
+                pd += (double)part;
+            });
+            if (fill) flush();
+            c = wave_sum(c);
         }
-        c = wave_sum(c);
         pd = wave_sum(pd);
         if (lane == 0) {
             scr_n[w] = c;
@@ -1415,29 +1502,54 @@ __global__ __launch_bounds__(kExactBlock) void k_octav_exact(dpl_octav_state* __
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            unsigned long long tg = n_ge[jb + 1];
-            double ts = s_ge[jb + 1];
+            unsigned long long tg = n_above;
+            double ts = s_above;
             for (int j = 0; j < kWaves; ++j) {
                 tg += scr_n[j];
                 ts += scr_s[j];
             }
-            s_step = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
+            const OctavStep q = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
+            s_step = q;
+            if (!q.done) {  // move the exact totals up to the new iterate's bin
+                const int jn = log_bin(q.s);
+                uint32_t nb = 0u;
+                if (q.decreased || jn < s_jb || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
+                    nb = 1u;
+                } else {
+                    double sa = s_above;
+                    unsigned long long na = n_above;
+                    for (int b2 = s_jb + 1; b2 <= jn; ++b2) {
+                        na -= gc[b2];
+                        sa -= (double)gs[b2] * log_bin_scale(b2);
+                    }
+                    s_above = sa;
+                    n_above = na;
+                    s_jb = jn;
+                }
+                s_bad = nb;
+            }
         }
         __syncthreads();
         const OctavStep q = s_step;
         s = q.s;
         iters = q.iters;
         done = q.done;
+        bad = done ? 0u : s_bad;
+        jb = s_jb;
+        if (!in_regs) {
+            n = s_cursor;
+            cur = 1u - cur;
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        if (bad) {  // restart this pair on the compaction route from s_0 (state as k_octav_update<true> leaves it)
+        if (bad) {  // restart this pair on the compaction route from s_0 (state as k_octav_update<true> leaves it;
+                    // s_0 is still in me->s: this kernel only writes it back on success)
             me->mode = 1u;
             me->iters = 0u;
             me->len[0] = 0u;
             me->len[1] = 0u;
             me->cur = 2u;
-            // (s_0 is still in me->s: this kernel only writes it back on success)
             atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
         } else {
             me->s = s;
@@ -1872,11 +1984,12 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
     hipLaunchKernelGGL(k_octav_bracket, pairs, pb, 0, st, d_states, ctl, d_lh_cnt,
                        reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);
     if (max_iters > 0) {
-        hipLaunchKernelGGL(k_octav_gather, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
-                           d_bitmap, d_pair_base, d_list0);
-        hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock), 0, st, d_states, ctl, d_pair_order, d_lh_cnt,
-                           reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, d_pair_base, d_list0,
-                           max_iters);
+        hipLaunchKernelGGL(k_octav_gather, pg, pb, (size_t)kBlock * kQueueStride * sizeof(float), st, d_items,
+                           d_block_begin, d_seg_ptrs, d_states, d_bitmap, d_pair_base, d_list0);
+        hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock),
+                           (size_t)(kExactBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
+                           d_lh_cnt, reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, d_pair_base,
+                           d_list0, d_list1, max_iters);
         // 5. pairs the bracket could not serve (flat / degenerate distributions, values >= 2^14): compaction route
         hipLaunchKernelGGL(k_octav_compact_full, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
                            ctl, d_pair_base, d_list0);

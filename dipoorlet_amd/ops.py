@@ -124,12 +124,12 @@ class TensorSetPlan:
         return self._octav_scratch
 
     def octav_loghist_scratch(self):
-        """(count u32 [B*T, 2048], mantissa-sum u64 [B*T, 2048], bitmap u32 [B*T, 64]) for the bracket form."""
+        """(count u32 [B*T, 2048], mantissa-sum u64 [B*T, 2048], bitmap u32 [B*T, 66]) for the bracket form."""
         if getattr(self, "_octav_lh", None) is None:
             n = self.n_pairs
             self._octav_lh = (torch.empty(n, 2048, dtype=torch.int32, device=self.device),
                               torch.empty(n, 2048, dtype=torch.int64, device=self.device),
-                              torch.empty(n, 64, dtype=torch.int32, device=self.device))
+                              torch.empty(n, 66, dtype=torch.int32, device=self.device))
         return self._octav_lh
 
     def seg_table(self, tensors):

@@ -1035,9 +1035,13 @@ __device__ __forceinline__ double log_bin_scale(int b) {   // 2^(e - 150) for th
     return __longlong_as_double((long long)(e - 150 + 1023) << 52);
 }
 
+// One 64-bit LDS atomic per element: the bin word holds the count in bits 44..63 and the mantissa sum in bits
+// 0..43 (a sub-span has < 2^20 elements, a mantissa is < 2^24: neither field can overflow into the other).
+constexpr int kPackShift = 44;
+constexpr unsigned long long kPackMask = (1ull << kPackShift) - 1ull;
+
 struct LogHistOp {
-    uint32_t* cnt;
-    unsigned long long* msum;
+    unsigned long long* packed;
     float mn, mx;
     uint32_t nan, nz;
     double sum;
@@ -1050,10 +1054,8 @@ struct LogHistOp {
         sum += (double)a;
         const uint32_t u = __float_as_uint(a);
         const int b = log_bin(a);
-        if (b > 0) {  // bin 0 (zeros and |x| < 2^-18) is never needed: counts below come from n_elems
-            atomicAdd(cnt + b, 1u);
-            atomicAdd(msum + b, (unsigned long long)((u & 0x7FFFFFu) | 0x800000u));
-        }
+        if (b > 0)  // bin 0 (zeros and |x| < 2^-18) is never needed: counts below come from n_elems
+            atomicAdd(packed + b, (1ull << kPackShift) | (unsigned long long)((u & 0x7FFFFFu) | 0x800000u));
     }
 };
 
@@ -1063,9 +1065,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
                                                            dpl_octav_state* __restrict__ st,
                                                            uint32_t* __restrict__ lh_cnt,
                                                            unsigned long long* __restrict__ lh_sum) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long lds64[];
-    unsigned long long* l_sum = lds64;                       // kLogNB u64
-    uint32_t* l_cnt = reinterpret_cast<uint32_t*>(lds64 + kLogNB);  // kLogNB u32
+    extern __shared__ __attribute__((aligned(16))) unsigned long long l_packed[];  // kLogNB packed bins
     __shared__ double s_sum[kBlock / kWave];
     __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
     __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
@@ -1076,13 +1076,26 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
     for (uint32_t k = k0; k < k1; ++k) {
         const dpl_work_item it = items[k];
         dpl_octav_state* me = st + it.slot;
-        for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
-            l_cnt[b] = 0u;
-            l_sum[b] = 0ull;
-        }
+        for (int b = threadIdx.x; b < kLogNB; b += kBlock) l_packed[b] = 0ull;
         __syncthreads();
-        LogHistOp op{l_cnt, l_sum, INFINITY, -INFINITY, 0u, 0u, 0.0};
-        stream_span(segs[it.seg] + it.offset, it.count, op);
+        LogHistOp op{l_packed, INFINITY, -INFINITY, 0u, 0u, 0.0};
+        uint32_t* gc = lh_cnt + (uint64_t)it.slot * kLogNB;
+        unsigned long long* gs = lh_sum + (uint64_t)it.slot * kLogNB;
+        // sub-spans below 2^20 elements keep the packed count field from overflowing
+        constexpr uint32_t kSub = (1u << 20) - 4096u;
+        for (uint32_t s0 = 0; s0 < it.count; s0 += kSub) {
+            stream_span(segs[it.seg] + it.offset + s0, min(kSub, it.count - s0), op);
+            __syncthreads();
+            for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
+                const unsigned long long v = l_packed[b];
+                if (v) {
+                    atomicAdd(gc + b, (uint32_t)(v >> kPackShift));
+                    atomicAdd(gs + b, v & kPackMask);
+                    l_packed[b] = 0ull;
+                }
+            }
+            __syncthreads();
+        }
         const float mn = wave_min(op.mn), mx = wave_max(op.mx);
         const uint32_t nz = wave_sum(op.nz);
         const double sum = wave_sum(op.sum);
@@ -1114,15 +1127,6 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
                 atomicMax(&me->max_enc, enc_f32(tmx));
             }
             if (tnn) atomicOr(&me->nan_seen, 1u);
-        }
-        uint32_t* gc = lh_cnt + (uint64_t)it.slot * kLogNB;
-        unsigned long long* gs = lh_sum + (uint64_t)it.slot * kLogNB;
-        for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
-            const uint32_t c = l_cnt[b];
-            if (c) {
-                atomicAdd(gc + b, c);
-                atomicAdd(gs + b, l_sum[b]);
-            }
         }
         __syncthreads();
     }
@@ -1339,18 +1343,30 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
             cnt = 0;
         };
         for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t tile_base, bool full) {
+            // phase 1, branch-free: all 16 bitmap words are fetched back to back (one LDS wait for the tile)
+            float a[16];
+            uint32_t word[16];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float a4[4] = {fabsf(v[u].x), fabsf(v[u].y), fabsf(v[u].z), fabsf(v[u].w)};
+                a[4 * u + 0] = fabsf(v[u].x);
+                a[4 * u + 1] = fabsf(v[u].y);
+                a[4 * u + 2] = fabsf(v[u].z);
+                a[4 * u + 3] = fabsf(v[u].w);
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float a = a4[e];
-                    const bool real = full || (tile_base + u * 256 + lane * 4 + e < it.count);  // padding zeros are not data
-                    if (a >= rlo && a < rhi && real) {  // inside the span of marked bins: consult the bitmap
-                        const int b = log_bin(a);
-                        if ((bm[b >> 5] >> (b & 31)) & 1u) q[cnt++] = a;
-                    }
-                }
+            for (int j = 0; j < 16; ++j) word[j] = bm[log_bin(a[j]) >> 5];
+            uint32_t gm = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const bool real = full || (tile_base + (j >> 2) * 256 + lane * 4 + (j & 3) < it.count);  // padding is not data
+                const bool g = a[j] >= rlo && a[j] < rhi && real && ((word[j] >> (log_bin(a[j]) & 31)) & 1u);
+                gm |= g ? (1u << j) : 0u;
+            }
+            // phase 2: the (rare) survivors go to the lane's queue
+            if (__any(gm != 0u)) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if ((gm >> j) & 1u) q[cnt++] = a[j];
             }
             if (__any(cnt > (uint32_t)(kQueueCap - 16))) flush();
         });
@@ -1365,9 +1381,9 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
 // current bin are updated incrementally.  An iterate that lands in an unmarked bin, or moves down, sends the
 // pair to the compaction route.
 constexpr int kExactBlock = 256;
-constexpr int kExactRegs = 32;  // gathered values held per lane once the list is short (256 * 32 = 8 K)
+constexpr int kExactRegs = 16;  // gathered values held per lane once the list is short (256 * 16 = 4 K)
 
-__global__ __launch_bounds__(kExactBlock, 4) void k_octav_exact(dpl_octav_state* __restrict__ st,
+__global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state* __restrict__ st,
                                                               dpl_octav_state* __restrict__ ctl,
                                                               const uint32_t* __restrict__ pair_order,
                                                               const uint32_t* __restrict__ lh_cnt,
@@ -1979,7 +1995,7 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
     hipError_t e2 = hipMemsetAsync(d_lh_sum, 0, (size_t)n_pairs * kLogNB * sizeof(uint64_t), st);
     if (e1 != hipSuccess || e2 != hipSuccess) return fail("hipMemsetAsync", e1 != hipSuccess ? e1 : e2);
     // 1. statistics + log-scale histogram   2. s_0 and the bracket walk   3. gather the marked bins   4. exact walk
-    hipLaunchKernelGGL(k_octav_loghist, pg, pb, (size_t)kLogNB * 12, st, d_items, d_block_begin, d_seg_ptrs, d_states,
+    hipLaunchKernelGGL(k_octav_loghist, pg, pb, (size_t)kLogNB * 8, st, d_items, d_block_begin, d_seg_ptrs, d_states,
                        d_lh_cnt, reinterpret_cast<unsigned long long*>(d_lh_sum));
     hipLaunchKernelGGL(k_octav_bracket, pairs, pb, 0, st, d_states, ctl, d_lh_cnt,
                        reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);

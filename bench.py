@@ -7,7 +7,7 @@ resident in HBM:
     -A hist  (default, BASELINE configs[1]): range pass (k_minmax) + histogram pass (k_abs_hist) over the
              batch = both reads the algorithm inherently needs (212.79 MB / image algorithmic);
     -A minmax: range pass only (106.39 MB / image);   -A mse: OCTAV (106.39 MB / image credited).
-Default: B = 16, 64 steps = one whole N = 1024 calibration set.
+Default: B = 32, 32 steps = one whole N = 1024 calibration set per GPU.
 
 Prints ONE JSON line (rank 0).  `value` is whole-job images/s; `roofline` is for the dominant kernel
 (k_abs_hist for hist), its duration measured with HIP events on the launch stream inside the timed
@@ -37,9 +37,9 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s me
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=64)
+    p.add_argument("--steps", type=int, default=32)
     p.add_argument("--warmup", type=int, default=4)
-    p.add_argument("--batch", type=int, default=16, help="calibration images per step and per GPU")
+    p.add_argument("--batch", type=int, default=32, help="calibration images per step and per GPU")
     p.add_argument("--algo", choices=["hist", "minmax", "mse"], default="hist")
     p.add_argument("--bins", type=int, default=2048)
     p.add_argument("--pool", type=int, default=2, help="distinct resident batches cycled through")

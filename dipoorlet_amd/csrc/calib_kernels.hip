@@ -592,6 +592,7 @@ __global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int 
         if (me->done || me->mode == 2u) return;
         // list mode evaluates only the tail: everything not above s is below or equal (no NaN: those pairs are done)
         const unsigned long long cnt_le = me->mode == 1u ? me->n_elems - me->cnt_gt : me->cnt_le;
+        const float s_before = me->s;
         const OctavStep r = octav_step(me->sum, me->cnt_gt, cnt_le, me->unsigned_div, me->s, me->iters, max_iters);
         me->s = r.s;
         me->iters = r.iters;
@@ -604,6 +605,7 @@ __global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int 
         if (me->mode == 1u) {
             me->cur = (me->cur == 2u) ? 0u : 1u - me->cur;  // the freshly written list is the next source
             me->len[1u - me->cur] = 0u;                       // ... and the other one the next destination
+            me->reserved = __float_as_uint(s_before);         // ... which holds the values above the iterate it was built at
         }
     }
     me->sum = 0.0;
@@ -809,6 +811,8 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
     float s = me->s;
     uint32_t iters = me->iters, cur = me->cur, n = me->len[cur];
     uint32_t done = 0u, decreased = 0u;
+    // list[cur] holds exactly the values above the iterate it was produced at (kept by k_octav_update in `reserved`)
+    float s_floor_l = __uint_as_float(me->reserved);
     while (!done && !decreased) {
         const float* src = (cur == 0 ? list0 : list1) + base_off;
         float* dst = (cur == 0 ? list1 : list0) + base_off;
@@ -822,6 +826,7 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
                 const uint32_t idx = j * kIterBlock + threadIdx.x;
                 r[j] = idx < n ? g[idx] : 0.0f;  // zeros never exceed s >= 0
             }
+            const float floor_s = s_floor_l;  // every value above this is in the registers
             while (!done && !decreased) {
                 uint32_t c = 0;
                 float p0 = 0.0f, p1 = 0.0f;
@@ -853,7 +858,7 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
                 s = st2.s;
                 iters = st2.iters;
                 done = st2.done;
-                decreased = st2.decreased;
+                decreased = st2.decreased && !(st2.s >= floor_s);  // a dip is fine while nothing needed was dropped
                 __syncthreads();
             }
             break;
@@ -893,6 +898,7 @@ __global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_st
         __syncthreads();
         const OctavStep r = s_step;
         n = s_cursor;
+        s_floor_l = s;  // the list just written holds the values above the iterate it was evaluated at
         s = r.s;
         iters = r.iters;
         done = r.done;
@@ -1403,6 +1409,7 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
     __shared__ unsigned long long n_above;
     __shared__ int s_jb;
     __shared__ uint32_t s_bad;
+    __shared__ float s_floor;  // the list holds every gathered value above this (-inf: nothing dropped yet)
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
     dpl_octav_state* me = st + pair;
     if (me->done || me->mode != 2u) return;  // uniform per workgroup
@@ -1444,6 +1451,7 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
             s_above = ts;
             n_above = tn;
             s_jb = jb;
+            s_floor = -INFINITY;
             s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
         }
         __syncthreads();
@@ -1524,12 +1532,14 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
                 tg += scr_n[j];
                 ts += scr_s[j];
             }
+            if (!in_regs) s_floor = s;  // this pass compacted the list: values not above s are gone
             const OctavStep q = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
             s_step = q;
-            if (!q.done) {  // move the exact totals up to the new iterate's bin
+            if (!q.done) {  // move the exact totals to the new iterate's bin (up, or down while the values are kept)
                 const int jn = log_bin(q.s);
                 uint32_t nb = 0u;
-                if (q.decreased || jn < s_jb || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
+                // a smaller iterate can only be answered if nothing above it has been dropped from the list
+                if (!(q.s >= s_floor) || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
                     nb = 1u;
                 } else {
                     double sa = s_above;
@@ -1537,6 +1547,10 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
                     for (int b2 = s_jb + 1; b2 <= jn; ++b2) {
                         na -= gc[b2];
                         sa -= (double)gs[b2] * log_bin_scale(b2);
+                    }
+                    for (int b2 = jn + 1; b2 <= s_jb; ++b2) {
+                        na += gc[b2];
+                        sa += (double)gs[b2] * log_bin_scale(b2);
                     }
                     s_above = sa;
                     n_above = na;

@@ -71,7 +71,7 @@ typedef struct dpl_octav_state {
     uint64_t n_elems;   /* elements of the pair (counted by the first pass) */
     uint32_t len[2];    /* lengths of the two tail lists */
     uint32_t cur;       /* list holding the values above the previous iterate: 0, 1, or 2 = none yet */
-    uint32_t reserved;
+    uint32_t reserved;  /* compaction route: float bits of the iterate the current tail list was built at */
 } dpl_octav_state;
 
 int dpl_abi_version(void);

@@ -1407,7 +1407,7 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
     __shared__ OctavStep s_step;
     __shared__ double s_above;             // exact totals of the bins above the current one
     __shared__ unsigned long long n_above;
-    __shared__ int s_jb;
+    __shared__ int s_jb, s_jn;
     __shared__ uint32_t s_bad;
     __shared__ float s_floor;  // the list holds every gathered value above this (-inf: nothing dropped yet)
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
@@ -1451,6 +1451,7 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
             s_above = ts;
             n_above = tn;
             s_jb = jb;
+            s_jn = jb;
             s_floor = -INFINITY;
             s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
         }
@@ -1542,21 +1543,46 @@ __global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state*
                 if (!(q.s >= s_floor) || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
                     nb = 1u;
                 } else {
-                    double sa = s_above;
-                    unsigned long long na = n_above;
-                    for (int b2 = s_jb + 1; b2 <= jn; ++b2) {
-                        na -= gc[b2];
-                        sa -= (double)gs[b2] * log_bin_scale(b2);
-                    }
-                    for (int b2 = jn + 1; b2 <= s_jb; ++b2) {
-                        na += gc[b2];
-                        sa += (double)gs[b2] * log_bin_scale(b2);
-                    }
-                    s_above = sa;
-                    n_above = na;
-                    s_jb = jn;
+                    s_jn = jn;  // the totals are moved below, by the whole workgroup
                 }
                 s_bad = nb;
+            }
+        }
+        __syncthreads();
+        {   // move the exact totals from bin s_jb to bin s_jn: one bin per lane, a single memory round trip
+            const OctavStep q0 = s_step;
+            if (!q0.done && !s_bad && s_jn != s_jb) {
+                const int lo = s_jn < s_jb ? s_jn : s_jb, hi = s_jn < s_jb ? s_jb : s_jn;  // bins lo+1 .. hi change sides
+                double ds = 0.0;
+                unsigned long long dn = 0;
+                for (int b2 = lo + 1 + (int)threadIdx.x; b2 <= hi; b2 += kExactBlock) {
+                    dn += gc[b2];
+                    ds += (double)gs[b2] * log_bin_scale(b2);
+                }
+                ds = wave_sum(ds);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) dn += __shfl_xor(dn, o, kWave);
+                if (lane == 0) {
+                    scr_s[w] = ds;
+                    scr_n[w] = dn;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    double ts = 0.0;
+                    unsigned long long tn = 0;
+                    for (int j = 0; j < kWaves; ++j) {
+                        ts += scr_s[j];
+                        tn += scr_n[j];
+                    }
+                    if (s_jn > s_jb) {  // moved up: those bins are no longer "above"
+                        s_above -= ts;
+                        n_above -= tn;
+                    } else {
+                        s_above += ts;
+                        n_above += tn;
+                    }
+                    s_jb = s_jn;
+                }
             }
         }
         __syncthreads();

@@ -97,13 +97,16 @@ def main(argv=None):
         graph_after_wt = ONNXGraph.load(args.model, args.output_dir, args.deploy, args.model_type)
         weight_clip_val = find_clip_val_minmax_weight(graph_after_wt, args)
     if not args.skip_profiling:
-        from .profiling import quantize_profiling_multipass, show_model_profiling_res
+        from .profiling import (quantize_profiling_multipass, show_model_profiling_res, show_model_ranges,
+                                weight_need_perchannel)
         if rank == 0:
             logger.info("Profiling...")
         layer_cos, model_cos, qnodes = quantize_profiling_multipass(graph_after_wt, graph_ori, act_clip_val,
                                                                     weight_clip_val, args)
         if rank == 0:
             show_model_profiling_res(graph_after_wt, layer_cos, model_cos, qnodes, args)
+            show_model_ranges(graph_after_wt, act_clip_val, weight_clip_val, args)
+            weight_need_perchannel(graph_after_wt, args)
     if rank == 0:
         logger.info("Deploy to " + args.deploy + "...")
         to_deploy(graph_after_wt, act_clip_val, weight_clip_val, args)

@@ -21,6 +21,11 @@ import torch.distributed as dist
 
 
 def _backend():
+    """'nccl' (= RCCL on ROCm) whenever a GPU is visible, as the reference hard-codes (__main__.py:62); 'gloo'
+    otherwise.  DPL_DIST_BACKEND overrides (used to run two ranks on ONE GPU in tests: RCCL refuses that)."""
+    forced = os.environ.get("DPL_DIST_BACKEND")
+    if forced:
+        return forced
     return "nccl" if torch.cuda.is_available() and torch.cuda.device_count() > 0 else "gloo"
 
 
@@ -114,5 +119,10 @@ def gather_rows(rows, world_size):
     if not _active(world_size):
         return rows
     out = torch.empty((world_size * rows.shape[0],) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
-    dist.all_gather_into_tensor(out, rows.contiguous())
+    try:
+        dist.all_gather_into_tensor(out, rows.contiguous())
+    except (RuntimeError, NotImplementedError):  # a backend without the fused form (gloo with device tensors)
+        parts = [torch.empty_like(rows) for _ in range(world_size)]
+        dist.all_gather(parts, rows.contiguous())
+        out = torch.cat(parts)
     return out

@@ -127,3 +127,39 @@ def show_model_profiling_res(graph_after_wt, layer_cosine_dict, model_cosine_dic
             logger.info("{:40} avgcos : {:<.5f}    mincos : {:<.5f}".format(name, *model_cosine_dict[name]))
         else:
             logger.info("{:40} tolcos : {:<.5f}".format(name, model_cosine_dict[name][0]))
+
+
+def show_model_ranges(graph, act_clip_val, weight_clip_val, args):
+    """profiling.py:210-224 — log every activation / weight range with its tensor shape."""
+    from .platform_settings import platform_setting_table
+    logger.info("Model ranges:")
+    ranges_all = act_clip_val.copy()
+    ranges_all.update(weight_clip_val)
+    per_channel = "per channel " if platform_setting_table[args.deploy]["qw_params"].get("per_channel", False) else ""
+    for name, rng in ranges_all.items():
+        shape = str(graph.tensor_name_shape_map.get(name))
+        if isinstance(rng[0], np.ndarray) and rng[0].ndim > 0:
+            logger.info("{:<30} Shape: {:<20} Range: {}[{:<10f} {:<10f}]".format(name, shape, per_channel,
+                                                                                 rng[0].min(), rng[1].max()))
+        else:
+            logger.info("{:<30} Shape: {:<20} Range: [{:<10f} {:<10f}]".format(name, shape, float(rng[0]), float(rng[1])))
+
+
+def weight_need_perchannel(graph, args):
+    """profiling.py:227-243 — for per-tensor weight platforms, rank Conv layers by mean per-channel range /
+    per-layer range (a small ratio means per-layer quantisation wastes most of the grid on that layer)."""
+    import heapq
+
+    from .platform_settings import platform_setting_table
+    if platform_setting_table[args.deploy]["qw_params"].get("per_channel", False):
+        return
+    logger.info("Layer degradate by per layer: ")
+    heap = []
+    for node in graph.graph.node:
+        if node.op_type == "Conv":
+            w = np.asarray(graph.get_initializer(node.input[1]))
+            w2 = w.reshape(w.shape[0], -1)
+            ratio = (w2.max(-1) - w2.min(-1)).mean() / (w.max() - w.min())
+            heapq.heappush(heap, (float(ratio), node.name))
+    for ratio, name in heapq.nsmallest(len(heap), heap):
+        logger.info("{:40} ratio : {:<.5f}".format(name, ratio))

@@ -25,7 +25,10 @@
 namespace {
 
 constexpr int kBlock = 256;   // 4 waves of 64
-constexpr int kUnroll = 4;    // float4 loads in flight per lane
+#ifndef DPL_UNROLL
+#define DPL_UNROLL 4
+#endif
+constexpr int kUnroll = DPL_UNROLL;    // float4 loads per lane per register set (two sets are in flight)
 constexpr int kWave = 64;
 using f4 = __attribute__((ext_vector_type(4))) float;  // native vector: nontemporal builtins need it
 

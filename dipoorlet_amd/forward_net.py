@@ -48,15 +48,15 @@ def input_data_generator(input_dir, input_name_list, data_st_idx, data_ed_idx):
         yield {n: np.fromfile(f"{input_dir}/{n}/{idx}.bin", "float32") for n in input_name_list}
 
 
-def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
-    """Images [idx0, idx1) of every network input as device tensors [B, *shape[1:]]: files are read
-    into one pinned staging buffer per input and copied with a single async H2D transfer."""
+def stage_input_batch(input_dir, input_names, shapes, idx0, idx1, pinned):
+    """HOST: images [idx0, idx1) of every network input read into one (pinned) staging tensor per input.
+    Returns {name: (host tensor [b, per_image], device shape)}."""
     out = {}
     b = idx1 - idx0
     for n in input_names:
         shape = tuple(int(d) for d in shapes[n])
         per = int(np.prod(shape))
-        stage = torch.empty((b, per), dtype=torch.float32, pin_memory=device.type == "cuda")
+        stage = torch.empty((b, per), dtype=torch.float32, pin_memory=pinned)
         sv = stage.numpy()
         for j, idx in enumerate(range(idx0, idx1)):
             a = np.fromfile(f"{input_dir}/{n}/{idx}.bin", "float32")
@@ -65,8 +65,15 @@ def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
             sv[j] = a
         lead = shape[0] if len(shape) > 0 else 1
         full = (b * lead,) + shape[1:] if len(shape) > 1 else (b * per,)
-        out[n] = stage.to(device, non_blocking=True).reshape(full)
+        out[n] = (stage, full)
     return out
+
+
+def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
+    """Images [idx0, idx1) of every network input as device tensors [B, *shape[1:]]: files are read
+    into one pinned staging buffer per input and copied with a single async H2D transfer."""
+    staged = stage_input_batch(input_dir, input_names, shapes, idx0, idx1, device.type == "cuda")
+    return {n: h.to(device, non_blocking=True).reshape(full) for n, (h, full) in staged.items()}
 
 
 class CalibrationRun:
@@ -105,23 +112,50 @@ class CalibrationRun:
             yield i, j
             i = j
 
+    def _input_batches(self):
+        """(b, {input: device tensor}) per batch; the .bin files of the NEXT batch are read into pinned memory by
+        a helper thread while the GPU works on the current one (file I/O releases the GIL)."""
+        import queue
+        import threading
+        shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
+        bounds = list(self.batches())
+        if not bounds:
+            return
+        q = queue.Queue(maxsize=2)
+
+        def reader():
+            try:
+                for i, j in bounds:
+                    q.put((j - i, stage_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j,
+                                                    self.device.type == "cuda")))
+            except BaseException as e:  # surfaced in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=reader, daemon=True)
+        t.start()
+        for _ in bounds:
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            b, staged = item
+            yield b, {n: h.to(self.device, non_blocking=True).reshape(full) for n, (h, full) in staged.items()}
+        t.join()
+
     def forward(self, keep=False):
         """Yields (b, tensors) per batch.  With keep=True the tensor sets stay resident in HBM (up to
         args.resident_gb) so a second pass re-reads them instead of re-running the network."""
-        shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
-        for i, j in self.batches():
-            inputs = load_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, self.device)
+        for b, inputs in self._input_batches():
             tensors = self.session.run(inputs)
             if keep and self._resident_ok:
                 nbytes = sum(t.numel() * 4 for t in tensors)
                 if self._resident_bytes + nbytes <= self._budget:
-                    self._resident.append((j - i, tensors))
+                    self._resident.append((b, tensors))
                     self._resident_bytes += nbytes
                 else:
                     self._resident_ok = False
                     self._resident = []
                     self._resident_bytes = 0
-            yield j - i, tensors
+            yield b, tensors
 
     def second_pass(self):
         if self._resident_ok and self._resident:

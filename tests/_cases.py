@@ -10,7 +10,7 @@ import zlib
 
 import numpy as np
 
-KINDS = ("normal", "relu", "laplace", "uniform", "zeros", "spike", "edges", "neg_only", "tiny")
+KINDS = ("normal", "relu", "laplace", "uniform", "zeros", "spike", "edges", "neg_only", "tiny", "with_nan")
 SIZES = (1000, 2048, 25088, 150528, 802816)
 
 
@@ -48,6 +48,9 @@ def make_tensor(kind, n, seed):
     elif kind == "tiny":  # data_min within 1e-6 of zero (dynamic_sym trigger), small magnitudes
         x = np.abs(rng.standard_normal(n, dtype=np.float32)) * np.float32(1e-2)
         x[1] = np.float32(3e-7)
+    elif kind == "with_nan":  # numpy max/min propagate it; np.histogram then refuses the range
+        x = rng.standard_normal(n, dtype=np.float32)
+        x[rng.integers(0, n, 3)] = np.float32(np.nan)
     else:
         raise ValueError(kind)
     return np.ascontiguousarray(x, dtype=np.float32)

@@ -105,9 +105,9 @@ def kernel_level(fn, ba):
     out = {}
     meta = []
     cases = []
-    for kind in ("normal", "relu", "laplace", "uniform", "zeros", "spike", "edges", "neg_only", "tiny"):
+    for kind in ("normal", "relu", "laplace", "uniform", "zeros", "spike", "edges", "neg_only", "tiny", "with_nan"):
         for n in SIZES:
-            if kind in ("zeros", "neg_only", "tiny") and n > 25088:
+            if kind in ("zeros", "neg_only", "tiny", "with_nan") and n > 25088:
                 continue
             if kind in ("laplace", "uniform", "spike") and n in (2048, 150528):
                 continue
@@ -130,6 +130,14 @@ def kernel_level(fn, ba):
             args = mk_args(input_dir=td)
             mm = fn.forward_get_minmax(g, args)
             out[f"{key}/minmax"] = np.array([mm["input"]["min"][0], mm["input"]["max"][0]], np.float32)
+            if kind == "with_nan":  # the reference's histogram pass raises on a NaN range: record that, no vectors
+                try:
+                    fn.forward_get_hist(g, mm, mk_args(input_dir=td))
+                    raised = False
+                except ValueError:
+                    raised = True
+                meta.append({"key": key, "kind": kind, "n": n, "seed": seed, "crc": checksum(x), "hist_raises": raised})
+                continue
             for bins in (2048, 1000):
                 for scale in (1.0, 1.5):
                     st = {"input": {"max": [np.float32(mm["input"]["max"][0] * np.float32(scale))],
@@ -167,6 +175,7 @@ def pipeline_level(fn, ba, ut):
             ("hist", "snpe", 1000, 0.999, 1), ("hist", "trt", 2048, 0.99999, 3),
             ("mse", "trt", 2048, 0.99999, 1), ("mse", "ti", 2048, 0.99999, 1),
             ("mse", "trt", 2048, 0.99999, 2), ("mse", "ti", 2048, 0.99999, 4),
+            ("minmax", "trt", 2048, 0.99999, 8), ("hist", "trt", 2048, 0.99999, 8), ("mse", "trt", 2048, 0.99999, 8),
         ]:
             run = {"algo": algo, "deploy": deploy, "bins": bins, "threshold": thr, "world_size": world,
                    "ranks": []}

@@ -33,7 +33,11 @@ def test_minmax_bit_exact(kl):
     for c in meta["cases"]:
         x = make_tensor(c["kind"], c["n"], c["seed"])
         lo, hi = O.minmax(x)
-        assert np.array_equal(_bits([lo, hi]), _bits(g[c["key"] + "/minmax"])), c["key"]
+        ref = g[c["key"] + "/minmax"]
+        if c["kind"] == "with_nan":
+            assert np.isnan(ref).all() and np.isnan([lo, hi]).all()  # numpy max / min propagate NaN
+        else:
+            assert np.array_equal(_bits([lo, hi]), _bits(ref)), c["key"]
 
 
 def test_abs_hist_bit_exact_and_percentile(kl):
@@ -41,6 +45,11 @@ def test_abs_hist_bit_exact_and_percentile(kl):
     for c in meta["cases"]:
         x = make_tensor(c["kind"], c["n"], c["seed"])
         gmin0, gmax0 = g[c["key"] + "/minmax"]
+        if c["kind"] == "with_nan":  # the reference's histogram pass raises on the NaN range; so does the oracle
+            assert c["hist_raises"]
+            with pytest.raises(ValueError):
+                O.abs_hist(x, 2048, O.hist_dmax(gmin0, gmax0))
+            continue
         for bins in (2048, 1000):
             for scale in (1.0, 1.5):
                 gmin, gmax = np.float32(gmin0 * np.float32(scale)), np.float32(gmax0 * np.float32(scale))
@@ -175,6 +184,12 @@ def test_c_oracle_bit_exact_against_goldens(kl):
     for c in meta["cases"]:
         x = make_tensor(c["kind"], c["n"], c["seed"])
         gmin0, gmax0 = g[c["key"] + "/minmax"]
+        if c["kind"] == "with_nan":
+            assert np.isnan(CO.minmax(x)).all()
+            with pytest.raises(ValueError):
+                CO.abs_hist(x, 2048, O.hist_dmax(gmin0, gmax0))
+            assert np.isnan(CO.octav_scale(x, 1))
+            continue
         assert np.array_equal(_bits(CO.minmax(x)), _bits([gmin0, gmax0])), c["key"]
         for bins in (2048, 1000):
             for scale in (1.0, 1.5):

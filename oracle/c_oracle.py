@@ -10,11 +10,31 @@ _SO = os.path.join(_HERE, "_build", "liboracle.so")
 _lib = None
 
 
+def _cpu_tag():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "c_oracle.c")):
+        # built with -march=native: rebuild when the library came from another machine (the build container's
+        # .so travels to the GPU box with the snapshot) or is older than the source
+        tag_file = os.path.join(_HERE, "_build", "cpu.txt")
+        tag = _cpu_tag()
+        stale = (not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "c_oracle.c"))
+                 or not os.path.exists(tag_file) or open(tag_file).read() != tag)
+        if stale:
+            subprocess.run(["make", "-s", "-C", _HERE, "clean"], check=True)
             subprocess.run(["make", "-s", "-C", _HERE], check=True)
+            with open(tag_file, "w") as f:
+                f.write(tag)
         l = C.CDLL(_SO)
         l.dplo_minmax.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_float)]
         l.dplo_abs_hist.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_void_p]

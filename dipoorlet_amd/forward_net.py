@@ -257,10 +257,52 @@ forward_get_hist_transformer = forward_get_hist
 forward_net_octav_transformer = forward_net_octav
 
 
+class ActivationCache:
+    """Counterpart of forward_net.py:23-190 for callers that want activations by tensor name.
+
+    The reference splits the network into single-node ONNX models, runs one ORT session per node and keeps
+    every image's activation of every live tensor on the HOST, evicting by reference count.  Here one batched
+    forward of the shard keeps all calibration tensors resident in HBM (288 GB: 1024 ResNet-50 images are
+    109 GB) and `cache[name]` returns the list of per-image device tensors (views, no copies), `cache[initializer]`
+    the initializer array.  `reset()` drops the cached activations."""
+
+    def __init__(self, graph, args, st=None, ed=None):
+        self.graph, self.args = graph, args
+        self.st = 0 if st is None else st
+        self.ed = args.data_num if ed is None else ed
+        self.activation_cache = {}
+        self._filled = False
+
+    def reset(self):
+        self.activation_cache.clear()
+        self._filled = False
+
+    def _fill(self):
+        sess = self.graph.make_session(self.args)
+        dev = sess.device if hasattr(sess, "device") else torch.device("cuda", torch.cuda.current_device())
+        shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
+        batch = int(getattr(self.args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
+        per_name = {n: [] for n in sess.tensor_names}
+        for i in range(self.st, self.ed, batch):
+            j = min(i + batch, self.ed)
+            inputs = load_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, dev)
+            for n, t in zip(sess.tensor_names, sess.run(inputs)):
+                per_name[n].extend(t[k] for k in range(j - i))
+        self.activation_cache = per_name
+        self._filled = True
+
+    def __getitem__(self, tensor_name):
+        if tensor_name in getattr(self.graph, "initializer", {}):
+            return self.graph.get_initializer(tensor_name)
+        if not self._filled:
+            self._fill()
+        return self.activation_cache[tensor_name]
+
+
 def log_forward_time(seconds):
     logger.info("Forward time: {:.2f} seconds".format(seconds))
 
 
-__all__ = ["ActivationSession", "CalibrationRun", "input_data_generator", "load_input_batch", "forward_get_minmax",
+__all__ = ["ActivationSession", "ActivationCache", "CalibrationRun", "input_data_generator", "load_input_batch", "forward_get_minmax",
            "forward_get_hist", "forward_net_octav", "forward_get_minmax_transformer", "forward_get_hist_transformer",
            "forward_net_octav_transformer", "hist_pass", "DEFAULT_BATCH"]

@@ -237,3 +237,18 @@ def test_vit_calibration_mse_and_cli_bc(tmp_path):
                str(tmp_path / "out"), "--calib_batch", "4", "--bc"])
     assert rc == 0
     assert os.path.exists(tmp_path / "out" / "update_bias_model.onnx") and os.path.exists(tmp_path / "out" / "trt_clip_val.json")
+
+
+def test_activation_cache_by_name(workdir, activations):
+    import types
+
+    from dipoorlet_amd.forward_net import ActivationCache
+    g, acts = activations
+    args = types.SimpleNamespace(input_dir=str(workdir / "calib"), data_num=N, calib_batch=BATCH)
+    cache = ActivationCache(g, args, 2, 7)
+    t = cache["layer1.0.add_out"]
+    assert len(t) == 5 and t[0].is_cuda and tuple(t[0].shape) == tuple(g.get_tensor_shape("layer1.0.add_out")[1:])
+    assert np.allclose(t[0].cpu().numpy().ravel(), acts["layer1.0.add_out"][2], rtol=1e-4, atol=1e-5)
+    assert cache["conv1.weight"].shape == (64, 3, 7, 7)
+    cache.reset()
+    assert not cache.activation_cache

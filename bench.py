@@ -226,7 +226,7 @@ def main():
                    "chunk_elems": plan.chunk, "device": devname},
         "algorithmic_GBps_job": bytes_per_img * images / dt / 1e9,
         "roofline": {"bound": "hbm", "kernel": {"hist": "k_abs_hist", "minmax": "k_minmax",
-                                               "mse": "k_octav_pass (all rounds)"}[a.algo],
+                                               "mse": "octav_batch (k_octav_loghist + bracket + gather + exact)"}[a.algo],
                      "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                      "traffic": traffic, "bytes_per_launch": kernel_bytes, "avg_kernel_ms": kern_ms},
     }

@@ -9,8 +9,8 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, "calib_kernels.hip")]
-HDR = os.path.join(HERE, "..", "..", "include", "dipoorlet_hip.h")
+SRC = [os.path.join(HERE, f) for f in ("calib_kernels.hip", "octav_kernels.hip")]
+HDR = [os.path.join(HERE, "..", "..", "include", "dipoorlet_hip.h"), os.path.join(HERE, "common.hpp")]
 OUT = os.path.join(HERE, "libdipoorlet_hip.so")
 
 
@@ -25,7 +25,7 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(f) > t for f in SRC + [HDR, os.path.abspath(__file__)])
+    return any(os.path.getmtime(f) > t for f in SRC + HDR + [os.path.abspath(__file__)])
 
 
 def build(force=False, verbose=False):
@@ -33,6 +33,7 @@ def build(force=False, verbose=False):
         return OUT
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-fno-fast-math", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-o", OUT] + SRC
+    cmd += os.environ.get("DPL_HIPCC_EXTRA", "").split()  # tuning knobs (-DDPL_...=N), see scripts/variant_bench.sh
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

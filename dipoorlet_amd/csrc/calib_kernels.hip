@@ -8,14 +8,7 @@
 //   * histograms privatised in LDS (ds_add_u32), exact zeros counted in registers (ReLU outputs are
 //     ~50 % zeros and would otherwise serialise on one LDS address), one flush per workgroup;
 //   * order-encoded integer atomics for fp32 min/max, so accumulators persist across launches.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <string.h>
-#include <stdio.h>
-#include <math.h>
-#include <stdlib.h>
-
-#include "../../include/dipoorlet_hip.h"
+#include "common.hpp"
 
 // Bit-exact numpy parity needs every fp32 operation rounded on its own: HIP's default
 // -ffp-contract=fast would fuse i*step + first into one FMA (__fmul_rn/__fadd_rn are plain * and +
@@ -23,134 +16,6 @@
 #pragma clang fp contract(off)
 
 namespace {
-
-constexpr int kBlock = 256;   // 4 waves of 64
-#ifndef DPL_UNROLL
-#define DPL_UNROLL 4
-#endif
-constexpr int kUnroll = DPL_UNROLL;    // float4 loads per lane per register set (two sets are in flight)
-constexpr int kWave = 64;
-using f4 = __attribute__((ext_vector_type(4))) float;  // native vector: nontemporal builtins need it
-
-thread_local char g_err[512] = "";
-
-int fail(const char* what, hipError_t e) {
-    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
-    return -1;
-}
-int fail_msg(const char* what) {
-    snprintf(g_err, sizeof(g_err), "%s", what);
-    return -2;
-}
-#define DPL_LAUNCH_CHECK(name)                              \
-    do {                                                    \
-        hipError_t e__ = hipGetLastError();                 \
-        if (e__ != hipSuccess) return fail(name, e__);      \
-    } while (0)
-
-// ---------------------------------------------------------------- fp32 <-> order-preserving u32
-__host__ __device__ inline uint32_t enc_f32(float f) {
-    uint32_t b;
-    memcpy(&b, &f, 4);
-    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
-__host__ __device__ inline float dec_f32(uint32_t u) {
-    uint32_t b = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
-    float f;
-    memcpy(&f, &b, 4);
-    return f;
-}
-
-// ---------------------------------------------------------------- wave / block reductions
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, kWave));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, kWave));
-    return v;
-}
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
-}
-
-// ---------------------------------------------------------------- the streaming skeleton
-// Applies op(float) to every element of p[0..n).  Scalar head up to 16-B alignment, float4 body with
-// kUnroll independent loads per lane (each wave instruction covers 1 KiB contiguous), scalar tail.
-// Pointers fetched from the segment table are generic to the compiler; casting to address space 1
-// makes the loads global_load_dwordx4 (flat loads would also tick the LDS counter and stall ds ops).
-typedef const __attribute__((address_space(1))) f4* gptr_f4;
-typedef const __attribute__((address_space(1))) float* gptr_f32;
-
-template <class Op>
-__device__ __forceinline__ void stream_span(const float* __restrict__ p_generic, uint32_t n, Op& op) {
-    const uint32_t tid = threadIdx.x;
-    gptr_f32 p = (gptr_f32)p_generic;
-    uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)p_generic & 15u)) & 15u) >> 2);
-    if (head > n) head = n;
-    if (tid < head) op(p[tid]);
-    p += head;
-    n -= head;
-    const uint32_t nvec = n >> 2;
-    gptr_f4 pv = (gptr_f4)p;
-    uint32_t i = tid;
-    constexpr uint32_t kStride = kUnroll * kBlock;
-    // software pipeline: the next kUnroll loads are issued before the current ones are consumed, so a wave
-    // always has 4-8 KiB in flight and few waves per SIMD suffice (fewer, larger work items stream
-    // measurably faster from HBM than many small ones)
-    // (ping-pong register sets A/B, loop unrolled by two: a register copy nxt -> cur would make the compiler
-    // wait for the loads it just issued)
-#define DPL_LOAD(buf, base)                                                                       \
-    _Pragma("unroll") for (int u = 0; u < kUnroll; ++u) buf[u] = __builtin_nontemporal_load(pv + (base) + u * kBlock)
-#define DPL_EAT(buf)                                 \
-    _Pragma("unroll") for (int u = 0; u < kUnroll; ++u) { \
-        op(buf[u].x);                                \
-        op(buf[u].y);                                \
-        op(buf[u].z);                                \
-        op(buf[u].w);                                \
-    }
-    if (i + (kUnroll - 1) * kBlock < nvec) {
-        f4 A[kUnroll], B[kUnroll];
-        DPL_LOAD(A, i);
-        i += kStride;
-        for (;;) {
-            if (!(i + (kUnroll - 1) * kBlock < nvec)) {
-                DPL_EAT(A);
-                break;
-            }
-            DPL_LOAD(B, i);
-            i += kStride;
-            DPL_EAT(A);
-            if (!(i + (kUnroll - 1) * kBlock < nvec)) {
-                DPL_EAT(B);
-                break;
-            }
-            DPL_LOAD(A, i);
-            i += kStride;
-            DPL_EAT(B);
-        }
-    }
-#undef DPL_LOAD
-#undef DPL_EAT
-    for (; i < nvec; i += kBlock) {
-        f4 v = __builtin_nontemporal_load(pv + i);
-        op(v.x);
-        op(v.y);
-        op(v.z);
-        op(v.w);
-    }
-    const uint32_t t = (nvec << 2) + tid;
-    if (t < n) op(p[t]);
-}
 
 // ================================================================ K1: running min / max
 struct MinMaxOp {
@@ -162,18 +27,6 @@ struct MinMaxOp {
         nan |= (x != x);
     }
 };
-
-// Work distribution shared by the streaming kernels: block b owns items [bb[b], bb[b+1]) (a balanced,
-// contiguous share of the launch's elements, dpl_build_balanced_items) or, when bb is null, item b alone.
-__device__ __forceinline__ void block_items(const uint32_t* __restrict__ bb, uint32_t& k0, uint32_t& k1) {
-    if (bb) {
-        k0 = bb[blockIdx.x];
-        k1 = bb[blockIdx.x + 1];
-    } else {
-        k0 = blockIdx.x;
-        k1 = k0 + 1;
-    }
-}
 
 __global__ __launch_bounds__(kBlock) void k_minmax(const dpl_work_item* __restrict__ items,
                                                     const uint32_t* __restrict__ bb,
@@ -441,1183 +294,6 @@ __global__ __launch_bounds__(kWave) void k_hist_percentile(const uint64_t* __res
     }
 }
 
-// ================================================================ K3: OCTAV (forward_net.py:315-330)
-struct OctavFirstOp {
-    float mn, mx;
-    uint32_t nan, nz;
-    double sum;
-    __device__ __forceinline__ void operator()(float x) {
-        mn = fminf(mn, x);
-        mx = fmaxf(mx, x);
-        nan |= (x != x);
-        const float a = fabsf(x);
-        nz += (a > 0.0f);
-        sum += (double)a;
-    }
-};
-struct OctavIterOp {
-    float s;
-    uint32_t gt, le;
-    double sum;
-    __device__ __forceinline__ void operator()(float x) {
-        const float a = fabsf(x);
-        const bool g = a > s;
-        gt += g;
-        le += (a <= s);
-        sum += g ? (double)a : 0.0;
-    }
-};
-
-template <bool kFirst>
-__global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __restrict__ items,
-                                                        const uint32_t* __restrict__ bb,
-                                                        const float* const* __restrict__ segs,
-                                                        dpl_octav_state* __restrict__ st,
-                                                        const dpl_octav_state* __restrict__ ctl) {
-    // ctl (the extra state slot behind the pairs) counts the pairs in full-pass mode: nothing to do when 0
-    if (!kFirst && ctl && ctl->cnt_gt == 0ull) return;
-    __shared__ double s_sum[kBlock / kWave];
-    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
-    __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
-    const int w = threadIdx.x / kWave;
-    const bool lead = (threadIdx.x & (kWave - 1)) == 0;
-    uint32_t k0, k1;
-    block_items(bb, k0, k1);
-    for (uint32_t k = k0; k < k1; ++k) {
-        const dpl_work_item it = items[k];
-        dpl_octav_state* me = st + it.slot;
-        const float* p = segs[it.seg] + it.offset;
-        if (kFirst) {
-            OctavFirstOp op{INFINITY, -INFINITY, 0u, 0u, 0.0};
-            stream_span(p, it.count, op);
-            const float mn = wave_min(op.mn), mx = wave_max(op.mx);
-            const uint32_t nz = wave_sum(op.nz);
-            const double sum = wave_sum(op.sum);
-            const uint32_t nn = __any(op.nan) ? 1u : 0u;
-            if (lead) {
-                s_sum[w] = sum;
-                s_a[w] = nz;
-                s_b[w] = nn;
-                s_mn[w] = mn;
-                s_mx[w] = mx;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double tsum = 0.0;
-                uint32_t tnz = 0, tnn = 0;
-                float tmn = INFINITY, tmx = -INFINITY;
-                for (int j = 0; j < kBlock / kWave; ++j) {
-                    tsum += s_sum[j];
-                    tnz += s_a[j];
-                    tnn |= s_b[j];
-                    tmn = fminf(tmn, s_mn[j]);
-                    tmx = fmaxf(tmx, s_mx[j]);
-                }
-                atomicAdd(&me->sum, tsum);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)it.count);
-                if (tmn <= tmx) {
-                    atomicMin(&me->min_enc, enc_f32(tmn));
-                    atomicMax(&me->max_enc, enc_f32(tmx));
-                }
-                if (tnn) atomicOr(&me->nan_seen, 1u);
-            }
-        } else {
-            if (me->done || me->mode == 1u) continue;  // uniform per workgroup; list-mode pairs: k_octav_compact_*
-            OctavIterOp op{me->s, 0u, 0u, 0.0};
-            stream_span(p, it.count, op);
-            const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
-            const double sum = wave_sum(op.sum);
-            if (lead) {
-                s_sum[w] = sum;
-                s_a[w] = gt;
-                s_b[w] = le;
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                double tsum = 0.0;
-                uint32_t tgt = 0, tle = 0;
-                for (int j = 0; j < kBlock / kWave; ++j) {
-                    tsum += s_sum[j];
-                    tgt += s_a[j];
-                    tle += s_b[j];
-                }
-                if (tgt) {
-                    atomicAdd(&me->sum, tsum);
-                    atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tgt);
-                }
-                if (tle) atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_le), (unsigned long long)tle);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// One fixed-point step (forward_net.py:326-330): s' = fl32(sum) / fl32(c/unsigned * cnt_le + cnt_gt) — the python-float
-// denominator is cast to float32 for the divide (NEP 50); |s' - s| < 1e-6 stops KEEPING the previous s.
-struct OctavStep {
-    float s;
-    uint32_t iters, done, decreased;
-};
-__device__ __forceinline__ OctavStep octav_step(double sum, unsigned long long cnt_gt, unsigned long long cnt_le,
-                                                float unsigned_div, float s, uint32_t iters, int max_iters) {
-    const double c = 1.0 / 65536.0 / 3.0 / (double)unsigned_div;
-    const double denom = c * (double)(long long)cnt_le + (double)(long long)cnt_gt;
-    const float s1 = __fdiv_rn((float)sum, (float)denom);
-    OctavStep r{s, iters, 0u, 0u};
-    if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
-        r.done = 1u;
-    } else {
-        r.decreased = !(s1 >= s) ? 1u : 0u;
-        r.s = s1;
-        r.iters = iters + 1u;
-        if ((int)r.iters >= max_iters || s1 != s1) r.done = 1u;
-    }
-    return r;
-}
-
-template <bool kFirst>
-__global__ void k_octav_update(dpl_octav_state* __restrict__ st, int64_t n, int dynamic_sym, int max_iters,
-                               dpl_octav_state* __restrict__ ctl) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    dpl_octav_state* me = st + i;
-    if (kFirst) {
-        const float mn = dec_f32(me->min_enc);
-        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
-        me->unsigned_div = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
-        // forward_net.py:324 — s_n = abs_x.sum() / abs_x[abs_x > 0].size   (float32 / int)
-        const float s0 = __fdiv_rn((float)me->sum, (float)(long long)me->cnt_gt);
-        me->s = s0;
-        me->iters = 0u;
-        me->done = (s0 != s0 || max_iters <= 0) ? 1u : 0u;  // NaN is a fixed point of the iteration
-    } else {
-        if (me->done || me->mode == 2u) return;
-        // list mode evaluates only the tail: everything not above s is below or equal (no NaN: those pairs are done)
-        const unsigned long long cnt_le = me->mode == 1u ? me->n_elems - me->cnt_gt : me->cnt_le;
-        const float s_before = me->s;
-        const OctavStep r = octav_step(me->sum, me->cnt_gt, cnt_le, me->unsigned_div, me->s, me->iters, max_iters);
-        me->s = r.s;
-        me->iters = r.iters;
-        me->done = r.done;
-        // the list just written holds the values above the old s: it cannot answer for a smaller threshold
-        if (me->mode == 1u && r.decreased && !r.done) {
-            me->mode = 0u;
-            if (ctl) atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_gt), 1ull);
-        }
-        if (me->mode == 1u) {
-            me->cur = (me->cur == 2u) ? 0u : 1u - me->cur;  // the freshly written list is the next source
-            me->len[1u - me->cur] = 0u;                       // ... and the other one the next destination
-            me->reserved = __float_as_uint(s_before);         // ... which holds the values above the iterate it was built at
-        }
-    }
-    me->sum = 0.0;
-    me->cnt_gt = 0ull;
-    me->cnt_le = 0ull;
-}
-
-// ---------------------------------------------------------------- OCTAV with tail compaction
-// The iterates climb (s_{k+1} >= s_k while below the fixed point), so evaluation k only needs the values
-// above s_{k-1}.  The first evaluation reads the full data once and writes the values above s_0; each later
-// one reads the previous list and writes the next, and the lists shrink ~2.5x per step.  Exactly the same
-// iterate sequence as the full-pass form; a pair whose iterate ever decreases drops back to full passes.
-constexpr int kStageCap = 2048;  // floats of LDS staging per wave
-
-struct TailAcc {
-    uint32_t gt;  // wave-uniform: survivors this wave has seen
-    double sum;   // per lane
-};
-
-// One wave, one 1024-element tile in registers: survivors (|x| > s) go to the wave's LDS stage.
-// Per element column j: the wave's ballot gives every surviving lane its slot (v_mbcnt) and the stage
-// cursor advances by the population count on the scalar unit — no cross-lane scan, conflict-free writes.
-// Values are summed in fp32 over the lane's 16 elements, then added to the fp64 accumulator (at least as
-// accurate as numpy's blocked fp32 pairwise sum).
-template <int kCap = kStageCap, class FlushFn>
-__device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stage, uint32_t& fill, TailAcc& acc,
-                                          FlushFn&& flush) {
-    if (fill + 1024u > (uint32_t)kCap) flush();  // wave-uniform
-    float a[16];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        a[4 * u + 0] = fabsf(v[u].x);
-        a[4 * u + 1] = fabsf(v[u].y);
-        a[4 * u + 2] = fabsf(v[u].z);
-        a[4 * u + 3] = fabsf(v[u].w);
-    }
-    float part = 0.0f;
-    const uint32_t fill0 = fill;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const bool g = a[j] > s;
-        const unsigned long long m = __ballot(g);
-        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (g) stage[fill + off] = a[j];
-        fill += (uint32_t)__popcll(m);
-        part += g ? a[j] : 0.0f;
-    }
-    acc.gt += fill - fill0;
-    acc.sum += (double)part;
-}
-
-__device__ __forceinline__ void load_tile(const float* __restrict__ p_generic, uint32_t base, uint32_t n, bool aligned,
-                                          f4 (&v)[4]) {
-    gptr_f32 p = (gptr_f32)p_generic;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t idx = base + u * 256 + lane * 4;
-        if (aligned && idx + 3 < n) {
-            v[u] = __builtin_nontemporal_load((gptr_f4)(p + idx));
-        } else {  // zeros never survive (s >= 0)
-            v[u].x = idx + 0 < n ? p[idx + 0] : 0.0f;
-            v[u].y = idx + 1 < n ? p[idx + 1] : 0.0f;
-            v[u].z = idx + 2 < n ? p[idx + 2] : 0.0f;
-            v[u].w = idx + 3 < n ? p[idx + 3] : 0.0f;
-        }
-    }
-}
-
-// Tile walker for the compaction-style kernels: wave w of the workgroup takes the 1024-element tiles
-// w, w + waves, ... of p[0..n).  Full tiles of an aligned span go through a branch-free, software-pipelined
-// loop (two register sets; the next tile's four 16-byte loads are in flight while the current tile is
-// consumed); the ragged end (< one workgroup tile) or an unaligned span uses the bounds-checked loader, which
-// pads with zeros.  eat(v, tile_base, full): `full` tells the consumer that no element is padding.
-template <int kThreads, class Eat>
-__device__ __forceinline__ void for_each_tile(const float* __restrict__ p, uint32_t n, Eat&& eat) {
-    const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-    constexpr uint32_t kStep = kThreads * 16;
-    const bool aligned = (((uintptr_t)p) & 15u) == 0;
-    const uint32_t n_main = aligned ? (n / kStep) * kStep : 0u;
-    gptr_f4 pv = (gptr_f4)p;
-#define DPL_TLOAD(buf, t0)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[u] = __builtin_nontemporal_load(pv + ((t0) >> 2) + u * 64 + lane)
-    uint32_t tile = w * 1024;
-    if (tile < n_main) {
-        f4 A[4], B[4];
-        DPL_TLOAD(A, tile);
-        for (;;) {
-            uint32_t nxt = tile + kStep;
-            if (nxt >= n_main) {
-                eat(A, tile, true);
-                break;
-            }
-            DPL_TLOAD(B, nxt);
-            eat(A, tile, true);
-            tile = nxt;
-            nxt = tile + kStep;
-            if (nxt >= n_main) {
-                eat(B, tile, true);
-                break;
-            }
-            DPL_TLOAD(A, nxt);
-            eat(B, tile, true);
-            tile = nxt;
-        }
-    }
-#undef DPL_TLOAD
-    for (uint32_t t2 = n_main + w * 1024; t2 < n; t2 += kStep) {
-        f4 v[4];
-        load_tile(p, t2, n, aligned, v);
-        eat(v, t2, false);
-    }
-}
-
-// First evaluation: full data -> list 0, several workgroups per pair (global cursor + atomics).
-__global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_item* __restrict__ items,
-                                                                const uint32_t* __restrict__ bb,
-                                                                const float* const* __restrict__ segs,
-                                                                dpl_octav_state* __restrict__ st,
-                                                                const dpl_octav_state* __restrict__ ctl,
-                                                                const uint64_t* __restrict__ pair_base,
-                                                                float* __restrict__ list0) {
-    extern __shared__ __attribute__((aligned(16))) float stage_all[];
-    __shared__ double s_sum[kBlock / kWave];
-    __shared__ uint32_t s_gt[kBlock / kWave];
-    const int w = threadIdx.x / kWave;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* stage = stage_all + w * kStageCap;
-    if (ctl && ctl->cnt_le == 0ull) return;  // no pair on the compaction route
-    uint32_t k0, k1;
-    block_items(bb, k0, k1);
-    for (uint32_t k = k0; k < k1; ++k) {
-        const dpl_work_item it = items[k];
-        dpl_octav_state* me = st + it.slot;
-        if (me->done || me->mode != 1u) continue;
-        const float s = me->s;
-        const float* p = segs[it.seg] + it.offset;
-        float* dst = list0 + pair_base[it.slot];
-        uint32_t fill = 0;
-        TailAcc acc{0u, 0.0};
-        auto flush = [&]() {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&me->len[0], fill);
-            base = __shfl(base, 0, kWave);
-            for (uint32_t j = lane; j < fill; j += kWave) dst[base + j] = stage[j];
-            fill = 0;
-        };
-        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t, bool) { tail_tile(v, s, stage, fill, acc, flush); });
-        if (fill) flush();
-        const uint32_t gt = acc.gt;  // already wave-uniform
-        const double sum = wave_sum(acc.sum);
-        if (lane == 0) {
-            s_gt[w] = gt;
-            s_sum[w] = sum;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tg = 0;
-            double ts = 0.0;
-            for (int j = 0; j < kBlock / kWave; ++j) {
-                tg += s_gt[j];
-                ts += s_sum[j];
-            }
-            if (tg) {
-                atomicAdd(&me->sum, ts);
-                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tg);
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// Later evaluations: ONE persistent workgroup per pair walks the remaining iterations by itself — evaluate
-// at s over list[cur], compact the survivors into list[1 - cur], take the fixed-point step, swap — with no
-// kernel boundary in between (the lists shrink ~2.5x per step and stay in this XCD's L2).
-constexpr int kIterBlock = 512;      // 8 waves per pair; 64 KiB of LDS staging -> 2 workgroups per CU
-constexpr int kIterStageCap = 2048;  // floats of LDS staging per wave (two full tiles)
-
-__global__ __launch_bounds__(kIterBlock) void k_octav_iterate_lists(dpl_octav_state* __restrict__ st,
-                                                                     dpl_octav_state* __restrict__ ctl,
-                                                                     const uint32_t* __restrict__ pair_order,
-                                                                     const uint64_t* __restrict__ pair_base,
-                                                                     float* __restrict__ list0,
-                                                                     float* __restrict__ list1, int max_iters) {
-    extern __shared__ __attribute__((aligned(16))) float stage_all[];
-    constexpr int kWaves = kIterBlock / kWave;
-    __shared__ double s_sum[kWaves];
-    __shared__ uint32_t s_gt[kWaves];
-    __shared__ uint32_t s_cursor;
-    __shared__ OctavStep s_step;
-    // largest pairs first (pair_order is sorted by size): the long sequential chains start at once and the
-    // short ones fill the tail of the launch
-    if (ctl->cnt_le == 0ull) return;  // no pair on the compaction route
-    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
-    dpl_octav_state* me = st + pair;
-    if (me->done || me->mode != 1u || me->cur > 1u) return;  // uniform per workgroup
-    const int w = threadIdx.x / kWave;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* stage = stage_all + w * kIterStageCap;
-    const uint64_t base_off = pair_base[pair];
-    const unsigned long long n_elems = me->n_elems;
-    const float unsigned_div = me->unsigned_div;
-    float s = me->s;
-    uint32_t iters = me->iters, cur = me->cur, n = me->len[cur];
-    uint32_t done = 0u, decreased = 0u;
-    // list[cur] holds exactly the values above the iterate it was produced at (kept by k_octav_update in `reserved`)
-    float s_floor_l = __uint_as_float(me->reserved);
-    while (!done && !decreased) {
-        const float* src = (cur == 0 ? list0 : list1) + base_off;
-        float* dst = (cur == 0 ? list1 : list0) + base_off;
-        if (n <= (uint32_t)(kIterBlock * 32)) {
-            // the tail now fits the workgroup's registers (32 values per lane): finish every remaining
-            // iteration without touching memory again — each one is a compare, a reduction and a step
-            gptr_f32 g = (gptr_f32)src;
-            float r[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const uint32_t idx = j * kIterBlock + threadIdx.x;
-                r[j] = idx < n ? g[idx] : 0.0f;  // zeros never exceed s >= 0
-            }
-            const float floor_s = s_floor_l;  // every value above this is in the registers
-            while (!done && !decreased) {
-                uint32_t c = 0;
-                float p0 = 0.0f, p1 = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 32; j += 2) {
-                    const bool g0 = r[j] > s, g1 = r[j + 1] > s;
-                    c += (uint32_t)g0 + (uint32_t)g1;
-                    p0 += g0 ? r[j] : 0.0f;
-                    p1 += g1 ? r[j + 1] : 0.0f;
-                }
-                c = wave_sum(c);
-                double sm = wave_sum((double)p0 + (double)p1);
-                if (lane == 0) {
-                    s_gt[w] = c;
-                    s_sum[w] = sm;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    unsigned long long tg = 0;
-                    double ts = 0.0;
-                    for (int j = 0; j < kWaves; ++j) {
-                        tg += s_gt[j];
-                        ts += s_sum[j];
-                    }
-                    s_step = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
-                }
-                __syncthreads();
-                const OctavStep st2 = s_step;
-                s = st2.s;
-                iters = st2.iters;
-                done = st2.done;
-                decreased = st2.decreased && !(st2.s >= floor_s);  // a dip is fine while nothing needed was dropped
-                __syncthreads();
-            }
-            break;
-        }
-        if (threadIdx.x == 0) s_cursor = 0u;
-        __syncthreads();
-        uint32_t fill = 0;
-        TailAcc acc{0u, 0.0};
-        auto flush = [&]() {
-            uint32_t b0 = 0;
-            if (lane == 0) b0 = atomicAdd(&s_cursor, fill);
-            b0 = __shfl(b0, 0, kWave);
-            for (uint32_t j = lane; j < fill; j += kWave) dst[b0 + j] = stage[j];
-            fill = 0;
-        };
-        for_each_tile<kIterBlock>(src, n, [&](const f4 (&v)[4], uint32_t, bool) {
-            tail_tile<kIterStageCap>(v, s, stage, fill, acc, flush);
-        });
-        if (fill) flush();
-        const uint32_t gt = acc.gt;  // already wave-uniform
-        const double sum = wave_sum(acc.sum);
-        if (lane == 0) {
-            s_gt[w] = gt;
-            s_sum[w] = sum;
-        }
-        __syncthreads();  // also orders every wave's dst stores before the next round reads them
-        if (threadIdx.x == 0) {
-            unsigned long long tg = 0;
-            double ts = 0.0;
-            for (int j = 0; j < kWaves; ++j) {
-                tg += s_gt[j];
-                ts += s_sum[j];
-            }
-            s_step = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
-        }
-        __threadfence_block();
-        __syncthreads();
-        const OctavStep r = s_step;
-        n = s_cursor;
-        s_floor_l = s;  // the list just written holds the values above the iterate it was evaluated at
-        s = r.s;
-        iters = r.iters;
-        done = r.done;
-        decreased = r.decreased;
-        cur = 1u - cur;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        me->s = s;
-        me->iters = iters;
-        me->done = done;
-        me->cur = cur;
-        me->len[cur] = n;
-        me->len[1u - cur] = 0u;
-        me->sum = 0.0;
-        me->cnt_gt = 0ull;
-        me->cnt_le = 0ull;
-        if (!done && decreased) {  // the iterate went down: the tail list cannot answer; finish on the full data
-            me->mode = 0u;
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_gt), 1ull);
-        }
-    }
-}
-
-// Fallback for the (degenerate) pairs that left list mode: one workgroup per pair finishes the iteration on
-// the pair's full data.  Returns at once when the control block counts no such pair.
-__global__ __launch_bounds__(kBlock) void k_octav_iterate_full(dpl_octav_state* __restrict__ st,
-                                                                const dpl_octav_state* __restrict__ ctl,
-                                                                const dpl_span* __restrict__ pair_spans,
-                                                                const float* const* __restrict__ segs, int max_iters) {
-    if (ctl->cnt_gt == 0ull) return;
-    __shared__ double s_sum[kBlock / kWave];
-    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
-    __shared__ OctavStep s_step;
-    dpl_octav_state* me = st + blockIdx.x;
-    if (me->done || me->mode != 0u) return;
-    const dpl_span sp = pair_spans[blockIdx.x];
-    const float* p = segs[sp.seg] + sp.offset;
-    const int w = threadIdx.x / kWave;
-    const bool lead = (threadIdx.x & (kWave - 1)) == 0;
-    float s = me->s;
-    uint32_t iters = me->iters, done = 0u;
-    const float unsigned_div = me->unsigned_div;
-    while (!done) {
-        OctavIterOp op{s, 0u, 0u, 0.0};
-        stream_span(p, (uint32_t)sp.count, op);
-        const uint32_t gt = wave_sum(op.gt), le = wave_sum(op.le);
-        const double sum = wave_sum(op.sum);
-        if (lead) {
-            s_sum[w] = sum;
-            s_a[w] = gt;
-            s_b[w] = le;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double ts = 0.0;
-            unsigned long long tg = 0, tl = 0;
-            for (int j = 0; j < kBlock / kWave; ++j) {
-                ts += s_sum[j];
-                tg += s_a[j];
-                tl += s_b[j];
-            }
-            s_step = octav_step(ts, tg, tl, unsigned_div, s, iters, max_iters);
-        }
-        __syncthreads();
-        const OctavStep r = s_step;
-        s = r.s;
-        iters = r.iters;
-        done = r.done;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        me->s = s;
-        me->iters = iters;
-        me->done = 1u;
-    }
-}
-
-__global__ void k_octav_init(dpl_octav_state* st, int64_t n, uint32_t mode) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n) return;  // slot n is the control block
-    dpl_octav_state z;
-    z.sum = 0.0;
-    z.cnt_gt = 0;
-    z.cnt_le = 0;
-    z.min_enc = 0xFFFFFFFFu;
-    z.max_enc = 0u;
-    z.nan_seen = 0u;
-    z.done = 0u;
-    z.s = 0.0f;
-    z.unsigned_div = 1.0f;
-    z.iters = 0u;
-    z.mode = mode;
-    z.n_elems = 0ull;
-    z.len[0] = 0u;
-    z.len[1] = 0u;
-    z.cur = 2u;
-    z.reserved = 0u;
-    if (i == n) {  // control block: cnt_gt = pairs in full-pass mode, cnt_le = pairs on the compaction route
-        z.cnt_gt = mode == 0u ? (unsigned long long)n : 0ull;
-        z.cnt_le = mode == 1u ? (unsigned long long)n : 0ull;
-    }
-    st[i] = z;
-}
-
-__global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool bad = st[i].nan_seen != 0u || st[i].min_enc == 0xFFFFFFFFu;
-    out[3 * i + 0] = st[i].s;
-    out[3 * i + 1] = bad ? NAN : dec_f32(st[i].min_enc);
-    out[3 * i + 2] = bad ? NAN : dec_f32(st[i].max_enc);
-}
-
-
-// ================================================================ K3c: OCTAV through a log-scale histogram
-// Goal: two reads of the data, no tail lists.  Pass 1 (with the statistics) bins |x| by its float bit
-// pattern — 64 sub-bins per octave over 2^-18 .. 2^14, i.e. bin = (bits >> 17) - key0 — keeping per bin an
-// exact count and an exact integer sum of mantissas (all values of a bin share the exponent, so
-// sum = (sum of 24-bit mantissas) * 2^(e-150): order-independent, deterministic).  F(s) is then exact at every
-// bin edge.  A small per-pair kernel walks the iteration in BRACKET form over the edges and marks the few
-// dozen bins the true iterates can fall into (3-8 % of the elements); pass 2 gathers just those elements; a
-// per-pair kernel then runs the reference's exact iteration from (exact bin totals above the current bin) +
-// (gathered elements of the current bin).  Every iterate is verified to land in a marked bin; a pair that
-// fails (or whose bracket explodes: flat / degenerate distributions) takes the compaction path instead.
-constexpr int kLogNB = 2048;
-constexpr int kLogShift = 17;                               // 23 - 6: six mantissa bits per bin
-constexpr uint32_t kLogKey0 = (uint32_t)(127 - 18) << 6;    // key of 2^-18
-constexpr int kLogWords = kLogNB / 32;
-constexpr int kBitmapRow = kLogWords + 2;                   // + the gather range [lo, hi) as float bits
-constexpr int kLogMaxMarked = 256;
-constexpr uint32_t kSmallPair = 16384;                      // pairs this small are gathered whole
-
-__device__ __forceinline__ int log_bin(float a) {
-    const int b = (int)(__float_as_uint(a) >> kLogShift) - (int)kLogKey0;
-    return b < 0 ? 0 : (b > kLogNB - 1 ? kLogNB - 1 : b);
-}
-__device__ __forceinline__ double log_bin_scale(int b) {   // 2^(e - 150) for the exponent field e of bin b
-    const int e = (int)(((uint32_t)b + kLogKey0) >> 6);
-    return __longlong_as_double((long long)(e - 150 + 1023) << 52);
-}
-
-// One 64-bit LDS atomic per element: the bin word holds the count in bits 44..63 and the mantissa sum in bits
-// 0..43 (a sub-span has < 2^20 elements, a mantissa is < 2^24: neither field can overflow into the other).
-constexpr int kPackShift = 44;
-constexpr unsigned long long kPackMask = (1ull << kPackShift) - 1ull;
-
-struct LogHistOp {
-    unsigned long long* packed;
-    float mn, mx;
-    uint32_t nan, nz;
-    double sum;
-    __device__ __forceinline__ void operator()(float x) {
-        mn = fminf(mn, x);
-        mx = fmaxf(mx, x);
-        nan |= (x != x);
-        const float a = fabsf(x);
-        nz += (a > 0.0f);
-        sum += (double)a;
-        const uint32_t u = __float_as_uint(a);
-        const int b = log_bin(a);
-        if (b > 0)  // bin 0 (zeros and |x| < 2^-18) is never needed: counts below come from n_elems
-            atomicAdd(packed + b, (1ull << kPackShift) | (unsigned long long)((u & 0x7FFFFFu) | 0x800000u));
-    }
-};
-
-__global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* __restrict__ items,
-                                                           const uint32_t* __restrict__ bb,
-                                                           const float* const* __restrict__ segs,
-                                                           dpl_octav_state* __restrict__ st,
-                                                           uint32_t* __restrict__ lh_cnt,
-                                                           unsigned long long* __restrict__ lh_sum) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long l_packed[];  // kLogNB packed bins
-    __shared__ double s_sum[kBlock / kWave];
-    __shared__ uint32_t s_a[kBlock / kWave], s_b[kBlock / kWave];
-    __shared__ float s_mn[kBlock / kWave], s_mx[kBlock / kWave];
-    const int w = threadIdx.x / kWave;
-    const bool lead = (threadIdx.x & (kWave - 1)) == 0;
-    uint32_t k0, k1;
-    block_items(bb, k0, k1);
-    for (uint32_t k = k0; k < k1; ++k) {
-        const dpl_work_item it = items[k];
-        dpl_octav_state* me = st + it.slot;
-        for (int b = threadIdx.x; b < kLogNB; b += kBlock) l_packed[b] = 0ull;
-        __syncthreads();
-        LogHistOp op{l_packed, INFINITY, -INFINITY, 0u, 0u, 0.0};
-        uint32_t* gc = lh_cnt + (uint64_t)it.slot * kLogNB;
-        unsigned long long* gs = lh_sum + (uint64_t)it.slot * kLogNB;
-        // sub-spans below 2^20 elements keep the packed count field from overflowing
-        constexpr uint32_t kSub = (1u << 20) - 4096u;
-        for (uint32_t s0 = 0; s0 < it.count; s0 += kSub) {
-            stream_span(segs[it.seg] + it.offset + s0, min(kSub, it.count - s0), op);
-            __syncthreads();
-            for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
-                const unsigned long long v = l_packed[b];
-                if (v) {
-                    atomicAdd(gc + b, (uint32_t)(v >> kPackShift));
-                    atomicAdd(gs + b, v & kPackMask);
-                    l_packed[b] = 0ull;
-                }
-            }
-            __syncthreads();
-        }
-        const float mn = wave_min(op.mn), mx = wave_max(op.mx);
-        const uint32_t nz = wave_sum(op.nz);
-        const double sum = wave_sum(op.sum);
-        const uint32_t nn = __any(op.nan) ? 1u : 0u;
-        if (lead) {
-            s_sum[w] = sum;
-            s_a[w] = nz;
-            s_b[w] = nn;
-            s_mn[w] = mn;
-            s_mx[w] = mx;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double tsum = 0.0;
-            uint32_t tnz = 0, tnn = 0;
-            float tmn = INFINITY, tmx = -INFINITY;
-            for (int j = 0; j < kBlock / kWave; ++j) {
-                tsum += s_sum[j];
-                tnz += s_a[j];
-                tnn |= s_b[j];
-                tmn = fminf(tmn, s_mn[j]);
-                tmx = fmaxf(tmx, s_mx[j]);
-            }
-            atomicAdd(&me->sum, tsum);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)it.count);
-            if (tmn <= tmx) {
-                atomicMin(&me->min_enc, enc_f32(tmn));
-                atomicMax(&me->max_enc, enc_f32(tmx));
-            }
-            if (tnn) atomicOr(&me->nan_seen, 1u);
-        }
-        __syncthreads();
-    }
-}
-
-// Shared by the bracket walk and the exact walk: suffix totals over the bins, S_ge[j] / N_ge[j] = everything
-// in bins >= j.  Built by one workgroup per pair into LDS (N as u32, S as fp64; j = 0 .. kLogNB).
-__device__ __forceinline__ void build_suffix(const uint32_t* __restrict__ gc, const unsigned long long* __restrict__ gs,
-                                             uint32_t* n_ge, double* s_ge, double* scratch_s, uint32_t* scratch_n) {
-    // each thread owns a run of consecutive bins (thread 0 the top ones); exclusive prefix over threads by a
-    // wave-level shuffle scan + a serial pass over the (<= 16) wave totals
-    const int per = (kLogNB + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int hi = kLogNB - 1 - (int)threadIdx.x * per;  // my highest bin
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    const int w = threadIdx.x / kWave, nw = (int)blockDim.x / kWave;
-    double ls = 0.0;
-    uint32_t ln = 0;
-    for (int q = 0; q < per; ++q) {
-        const int bq = hi - q;
-        if (bq >= 0) {
-            ln += gc[bq];
-            ls += (double)gs[bq] * log_bin_scale(bq);
-        }
-    }
-    double is = ls;
-    uint32_t in = ln;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const double ts = __shfl_up(is, o, kWave);
-        const uint32_t tn = __shfl_up(in, o, kWave);
-        if (lane >= (uint32_t)o) {
-            is += ts;
-            in += tn;
-        }
-    }
-    if (lane == kWave - 1) {
-        scratch_s[w] = is;
-        scratch_n[w] = in;
-    }
-    __syncthreads();
-    double rs = is - ls;  // exclusive within the wave
-    uint32_t rn = in - ln;
-    for (int q = 0; q < w && q < nw; ++q) {
-        rs += scratch_s[q];
-        rn += scratch_n[q];
-    }
-    for (int q = 0; q < per; ++q) {
-        const int bq = hi - q;
-        if (bq >= 0) {
-            rn += gc[bq];
-            rs += (double)gs[bq] * log_bin_scale(bq);
-            n_ge[bq] = rn;
-            s_ge[bq] = rs;
-        }
-    }
-    if (threadIdx.x == 0) {
-        n_ge[kLogNB] = 0u;
-        s_ge[kLogNB] = 0.0;
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ float log_edge(int b) {  // lower edge of bin b (bin 0 starts at 0)
-    return b <= 0 ? 0.0f : __uint_as_float(((uint32_t)b + kLogKey0) << kLogShift);
-}
-
-// Per pair: s_0, then the bracket walk over the bin edges; marks the bins the iterates can visit.
-__global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __restrict__ st,
-                                                           dpl_octav_state* __restrict__ ctl,
-                                                           const uint32_t* __restrict__ lh_cnt,
-                                                           const unsigned long long* __restrict__ lh_sum,
-                                                           uint32_t* __restrict__ bitmap, int dynamic_sym, int max_iters) {
-    __shared__ uint32_t n_ge[kLogNB + 1];
-    __shared__ double s_ge[kLogNB + 1];
-    __shared__ double scr_s[kBlock];
-    __shared__ uint32_t scr_n[kBlock];
-    __shared__ uint32_t bm[kLogWords];
-    __shared__ uint32_t route;  // 0: done already, 2: bracket route, 1: compaction route
-    __shared__ int jmin_s, jmax_s;
-    if (threadIdx.x == 0) {
-        jmin_s = kLogNB;
-        jmax_s = -1;
-    }
-    const int64_t pr = blockIdx.x;
-    dpl_octav_state* me = st + pr;
-    const uint32_t* gc = lh_cnt + pr * kLogNB;
-    const unsigned long long* gs = lh_sum + pr * kLogNB;
-    if (threadIdx.x < kLogWords) bm[threadIdx.x] = 0u;
-    build_suffix(gc, gs, n_ge, s_ge, scr_s, scr_n);
-    if (threadIdx.x == 0) {
-        const float mn = dec_f32(me->min_enc);
-        const float ud = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
-        const float s0 = __fdiv_rn((float)me->sum, (float)(long long)me->cnt_gt);
-        const unsigned long long n = me->n_elems;
-        me->unsigned_div = ud;
-        me->s = s0;
-        me->iters = 0u;
-        me->sum = 0.0;
-        me->cnt_gt = 0ull;
-        me->cnt_le = 0ull;
-        me->len[0] = 0u;
-        me->len[1] = 0u;
-        me->cur = 2u;
-        uint32_t r = 2u;
-        if (s0 != s0 || max_iters <= 0) {
-            me->done = 1u;  // NaN is a fixed point of the iteration
-            r = 0u;
-        } else if (n <= (unsigned long long)kSmallPair) {
-            for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair
-            jmin_s = 0;
-            jmax_s = kLogNB - 1;
-        } else if (n_ge[kLogNB - 1] != 0u) {
-            r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
-        } else {
-            const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
-            double lo = (double)s0, hi = (double)s0;
-            int marked = 0;
-            jmin_s = kLogNB;
-            jmax_s = -1;
-            for (int itn = 0; itn < 20 && r == 2u; ++itn) {
-                const int jl = log_bin((float)lo), jh = log_bin((float)hi);
-                if (jl <= 1 || jh >= kLogNB - 2 || !(lo == lo) || !(hi == hi)) {
-                    r = 1u;
-                    break;
-                }
-                for (int j = jl - 1; j <= jh + 1; ++j) {
-                    const uint32_t bit = 1u << (j & 31);
-                    if (!(bm[j >> 5] & bit)) {
-                        bm[j >> 5] |= bit;
-                        ++marked;
-                    }
-                }
-                jmin_s = jl - 1 < jmin_s ? jl - 1 : jmin_s;
-                jmax_s = jh + 1 > jmax_s ? jh + 1 : jmax_s;
-                if (marked > kLogMaxMarked) {
-                    r = 1u;
-                    break;
-                }
-                double nlo = INFINITY, nhi = -INFINITY;
-                for (int j = jl; j <= jh + 1; ++j) {  // F with everything in bins >= j counted as "above"
-                    const double ng = (double)n_ge[j];
-                    const double f = s_ge[j] / (c * ((double)(long long)n - ng) + ng);
-                    nlo = fmin(nlo, f);
-                    nhi = fmax(nhi, f);
-                }
-                if (nlo == lo && nhi == hi) break;  // the bracket stopped moving
-                lo = nlo;
-                hi = nhi;
-            }
-        }
-        if (r == 1u) {  // compaction route (k_octav_compact_full and friends)
-            me->mode = 1u;
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
-        } else {
-            me->mode = 2u;
-        }
-        route = r;
-    }
-    __syncthreads();
-    // bitmap row: kLogWords words of marks + [lowest marked edge, edge above the highest marked bin] as float bits
-    if (threadIdx.x < kLogWords) bitmap[pr * kBitmapRow + threadIdx.x] = (route == 2u) ? bm[threadIdx.x] : 0u;
-    if (threadIdx.x == 0) {
-        const int jmin = route == 2u ? jmin_s : kLogNB, jmax = route == 2u ? jmax_s : -1;
-        const float rlo = jmax < 0 ? INFINITY : log_edge(jmin);
-        const float rhi = jmax < 0 ? -INFINITY : (jmax >= kLogNB - 1 ? INFINITY : log_edge(jmax + 1));
-        bitmap[pr * kBitmapRow + kLogWords] = __float_as_uint(rlo);
-        bitmap[pr * kBitmapRow + kLogWords + 1] = __float_as_uint(rhi);
-    }
-}
-
-// Pass 2: collect the elements that fall in marked bins (|x| values) into the pair's list 0.  Survivors are
-// rare (3-8 %), so each lane appends to a private LDS queue (no cross-lane work per element); a wave flushes
-// its queues behind one scan + one returning atomic when any queue is half full.
-constexpr int kQueueCap = 32;
-constexpr int kQueueStride = kQueueCap + 1;  // odd stride: lanes with equal fill hit different banks
-
-__global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __restrict__ items,
-                                                          const uint32_t* __restrict__ bb,
-                                                          const float* const* __restrict__ segs,
-                                                          dpl_octav_state* __restrict__ st,
-                                                          const uint32_t* __restrict__ bitmap,
-                                                          const uint64_t* __restrict__ pair_base,
-                                                          float* __restrict__ list0) {
-    extern __shared__ __attribute__((aligned(16))) float queues[];  // [waves][64][kQueueStride]
-    __shared__ uint32_t bm[kBitmapRow];
-    const int w = threadIdx.x / kWave;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* q = queues + ((size_t)w * kWave + lane) * kQueueStride;
-    uint32_t k0, k1;
-    block_items(bb, k0, k1);
-    for (uint32_t k = k0; k < k1; ++k) {
-        const dpl_work_item it = items[k];
-        dpl_octav_state* me = st + it.slot;
-        if (me->done || me->mode != 2u) continue;  // uniform per workgroup
-        __syncthreads();
-        if (threadIdx.x < kBitmapRow) bm[threadIdx.x] = bitmap[(uint64_t)it.slot * kBitmapRow + threadIdx.x];
-        __syncthreads();
-        const float rlo = __uint_as_float(bm[kLogWords]), rhi = __uint_as_float(bm[kLogWords + 1]);
-        const float* p = segs[it.seg] + it.offset;
-        float* dst = list0 + pair_base[it.slot];
-        uint32_t cnt = 0;
-        auto flush = [&]() {
-            uint32_t inc = cnt;
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t t = __shfl_up(inc, o, kWave);
-                if (lane >= (uint32_t)o) inc += t;
-            }
-            const uint32_t total = __shfl(inc, kWave - 1, kWave);
-            uint32_t base = 0;
-            if (lane == kWave - 1) base = atomicAdd(&me->len[0], total);
-            base = __shfl(base, kWave - 1, kWave) + inc - cnt;
-            for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j];
-            cnt = 0;
-        };
-        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t tile_base, bool full) {
-            // phase 1, branch-free: all 16 bitmap words are fetched back to back (one LDS wait for the tile)
-            float a[16];
-            uint32_t word[16];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[4 * u + 0] = fabsf(v[u].x);
-                a[4 * u + 1] = fabsf(v[u].y);
-                a[4 * u + 2] = fabsf(v[u].z);
-                a[4 * u + 3] = fabsf(v[u].w);
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) word[j] = bm[log_bin(a[j]) >> 5];
-            uint32_t gm = 0u;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bool real = full || (tile_base + (j >> 2) * 256 + lane * 4 + (j & 3) < it.count);  // padding is not data
-                const bool g = a[j] >= rlo && a[j] < rhi && real && ((word[j] >> (log_bin(a[j]) & 31)) & 1u);
-                gm |= g ? (1u << j) : 0u;
-            }
-            // phase 2: the (rare) survivors go to the lane's queue
-            if (__any(gm != 0u)) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if ((gm >> j) & 1u) q[cnt++] = a[j];
-            }
-            if (__any(cnt > (uint32_t)(kQueueCap - 16))) flush();
-        });
-        if (__any(cnt != 0u)) flush();
-    }
-}
-
-// Per pair: the reference's exact iteration from the exact bin totals + the gathered elements.
-// For the iterate s in bin jb:  count(|x| > s) = (exact total of the bins above jb) + (gathered values v with
-// s < v < edge(jb+1)).  The iterates climb, so values not above s are dropped from the gathered list as it is
-// walked (the same tail compaction as k_octav_iterate_lists, list 0 -> list 1 -> ...), and the totals above the
-// current bin are updated incrementally.  An iterate that lands in an unmarked bin, or moves down, sends the
-// pair to the compaction route.
-constexpr int kExactBlock = 256;
-constexpr int kExactRegs = 16;  // gathered values held per lane once the list is short (256 * 16 = 4 K)
-
-__global__ __launch_bounds__(kExactBlock, 3) void k_octav_exact(dpl_octav_state* __restrict__ st,
-                                                              dpl_octav_state* __restrict__ ctl,
-                                                              const uint32_t* __restrict__ pair_order,
-                                                              const uint32_t* __restrict__ lh_cnt,
-                                                              const unsigned long long* __restrict__ lh_sum,
-                                                              const uint32_t* __restrict__ bitmap,
-                                                              const uint64_t* __restrict__ pair_base,
-                                                              float* __restrict__ list0, float* __restrict__ list1,
-                                                              int max_iters) {
-    extern __shared__ __attribute__((aligned(16))) float stage_all[];
-    constexpr int kWaves = kExactBlock / kWave;
-    __shared__ double scr_s[kWaves];
-    __shared__ unsigned long long scr_n[kWaves];
-    __shared__ uint32_t bm[kLogWords];
-    __shared__ uint32_t s_cursor;
-    __shared__ OctavStep s_step;
-    __shared__ double s_above;             // exact totals of the bins above the current one
-    __shared__ unsigned long long n_above;
-    __shared__ int s_jb, s_jn;
-    __shared__ uint32_t s_bad;
-    __shared__ float s_floor;  // the list holds every gathered value above this (-inf: nothing dropped yet)
-    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
-    dpl_octav_state* me = st + pair;
-    if (me->done || me->mode != 2u) return;  // uniform per workgroup
-    const int w = threadIdx.x / kWave;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* stage = stage_all + w * kIterStageCap;
-    const uint32_t* gc = lh_cnt + (uint64_t)pair * kLogNB;
-    const unsigned long long* gs = lh_sum + (uint64_t)pair * kLogNB;
-    if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)pair * kBitmapRow + threadIdx.x];
-    const unsigned long long n_elems = me->n_elems;
-    const float unsigned_div = me->unsigned_div;
-    const uint64_t base_off = pair_base[pair];
-    float s = me->s;
-    uint32_t iters = me->iters, n = me->len[0], cur = 0u;
-    // totals above the first iterate's bin: one block-wide reduction over the histogram
-    int jb = log_bin(s);
-    {
-        double ls = 0.0;
-        unsigned long long ln = 0;
-        for (int b2 = jb + 1 + (int)threadIdx.x; b2 < kLogNB; b2 += kExactBlock) {
-            ln += gc[b2];
-            ls += (double)gs[b2] * log_bin_scale(b2);
-        }
-        ls = wave_sum(ls);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ln += __shfl_xor(ln, o, kWave);
-        if (lane == 0) {
-            scr_s[w] = ls;
-            scr_n[w] = ln;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double ts = 0.0;
-            unsigned long long tn = 0;
-            for (int j = 0; j < kWaves; ++j) {
-                ts += scr_s[j];
-                tn += scr_n[j];
-            }
-            s_above = ts;
-            n_above = tn;
-            s_jb = jb;
-            s_jn = jb;
-            s_floor = -INFINITY;
-            s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
-        }
-        __syncthreads();
-    }
-    uint32_t done = 0u, bad = s_bad;
-    bool in_regs = false;
-    float r[kExactRegs];
-    while (!done && !bad) {
-        const float e_hi = log_edge(jb + 1);
-        const float* src = (cur == 0 ? list0 : list1) + base_off;
-        float* dst = (cur == 0 ? list1 : list0) + base_off;
-        uint32_t c = 0;
-        double pd = 0.0;
-        if (!in_regs && n <= (uint32_t)(kExactBlock * kExactRegs)) {
-            gptr_f32 g = (gptr_f32)src;
-#pragma unroll
-            for (int j = 0; j < kExactRegs; ++j) {
-                const uint32_t idx = j * kExactBlock + threadIdx.x;
-                r[j] = idx < n ? g[idx] : 0.0f;
-            }
-            in_regs = true;
-        }
-        if (in_regs) {
-            float p0 = 0.0f;
-#pragma unroll
-            for (int j = 0; j < kExactRegs; ++j) {
-                const bool gq = r[j] > s && r[j] < e_hi;
-                c += gq;
-                p0 += gq ? r[j] : 0.0f;
-            }
-            pd = (double)p0;
-            c = wave_sum(c);
-        } else {
-            if (threadIdx.x == 0) s_cursor = 0u;
-            __syncthreads();
-            uint32_t fill = 0;
-            auto flush = [&]() {
-                uint32_t b0 = 0;
-                if (lane == 0) b0 = atomicAdd(&s_cursor, fill);
-                b0 = __shfl(b0, 0, kWave);
-                for (uint32_t j = lane; j < fill; j += kWave) dst[b0 + j] = stage[j];
-                fill = 0;
-            };
-            for_each_tile<kExactBlock>(src, n, [&](const f4 (&v)[4], uint32_t, bool) {
-                if (fill + 1024u > (uint32_t)kIterStageCap) flush();
-                float part = 0.0f;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float a4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = a4[e];
-                        const bool keep = a > s;                 // stays in the list for later iterates
-                        const bool cntit = keep && a < e_hi;     // belongs to the current bin
-                        const unsigned long long m = __ballot(keep);
-                        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (keep) stage[fill + off] = a;
-                        fill += (uint32_t)__popcll(m);
-                        c += cntit;
-                        part += cntit ? a : 0.0f;
-                    }
-                }
-                pd += (double)part;
-            });
-            if (fill) flush();
-            c = wave_sum(c);
-        }
-        pd = wave_sum(pd);
-        if (lane == 0) {
-            scr_n[w] = c;
-            scr_s[w] = pd;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long tg = n_above;
-            double ts = s_above;
-            for (int j = 0; j < kWaves; ++j) {
-                tg += scr_n[j];
-                ts += scr_s[j];
-            }
-            if (!in_regs) s_floor = s;  // this pass compacted the list: values not above s are gone
-            const OctavStep q = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
-            s_step = q;
-            if (!q.done) {  // move the exact totals to the new iterate's bin (up, or down while the values are kept)
-                const int jn = log_bin(q.s);
-                uint32_t nb = 0u;
-                // a smaller iterate can only be answered if nothing above it has been dropped from the list
-                if (!(q.s >= s_floor) || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
-                    nb = 1u;
-                } else {
-                    s_jn = jn;  // the totals are moved below, by the whole workgroup
-                }
-                s_bad = nb;
-            }
-        }
-        __syncthreads();
-        {   // move the exact totals from bin s_jb to bin s_jn: one bin per lane, a single memory round trip
-            const OctavStep q0 = s_step;
-            if (!q0.done && !s_bad && s_jn != s_jb) {
-                const int lo = s_jn < s_jb ? s_jn : s_jb, hi = s_jn < s_jb ? s_jb : s_jn;  // bins lo+1 .. hi change sides
-                double ds = 0.0;
-                unsigned long long dn = 0;
-                for (int b2 = lo + 1 + (int)threadIdx.x; b2 <= hi; b2 += kExactBlock) {
-                    dn += gc[b2];
-                    ds += (double)gs[b2] * log_bin_scale(b2);
-                }
-                ds = wave_sum(ds);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) dn += __shfl_xor(dn, o, kWave);
-                if (lane == 0) {
-                    scr_s[w] = ds;
-                    scr_n[w] = dn;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    double ts = 0.0;
-                    unsigned long long tn = 0;
-                    for (int j = 0; j < kWaves; ++j) {
-                        ts += scr_s[j];
-                        tn += scr_n[j];
-                    }
-                    if (s_jn > s_jb) {  // moved up: those bins are no longer "above"
-                        s_above -= ts;
-                        n_above -= tn;
-                    } else {
-                        s_above += ts;
-                        n_above += tn;
-                    }
-                    s_jb = s_jn;
-                }
-            }
-        }
-        __syncthreads();
-        const OctavStep q = s_step;
-        s = q.s;
-        iters = q.iters;
-        done = q.done;
-        bad = done ? 0u : s_bad;
-        jb = s_jb;
-        if (!in_regs) {
-            n = s_cursor;
-            cur = 1u - cur;
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        if (bad) {  // restart this pair on the compaction route from s_0 (state as k_octav_update<true> leaves it;
-                    // s_0 is still in me->s: this kernel only writes it back on success)
-            me->mode = 1u;
-            me->iters = 0u;
-            me->len[0] = 0u;
-            me->len[1] = 0u;
-            me->cur = 2u;
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
-        } else {
-            me->s = s;
-            me->iters = iters;
-            me->done = 1u;
-        }
-    }
-}
-
 // ================================================================ K5: per-row min / max of a [rows, cols] matrix
 __global__ __launch_bounds__(kBlock) void k_rowwise_minmax(const float* __restrict__ w, int64_t cols,
                                                             float* __restrict__ omn, float* __restrict__ omx) {
@@ -1783,8 +459,6 @@ __global__ __launch_bounds__(kBlock) void k_cos_items(const dpl_work_item* __res
     }
 }
 
-inline int grid_for(int64_t n, int per_block) { return (int)((n + per_block - 1) / per_block); }
-
 }  // namespace
 
 // =================================================================================== C ABI
@@ -1899,14 +573,6 @@ int64_t dpl_build_balanced_items(const dpl_span* spans, int64_t n_spans, int64_t
 
 // n_blocks = number of workgroups; d_block_begin (n_blocks + 1 entries) may be null, then n_blocks must equal
 // n_items and workgroup b processes item b.
-static int check_blocks(const char* who, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks) {
-    if (n_blocks <= 0 || n_blocks > 0x7FFFFFFFll || (!d_block_begin && n_blocks != n_items)) {
-        snprintf(g_err, sizeof(g_err), "%s: n_blocks must be positive and equal n_items when d_block_begin is null", who);
-        return -2;
-    }
-    return 0;
-}
-
 int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
                           int64_t n_blocks, const float* const* d_seg_ptrs, uint32_t* d_min_enc,
                           uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s) {
@@ -1965,108 +631,6 @@ int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float*
     hipLaunchKernelGGL(k_hist_percentile, dim3((unsigned)n_slots), dim3(kWave), 0, (hipStream_t)s, d_hist, d_min,
                        d_max, bins, threshold, d_clip);
     DPL_LAUNCH_CHECK("k_hist_percentile");
-    return 0;
-}
-
-int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, int list_mode, dpl_stream_t s) {
-    if (n_pairs <= 0) return 0;
-    if (list_mode < 0 || list_mode > 2) return fail_msg("dpl_octav_init: mode must be 0 (full), 1 (compaction) or 2 (bracket)");
-    hipLaunchKernelGGL(k_octav_init, dim3(grid_for(n_pairs + 1, 256)), dim3(256), 0, (hipStream_t)s, d_states,
-                       n_pairs, (uint32_t)list_mode);
-    DPL_LAUNCH_CHECK("k_octav_init");
-    return 0;
-}
-
-int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
-                  const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym,
-                  int max_iters, dpl_stream_t s) {
-    if (n_items <= 0 || n_pairs <= 0) return 0;
-    if (int e = check_blocks("dpl_octav_run", n_items, d_block_begin, n_blocks)) return e;
-    hipStream_t st = (hipStream_t)s;
-    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock);
-    dpl_octav_state* ctl = d_states + n_pairs;
-    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states, ctl);
-    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
-    for (int k = 0; k < max_iters; ++k) {
-        hipLaunchKernelGGL(k_octav_pass<false>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states, ctl);
-        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
-    }
-    DPL_LAUNCH_CHECK("k_octav");
-    return 0;
-}
-
-int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
-                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
-                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
-                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym,
-                          int max_iters, dpl_stream_t s) {
-    if (n_items <= 0 || n_pairs <= 0) return 0;
-    if (int e = check_blocks("dpl_octav_run_compact", n_items, d_block_begin, n_blocks)) return e;
-    hipStream_t st = (hipStream_t)s;
-    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock);
-    dpl_octav_state* ctl = d_states + n_pairs;
-    // 1. statistics + s_0             2. evaluate at s_0 over the full data, keep the values above s_0
-    hipLaunchKernelGGL(k_octav_pass<true>, pg, pb, 0, st, d_items, d_block_begin, d_seg_ptrs, d_states, ctl);
-    hipLaunchKernelGGL(k_octav_update<true>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
-    if (max_iters > 0) {
-        hipLaunchKernelGGL(k_octav_compact_full, pg, pb, (size_t)(kBlock / kWave) * kStageCap * sizeof(float), st,
-                           d_items, d_block_begin, d_seg_ptrs, d_states, ctl, d_pair_base, d_list0);
-        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
-        // 3. every remaining iteration of every pair inside one launch    4. degenerate pairs on the full data
-        hipLaunchKernelGGL(k_octav_iterate_lists, dim3((unsigned)n_pairs), dim3(kIterBlock),
-                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
-                           d_pair_base, d_list0, d_list1, max_iters);
-        hipLaunchKernelGGL(k_octav_iterate_full, dim3((unsigned)n_pairs), pb, 0, st, d_states, ctl, d_pair_spans,
-                           d_seg_ptrs, max_iters);
-    }
-    DPL_LAUNCH_CHECK("k_octav_compact");
-    return 0;
-}
-
-int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
-                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
-                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
-                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
-                          uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s) {
-    if (n_items <= 0 || n_pairs <= 0) return 0;
-    if (int e = check_blocks("dpl_octav_run_bracket", n_items, d_block_begin, n_blocks)) return e;
-    hipStream_t st = (hipStream_t)s;
-    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock), pairs((unsigned)n_pairs);
-    dpl_octav_state* ctl = d_states + n_pairs;
-    const size_t stage_bytes = (size_t)(kBlock / kWave) * kStageCap * sizeof(float);
-    hipError_t e1 = hipMemsetAsync(d_lh_cnt, 0, (size_t)n_pairs * kLogNB * sizeof(uint32_t), st);
-    hipError_t e2 = hipMemsetAsync(d_lh_sum, 0, (size_t)n_pairs * kLogNB * sizeof(uint64_t), st);
-    if (e1 != hipSuccess || e2 != hipSuccess) return fail("hipMemsetAsync", e1 != hipSuccess ? e1 : e2);
-    // 1. statistics + log-scale histogram   2. s_0 and the bracket walk   3. gather the marked bins   4. exact walk
-    hipLaunchKernelGGL(k_octav_loghist, pg, pb, (size_t)kLogNB * 8, st, d_items, d_block_begin, d_seg_ptrs, d_states,
-                       d_lh_cnt, reinterpret_cast<unsigned long long*>(d_lh_sum));
-    hipLaunchKernelGGL(k_octav_bracket, pairs, pb, 0, st, d_states, ctl, d_lh_cnt,
-                       reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);
-    if (max_iters > 0) {
-        hipLaunchKernelGGL(k_octav_gather, pg, pb, (size_t)kBlock * kQueueStride * sizeof(float), st, d_items,
-                           d_block_begin, d_seg_ptrs, d_states, d_bitmap, d_pair_base, d_list0);
-        hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock),
-                           (size_t)(kExactBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
-                           d_lh_cnt, reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, d_pair_base,
-                           d_list0, d_list1, max_iters);
-        // 5. pairs the bracket could not serve (flat / degenerate distributions, values >= 2^14): compaction route
-        hipLaunchKernelGGL(k_octav_compact_full, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
-                           ctl, d_pair_base, d_list0);
-        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
-        hipLaunchKernelGGL(k_octav_iterate_lists, pairs, dim3(kIterBlock),
-                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
-                           d_pair_base, d_list0, d_list1, max_iters);
-        hipLaunchKernelGGL(k_octav_iterate_full, pairs, pb, 0, st, d_states, ctl, d_pair_spans, d_seg_ptrs, max_iters);
-    }
-    DPL_LAUNCH_CHECK("k_octav_bracket");
-    return 0;
-}
-
-int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s) {
-    if (n_pairs <= 0) return 0;
-    hipLaunchKernelGGL(k_octav_finalize, dim3(grid_for(n_pairs, 256)), dim3(256), 0, (hipStream_t)s, d_states,
-                       n_pairs, d_out);
-    DPL_LAUNCH_CHECK("k_octav_finalize");
     return 0;
 }
 

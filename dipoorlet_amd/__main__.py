@@ -3,8 +3,8 @@
 
 Same flags; same phases where they are in scope: load model -> tensor calibration (sharded over ranks)
 -> per-rank clip JSON -> rank-0 reduce -> load -> profiling (cosine similarity of the fake-quantised
-model, optional) -> platform deploy file.  Flags of the out-of-scope fine-tuning phases (--adaround,
---brecq, --drop, --sparse, --we, --update_bn) are accepted and rejected with a clear message.
+model, optional) -> weight transforms (--bc, --adaround, --brecq [--drop]) -> platform deploy file.  Flags of the phases
+that are not built (--sparse, --we, --update_bn) are accepted and rejected with a clear message.
 Extra flags: --calib_batch, --resident_gb, --merge {allreduce,reference}, --skip_profiling.
 """
 import argparse
@@ -53,10 +53,10 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    for flag in ("we", "update_bn", "adaround", "brecq", "drop", "sparse"):
+    for flag in ("we", "update_bn", "sparse"):
         if getattr(args, flag):
-            sys.exit(f"--{flag} belongs to the fine-tuning phases that are out of this package's scope "
-                     "(activation calibration hot path); run it with the reference after calibration.")
+            sys.exit(f"--{flag} is not built in this package (weight equalisation / BN re-estimation / sparse "
+                     "fine-tuning are outside its scope); run it with the reference after calibration.")
     if args.slurm:
         dist_helper.init_from_slurm()
     elif args.mpirun:
@@ -85,17 +85,12 @@ def main(argv=None):
         reduce_clip_val(world, args)
     dist.barrier()
     act_clip_val, weight_clip_val = load_clip_val(args)
-    graph_ori, graph_after_wt = onnx_graph, onnx_graph
-    if args.bc:  # weight_trans_base.py:21-29 — rank 0 corrects, everyone reloads, weight (bias) ranges refreshed
-        from .tensor_cali import find_clip_val_minmax_weight
-        from .weight_transform import bias_correction
-        if rank == 0:
-            logger.info("Weight transform: bias correction...")
-            bias_correction(onnx_graph, act_clip_val, weight_clip_val, args)
-        dist.barrier()
-        args.model = os.path.join(args.output_dir, "update_bias_model.onnx")
-        graph_after_wt = ONNXGraph.load(args.model, args.output_dir, args.deploy, args.model_type)
-        weight_clip_val = find_clip_val_minmax_weight(graph_after_wt, args)
+    from .weight_transform import weight_calibration
+    if rank == 0:
+        logger.info("Weight transform...")
+    graph_after_wt, graph_ori, act_clip_val, weight_clip_val = weight_calibration(onnx_graph, act_clip_val,
+                                                                                  weight_clip_val, args)
+    dist.barrier()
     if not args.skip_profiling:
         from .profiling import (quantize_profiling_multipass, show_model_profiling_res, show_model_ranges,
                                 weight_need_perchannel)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_BINS = 16384
 
 
@@ -39,6 +39,14 @@ class OctavState(C.Structure):
                 ("len0", C.c_uint32), ("len1", C.c_uint32), ("cur", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class RoundStepParams(C.Structure):
+    _fields_ = [("lr", C.c_double), ("adam_beta1", C.c_double), ("adam_beta2", C.c_double), ("adam_eps", C.c_double),
+                ("step", C.c_int32), ("adam", C.c_int32), ("clamp", C.c_int32), ("reserved", C.c_int32),
+                ("grad_scale", C.c_float), ("reg_beta", C.c_float), ("reg_lambda", C.c_float),
+                ("reserved2", C.c_float)]
+
+
+assert C.sizeof(RoundStepParams) == 64
 assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 80
 
 _P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
@@ -67,6 +75,13 @@ SIGNATURES = {
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
     "dpl_cos_items_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "dpl_round_init": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
+    "dpl_round_quant": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, C.c_int, _P, _P]),
+    "dpl_round_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.POINTER(RoundStepParams), _P, _P,
+                                 _P, _P]),
+    "dpl_l2_loss": (C.c_int, [_P, _P, _I64, C.c_int, C.c_float, _DBL, _P, _P, _P]),
+    "dpl_acti_drop_fwd": (C.c_int, [_P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
+    "dpl_acti_drop_bwd": (C.c_int, [_P, _P, _I64, C.c_float, _P, _P]),
 }
 
 _lib = None

@@ -205,9 +205,14 @@ def _gemm(s, node, a, b, c=None):
         a = a.t()
     if node.attrs.get("transB", 0):
         b = b.t()
-    y = torch.matmul(a, b) * float(node.attrs.get("alpha", 1.0))
+    alpha, beta = float(node.attrs.get("alpha", 1.0)), float(node.attrs.get("beta", 1.0))
+    if c is not None and a.dim() == 2 and b.dim() == 2 and c.dim() <= 2:
+        return torch.addmm(c, a, b, beta=beta, alpha=alpha)      # one hipBLASLt call, bias in the epilogue
+    y = torch.matmul(a, b)
+    if alpha != 1.0:
+        y = y * alpha
     if c is not None:
-        y = y + c * float(node.attrs.get("beta", 1.0))
+        y = y + (c if beta == 1.0 else c * beta)
     return y
 
 
@@ -467,6 +472,14 @@ class GraphSession(ActivationSession):
 
     def match_batch(self, a, b):
         return a, b
+
+    def set_const(self, name, tensor):
+        """Replace an initializer on the device (a weight updated by a weight transform) and refresh the folded
+        fake-quantised copy that depends on it."""
+        self.consts[name] = tensor.to(self.device)
+        for node in self.graph.graph.node:
+            if node.name in self._folded and node.input[0] == name:
+                self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, self.consts[name])
 
     def _forward(self, feeds, batch):
         self.batch = batch

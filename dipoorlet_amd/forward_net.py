@@ -263,14 +263,15 @@ class ActivationCache:
     The reference splits the network into single-node ONNX models, runs one ORT session per node and keeps
     every image's activation of every live tensor on the HOST, evicting by reference count.  Here one batched
     forward of the shard keeps all calibration tensors resident in HBM (288 GB: 1024 ResNet-50 images are
-    109 GB) and `cache[name]` returns the list of per-image device tensors (views, no copies), `cache[initializer]`
-    the initializer array.  `reset()` drops the cached activations."""
+    109 GB).  `cache[name]` returns the list of per-image device tensors (views, no copies), `cache.chunks(name)`
+    the per-batch tensors [b, ...] behind them, `cache[initializer]` the initializer array.  `reset()` drops the
+    cached activations."""
 
     def __init__(self, graph, args, st=None, ed=None):
         self.graph, self.args = graph, args
         self.st = 0 if st is None else st
         self.ed = args.data_num if ed is None else ed
-        self.activation_cache = {}
+        self.activation_cache = {}     # name -> [per-batch device tensors]
         self._filled = False
 
     def reset(self):
@@ -287,16 +288,19 @@ class ActivationCache:
             j = min(i + batch, self.ed)
             inputs = load_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, dev)
             for n, t in zip(sess.tensor_names, sess.run(inputs)):
-                per_name[n].extend(t[k] for k in range(j - i))
+                per_name[n].append(t)
         self.activation_cache = per_name
         self._filled = True
+
+    def chunks(self, tensor_name):
+        if not self._filled:
+            self._fill()
+        return self.activation_cache[tensor_name]
 
     def __getitem__(self, tensor_name):
         if tensor_name in getattr(self.graph, "initializer", {}):
             return self.graph.get_initializer(tensor_name)
-        if not self._filled:
-            self._fill()
-        return self.activation_cache[tensor_name]
+        return [t[k] for t in self.chunks(tensor_name) for k in range(t.shape[0])]
 
 
 def log_forward_time(seconds):

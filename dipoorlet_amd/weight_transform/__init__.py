@@ -1,0 +1,7 @@
+"""Weight transforms that run between calibration and deployment (dipoorlet/weight_transform/)."""
+from .adaround import adaround
+from .bias_correction import bias_correction
+from .brecq import brecq
+from .weight_trans_base import weight_calibration
+
+__all__ = ["adaround", "bias_correction", "brecq", "weight_calibration"]

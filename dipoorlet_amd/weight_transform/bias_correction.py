@@ -17,11 +17,11 @@ The fake-quant structure does not depend on bias values, so the quantised graph 
 import numpy as np
 import torch
 
-from .executor import _OPS, GraphSession
-from .forward_net import load_input_batch
-from .graph import ONNXGraph
-from .quantize import quant_graph
-from .utils import logger
+from ..executor import _OPS, GraphSession
+from ..forward_net import load_input_batch
+from ..graph import ONNXGraph
+from ..quantize import quant_graph
+from ..utils import logger
 
 BIAS_CORRECTION_NODE_TYPE = ["Conv", "Gemm"]
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 4
+#define DPL_ABI_VERSION 5
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -172,6 +172,51 @@ int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_
 int dpl_cos_items_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
                              int64_t n_blocks, const float* const* d_seg_a, const float* const* d_seg_b,
                              double* d_acc, dpl_stream_t s);
+
+/* ------------------------------------------------------------------ AdaRound / BRECQ / QDrop inner loop (N4)
+ * Replaces the eager torch arithmetic of weight_transform/ada_quant_layer.py:28-50 (quant_acti, quant_weight),
+ * :96-112 (adaround_reg), :115-116 (L2_norm), :147 (round-mask initialisation) and the torch.optim.Adam update of
+ * adaround.py:119-133 / brecq.py:158-186.  Weights are viewed as [n_channels, inner] (output channel first; a
+ * ConvTranspose weight is transposed by the caller as adaround.py:58-59 does); scale / q_min / q_max hold
+ * n_channels entries (1 for per-tensor).  `clamp` follows the reference: only its per-channel branch clamps
+ * (the per-tensor branch discards the clamp result, ada_quant_layer.py:44-45). */
+typedef struct dpl_round_step_params {
+    double lr, adam_beta1, adam_beta2, adam_eps; /* torch.optim.Adam defaults: 1e-3, 0.9, 0.999, 1e-8 */
+    int32_t step;      /* Adam step t >= 1 of this update */
+    int32_t adam;      /* 0: gradients only (mask, moments and weight are left untouched) */
+    int32_t clamp;
+    int32_t reserved;
+    float grad_scale;  /* multiplies dL/d(qw): 1 / world_size after a SUM all-reduce (DDP's mean), else 1 */
+    float reg_beta;    /* regulariser temperature of this iteration (TempDecay, ada_quant_layer.py:119-134); 0: off */
+    float reg_lambda;  /* regulariser weight (adaround_reg.alpha = 0.01) */
+    float reserved2;
+} dpl_round_step_params;
+
+/* wfloor = floor(w / scale);  alpha = -log((zeta - gamma) / (w / scale - wfloor - gamma) - 1) */
+int dpl_round_init(const float* d_w, const float* d_scale, int64_t n, int64_t n_channels, int64_t inner,
+                   float* d_wfloor, float* d_alpha, dpl_stream_t s);
+/* qw = clamp?(wfloor + h(alpha)) * scale;  h = rectified sigmoid (soft) or (alpha >= 0) (hard) */
+int dpl_round_quant(const float* d_wfloor, const float* d_alpha, const float* d_scale, const float* d_qmin,
+                    const float* d_qmax, int64_t n, int64_t n_channels, int64_t inner, int clamp, int soft,
+                    float* d_qw, dpl_stream_t s);
+/* One learning step in one pass: g = dL/d(alpha) from d_grad_qw (may be null) through the soft quantiser, plus
+ * the regulariser's gradient; *d_reg_loss += lambda * sum(1 - |2h - 1|^beta) (may be null); Adam update of
+ * alpha / m / v in place; d_qw_next (may be null) = the soft-quantised weight at the updated alpha;
+ * d_grad_alpha (may be null) receives g. */
+int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha, float* d_m, float* d_v,
+                   const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
+                   int64_t inner, const dpl_round_step_params* p, float* d_qw_next, float* d_grad_alpha,
+                   double* d_reg_loss, dpl_stream_t s);
+/* *d_loss += sum((y - target)^2) * inv_m with y = relu ? max(z, 0) : z  (L2_norm: inv_m = 1 / (elements / dim 1));
+ * d_grad (may be null) = grad_coef * (y - target), zero where the ReLU is closed. */
+int dpl_l2_loss(const float* d_z, const float* d_target, int64_t n, int relu, float grad_coef, double inv_m,
+                float* d_grad, double* d_loss, dpl_stream_t s);
+/* quant_acti with QDrop: y = rand < prob ? fake_quant(x) : x  (d_rand null: always quantised);
+ * gradient as torch autograd defines it for the reference code: 0 through round(), 1 through the kept values. */
+int dpl_acti_drop_fwd(const float* d_x, const float* d_rand, int64_t n, float scale, float qmin, float qmax,
+                      float prob, float* d_y, dpl_stream_t s);
+int dpl_acti_drop_bwd(const float* d_rand, const float* d_grad_y, int64_t n, float prob, float* d_grad_x,
+                      dpl_stream_t s);
 
 #ifdef __cplusplus
 }

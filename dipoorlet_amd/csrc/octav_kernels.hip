@@ -611,26 +611,36 @@ __device__ __forceinline__ double log_bin_scale(int b) {   // 2^(e - 150) for th
 }
 
 // One 64-bit LDS atomic per element: the bin word holds the count in bits 44..63 and the mantissa sum in bits
-// 0..43 (a sub-span has < 2^20 elements, a mantissa is < 2^24: neither field can overflow into the other).
+// 0..43 (a sub-span has < 2^20 elements, an explicit mantissa is < 2^23: neither field can overflow into the other).
 constexpr int kPackShift = 44;
 constexpr unsigned long long kPackMask = (1ull << kPackShift) - 1ull;
 
 struct LogHistOp {
     unsigned long long* packed;
     float mn, mx;
-    uint32_t nan, nz;
-    double sum;
+    uint32_t nan;         // only ever examined on the rare path below
+    uint32_t nz_out;      // nonzero values outside the binned window (|x| < 2^-18 or >= 2^14)
+    double sum_out;
     __device__ __forceinline__ void operator()(float x) {
         mn = fminf(mn, x);
         mx = fmaxf(mx, x);
-        nan |= (x != x);
-        const float a = fabsf(x);
-        nz += (a > 0.0f);
-        sum += (double)a;
-        const uint32_t u = __float_as_uint(a);
-        const int b = log_bin(a);
-        if (b > 0)  // bin 0 (zeros and |x| < 2^-18) is never needed: counts below come from n_elems
-            atomicAdd(packed + b, (1ull << kPackShift) | (unsigned long long)((u & 0x7FFFFFu) | 0x800000u));
+        // window bins 1 .. kLogNB-1 (bin 0 = everything below 2^-18 is never needed: counts below an iterate come
+        // from n_elems).  In-window values are all positive and finite, so the pair's sum(|x|) and count(|x| > 0)
+        // follow from the histogram itself; only what falls outside (zeros, denormal-small, huge, inf, NaN) takes
+        // the second branch, and only its nonzero members (rare) are accumulated directly.
+        const uint32_t bits = __float_as_uint(x);
+        const uint32_t t = ((bits >> kLogShift) & 0x3FFFu) - (kLogKey0 + 1u);
+        if (t < (uint32_t)(kLogNB - 1)) {
+            // the packed word sums the 23 explicit mantissa bits; the implicit ones are count << 23 (flush)
+            atomicAdd(packed + t + 1u, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu));
+        } else if (__any(!(fabsf(x) <= 0.0f))) {     // wave-uniform: zeros alone skip the block
+            const float a = fabsf(x);
+            if (a > 0.0f) {
+                sum_out += (double)a;
+                ++nz_out;
+            }
+            nan |= (a != a);
+        }
     }
 };
 
@@ -653,7 +663,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
         dpl_octav_state* me = st + it.slot;
         for (int b = threadIdx.x; b < kLogNB; b += kBlock) l_packed[b] = 0ull;
         __syncthreads();
-        LogHistOp op{l_packed, INFINITY, -INFINITY, 0u, 0u, 0.0};
+        LogHistOp op{l_packed, INFINITY, -INFINITY, 0u, 0u, 0.0};  // mn, mx, nan, nz_out, sum_out
         uint32_t* gc = lh_cnt + (uint64_t)it.slot * kLogNB;
         unsigned long long* gs = lh_sum + (uint64_t)it.slot * kLogNB;
         // sub-spans below 2^20 elements keep the packed count field from overflowing
@@ -664,16 +674,17 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
             for (int b = threadIdx.x; b < kLogNB; b += kBlock) {
                 const unsigned long long v = l_packed[b];
                 if (v) {
-                    atomicAdd(gc + b, (uint32_t)(v >> kPackShift));
-                    atomicAdd(gs + b, v & kPackMask);
+                    const unsigned long long c = v >> kPackShift;
+                    atomicAdd(gc + b, (uint32_t)c);
+                    atomicAdd(gs + b, (v & kPackMask) + (c << 23));   // full 24-bit mantissas
                     l_packed[b] = 0ull;
                 }
             }
             __syncthreads();
         }
         const float mn = wave_min(op.mn), mx = wave_max(op.mx);
-        const uint32_t nz = wave_sum(op.nz);
-        const double sum = wave_sum(op.sum);
+        const uint32_t nz = wave_sum(op.nz_out);
+        const double sum = wave_sum(op.sum_out);
         const uint32_t nn = __any(op.nan) ? 1u : 0u;
         if (lead) {
             s_sum[w] = sum;
@@ -694,8 +705,10 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
                 tmn = fminf(tmn, s_mn[j]);
                 tmx = fmaxf(tmx, s_mx[j]);
             }
-            atomicAdd(&me->sum, tsum);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+            if (tnz) {  // out-of-window part only: the bracket kernel adds the histogram totals
+                atomicAdd(&me->sum, tsum);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+            }
             atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)it.count);
             if (tmn <= tmx) {
                 atomicMin(&me->min_enc, enc_f32(tmn));
@@ -794,7 +807,10 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
     if (threadIdx.x == 0) {
         const float mn = dec_f32(me->min_enc);
         const float ud = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
-        const float s0 = __fdiv_rn((float)me->sum, (float)(long long)me->cnt_gt);
+        // sum(|x|) and count(|x| > 0): exact window totals + the directly accumulated out-of-window part
+        const float s0 = me->nan_seen ? __uint_as_float(0x7FC00000u)
+                                      : __fdiv_rn((float)(me->sum + s_ge[1]), (float)(long long)(me->cnt_gt + n_ge[1]));
+        const float max_abs = fmaxf(fabsf(mn), fabsf(dec_f32(me->max_enc)));
         const unsigned long long n = me->n_elems;
         me->unsigned_div = ud;
         me->s = s0;
@@ -809,12 +825,12 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
         if (s0 != s0 || max_iters <= 0) {
             me->done = 1u;  // NaN is a fixed point of the iteration
             r = 0u;
+        } else if (!(max_abs < log_edge(kLogNB))) {
+            r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
         } else if (n <= (unsigned long long)kSmallPair) {
-            for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair
+            for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair's window
             jmin_s = 0;
             jmax_s = kLogNB - 1;
-        } else if (n_ge[kLogNB - 1] != 0u) {
-            r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
         } else {
             const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
             double lo = (double)s0, hi = (double)s0;
@@ -873,10 +889,18 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
 }
 
 // Pass 2: collect the elements that fall in marked bins (|x| values) into the pair's list 0.  Survivors are
-// rare (3-8 %), so each lane appends to a private LDS queue (no cross-lane work per element); a wave flushes
+// sparse (3-8 %), so each lane appends to a private LDS queue (no cross-lane work per element); a wave flushes
 // its queues behind one scan + one returning atomic when any queue is half full.
+// The membership test is one LDS word + a bit extract per element: the pair's 2048 window marks are placed inside a
+// bitmap over the WHOLE key space (bits >> 17 of any non-negative float: 16384 keys = 2 KiB), so no clamping or
+// rebasing is needed per element and zeros / padding / out-of-window values fall on words that are never set.
+// The append is branch-free: every element is written at the lane's queue tail and the tail only advances for a
+// survivor (2 VALU + 1 LDS write per element instead of a predicated block per element).
 constexpr int kQueueCap = 32;
 constexpr int kQueueStride = kQueueCap + 1;  // odd stride: lanes with equal fill hit different banks
+constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;   // 512
+constexpr int kKeyWord0 = (int)(kLogKey0 >> 5);           // word of the window's first bin (kLogKey0 is a multiple of 32)
+static_assert((kLogKey0 & 31u) == 0u, "the window must start on a bitmap word");
 
 __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __restrict__ items,
                                                           const uint32_t* __restrict__ bb,
@@ -885,11 +909,11 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
                                                           const uint32_t* __restrict__ bitmap,
                                                           const uint64_t* __restrict__ pair_base,
                                                           float* __restrict__ list0) {
-    extern __shared__ __attribute__((aligned(16))) float queues[];  // [waves][64][kQueueStride]
-    __shared__ uint32_t bm[kBitmapRow];
+    extern __shared__ __attribute__((aligned(16))) uint32_t queues[];  // [waves][64][kQueueStride]
+    __shared__ uint32_t bm[kKeyWords];
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* q = queues + ((size_t)w * kWave + lane) * kQueueStride;
+    uint32_t* q = queues + ((size_t)w * kWave + lane) * kQueueStride;
     uint32_t k0, k1;
     block_items(bb, k0, k1);
     for (uint32_t k = k0; k < k1; ++k) {
@@ -897,11 +921,13 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
         dpl_octav_state* me = st + it.slot;
         if (me->done || me->mode != 2u) continue;  // uniform per workgroup
         __syncthreads();
-        if (threadIdx.x < kBitmapRow) bm[threadIdx.x] = bitmap[(uint64_t)it.slot * kBitmapRow + threadIdx.x];
+        for (int i = threadIdx.x; i < kKeyWords; i += kBlock) {
+            const int j = i - kKeyWord0;
+            bm[i] = (j >= 0 && j < kLogWords) ? bitmap[(uint64_t)it.slot * kBitmapRow + j] : 0u;
+        }
         __syncthreads();
-        const float rlo = __uint_as_float(bm[kLogWords]), rhi = __uint_as_float(bm[kLogWords + 1]);
         const float* p = segs[it.seg] + it.offset;
-        float* dst = list0 + pair_base[it.slot];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(list0 + pair_base[it.slot]);
         uint32_t cnt = 0;
         auto flush = [&]() {
             uint32_t inc = cnt;
@@ -917,31 +943,31 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
             for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j];
             cnt = 0;
         };
-        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t tile_base, bool full) {
-            // phase 1, branch-free: all 16 bitmap words are fetched back to back (one LDS wait for the tile)
-            float a[16];
-            uint32_t word[16];
+        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t, bool) {
+            // phase 1: all 16 bitmap words are fetched back to back (one LDS wait for the tile)
+            uint32_t u[16], word[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a[4 * u + 0] = fabsf(v[u].x);
-                a[4 * u + 1] = fabsf(v[u].y);
-                a[4 * u + 2] = fabsf(v[u].z);
-                a[4 * u + 3] = fabsf(v[u].w);
+            for (int c = 0; c < 4; ++c) {
+                u[4 * c + 0] = __float_as_uint(v[c].x) & 0x7FFFFFFFu;
+                u[4 * c + 1] = __float_as_uint(v[c].y) & 0x7FFFFFFFu;
+                u[4 * c + 2] = __float_as_uint(v[c].z) & 0x7FFFFFFFu;
+                u[4 * c + 3] = __float_as_uint(v[c].w) & 0x7FFFFFFFu;
             }
 #pragma unroll
-            for (int j = 0; j < 16; ++j) word[j] = bm[log_bin(a[j]) >> 5];
-            uint32_t gm = 0u;
+            for (int j = 0; j < 16; ++j) word[j] = bm[u[j] >> (kLogShift + 5)];
+            uint32_t hit[16], any = 0u;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const bool real = full || (tile_base + (j >> 2) * 256 + lane * 4 + (j & 3) < it.count);  // padding is not data
-                const bool g = a[j] >= rlo && a[j] < rhi && real && ((word[j] >> (log_bin(a[j]) & 31)) & 1u);
-                gm |= g ? (1u << j) : 0u;
+                hit[j] = (word[j] >> ((u[j] >> kLogShift) & 31u)) & 1u;
+                any |= hit[j];
             }
-            // phase 2: the (rare) survivors go to the lane's queue
-            if (__any(gm != 0u)) {
+            // phase 2: branch-free append (a tile without any survivor in the wave skips it)
+            if (__any(any != 0u)) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    if ((gm >> j) & 1u) q[cnt++] = a[j];
+                for (int j = 0; j < 16; ++j) {
+                    q[cnt] = u[j];
+                    cnt += hit[j];
+                }
             }
             if (__any(cnt > (uint32_t)(kQueueCap - 16))) flush();
         });
@@ -1268,7 +1294,7 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
     hipLaunchKernelGGL(k_octav_bracket, pairs, pb, 0, st, d_states, ctl, d_lh_cnt,
                        reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);
     if (max_iters > 0) {
-        hipLaunchKernelGGL(k_octav_gather, pg, pb, (size_t)kBlock * kQueueStride * sizeof(float), st, d_items,
+        hipLaunchKernelGGL(k_octav_gather, pg, pb, (size_t)kBlock * kQueueStride * sizeof(uint32_t), st, d_items,
                            d_block_begin, d_seg_ptrs, d_states, d_bitmap, d_pair_base, d_list0);
         hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock),
                            (size_t)(kExactBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,

@@ -722,8 +722,8 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
 
 // Shared by the bracket walk and the exact walk: suffix totals over the bins, S_ge[j] / N_ge[j] = everything
 // in bins >= j.  Built by one workgroup per pair into LDS (N as u32, S as fp64; j = 0 .. kLogNB).
-__device__ __forceinline__ void build_suffix(const uint32_t* __restrict__ gc, const unsigned long long* __restrict__ gs,
-                                             uint32_t* n_ge, double* s_ge, double* scratch_s, uint32_t* scratch_n) {
+__device__ __forceinline__ void build_suffix(uint32_t* gc, unsigned long long* gs, uint32_t* n_ge, double* s_ge,
+                                             double* scratch_s, uint32_t* scratch_n, bool write_back) {
     // each thread owns a run of consecutive bins (thread 0 the top ones); exclusive prefix over threads by a
     // wave-level shuffle scan + a serial pass over the (<= 16) wave totals
     const int per = (kLogNB + (int)blockDim.x - 1) / (int)blockDim.x;
@@ -768,6 +768,10 @@ __device__ __forceinline__ void build_suffix(const uint32_t* __restrict__ gc, co
             rs += (double)gs[bq] * log_bin_scale(bq);
             n_ge[bq] = rn;
             s_ge[bq] = rs;
+            if (write_back) {  // each thread owns its bins: the raw histogram is replaced by the suffix totals
+                gc[bq] = rn;
+                gs[bq] = (unsigned long long)__double_as_longlong(rs);
+            }
         }
     }
     if (threadIdx.x == 0) {
@@ -784,8 +788,8 @@ __device__ __forceinline__ float log_edge(int b) {  // lower edge of bin b (bin 
 // Per pair: s_0, then the bracket walk over the bin edges; marks the bins the iterates can visit.
 __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __restrict__ st,
                                                            dpl_octav_state* __restrict__ ctl,
-                                                           const uint32_t* __restrict__ lh_cnt,
-                                                           const unsigned long long* __restrict__ lh_sum,
+                                                           uint32_t* __restrict__ lh_cnt,
+                                                           unsigned long long* __restrict__ lh_sum,
                                                            uint32_t* __restrict__ bitmap, int dynamic_sym, int max_iters) {
     __shared__ uint32_t n_ge[kLogNB + 1];
     __shared__ double s_ge[kLogNB + 1];
@@ -800,10 +804,12 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
     }
     const int64_t pr = blockIdx.x;
     dpl_octav_state* me = st + pr;
-    const uint32_t* gc = lh_cnt + pr * kLogNB;
-    const unsigned long long* gs = lh_sum + pr * kLogNB;
+    uint32_t* gc = lh_cnt + pr * kLogNB;
+    unsigned long long* gs = lh_sum + pr * kLogNB;
     if (threadIdx.x < kLogWords) bm[threadIdx.x] = 0u;
-    build_suffix(gc, gs, n_ge, s_ge, scr_s, scr_n);
+    // the exact walk (k_octav_exact) needs the totals above a bin, never a single bin: from here on the pair's
+    // histogram rows hold the suffix totals  N_ge[j] (u32)  and  S_ge[j] (fp64 bits)
+    build_suffix(gc, gs, n_ge, s_ge, scr_s, scr_n, true);
     if (threadIdx.x == 0) {
         const float mn = dec_f32(me->min_enc);
         const float ud = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
@@ -896,7 +902,10 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
 // rebasing is needed per element and zeros / padding / out-of-window values fall on words that are never set.
 // The append is branch-free: every element is written at the lane's queue tail and the tail only advances for a
 // survivor (2 VALU + 1 LDS write per element instead of a predicated block per element).
-constexpr int kQueueCap = 32;
+#ifndef DPL_QUEUE_CAP
+#define DPL_QUEUE_CAP 32
+#endif
+constexpr int kQueueCap = DPL_QUEUE_CAP;     // a tile adds at most 16: flush once a queue holds more than cap - 16
 constexpr int kQueueStride = kQueueCap + 1;  // odd stride: lanes with equal fill hit different banks
 constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;   // 512
 constexpr int kKeyWord0 = (int)(kLogKey0 >> 5);           // word of the window's first bin (kLogKey0 is a multiple of 32)
@@ -982,13 +991,16 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
 // current bin are updated incrementally.  An iterate that lands in an unmarked bin, or moves down, sends the
 // pair to the compaction route.
 #ifndef DPL_EXACT_BLOCK
-#define DPL_EXACT_BLOCK 256
+#define DPL_EXACT_BLOCK 128   // measured: 128 > 256 > 64 threads per pair (more pairs in flight vs. longer list passes)
 #endif
 #ifndef DPL_EXACT_WAVES
 #define DPL_EXACT_WAVES 3
 #endif
 constexpr int kExactBlock = DPL_EXACT_BLOCK;
-constexpr int kExactRegs = 16;  // gathered values held per lane once the list is short (256 * 16 = 4 K)
+#ifndef DPL_EXACT_REGS
+#define DPL_EXACT_REGS 16
+#endif
+constexpr int kExactRegs = DPL_EXACT_REGS;  // gathered values held per lane once the list is short
 
 __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dpl_octav_state* __restrict__ st,
                                                               dpl_octav_state* __restrict__ ctl,
@@ -1006,9 +1018,7 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
     __shared__ uint32_t bm[kLogWords];
     __shared__ uint32_t s_cursor;
     __shared__ OctavStep s_step;
-    __shared__ double s_above;             // exact totals of the bins above the current one
-    __shared__ unsigned long long n_above;
-    __shared__ int s_jb, s_jn;
+    __shared__ int s_jb;
     __shared__ uint32_t s_bad;
     __shared__ float s_floor;  // the list holds every gathered value above this (-inf: nothing dropped yet)
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
@@ -1025,39 +1035,23 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
     const uint64_t base_off = pair_base[pair];
     float s = me->s;
     uint32_t iters = me->iters, n = me->len[0], cur = 0u;
-    // totals above the first iterate's bin: one block-wide reduction over the histogram
+    // exact totals of the bins above the current one: thread 0 reads them from the suffix rows the bracket kernel
+    // left in the histogram buffers (N_ge[j] as u32, S_ge[j] as fp64 bits; j = kLogNB means nothing above)
     int jb = log_bin(s);
-    {
-        double ls = 0.0;
-        unsigned long long ln = 0;
-        for (int b2 = jb + 1 + (int)threadIdx.x; b2 < kLogNB; b2 += kExactBlock) {
-            ln += gc[b2];
-            ls += (double)gs[b2] * log_bin_scale(b2);
-        }
-        ls = wave_sum(ls);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ln += __shfl_xor(ln, o, kWave);
-        if (lane == 0) {
-            scr_s[w] = ls;
-            scr_n[w] = ln;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double ts = 0.0;
-            unsigned long long tn = 0;
-            for (int j = 0; j < kWaves; ++j) {
-                ts += scr_s[j];
-                tn += scr_n[j];
-            }
-            s_above = ts;
-            n_above = tn;
-            s_jb = jb;
-            s_jn = jb;
-            s_floor = -INFINITY;
-            s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
-        }
-        __syncthreads();
+    double s_above = 0.0;                // (thread 0 only)
+    unsigned long long n_above = 0ull;
+    auto load_above = [&](int j) {
+        n_above = (j + 1 < kLogNB) ? (unsigned long long)gc[j + 1] : 0ull;
+        s_above = (j + 1 < kLogNB) ? __longlong_as_double((long long)gs[j + 1]) : 0.0;
+    };
+    __syncthreads();  // bm
+    if (threadIdx.x == 0) {
+        load_above(jb);
+        s_jb = jb;
+        s_floor = -INFINITY;
+        s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
     }
+    __syncthreads();
     uint32_t done = 0u, bad = s_bad;
     bool in_regs = false;
     float r[kExactRegs];
@@ -1137,53 +1131,17 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
             if (!in_regs) s_floor = s;  // this pass compacted the list: values not above s are gone
             const OctavStep q = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
             s_step = q;
-            if (!q.done) {  // move the exact totals to the new iterate's bin (up, or down while the values are kept)
+            if (!q.done) {  // the totals of the new iterate's bin (up, or down while the values are still held)
                 const int jn = log_bin(q.s);
                 uint32_t nb = 0u;
                 // a smaller iterate can only be answered if nothing above it has been dropped from the list
                 if (!(q.s >= s_floor) || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
                     nb = 1u;
-                } else {
-                    s_jn = jn;  // the totals are moved below, by the whole workgroup
+                } else if (jn != s_jb) {
+                    load_above(jn);
+                    s_jb = jn;
                 }
                 s_bad = nb;
-            }
-        }
-        __syncthreads();
-        {   // move the exact totals from bin s_jb to bin s_jn: one bin per lane, a single memory round trip
-            const OctavStep q0 = s_step;
-            if (!q0.done && !s_bad && s_jn != s_jb) {
-                const int lo = s_jn < s_jb ? s_jn : s_jb, hi = s_jn < s_jb ? s_jb : s_jn;  // bins lo+1 .. hi change sides
-                double ds = 0.0;
-                unsigned long long dn = 0;
-                for (int b2 = lo + 1 + (int)threadIdx.x; b2 <= hi; b2 += kExactBlock) {
-                    dn += gc[b2];
-                    ds += (double)gs[b2] * log_bin_scale(b2);
-                }
-                ds = wave_sum(ds);
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) dn += __shfl_xor(dn, o, kWave);
-                if (lane == 0) {
-                    scr_s[w] = ds;
-                    scr_n[w] = dn;
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    double ts = 0.0;
-                    unsigned long long tn = 0;
-                    for (int j = 0; j < kWaves; ++j) {
-                        ts += scr_s[j];
-                        tn += scr_n[j];
-                    }
-                    if (s_jn > s_jb) {  // moved up: those bins are no longer "above"
-                        s_above -= ts;
-                        n_above -= tn;
-                    } else {
-                        s_above += ts;
-                        n_above += tn;
-                    }
-                    s_jb = s_jn;
-                }
             }
         }
         __syncthreads();
@@ -1292,7 +1250,7 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
     hipLaunchKernelGGL(k_octav_loghist, pg, pb, (size_t)kLogNB * 8, st, d_items, d_block_begin, d_seg_ptrs, d_states,
                        d_lh_cnt, reinterpret_cast<unsigned long long*>(d_lh_sum));
     hipLaunchKernelGGL(k_octav_bracket, pairs, pb, 0, st, d_states, ctl, d_lh_cnt,
-                       reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);
+                       reinterpret_cast<unsigned long long*>(d_lh_sum), d_bitmap, dynamic_sym, max_iters);
     if (max_iters > 0) {
         hipLaunchKernelGGL(k_octav_gather, pg, pb, (size_t)kBlock * kQueueStride * sizeof(uint32_t), st, d_items,
                            d_block_begin, d_seg_ptrs, d_states, d_bitmap, d_pair_base, d_list0);

@@ -142,7 +142,8 @@ int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const u
  * exact iteration from (exact totals of the bins above) + (gathered elements of the current bin), verifying
  * that every iterate lands in a marked bin.  Pairs it cannot serve (bracket explodes on flat / degenerate
  * distributions, values >= 2^14, failed verification) are finished by the compaction route above.
- * d_lh_cnt: uint32 [n_pairs, 2048]; d_lh_sum: uint64 [n_pairs, 2048]; d_bitmap: uint32 [n_pairs, 66]
+ * d_lh_cnt: uint32 [n_pairs, 2048]; d_lh_sum: uint64 [n_pairs, 2048] (scratch: after the bracket walk they hold the
+ * suffix totals N_ge[j] / S_ge[j] (fp64 bits) the exact walk reads); d_bitmap: uint32 [n_pairs, 66]
  * (64 words of marks + the gathered value range as two float bit patterns). */
 int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
                           int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,

@@ -985,22 +985,24 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
 }
 
 // Per pair: the reference's exact iteration from the exact bin totals + the gathered elements.
-// For the iterate s in bin jb:  count(|x| > s) = (exact total of the bins above jb) + (gathered values v with
-// s < v < edge(jb+1)).  The iterates climb, so values not above s are dropped from the gathered list as it is
-// walked (the same tail compaction as k_octav_iterate_lists, list 0 -> list 1 -> ...), and the totals above the
-// current bin are updated incrementally.  An iterate that lands in an unmarked bin, or moves down, sends the
-// pair to the compaction route.
+// For the iterate s in bin jb:  count(|x| > s) = (exact total of the bins above jb) + (gathered values v of bin jb
+// with v > s), and the same for the sums.  The gathered values are first bucketed by bin (one pass over list 0 into
+// list 1: the bin's position comes from the exact counts, the rank inside the bin from an LDS counter), so that an
+// iteration touches only the values of ITS bin - usually a few hundred, held in registers while the iterate stays
+// in the bin - instead of walking the whole gathered list.  The totals above a bin are the suffix rows the bracket
+// kernel left in the histogram buffers.  An iterate that lands in an unmarked bin sends the pair to the
+// compaction route.
 #ifndef DPL_EXACT_BLOCK
-#define DPL_EXACT_BLOCK 128   // measured: 128 > 256 > 64 threads per pair (more pairs in flight vs. longer list passes)
+#define DPL_EXACT_BLOCK 128   // threads per pair
 #endif
 #ifndef DPL_EXACT_WAVES
-#define DPL_EXACT_WAVES 3
+#define DPL_EXACT_WAVES 4
 #endif
-constexpr int kExactBlock = DPL_EXACT_BLOCK;
 #ifndef DPL_EXACT_REGS
 #define DPL_EXACT_REGS 16
 #endif
-constexpr int kExactRegs = DPL_EXACT_REGS;  // gathered values held per lane once the list is short
+constexpr int kExactBlock = DPL_EXACT_BLOCK;
+constexpr int kExactRegs = DPL_EXACT_REGS;  // values of the current bin held per lane (128 * 16 = 2 K)
 
 __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dpl_octav_state* __restrict__ st,
                                                               dpl_octav_state* __restrict__ ctl,
@@ -1009,112 +1011,152 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
                                                               const unsigned long long* __restrict__ lh_sum,
                                                               const uint32_t* __restrict__ bitmap,
                                                               const uint64_t* __restrict__ pair_base,
-                                                              float* __restrict__ list0, float* __restrict__ list1,
+                                                              const float* __restrict__ list0, float* __restrict__ list1,
                                                               int max_iters) {
-    extern __shared__ __attribute__((aligned(16))) float stage_all[];
     constexpr int kWaves = kExactBlock / kWave;
+    constexpr int kPer = kLogNB / kExactBlock;     // consecutive bins owned by a thread in the offset scan
+    static_assert(kLogNB % kExactBlock == 0, "bins must split evenly over the workgroup");
+    __shared__ uint32_t boff[kLogNB];              // start of the bin's values inside the pair's list-1 region
+    __shared__ uint32_t cursor[kLogNB];            // values placed so far (= the bin's count after the bucket pass)
     __shared__ double scr_s[kWaves];
-    __shared__ unsigned long long scr_n[kWaves];
+    __shared__ uint32_t scr_n[kWaves];
     __shared__ uint32_t bm[kLogWords];
-    __shared__ uint32_t s_cursor;
     __shared__ OctavStep s_step;
     __shared__ int s_jb;
     __shared__ uint32_t s_bad;
-    __shared__ float s_floor;  // the list holds every gathered value above this (-inf: nothing dropped yet)
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
     dpl_octav_state* me = st + pair;
     if (me->done || me->mode != 2u) return;  // uniform per workgroup
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    float* stage = stage_all + w * kIterStageCap;
-    const uint32_t* gc = lh_cnt + (uint64_t)pair * kLogNB;
-    const unsigned long long* gs = lh_sum + (uint64_t)pair * kLogNB;
+    const uint32_t* nge = lh_cnt + (uint64_t)pair * kLogNB;            // N_ge[j]
+    const unsigned long long* sge = lh_sum + (uint64_t)pair * kLogNB;  // S_ge[j] (fp64 bits)
     if (threadIdx.x < kLogWords) bm[threadIdx.x] = bitmap[(uint64_t)pair * kBitmapRow + threadIdx.x];
     const unsigned long long n_elems = me->n_elems;
     const float unsigned_div = me->unsigned_div;
     const uint64_t base_off = pair_base[pair];
     float s = me->s;
-    uint32_t iters = me->iters, n = me->len[0], cur = 0u;
-    // exact totals of the bins above the current one: thread 0 reads them from the suffix rows the bracket kernel
-    // left in the histogram buffers (N_ge[j] as u32, S_ge[j] as fp64 bits; j = kLogNB means nothing above)
+    uint32_t iters = me->iters;
+    const uint32_t n = me->len[0];
+    __syncthreads();
+    // ---- where each marked bin's values go: exclusive scan of the marked bins' exact counts, in bin order
+    {
+        const int b0 = (int)threadIdx.x * kPer;
+        uint32_t cnt[kPer], local = 0u;
+        uint32_t above = nge[b0];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int bq = b0 + q;
+            const uint32_t next = (bq + 1 < kLogNB) ? nge[bq + 1] : 0u;
+            const bool marked = (bm[bq >> 5] >> (bq & 31)) & 1u;
+            cnt[q] = marked ? above - next : 0u;      // N_ge[b] - N_ge[b+1]
+            above = next;
+            local += cnt[q];
+        }
+        uint32_t inc = local;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, kWave);
+            if (lane >= (uint32_t)o) inc += t;
+        }
+        if (lane == kWave - 1) scr_n[w] = inc;
+        __syncthreads();
+        uint32_t run = inc - local;
+        for (int q = 0; q < w; ++q) run += scr_n[q];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            boff[b0 + q] = run;
+            cursor[b0 + q] = 0u;
+            run += cnt[q];
+        }
+    }
+    __syncthreads();
+    // ---- bucket pass: list 0 (as gathered) -> list 1 (grouped by bin); 16 values per thread in flight
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(list0 + base_off);   // 16-byte aligned region
+        uint32_t* dst = reinterpret_cast<uint32_t*>(list1 + base_off);
+        using u4 = __attribute__((ext_vector_type(4))) uint32_t;
+        const u4* src4 = reinterpret_cast<const u4*>(src);
+        const uint32_t n4 = n >> 2;
+        auto place = [&](uint32_t u) {
+            const int b = log_bin(__uint_as_float(u));
+            const uint32_t r = atomicAdd(&cursor[b], 1u);
+            dst[boff[b] + r] = u;
+        };
+        for (uint32_t i0 = threadIdx.x; i0 < n4; i0 += kExactBlock * 4) {
+            u4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t i = i0 + q * kExactBlock;
+                v[q] = i < n4 ? __builtin_nontemporal_load(src4 + i) : u4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (i0 + q * kExactBlock < n4) {
+                    place(v[q].x);
+                    place(v[q].y);
+                    place(v[q].z);
+                    place(v[q].w);
+                }
+            }
+        }
+        for (uint32_t i = (n4 << 2) + threadIdx.x; i < n; i += kExactBlock) place(src[i]);
+    }
+    // exact totals of the bins above the current one (thread 0): N_ge[j+1], S_ge[j+1]; nothing above the top bin
     int jb = log_bin(s);
-    double s_above = 0.0;                // (thread 0 only)
+    double s_above = 0.0;
     unsigned long long n_above = 0ull;
     auto load_above = [&](int j) {
-        n_above = (j + 1 < kLogNB) ? (unsigned long long)gc[j + 1] : 0ull;
-        s_above = (j + 1 < kLogNB) ? __longlong_as_double((long long)gs[j + 1]) : 0.0;
+        n_above = (j + 1 < kLogNB) ? (unsigned long long)nge[j + 1] : 0ull;
+        s_above = (j + 1 < kLogNB) ? __longlong_as_double((long long)sge[j + 1]) : 0.0;
     };
-    __syncthreads();  // bm
     if (threadIdx.x == 0) {
         load_above(jb);
         s_jb = jb;
-        s_floor = -INFINITY;
         s_bad = (jb <= 0 || jb >= kLogNB - 1 || !((bm[jb >> 5] >> (jb & 31)) & 1u)) ? 1u : 0u;
     }
-    __syncthreads();
+    __syncthreads();   // list 1 and the counters are complete
     uint32_t done = 0u, bad = s_bad;
-    bool in_regs = false;
+    int held = -1;             // the bin whose values are in r[]
     float r[kExactRegs];
+    const float* grouped = list1 + base_off;
     while (!done && !bad) {
-        const float e_hi = log_edge(jb + 1);
-        const float* src = (cur == 0 ? list0 : list1) + base_off;
-        float* dst = (cur == 0 ? list1 : list0) + base_off;
+        const uint32_t nb = cursor[jb];
+        const float* src = grouped + boff[jb];
         uint32_t c = 0;
+        float p0 = 0.0f;
         double pd = 0.0;
-        if (!in_regs && n <= (uint32_t)(kExactBlock * kExactRegs)) {
-            gptr_f32 g = (gptr_f32)src;
+        if (nb <= (uint32_t)(kExactBlock * kExactRegs)) {
+            if (held != jb) {
 #pragma unroll
-            for (int j = 0; j < kExactRegs; ++j) {
-                const uint32_t idx = j * kExactBlock + threadIdx.x;
-                r[j] = idx < n ? g[idx] : 0.0f;
+                for (int j = 0; j < kExactRegs; ++j) {
+                    const uint32_t idx = j * kExactBlock + threadIdx.x;
+                    r[j] = idx < nb ? src[idx] : 0.0f;
+                }
+                held = jb;
             }
-            in_regs = true;
-        }
-        if (in_regs) {
-            float p0 = 0.0f;
 #pragma unroll
             for (int j = 0; j < kExactRegs; ++j) {
-                const bool gq = r[j] > s && r[j] < e_hi;
+                const bool gq = r[j] > s;
                 c += gq;
                 p0 += gq ? r[j] : 0.0f;
             }
             pd = (double)p0;
-            c = wave_sum(c);
-        } else {
-            if (threadIdx.x == 0) s_cursor = 0u;
-            __syncthreads();
-            uint32_t fill = 0;
-            auto flush = [&]() {
-                uint32_t b0 = 0;
-                if (lane == 0) b0 = atomicAdd(&s_cursor, fill);
-                b0 = __shfl(b0, 0, kWave);
-                for (uint32_t j = lane; j < fill; j += kWave) dst[b0 + j] = stage[j];
-                fill = 0;
-            };
-            for_each_tile<kExactBlock>(src, n, [&](const f4 (&v)[4], uint32_t, bool) {
-                if (fill + 1024u > (uint32_t)kIterStageCap) flush();
+        } else {  // a very full bin: walk its values from memory (L2) each time
+            for (uint32_t i0 = 0; i0 < nb; i0 += kExactBlock * 16) {
                 float part = 0.0f;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float a4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float a = a4[e];
-                        const bool keep = a > s;                 // stays in the list for later iterates
-                        const bool cntit = keep && a < e_hi;     // belongs to the current bin
-                        const unsigned long long m = __ballot(keep);
-                        const uint32_t off = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        if (keep) stage[fill + off] = a;
-                        fill += (uint32_t)__popcll(m);
-                        c += cntit;
-                        part += cntit ? a : 0.0f;
-                    }
+                for (int j = 0; j < 16; ++j) {
+                    const uint32_t idx = i0 + j * kExactBlock + threadIdx.x;
+                    const float v = idx < nb ? src[idx] : 0.0f;
+                    const bool gq = v > s;
+                    c += gq;
+                    part += gq ? v : 0.0f;
                 }
                 pd += (double)part;
-            });
-            if (fill) flush();
-            c = wave_sum(c);
+            }
         }
+        c = wave_sum(c);
         pd = wave_sum(pd);
         if (lane == 0) {
             scr_n[w] = c;
@@ -1128,20 +1170,16 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
                 tg += scr_n[j];
                 ts += scr_s[j];
             }
-            if (!in_regs) s_floor = s;  // this pass compacted the list: values not above s are gone
             const OctavStep q = octav_step(ts, tg, n_elems - tg, unsigned_div, s, iters, max_iters);
             s_step = q;
-            if (!q.done) {  // the totals of the new iterate's bin (up, or down while the values are still held)
+            if (!q.done) {
                 const int jn = log_bin(q.s);
-                uint32_t nb = 0u;
-                // a smaller iterate can only be answered if nothing above it has been dropped from the list
-                if (!(q.s >= s_floor) || jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
-                    nb = 1u;
+                if (jn <= 0 || jn >= kLogNB - 1 || !((bm[jn >> 5] >> (jn & 31)) & 1u)) {
+                    s_bad = 1u;      // the bracket did not foresee this bin
                 } else if (jn != s_jb) {
                     load_above(jn);
                     s_jb = jn;
                 }
-                s_bad = nb;
             }
         }
         __syncthreads();
@@ -1151,11 +1189,6 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
         done = q.done;
         bad = done ? 0u : s_bad;
         jb = s_jb;
-        if (!in_regs) {
-            n = s_cursor;
-            cur = 1u - cur;
-        }
-        __syncthreads();
     }
     if (threadIdx.x == 0) {
         if (bad) {  // restart this pair on the compaction route from s_0 (state as k_octav_update<true> leaves it;
@@ -1254,8 +1287,7 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
     if (max_iters > 0) {
         hipLaunchKernelGGL(k_octav_gather, pg, pb, (size_t)kBlock * kQueueStride * sizeof(uint32_t), st, d_items,
                            d_block_begin, d_seg_ptrs, d_states, d_bitmap, d_pair_base, d_list0);
-        hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock),
-                           (size_t)(kExactBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
+        hipLaunchKernelGGL(k_octav_exact, pairs, dim3(kExactBlock), 0, st, d_states, ctl, d_pair_order,
                            d_lh_cnt, reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, d_pair_base,
                            d_list0, d_list1, max_iters);
         // 5. pairs the bracket could not serve (flat / degenerate distributions, values >= 2^14): compaction route

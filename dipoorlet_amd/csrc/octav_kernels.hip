@@ -724,20 +724,26 @@ __global__ __launch_bounds__(kBlock) void k_octav_loghist(const dpl_work_item* _
 // in bins >= j.  Built by one workgroup per pair into LDS (N as u32, S as fp64; j = 0 .. kLogNB).
 __device__ __forceinline__ void build_suffix(uint32_t* gc, unsigned long long* gs, uint32_t* n_ge, double* s_ge,
                                              double* scratch_s, uint32_t* scratch_n, bool write_back) {
-    // each thread owns a run of consecutive bins (thread 0 the top ones); exclusive prefix over threads by a
-    // wave-level shuffle scan + a serial pass over the (<= 16) wave totals
-    const int per = (kLogNB + (int)blockDim.x - 1) / (int)blockDim.x;
-    const int hi = kLogNB - 1 - (int)threadIdx.x * per;  // my highest bin
+    // each thread owns a run of consecutive bins (thread 0 the top ones), read once into registers; exclusive
+    // prefix over threads by a wave-level shuffle scan + a serial pass over the wave totals  (kBlock threads)
+    constexpr int kPerT = kLogNB / kBlock;
+    static_assert(kLogNB % kBlock == 0, "bins must split evenly over the workgroup");
+    const int hi = kLogNB - 1 - (int)threadIdx.x * kPerT;  // my highest bin
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    const int w = threadIdx.x / kWave, nw = (int)blockDim.x / kWave;
+    const int w = threadIdx.x / kWave;
+    uint32_t cn[kPerT];
+    double cs[kPerT];
     double ls = 0.0;
     uint32_t ln = 0;
-    for (int q = 0; q < per; ++q) {
-        const int bq = hi - q;
-        if (bq >= 0) {
-            ln += gc[bq];
-            ls += (double)gs[bq] * log_bin_scale(bq);
-        }
+#pragma unroll
+    for (int q = 0; q < kPerT; ++q) {
+        cn[q] = gc[hi - q];
+        cs[q] = (double)gs[hi - q] * log_bin_scale(hi - q);
+    }
+#pragma unroll
+    for (int q = 0; q < kPerT; ++q) {
+        ln += cn[q];
+        ls += cs[q];
     }
     double is = ls;
     uint32_t in = ln;
@@ -757,21 +763,20 @@ __device__ __forceinline__ void build_suffix(uint32_t* gc, unsigned long long* g
     __syncthreads();
     double rs = is - ls;  // exclusive within the wave
     uint32_t rn = in - ln;
-    for (int q = 0; q < w && q < nw; ++q) {
+    for (int q = 0; q < w; ++q) {
         rs += scratch_s[q];
         rn += scratch_n[q];
     }
-    for (int q = 0; q < per; ++q) {
+#pragma unroll
+    for (int q = 0; q < kPerT; ++q) {
         const int bq = hi - q;
-        if (bq >= 0) {
-            rn += gc[bq];
-            rs += (double)gs[bq] * log_bin_scale(bq);
-            n_ge[bq] = rn;
-            s_ge[bq] = rs;
-            if (write_back) {  // each thread owns its bins: the raw histogram is replaced by the suffix totals
-                gc[bq] = rn;
-                gs[bq] = (unsigned long long)__double_as_longlong(rs);
-            }
+        rn += cn[q];
+        rs += cs[q];
+        n_ge[bq] = rn;
+        s_ge[bq] = rs;
+        if (write_back) {  // each thread owns its bins: the raw histogram is replaced by the suffix totals
+            gc[bq] = rn;
+            gs[bq] = (unsigned long long)__double_as_longlong(rs);
         }
     }
     if (threadIdx.x == 0) {
@@ -849,12 +854,12 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
                     r = 1u;
                     break;
                 }
-                for (int j = jl - 1; j <= jh + 1; ++j) {
-                    const uint32_t bit = 1u << (j & 31);
-                    if (!(bm[j >> 5] & bit)) {
-                        bm[j >> 5] |= bit;
-                        ++marked;
-                    }
+                for (int w0 = (jl - 1) >> 5; w0 <= (jh + 1) >> 5; ++w0) {   // one LDS read-modify-write per word
+                    const int lo_b = max(jl - 1, w0 << 5) & 31, hi_b = min(jh + 1, (w0 << 5) + 31) & 31;
+                    const uint32_t mask = (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
+                    const uint32_t old = bm[w0];
+                    bm[w0] = old | mask;
+                    marked += __popc(mask & ~old);
                 }
                 jmin_s = jl - 1 < jmin_s ? jl - 1 : jmin_s;
                 jmax_s = jh + 1 > jmax_s ? jh + 1 : jmax_s;

@@ -93,9 +93,15 @@ __global__ __launch_bounds__(kBlock) void k_round_step(const float* __restrict__
                                                         const float* __restrict__ wfloor, float* __restrict__ alpha,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         ChannelParams cp, uint32_t n, StepParams sp,
+                                                        const dpl_round_sched* __restrict__ sched,
                                                         float* __restrict__ qw_next, float* __restrict__ grad_alpha,
                                                         double* __restrict__ reg_loss) {
     __shared__ double s_red[kBlock / kWave];
+    if (sched) {  // captured in a hipGraph: this iteration's temperature and Adam corrections live on the device
+        sp.beta = sched->reg_beta;
+        sp.step_size = sched->step_size;
+        sp.bc2_sqrt = sched->bc2_sqrt;
+    }
     double reg_part = 0.0;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const uint32_t c = cp.channel(i);
@@ -142,6 +148,26 @@ __global__ __launch_bounds__(kBlock) void k_round_step(const float* __restrict__
             atomicAdd(reg_loss, (double)sp.lambda * t);
         }
     }
+}
+
+// One thread: advance the learner's schedule by one iteration (TempDecay, ada_quant_layer.py:119-134, and Adam's
+// bias corrections as torch computes them on the host, in double).
+__global__ void k_round_sched_advance(dpl_round_sched* __restrict__ sc, int32_t t_max, double lr, double beta1,
+                                      double beta2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t t = sc->iter;
+    const double start = 0.2 * (double)t_max;
+    double beta = 0.0;
+    if (!((double)t < start)) {
+        const double rel_t = ((double)t - start) / ((double)t_max - start);
+        beta = 2.0 + 0.5 * (20.0 - 2.0) * (1.0 + cos(rel_t * 3.141592653589793));
+    }
+    const int32_t step = sc->adam_step + 1;
+    sc->reg_beta = (float)beta;
+    sc->step_size = (float)(lr / (1.0 - pow(beta1, (double)step)));
+    sc->bc2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    sc->adam_step = step;
+    sc->iter = t + 1;
 }
 
 // loss += sum((relu?(z) - t)^2) * inv_m ;  grad = coef * (relu?(z) - t) * (z > 0 if relu)
@@ -260,19 +286,21 @@ int dpl_round_quant(const float* d_wfloor, const float* d_alpha, const float* d_
 
 int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha, float* d_m, float* d_v,
                    const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
-                   int64_t inner, const dpl_round_step_params* p, float* d_qw_next, float* d_grad_alpha,
-                   double* d_reg_loss, dpl_stream_t s) {
+                   int64_t inner, const dpl_round_step_params* p, const dpl_round_sched* d_sched, float* d_qw_next,
+                   float* d_grad_alpha, double* d_reg_loss, dpl_stream_t s) {
     if (int e = check_channels("dpl_round_step", n, n_channels, inner)) return e;
     if (!p) return fail_msg("dpl_round_step: params missing");
     if (p->clamp && (!d_qmin || !d_qmax)) return fail_msg("dpl_round_step: clamp needs q_min and q_max");
-    if (p->adam && (!d_m || !d_v || p->step < 1)) return fail_msg("dpl_round_step: Adam needs moments and step >= 1");
+    if (p->adam && (!d_m || !d_v || (p->step < 1 && !d_sched)))
+        return fail_msg("dpl_round_step: Adam needs moments and step >= 1 (or a device schedule)");
     StepParams sp;
     sp.grad_scale = p->grad_scale;
     sp.beta = p->reg_beta;
     sp.lambda = p->reg_lambda;
     // bias corrections as torch computes them: in double on the host, then cast
-    const double bc1 = 1.0 - pow(p->adam_beta1, (double)p->step);
-    const double bc2 = 1.0 - pow(p->adam_beta2, (double)p->step);
+    const int step = p->step < 1 ? 1 : p->step;
+    const double bc1 = 1.0 - pow(p->adam_beta1, (double)step);
+    const double bc2 = 1.0 - pow(p->adam_beta2, (double)step);
     sp.step_size = p->adam ? (float)(p->lr / bc1) : 0.0f;
     sp.bc2_sqrt = p->adam ? (float)sqrt(bc2) : 1.0f;
     sp.one_minus_beta1 = (float)(1.0 - p->adam_beta1);
@@ -283,8 +311,17 @@ int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha
     sp.adam = p->adam;
     const ChannelParams cp{d_scale, d_qmin, d_qmax, (uint32_t)n_channels, (uint32_t)inner};
     hipLaunchKernelGGL(k_round_step, dim3(blocks_for((uint64_t)n, 1)), dim3(kBlock), 0, (hipStream_t)s, d_grad_qw,
-                       d_wfloor, d_alpha, d_m, d_v, cp, (uint32_t)n, sp, d_qw_next, d_grad_alpha, d_reg_loss);
+                       d_wfloor, d_alpha, d_m, d_v, cp, (uint32_t)n, sp, d_sched, d_qw_next, d_grad_alpha, d_reg_loss);
     DPL_LAUNCH_CHECK("k_round_step");
+    return 0;
+}
+
+int dpl_round_sched_advance(dpl_round_sched* d_sched, int32_t t_max, double lr, double adam_beta1, double adam_beta2,
+                            dpl_stream_t s) {
+    if (!d_sched || t_max < 1) return fail_msg("dpl_round_sched_advance: bad arguments");
+    hipLaunchKernelGGL(k_round_sched_advance, dim3(1), dim3(1), 0, (hipStream_t)s, d_sched, t_max, lr, adam_beta1,
+                       adam_beta2);
+    DPL_LAUNCH_CHECK("k_round_sched_advance");
     return 0;
 }
 

@@ -20,7 +20,8 @@ from .. import _hip
 from ..executor import _OPS
 from ..ops import _ptr, _stream
 
-__all__ = ["quant_acti", "quant_weight", "adaround_reg", "TempDecay", "L2_norm", "RoundingParam", "AdaQLayer"]
+__all__ = ["quant_acti", "quant_weight", "adaround_reg", "TempDecay", "L2_norm", "RoundingParam", "RoundSchedule",
+           "AdaQLayer"]
 
 
 def _require_cuda(t, name="tensor"):
@@ -78,8 +79,8 @@ class adaround_reg:
         one = torch.ones(1, dtype=torch.float32, device=mask.device)
         p = _step_params(reg_beta=float(self.beta), reg_lambda=self.alpha)
         _hip.check(_hip.lib().dpl_round_step(None, _ptr(mask), _ptr(mask), None, None, _ptr(one), None, None,
-                                             mask.numel(), 1, mask.numel(), C.byref(p), None, _ptr(grad), _ptr(val),
-                                             _stream()), "dpl_round_step")
+                                             mask.numel(), 1, mask.numel(), C.byref(p), None, None, _ptr(grad),
+                                             _ptr(val), _stream()), "dpl_round_step")
         return val[0], grad
 
     def __call__(self, round_mask, iter):
@@ -162,6 +163,24 @@ def quant_weight(weight, round_mask, scale, q_min, q_max, per_channel, soft=True
     return out
 
 
+class RoundSchedule:
+    """The learner's iteration counter, regulariser temperature and Adam corrections in device memory
+    (dpl_round_sched), advanced by a one-thread kernel — what makes an iteration replayable as a hipGraph."""
+
+    def __init__(self, t_max, device, lr=1e-3, betas=(0.9, 0.999)):
+        self.t_max, self.lr, self.betas = int(t_max), lr, betas
+        self.buf = torch.zeros(6, dtype=torch.int32, device=device)     # 24 bytes, zero = nothing done yet
+
+    def advance(self):
+        _hip.check(_hip.lib().dpl_round_sched_advance(_ptr(self.buf), self.t_max, self.lr, self.betas[0], self.betas[1],
+                                                      _stream()), "dpl_round_sched_advance")
+
+    def state(self):
+        """HOST (synchronises): (iterations done, Adam steps done, temperature of the last iteration)."""
+        raw = self.buf.cpu()
+        return int(raw[0]), int(raw[1]), float(raw[2:3].view(torch.float32)[0])
+
+
 class RoundingParam:
     """Rounding state of one layer, resident in HBM: floor(w / scale), the round mask, Adam moments and the
     current soft-quantised weight (a leaf that autograd deposits dL/d(qw) into).  Weight layout: channel first."""
@@ -199,8 +218,10 @@ class RoundingParam:
         self._quant(out, soft=0)
         return out
 
-    def step(self, reg_beta, reg_lambda=0.01, grad_scale=1.0, reg_loss=None, grad_out=None):
-        """Consume qw.grad: mask gradient (+ regulariser), Adam update, refreshed soft weight — one kernel."""
+    def step(self, reg_beta, reg_lambda=0.01, grad_scale=1.0, reg_loss=None, grad_out=None, sched=None):
+        """Consume qw.grad: mask gradient (+ regulariser), Adam update, refreshed soft weight — one kernel.
+        sched: device schedule (RoundSchedule.buf) supplying the temperature and Adam corrections instead of the
+        host (hipGraph replay)."""
         g = self.qw.grad
         self.steps += 1
         p = _step_params(step=self.steps, adam=1, clamp=self.clamp, grad_scale=grad_scale, reg_beta=float(reg_beta),
@@ -208,7 +229,8 @@ class RoundingParam:
         _hip.check(_hip.lib().dpl_round_step(_ptr(g.contiguous()) if g is not None else None, _ptr(self.wfloor),
                                              _ptr(self.round_mask), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                              _ptr(self.scale), _ptr(self.q_min), _ptr(self.q_max), self.n, self.nch,
-                                             self.inner, C.byref(p), _ptr(self.qw),
+                                             self.inner, C.byref(p), _ptr(sched) if sched is not None else None,
+                                             _ptr(self.qw),
                                              _ptr(grad_out) if grad_out is not None else None,
                                              _ptr(reg_loss) if reg_loss is not None else None, _stream()),
                    "dpl_round_step")
@@ -239,6 +261,8 @@ class AdaQLayer:
         self.relu_flag = relu_flag
         self.qi_tensor = qi_tensor
         self.acti_quant = bool(acti_quant) and qi_tensor is not None
+        # per-tensor activation grid as host scalars, read back ONCE (never inside the learning loop)
+        self._qi = tuple(_scalar(qi_tensor[k]) for k in ("scale", "q_min", "q_max")) if self.acti_quant else None
         self.drop_ratio = drop_ratio
 
     @property
@@ -252,8 +276,7 @@ class AdaQLayer:
         if self.relu_flag and apply_relu:
             x = torch.relu(x)
         if self.acti_quant:
-            x = quant_acti(x, self.qi_tensor["scale"], self.qi_tensor["q_min"], self.qi_tensor["q_max"],
-                           self.drop_ratio)
+            x = _ActiDrop.apply(x, self._qi[0], self._qi[1], self._qi[2], float(self.drop_ratio))
         return x
 
     def new_weight(self):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 5
+#define DPL_ABI_VERSION 6
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -193,6 +193,18 @@ typedef struct dpl_round_step_params {
     float reserved2;
 } dpl_round_step_params;
 
+/* Device-resident schedule of a learner, so that a whole iteration can be captured in a hipGraph and replayed:
+ * dpl_round_sched_advance (one thread) sets this iteration's regulariser temperature (TempDecay over t_max
+ * iterations) and Adam bias corrections, then counts the iteration; dpl_round_step reads them when d_sched != NULL
+ * (p->step, p->reg_beta are then ignored).  Zero-initialise before the first iteration. */
+typedef struct dpl_round_sched {
+    int32_t iter;       /* iterations completed */
+    int32_t adam_step;  /* Adam steps completed */
+    float reg_beta, step_size, bc2_sqrt, reserved;
+} dpl_round_sched;
+int dpl_round_sched_advance(dpl_round_sched* d_sched, int32_t t_max, double lr, double adam_beta1, double adam_beta2,
+                            dpl_stream_t s);
+
 /* wfloor = floor(w / scale);  alpha = -log((zeta - gamma) / (w / scale - wfloor - gamma) - 1) */
 int dpl_round_init(const float* d_w, const float* d_scale, int64_t n, int64_t n_channels, int64_t inner,
                    float* d_wfloor, float* d_alpha, dpl_stream_t s);
@@ -206,8 +218,8 @@ int dpl_round_quant(const float* d_wfloor, const float* d_alpha, const float* d_
  * d_grad_alpha (may be null) receives g. */
 int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha, float* d_m, float* d_v,
                    const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
-                   int64_t inner, const dpl_round_step_params* p, float* d_qw_next, float* d_grad_alpha,
-                   double* d_reg_loss, dpl_stream_t s);
+                   int64_t inner, const dpl_round_step_params* p, const dpl_round_sched* d_sched, float* d_qw_next,
+                   float* d_grad_alpha, double* d_reg_loss, dpl_stream_t s);
 /* *d_loss += sum((y - target)^2) * inv_m with y = relu ? max(z, 0) : z  (L2_norm: inv_m = 1 / (elements / dim 1));
  * d_grad (may be null) = grad_coef * (y - target), zero where the ReLU is closed. */
 int dpl_l2_loss(const float* d_z, const float* d_target, int64_t n, int relu, float grad_coef, double inv_m,

@@ -71,6 +71,26 @@ def fused_loop(w, b, x, fp, scale, iters, total, pad, stride, k):
     return (time.perf_counter() - t0) / iters
 
 
+def learner_loop(w, b, x, fp, scale, iters, pad, stride, k, use_graph):
+    """The product's learn_rounding (eager launches or hipGraph replay) on the same layer: ms per iteration."""
+    from dipoorlet_amd.onnx_io import Node
+    from dipoorlet_amd.weight_transform.ada_quant_layer import AdaQLayer, adaround_reg
+    from dipoorlet_amd.weight_transform.reconstruction import learn_rounding
+    node = Node("Conv", ["x", "w", "b"], ["y"], name="c", attrs={"pads": [pad] * 4, "kernel_shape": [k, k],
+                                                                  "strides": [stride] * 2, "dilations": [1, 1], "group": 1})
+    qw = {"scale": scale, "q_min": torch.full_like(scale, -127.0), "q_max": torch.full_like(scale, 127.0),
+          "per_channel": True, "type": "Linear"}
+    layer = AdaQLayer(node, w, b, qw, None, True, False)
+    epochs = max(2, iters // 2)
+    fp_r = fp  # already ReLU'd
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    learn_rounding([layer], x, None, fp_r, adaround_reg(2 * epochs), x.shape[0] // 2, epochs, log_every=10 ** 9,
+                   use_graph=use_graph)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (2 * epochs)
+
+
 def main():
     p = argparse.ArgumentParser()
     p.add_argument("--iters", type=int, default=200)
@@ -89,6 +109,9 @@ def main():
                           ("fused", lambda n: fused_loop(w, b, x, fp, scale, n, 0, pad, stride, k))):
             fn(10)
             res[label + "_ms"] = round(fn(a.iters) * 1e3, 4)
+        for label, g in (("learner_eager", False), ("learner_graph", True)):
+            learner_loop(w, b, x, fp, scale, 20, pad, stride, k, g)
+            res[label + "_ms"] = round(learner_loop(w, b, x, fp, scale, a.iters * 2, pad, stride, k, g) * 1e3, 4)
         with torch.no_grad():
             torch.cuda.synchronize()
             t0 = time.perf_counter()

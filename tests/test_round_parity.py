@@ -37,7 +37,7 @@ def mask_gradient(rp, G, reg_beta=0.0):
     p = _step_params(adam=0, clamp=rp.clamp, reg_beta=reg_beta)
     _hip.check(_hip.lib().dpl_round_step(_ptr(G) if G is not None else None, _ptr(rp.wfloor), _ptr(rp.round_mask), None,
                                          None, _ptr(rp.scale), _ptr(rp.q_min), _ptr(rp.q_max), rp.n, rp.nch, rp.inner,
-                                         C.byref(p), None, _ptr(g), _ptr(val), _stream()), "dpl_round_step")
+                                         C.byref(p), None, None, _ptr(g), _ptr(val), _stream()), "dpl_round_step")
     return g, float(val[0])
 
 
@@ -182,3 +182,25 @@ def test_training_trajectory_golden(row):
         assert diff.max() <= 2.5e-3 * step
     assert np.mean(layer.new_weight().cpu().numpy() == Z[k + "_hard"]) >= 0.97
     assert layer.rp.steps == row["total_iter"]
+
+
+def test_graph_replay_equals_eager():
+    """The hipGraph-replayed loop and the eager loop run the same kernels: masks must agree to rounding noise of the
+    library convolutions, and both must have advanced the device schedule identically."""
+    from dipoorlet_amd.weight_transform.ada_quant_layer import AdaQLayer, adaround_reg
+    from dipoorlet_amd.weight_transform.reconstruction import learn_rounding
+    row = next(r for r in META["traj"] if r["kind"] == "conv")
+    k = row["key"]
+    res = {}
+    for mode in (False, True):
+        scale = dev(Z[k + "_scale"])
+        qw = {"scale": scale, "q_min": torch.full_like(scale, row["q_min"]), "q_max": torch.full_like(scale, row["q_max"]),
+              "per_channel": row["per_channel"], "type": "Linear"}
+        layer = AdaQLayer(_node("conv"), dev(Z[k + "_w"]), dev(Z[k + "_b"]), qw, None, row["relu"], False)
+        reg = adaround_reg(row["total_iter"])
+        learn_rounding([layer], dev(Z[k + "_x"]), None, dev(Z[k + "_fp"]), reg, row["bs"], row["epochs"], use_graph=mode)
+        res[mode] = (layer.round_mask.cpu().numpy().copy(), reg.beta, layer.rp.steps)
+    assert res[True][1] == res[False][1] and res[True][2] == res[False][2] == row["total_iter"]
+    diff = np.abs(res[True][0] - res[False][0])
+    assert np.mean(diff <= 1e-5) >= 0.99 and diff.max() <= 2.5e-3 * row["total_iter"]
+    assert np.mean(np.abs(res[True][0] - Z[f"{k}_mask_{row['total_iter']}"]) <= 1e-3) >= 0.95

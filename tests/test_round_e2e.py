@@ -108,6 +108,7 @@ def test_adaround_cli_beats_nearest_rounding(workdir, four_bit_weights):
     assert moved > 100          # it did not just reproduce round-to-nearest
     err_nearest = _network_error(str(workdir / "model.onnx"), workdir, act, args)
     err_ada = _network_error(str(out / "adaround.onnx"), workdir, act, args)
+    print("adaround / nearest output error:", err_ada / err_nearest)
     assert err_ada < 0.8 * err_nearest, (err_ada, err_nearest)
     assert os.path.exists(out / "trt_clip_val.json")     # the run went on to deployment with the original ranges
 
@@ -121,6 +122,7 @@ def test_brecq_qdrop_cli(workdir, four_bit_weights):
     assert _check_on_grid(str(out / "brecq.onnx"), workdir, args) > 100
     err_nearest = _network_error(str(workdir / "model.onnx"), workdir, act, args)
     err_brecq = _network_error(str(out / "brecq.onnx"), workdir, act, args)
+    print("brecq+qdrop / nearest output error:", err_brecq / err_nearest)
     assert err_brecq < 0.9 * err_nearest, (err_brecq, err_nearest)
     log = open(out / "log.txt").read() if os.path.exists(out / "log.txt") else ""
     assert "Qdrop for:" in log or log == ""

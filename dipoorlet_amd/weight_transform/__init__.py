@@ -2,6 +2,8 @@
 from .adaround import adaround
 from .bias_correction import bias_correction
 from .brecq import brecq
+from .update_bn import update_bn
+from .weight_equalization import weight_equalization
 from .weight_trans_base import weight_calibration
 
-__all__ = ["adaround", "bias_correction", "brecq", "weight_calibration"]
+__all__ = ["adaround", "bias_correction", "brecq", "update_bn", "weight_calibration", "weight_equalization"]

@@ -27,6 +27,7 @@ from ..quantize import quant_graph
 from ..utils import logger
 from .ada_quant_layer import AdaQLayer, L2_norm, RoundSchedule, adaround_reg
 from .bias_correction import _Frontier
+from .weight_equalization import node_has_equalized
 from .utils import (LEARNABLE_LAYER_TYPES, follow_relu, following_relu, get_block_from_first, get_quant_tensor,
                     update_weight)
 
@@ -185,6 +186,17 @@ def reconstruct(graph_ori, graph, act_clip_val, weight_clip_val, args, blockwise
             continue
         if node.name in learnable and node.name not in already:
             block = get_block_from_first(graph, ori_nodes[node.name], args) if blockwise else [ori_nodes[node.name]]
+            if getattr(args, "we", False):      # an equalised layer cannot be mimicked (adaround.py:36-37, brecq.py:39-41)
+                if not blockwise and node_has_equalized(graph, block[0]):
+                    with torch.no_grad():
+                        qf.run(node, len(bounds), sizes)
+                    continue
+                if blockwise and node_has_equalized(graph, block[-1]):
+                    block.pop(-1)
+                    if not block:           # (the reference would index an empty list here)
+                        with torch.no_grad():
+                            qf.run(node, len(bounds), sizes)
+                        continue
             if rank == 0:
                 logger.info("{} for: {}".format(head, " ".join(b.name for b in block)))
             already.update(b.name for b in block)

@@ -5,13 +5,34 @@ import os
 import torch.distributed as dist
 
 from ..graph import ONNXGraph
-from ..tensor_cali import find_clip_val_minmax_weight
-from ..utils import logger
+from ..tensor_cali import find_clip_val_minmax_weight, tensor_calibration
+from ..utils import load_clip_val, logger, reduce_clip_val, save_clip_val
 from .adaround import adaround
 from .bias_correction import bias_correction
 from .brecq import brecq
+from .update_bn import update_bn
+from .weight_equalization import weight_equalization
 
-NOT_BUILT = ("we", "update_bn", "sparse")
+NOT_BUILT = ("sparse",)
+
+
+def _reload(name, args):
+    args.model = os.path.join(args.output_dir, name + ".onnx")        # utils.update_model_path
+    return ONNXGraph.load(args.model, args.output_dir, args.deploy, getattr(args, "model_type", None))
+
+
+def _recalibrate(graph, args):
+    """Re-derive the ranges of a changed model on every rank and pass them through the same per-rank files ->
+    rank-0 reduce -> load sequence as __main__ (so all ranks end with identical, JSON-rounded values)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    act, weight = tensor_calibration(graph, args)
+    save_clip_val(act, weight, args, act_fname=f"act_clip_val.json.rank{rank}",
+                  weight_fname=f"weight_clip_val.json.rank{rank}")
+    dist.barrier()
+    if rank == 0:
+        reduce_clip_val(world, args)
+    dist.barrier()
+    return load_clip_val(args)
 
 
 def weight_calibration(onnx_graph, act_clip_val, weight_clip_val, args):
@@ -19,8 +40,7 @@ def weight_calibration(onnx_graph, act_clip_val, weight_clip_val, args):
     with the same model and ranges."""
     for flag in NOT_BUILT:
         if getattr(args, flag, False):
-            raise NotImplementedError(f"--{flag} (weight equalisation / BN re-estimation / sparse) is outside this "
-                                      "package's scope; see DESIGN.md")
+            raise NotImplementedError(f"--{flag} (sparse fine-tuning) is outside this package's scope; see DESIGN.md")
     graph_after_wt = ONNXGraph()
     graph_after_wt.copy_from(onnx_graph)
     if getattr(args, "bc", False):   # :21-29 — rank 0 corrects, everyone reloads, weight (bias) ranges refreshed
@@ -28,9 +48,24 @@ def weight_calibration(onnx_graph, act_clip_val, weight_clip_val, args):
             logger.info("Weight transform: bias correction...")
             bias_correction(graph_after_wt, act_clip_val, weight_clip_val, args)
         dist.barrier()
-        args.model = os.path.join(args.output_dir, "update_bias_model.onnx")
-        graph_after_wt = ONNXGraph.load(args.model, args.output_dir, args.deploy, getattr(args, "model_type", None))
+        graph_after_wt = _reload("update_bias_model", args)
         weight_clip_val = find_clip_val_minmax_weight(graph_after_wt, args)
+    if getattr(args, "we", False):   # :31-38 — equalise on rank 0, everyone reloads and re-calibrates
+        if dist.get_rank() == 0:
+            logger.info("Weight transform: cross-layer equalisation...")
+            weight_equalization(graph_after_wt, args)
+        dist.barrier()
+        graph_after_wt = _reload("weight_equal_model", args)
+        act_clip_val, weight_clip_val = _recalibrate(graph_after_wt, args)
+    if getattr(args, "update_bn", False):   # :40-53
+        if dist.get_rank() == 0:
+            logger.info("Weight transform: BN statistics of the quantised network...")
+            update_bn(graph_after_wt, act_clip_val, weight_clip_val, args, recalibrate=False)
+        dist.barrier()
+        graph_after_wt = _reload("update_bn_model", args)
+        if dist.get_rank() == 0:
+            logger.info("Re calibration...")
+        act_clip_val, weight_clip_val = _recalibrate(graph_after_wt, args)
     if getattr(args, "adaround", False):   # :55-57
         args.acti_quant = False
         graph_after_wt = adaround(onnx_graph, graph_after_wt, act_clip_val, weight_clip_val, args)

@@ -183,6 +183,97 @@ def trajectories(aq, out, meta):
                      "q_max": float(q_max.reshape(-1)[0])})
 
 
+class _Init(np.ndarray):
+    """An initializer stand-in: an array with the .name the reference reads (TensorProto.name)."""
+    def __new__(cls, arr, name):
+        o = np.asarray(arr).view(cls)
+        o.name = name
+        return o
+
+    def __array_finalize__(self, obj):
+        self.name = getattr(obj, "name", None)
+
+
+class _FakeGraph:
+    """What weight_equalization / update_bn_node touch of the reference's ONNXGraph."""
+    def __init__(self, nodes=(), inits=None):
+        import types
+        self.graph = types.SimpleNamespace(node=list(nodes))
+        self.initializer = {k: [_Init(v, k)] for k, v in (inits or {}).items()}
+        self.saved = None
+
+    def copy_from(self, g):
+        import copy
+        self.graph = copy.deepcopy(g.graph)
+        self.initializer = {k: [_Init(np.array(v[0]), k)] for k, v in g.initializer.items()}
+
+    def get_tensor_consumer(self, t):
+        res = [n for n in self.graph.node if t in n.input]
+        return res if res else ["OUTPUT_TOKEN"]
+
+    def set_initializer(self, name, arr, raw=True):
+        self.initializer[name] = [_Init(np.array(arr), name)]
+
+    def update_model(self):
+        pass
+
+    def save_onnx_model(self, name):
+        self.saved = name
+
+
+def we_case(out, meta):
+    """weight_equalization (weight_equalization.py:38-94) on a small chain: conv1 -> relu -> conv2 -> conv3(grouped)
+    -> conv4, plus a branch that must be left alone."""
+    import types
+    import dipoorlet.weight_transform.weight_equalization as we
+    import dipoorlet.weight_transform.utils as wu
+    we.numpy_helper.to_array = lambda t: np.asarray(t)
+    holder = {}
+
+    class G(_FakeGraph):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            holder["last"] = self
+    we.ONNXGraph = G
+    N = lambda op, i, o, name: types.SimpleNamespace(op_type=op, input=list(i), output=list(o), name=name)  # noqa: E731
+    nodes = [N("Conv", ["x", "w1", "b1"], ["c1"], "conv1"), N("Relu", ["c1"], ["r1"], "relu1"),
+             N("Conv", ["r1", "w2", "b2"], ["c2"], "conv2"), N("Conv", ["c2", "w3"], ["c3"], "conv3"),
+             N("PRelu", ["c3", "slope"], ["p3"], "prelu3"), N("Conv", ["p3", "w4", "b4"], ["c4"], "conv4"),
+             N("Conv", ["c4", "w5"], ["c5"], "conv5"), N("Add", ["c5", "c4"], ["y"], "add")]
+    g = torch.Generator().manual_seed(91)
+    rnd = lambda *s: (torch.randn(s, generator=g) * 0.3).numpy()  # noqa: E731
+    inits = {"w1": rnd(8, 3, 3, 3), "b1": rnd(8), "w2": rnd(12, 8, 3, 3) * 4.0, "b2": rnd(12),
+             "w3": rnd(12, 3, 3, 3), "w4": rnd(6, 12, 1, 1), "b4": rnd(6), "w5": rnd(6, 6, 3, 3), "slope": rnd(12)}
+    inits["w1"][2] *= 1e-8          # a dead output channel: range below 1e-6 -> s := 1
+    inits["w4"][:, 5] *= 30.0
+    args = types.SimpleNamespace()
+    we.weight_equalization(_FakeGraph(nodes, inits), args)
+    res = holder["last"]
+    assert res.saved == "weight_equal_model"
+    for k, v in inits.items():
+        out["we_in_" + k] = v
+        out["we_out_" + k] = np.array(res.initializer[k][0])
+    meta["we"] = {"nodes": [[n.op_type, n.input, n.output, n.name] for n in nodes]}
+
+
+def bn_case(out, meta):
+    """update_bn_node (update_bn.py:12-23)."""
+    import types
+    import dipoorlet.weight_transform.update_bn as ub
+    ub.numpy_helper.to_array = lambda t: np.asarray(t)
+    g = torch.Generator().manual_seed(17)
+    xs = [(torch.randn((1, 5, 6, 7), generator=g) * (1.0 + 0.2 * i) + 0.3 * i).numpy() for i in range(9)]
+    mean0 = torch.randn(5, generator=g).numpy()
+    var0 = torch.rand(5, generator=g).numpy() + 0.5
+    fg = _FakeGraph([], {"m": mean0, "v": var0})
+    node = types.SimpleNamespace(input=["x", "scale", "bias", "m", "v"])
+    ub.update_bn_node(fg, node, xs)
+    out["bn_x"] = np.stack(xs)
+    out["bn_mean0"], out["bn_var0"] = mean0, var0
+    out["bn_mean1"], out["bn_var1"] = np.array(fg.initializer["m"][0]), np.array(fg.initializer["v"][0])
+    meta["bn"] = {"dtype_mean": str(out["bn_mean1"].dtype), "dtype_var": str(out["bn_var1"].dtype)}
+
+
 def main():
     aq = import_reference()
     torch.set_num_threads(1)
@@ -193,6 +284,8 @@ def main():
     l2_cases(aq, out, meta["l2"])
     acti_drop_case(aq, out, meta["drop"])
     trajectories(aq, out, meta["traj"])
+    we_case(out, meta)
+    bn_case(out, meta)
     t = aq.TempDecay(1000)
     meta["temp_decay_1000"] = {str(i): float(t(i)) for i in (0, 199, 200, 500, 1000)}
     np.savez_compressed(os.path.join(HERE, "round_level.npz"), **out)

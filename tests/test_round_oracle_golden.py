@@ -75,3 +75,36 @@ def test_training_trajectory(row):
         assert np.mean(diff <= tol) >= 0.97, (step, float(diff.max()))
         assert diff.max() <= 2.5e-3 * step
     assert np.mean(hard == Z[k + "_hard"]) >= 0.98
+
+
+# ---- host-side weight transforms of the product (pure numpy: no GPU involved) against the same golden file
+def test_weight_equalization_matches_reference():
+    import types
+    from dipoorlet_amd.graph import ONNXGraph
+    from dipoorlet_amd.onnx_io import Node
+    from dipoorlet_amd.weight_transform.weight_equalization import (find_successor, node_has_equalized,
+                                                                    weight_equalization)
+    g = ONNXGraph()
+    g.graph.node = [Node(op, i, o, name=n) for op, i, o, n in META["we"]["nodes"]]
+    names = ("w1", "b1", "w2", "b2", "w3", "w4", "b4", "w5", "slope")
+    g.initializer = {k: Z["we_in_" + k].copy() for k in names}
+    g.update_model()
+    nodes = {n.name: n for n in g.graph.node}
+    assert [n.name for n in find_successor(nodes["conv1"], g)] == ["conv2"]
+    assert node_has_equalized(g, nodes["conv3"]) and not node_has_equalized(g, nodes["conv4"])   # conv4 feeds conv5 AND add
+    out = weight_equalization(g, types.SimpleNamespace(output_dir=None))
+    for k in names:
+        np.testing.assert_allclose(out.get_initializer(k), Z["we_out_" + k], rtol=2e-6, atol=1e-9, err_msg=k)
+    assert not np.array_equal(Z["we_in_w2"], Z["we_out_w2"])            # something was equalised
+    assert np.array_equal(g.get_initializer("w1"), Z["we_in_w1"])       # the caller's graph is untouched
+
+
+def test_update_bn_running_statistics_match_reference():
+    from dipoorlet_amd.weight_transform.update_bn import fold_running_stats
+    x = Z["bn_x"]                                                        # [n, 1, C, H, W]
+    means = np.stack([np.mean(t, axis=(0, 2, 3)) for t in x])
+    stds = np.stack([np.std(t, axis=(0, 2, 3)) for t in x])
+    m, v = fold_running_stats(Z["bn_mean0"], Z["bn_var0"], means, stds)
+    assert m.dtype == np.float32 and v.dtype == np.float32 == np.dtype(META["bn"]["dtype_var"])
+    np.testing.assert_array_equal(m, Z["bn_mean1"])
+    np.testing.assert_array_equal(v, Z["bn_var1"])

@@ -1,0 +1,118 @@
+"""GPU: `--we` and `--update_bn` through the CLI on a small Conv / BatchNorm network built with the package's own
+graph writer: equalisation must leave the network function unchanged, BN re-estimation must equal the reference
+recurrence evaluated on the very activations the fake-quantised network produced."""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, IMG = 12, 16
+
+
+def _build(d):
+    from dipoorlet_amd.models import _B
+    g = _B(5)
+    x = g.conv("input", 3, 8, 3, 1, 1, "c1", scale=3.0)
+    x = g.node("Relu", [x], out="r1")
+    x = g.conv(x, 8, 12, 3, 1, 1, "c2", scale=0.2)
+    for nm, arr in (("bn.scale", np.abs(g.rng.standard_normal(12)).astype(np.float32) + 0.5),
+                    ("bn.bias", (g.rng.standard_normal(12) * 0.1).astype(np.float32)),
+                    ("bn.mean", (g.rng.standard_normal(12) * 0.1).astype(np.float32)),
+                    ("bn.var", (np.abs(g.rng.standard_normal(12)) + 0.5).astype(np.float32))):
+        g.const(nm, arr)
+    x = g.node("BatchNormalization", [x, "bn.scale", "bn.bias", "bn.mean", "bn.var"], out="bn_out", epsilon=1e-5)
+    x = g.node("Relu", [x], out="r2")
+    x = g.conv(x, 12, 6, 1, 1, 0, "c3")
+    x = g.node("GlobalAveragePool", [x], out="gap")
+    x = g.node("Flatten", [x], out="output", axis=1)
+    graph = g.finish("input", [1, 3, IMG, IMG], "output")
+    graph.output_dir = str(d)
+    graph.save_onnx_model("model")
+    os.makedirs(os.path.join(d, "calib", "input"))
+    rng = np.random.default_rng(2)
+    for i in range(N):
+        rng.standard_normal(3 * IMG * IMG).astype(np.float32).tofile(os.path.join(d, "calib", "input", f"{i}.bin"))
+
+
+def _forward(model_path, d, names):
+    from dipoorlet_amd.forward_net import load_input_batch
+    from dipoorlet_amd.graph import ONNXGraph
+    g = ONNXGraph.load(model_path)
+    inp = load_input_batch(os.path.join(d, "calib"), g.network_inputs, {"input": g.get_tensor_shape("input")}, 0, N,
+                           torch.device("cuda:0"))
+    return g, [t.cpu().numpy() for t in g.make_session().run_named(inp, names)]
+
+
+def _cli(d, out, extra):
+    from dipoorlet_amd.__main__ import main
+    assert main(["-M", os.path.join(d, "model.onnx"), "-I", os.path.join(d, "calib"), "-N", str(N), "-A", "minmax", "-D",
+                 "trt", "-O", out, "--calib_batch", "4", "--skip_profiling", *extra]) == 0
+
+
+def test_we_cli_keeps_the_function_and_balances_ranges(tmp_path):
+    d = str(tmp_path)
+    _build(d)
+    out = os.path.join(d, "out_we")
+    _cli(d, out, ["--we"])
+    g0, (y0,) = _forward(os.path.join(d, "model.onnx"), d, ["output"])
+    g1, (y1,) = _forward(os.path.join(out, "weight_equal_model.onnx"), d, ["output"])
+    np.testing.assert_allclose(y1, y0, rtol=2e-4, atol=2e-5)         # positive per-channel rescaling commutes with ReLU
+    w1a, w2a = g0.get_initializer("c1.weight"), g0.get_initializer("c2.weight")
+    w1b, w2b = g1.get_initializer("c1.weight"), g1.get_initializer("c2.weight")
+    assert not np.array_equal(w1a, w1b)
+    r1 = np.abs(w1b).reshape(8, -1).max(1)
+    r2 = np.abs(w2b).transpose(1, 0, 2, 3).reshape(8, -1).max(1)
+    np.testing.assert_allclose(r1, r2, rtol=1e-3)                     # the equalised pair has matched channel ranges
+    spread = lambda w: np.abs(w).reshape(w.shape[0], -1).max(1)       # noqa: E731
+    assert spread(w1b).max() / spread(w1b).min() <= spread(w1a).max() / spread(w1a).min() * 1.5
+    act = json.load(open(os.path.join(out, "act_clip_val.json")))     # ranges were re-derived on the equalised model
+    _, (c1,) = _forward(os.path.join(out, "weight_equal_model.onnx"), d, ["c1_out"])
+    assert act["c1_out"] == [float(c1.min()), float(c1.max())]
+
+
+def test_update_bn_cli_matches_the_reference_recurrence(tmp_path):
+    from dipoorlet_amd.executor import GraphSession
+    from dipoorlet_amd.weight_transform.update_bn import fold_running_stats
+    d = str(tmp_path)
+    _build(d)
+    out = os.path.join(d, "out_bn")
+    rec = {}
+    orig = GraphSession.set_const
+
+    def spy(self, name, tensor):       # the BN input the product saw is whatever sits in the frontier right then
+        rec.setdefault("calls", []).append(name)
+        return orig(self, name, tensor)
+    GraphSession.set_const = spy
+    try:
+        _cli(d, out, ["--update_bn"])
+    finally:
+        GraphSession.set_const = orig
+    assert rec["calls"] == ["bn.mean", "bn.var"]
+    from dipoorlet_amd.graph import ONNXGraph
+    from dipoorlet_amd.quantize import quant_graph
+    from dipoorlet_amd.tensor_cali import tensor_calibration
+    g0 = ONNXGraph.load(os.path.join(d, "model.onnx"))
+    g1 = ONNXGraph.load(os.path.join(out, "update_bn_model.onnx"))
+    args = types.SimpleNamespace(input_dir=os.path.join(d, "calib"), data_num=N, rank=0, local_rank=0, world_size=1,
+                                 bins=2048, threshold=0.99999, deploy="trt", act_quant="minmax", skip_layers=[],
+                                 optim_transformer=False, merge="allreduce", calib_batch=4)
+    act, wt = tensor_calibration(g0, args)
+    gq, _ = quant_graph(g0, {k: [np.copy(v[0]), np.copy(v[1])] for k, v in {**act, **wt}.items()}, args)
+    from dipoorlet_amd.forward_net import load_input_batch
+    inp = load_input_batch(args.input_dir, g0.network_inputs, {"input": g0.get_tensor_shape("input")}, 0, N, torch.device("cuda:0"))
+    bn_node = next(n for n in gq.graph.node if n.op_type == "BatchNormalization")
+    x = gq.make_session().run_named(inp, [bn_node.input[0]])[0].cpu().numpy()      # [N, C, H, W] fake-quantised input
+    means = np.stack([np.mean(x[i:i + 1], axis=(0, 2, 3)) for i in range(N)])
+    stds = np.stack([np.std(x[i:i + 1], axis=(0, 2, 3)) for i in range(N)])
+    m, v = fold_running_stats(g0.get_initializer("bn.mean"), g0.get_initializer("bn.var"), means, stds)
+    np.testing.assert_allclose(g1.get_initializer("bn.mean"), m, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(g1.get_initializer("bn.var"), v, rtol=1e-5, atol=1e-6)
+    assert not np.allclose(g1.get_initializer("bn.mean"), g0.get_initializer("bn.mean"))
+    for k in ("c1.weight", "c2.weight", "bn.scale", "bn.bias"):                    # nothing else moved
+        assert np.array_equal(g1.get_initializer(k), g0.get_initializer(k))
+    assert os.path.exists(os.path.join(out, "trt_clip_val.json"))

@@ -3,8 +3,7 @@
 
 Same flags; same phases where they are in scope: load model -> tensor calibration (sharded over ranks)
 -> per-rank clip JSON -> rank-0 reduce -> load -> profiling (cosine similarity of the fake-quantised
-model, optional) -> weight transforms (--bc, --we, --update_bn, --adaround, --brecq [--drop]) -> platform deploy file.  --sparse
-is accepted and rejected with a clear message.
+model, optional) -> weight transforms (--bc, --we, --update_bn, --adaround, --brecq [--drop], --sparse) -> platform deploy file.
 Extra flags: --calib_batch, --resident_gb, --merge {allreduce,reference}, --skip_profiling.
 """
 import argparse
@@ -53,9 +52,6 @@ def build_parser():
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
-    if args.sparse:
-        sys.exit("--sparse is not built in this package (sparse fine-tuning is outside its scope); run it with the "
-                 "reference after calibration.")
     if args.slurm:
         dist_helper.init_from_slurm()
     elif args.mpirun:

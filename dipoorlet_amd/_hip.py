@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_BINS = 16384
 
 
@@ -80,6 +80,9 @@ SIGNATURES = {
     "dpl_round_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.POINTER(RoundStepParams), _P, _P,
                                  _P, _P, _P]),
     "dpl_round_sched_advance": (C.c_int, [_P, _I32, _DBL, _DBL, _DBL, _P]),
+    "dpl_sparse_quant": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, _P, _P]),
+    "dpl_sparse_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_int, C.c_int, _P, _P]),
     "dpl_l2_loss": (C.c_int, [_P, _P, _I64, C.c_int, C.c_float, _DBL, _P, _P, _P]),
     "dpl_acti_drop_fwd": (C.c_int, [_P, _P, _I64, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P]),
     "dpl_acti_drop_bwd": (C.c_int, [_P, _P, _I64, C.c_float, _P, _P]),

@@ -10,6 +10,8 @@
 //                  the weight-sized arrays
 //   k_l2_loss      L2_norm(relu?(z), target) and its gradient w.r.t. z in one read of both tensors
 //   k_acti_drop_*  quant_acti with QDrop mixing and its (reference-defined) gradient
+//   k_sparse_*     sparse + quantised weight with straight-through rounding, its gradient fused with the SGD update
+//                  (sparse_quant_layer.py:9-66, sparse_quant.py:107-109)
 //
 // All of it is launch- and HBM-bound elementwise work: 16 B per lane where the layout allows, fp32 arithmetic in
 // the reference's operation order (IEEE divide, no FMA contraction), fp64 block-reduced loss sums.
@@ -170,6 +172,52 @@ __global__ void k_round_sched_advance(dpl_round_sched* __restrict__ sc, int32_t 
     sc->iter = t + 1;
 }
 
+// ---------------------------------------------------------------- sparse + quantised weights (sparse_quant_layer.py)
+// qw = clamp?(rint(w * mask / scale)) * scale with a straight-through round (STE, :9-18): forward, and the fused
+// "backward + SGD" update  g = ((dL/dqw * gs * scale) * pass) / scale * mask;  g += wd * w;
+// buf = first ? g : momentum * buf + g;  w -= lr * buf   (torch.optim.SGD, single-tensor form).
+__global__ __launch_bounds__(kBlock) void k_sparse_quant(const float* __restrict__ w, const float* __restrict__ mask,
+                                                          ChannelParams cp, uint32_t n, int clamp,
+                                                          float* __restrict__ qw) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t c = cp.channel(i);
+        const float s = cp.scale[c];
+        float v = rintf(__fdiv_rn(mask ? w[i] * mask[i] : w[i], s));
+        if (clamp) clamp_pass(v, cp.qmin[c], cp.qmax[c], v);
+        qw[i] = v * s;
+    }
+}
+
+struct SgdParams {
+    float grad_scale, lr, momentum, weight_decay;
+    int clamp, first, update;
+};
+
+__global__ __launch_bounds__(kBlock) void k_sparse_step(const float* __restrict__ grad_qw, float* __restrict__ w,
+                                                         const float* __restrict__ mask, float* __restrict__ buf,
+                                                         ChannelParams cp, uint32_t n, SgdParams sp,
+                                                         float* __restrict__ grad_w) {
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const uint32_t c = cp.channel(i);
+        const float s = cp.scale[c];
+        const float wi = w[i];
+        const float mk = mask ? mask[i] : 1.0f;
+        float pass = 1.0f;
+        if (sp.clamp) {
+            float v = rintf(__fdiv_rn(wi * mk, s));
+            pass = clamp_pass(v, cp.qmin[c], cp.qmax[c], v);
+        }
+        float g = __fdiv_rn(((grad_qw[i] * sp.grad_scale) * s) * pass, s) * mk;
+        if (grad_w) grad_w[i] = g;
+        if (sp.update) {
+            if (sp.weight_decay != 0.0f) g = g + sp.weight_decay * wi;
+            const float b = sp.first ? g : buf[i] * sp.momentum + g;
+            buf[i] = b;
+            w[i] = wi + (-sp.lr) * b;
+        }
+    }
+}
+
 // loss += sum((relu?(z) - t)^2) * inv_m ;  grad = coef * (relu?(z) - t) * (z > 0 if relu)
 template <bool kVec>
 __global__ __launch_bounds__(kBlock) void k_l2_loss(const float* __restrict__ z, const float* __restrict__ t,
@@ -313,6 +361,34 @@ int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha
     hipLaunchKernelGGL(k_round_step, dim3(blocks_for((uint64_t)n, 1)), dim3(kBlock), 0, (hipStream_t)s, d_grad_qw,
                        d_wfloor, d_alpha, d_m, d_v, cp, (uint32_t)n, sp, d_sched, d_qw_next, d_grad_alpha, d_reg_loss);
     DPL_LAUNCH_CHECK("k_round_step");
+    return 0;
+}
+
+int dpl_sparse_quant(const float* d_w, const float* d_mask, const float* d_scale, const float* d_qmin,
+                     const float* d_qmax, int64_t n, int64_t n_channels, int64_t inner, int clamp, float* d_qw,
+                     dpl_stream_t s) {
+    if (int e = check_channels("dpl_sparse_quant", n, n_channels, inner)) return e;
+    if (clamp && (!d_qmin || !d_qmax)) return fail_msg("dpl_sparse_quant: clamp needs q_min and q_max");
+    const ChannelParams cp{d_scale, d_qmin, d_qmax, (uint32_t)n_channels, (uint32_t)inner};
+    hipLaunchKernelGGL(k_sparse_quant, dim3(blocks_for((uint64_t)n, 1)), dim3(kBlock), 0, (hipStream_t)s, d_w, d_mask,
+                       cp, (uint32_t)n, clamp, d_qw);
+    DPL_LAUNCH_CHECK("k_sparse_quant");
+    return 0;
+}
+
+int dpl_sparse_step(const float* d_grad_qw, float* d_w, const float* d_mask, float* d_momentum_buf,
+                    const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
+                    int64_t inner, int clamp, float grad_scale, float lr, float momentum, float weight_decay, int first,
+                    int update, float* d_grad_w, dpl_stream_t s) {
+    if (int e = check_channels("dpl_sparse_step", n, n_channels, inner)) return e;
+    if (!d_grad_qw) return fail_msg("dpl_sparse_step: gradient missing");
+    if (clamp && (!d_qmin || !d_qmax)) return fail_msg("dpl_sparse_step: clamp needs q_min and q_max");
+    if (update && !d_momentum_buf) return fail_msg("dpl_sparse_step: the update needs a momentum buffer");
+    const ChannelParams cp{d_scale, d_qmin, d_qmax, (uint32_t)n_channels, (uint32_t)inner};
+    const SgdParams sp{grad_scale, lr, momentum, weight_decay, clamp, first, update};
+    hipLaunchKernelGGL(k_sparse_step, dim3(blocks_for((uint64_t)n, 1)), dim3(kBlock), 0, (hipStream_t)s, d_grad_qw, d_w,
+                       d_mask, d_momentum_buf, cp, (uint32_t)n, sp, d_grad_w);
+    DPL_LAUNCH_CHECK("k_sparse_step");
     return 0;
 }
 

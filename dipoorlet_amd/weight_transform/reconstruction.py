@@ -27,6 +27,7 @@ from ..quantize import quant_graph
 from ..utils import logger
 from .ada_quant_layer import AdaQLayer, L2_norm, RoundSchedule, adaround_reg
 from .bias_correction import _Frontier
+from .sparse_quant_layer import SparseQLayer, cosine_lr
 from .weight_equalization import node_has_equalized
 from .utils import (LEARNABLE_LAYER_TYPES, follow_relu, following_relu, get_block_from_first, get_quant_tensor,
                     update_weight)
@@ -119,6 +120,32 @@ def learn_rounding(layers, q_in, fp_in, fp_out, reg, batch_size, max_epoch, drop
     return shown
 
 
+def learn_sparse(layer, q_in, fp_out, batch_size, max_epoch, log_every=50):
+    """sparse_quant.py:107-130 — SGD(lr 1e-3, momentum 0.9, weight decay 1e-4) with a per-epoch cosine schedule on
+    the layer's weight; one iteration = mask + fused quantiser, conv forward, fused L2 loss + gradient, conv
+    backward, fused straight-through gradient + SGD update."""
+    world = _world()
+    n = q_in.shape[0]
+    n_batches = math.ceil(n / batch_size)
+    loss = torch.zeros(1, dtype=torch.float64, device=q_in.device)
+    for epoch in range(max_epoch):
+        lr = cosine_lr(layer.base_lr, epoch, max_epoch)
+        for idx in range(n_batches):
+            st = idx * batch_size
+            z = layer(q_in[st:st + batch_size], apply_relu=False)
+            loss.zero_()
+            _, grad = L2_norm(z, fp_out[st:st + batch_size], relu=layer.relu_flag, loss=loss)
+            z.backward(grad)
+            if world > 1:
+                dist.all_reduce(layer.qw.grad)
+            layer.step(lr, 1.0 / world)
+        if epoch % log_every == 0 and _rank() == 0:
+            logger.info("Epoch: {:<4} L2 Loss: {:>10.6f}, LR: {:>10.6f}".format(epoch, float(loss), lr))
+    if _rank() == 0:
+        logger.info("Loss: {:>10.6f}".format(float(loss)))
+    return float(loss)
+
+
 def _cat(chunks):
     return chunks[0] if len(chunks) == 1 else torch.cat(chunks)
 
@@ -151,8 +178,24 @@ def _build_layer(graph, graph_new, node, clip_val, args, reg, dev, with_acti):
     return AdaQLayer(node, weight, bias, qw_tensor, qi_tensor, relu_flag, with_acti)
 
 
-def reconstruct(graph_ori, graph, act_clip_val, weight_clip_val, args, blockwise, save_name):
-    """Shared driver of adaround() and brecq(): returns the graph with the learned, hard-rounded weights."""
+def _build_sparse_layer(graph, graph_new, node, clip_val, args, dev):
+    """sparse_quant.py:57-84."""
+    plat = platform_setting_table[args.deploy]
+    weight = torch.from_numpy(np.ascontiguousarray(graph_new.get_initializer(node.input[1]), dtype=np.float32)).to(dev)
+    bias = None
+    if len(node.input) == 3:
+        bias = torch.from_numpy(np.ascontiguousarray(graph_new.get_initializer(node.input[2]), dtype=np.float32)).to(dev)
+    w_shape = list(weight.shape)
+    if node.op_type == "ConvTranspose":
+        w_shape[0], w_shape[1] = w_shape[1], w_shape[0]
+    scale, q_min, q_max = get_quant_tensor(w_shape, plat["qw_params"], clip_val[node.input[1]], dev)
+    qw_tensor = {"scale": scale, "q_min": q_min, "q_max": q_max, "per_channel": bool(plat["qw_params"].get("per_channel"))}
+    sparse_info = {"sparse": True, "rate": args.sparse_rate, "pattern": args.pattern}
+    return SparseQLayer(node, weight, bias, qw_tensor, follow_relu(graph, node), sparse_info)
+
+
+def reconstruct(graph_ori, graph, act_clip_val, weight_clip_val, args, blockwise, save_name, sparse=False):
+    """Shared driver of adaround(), brecq() and sparse_quant(): returns the graph with the learned weights."""
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
     clip_val = {k: [np.copy(v[0]), np.copy(v[1])] for k, v in {**act_clip_val, **weight_clip_val}.items()}
@@ -165,7 +208,7 @@ def reconstruct(graph_ori, graph, act_clip_val, weight_clip_val, args, blockwise
     skip = getattr(args, "skip_layers", []) or []
     drop = bool(getattr(args, "drop", False)) and blockwise
     with_acti = bool(getattr(args, "acti_quant", False))
-    head = ("Qdrop" if drop else "Brecq") if blockwise else "Adaround"
+    head = "sparse_quant" if sparse else (("Qdrop" if drop else "Brecq") if blockwise else "Adaround")
 
     with torch.no_grad():
         fp_cache = ActivationCache(graph_ori, args, st, ed)
@@ -202,15 +245,21 @@ def reconstruct(graph_ori, graph, act_clip_val, weight_clip_val, args, blockwise
             already.update(b.name for b in block)
             epochs = args.ada_epoch * len(block)
             reg = adaround_reg(epochs * math.ceil(num_per_rank / args.ada_bs))
-            layers = [_build_layer(graph, graph_new, b, clip_val, args, reg, dev, with_acti) for b in block]
+            if sparse:
+                layers = [_build_sparse_layer(graph, graph_new, block[0], clip_val, args, dev)]
+            else:
+                layers = [_build_layer(graph, graph_new, b, clip_val, args, reg, dev, with_acti) for b in block]
             with torch.no_grad():
                 q_in = _cat(qf.env[node.input[0]])            # already the fake-quantised tensor if the platform quantises it
                 fp_in = _cat(fp_cache.chunks(block[0].input[0])) if drop else None
                 fp_out = _cat(fp_cache.chunks(block[-1].output[0]))
                 if follow_relu(graph, block[-1]):
                     fp_out = torch.relu(fp_out)
-            learn_rounding(layers, q_in, fp_in, fp_out, reg, args.ada_bs, epochs, drop,
-                           log_every=100 if blockwise else 50, log_head="")
+            if sparse:
+                learn_sparse(layers[0], q_in, fp_out, args.ada_bs, epochs)
+            else:
+                learn_rounding(layers, q_in, fp_in, fp_out, reg, args.ada_bs, epochs, drop,
+                               log_every=100 if blockwise else 50, log_head="")
             with torch.no_grad():
                 for b, layer in zip(block, layers):
                     w_new = layer.new_weight()

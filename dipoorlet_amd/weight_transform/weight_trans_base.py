@@ -10,10 +10,10 @@ from ..utils import load_clip_val, logger, reduce_clip_val, save_clip_val
 from .adaround import adaround
 from .bias_correction import bias_correction
 from .brecq import brecq
+from .sparse_quant import sparse_quant
 from .update_bn import update_bn
 from .weight_equalization import weight_equalization
 
-NOT_BUILT = ("sparse",)
 
 
 def _reload(name, args):
@@ -38,9 +38,6 @@ def _recalibrate(graph, args):
 def weight_calibration(onnx_graph, act_clip_val, weight_clip_val, args):
     """Returns (graph_after_wt, onnx_graph, act_clip_val, weight_clip_val) like the reference; every rank ends
     with the same model and ranges."""
-    for flag in NOT_BUILT:
-        if getattr(args, flag, False):
-            raise NotImplementedError(f"--{flag} (sparse fine-tuning) is outside this package's scope; see DESIGN.md")
     graph_after_wt = ONNXGraph()
     graph_after_wt.copy_from(onnx_graph)
     if getattr(args, "bc", False):   # :21-29 — rank 0 corrects, everyone reloads, weight (bias) ranges refreshed
@@ -66,6 +63,10 @@ def weight_calibration(onnx_graph, act_clip_val, weight_clip_val, args):
         if dist.get_rank() == 0:
             logger.info("Re calibration...")
         act_clip_val, weight_clip_val = _recalibrate(graph_after_wt, args)
+    if getattr(args, "sparse", False):     # :65-66 — instead of AdaRound / BRECQ
+        args.acti_quant = False
+        graph_after_wt = sparse_quant(onnx_graph, graph_after_wt, act_clip_val, weight_clip_val, args)
+        return graph_after_wt, onnx_graph, act_clip_val, weight_clip_val
     if getattr(args, "adaround", False):   # :55-57
         args.acti_quant = False
         graph_after_wt = adaround(onnx_graph, graph_after_wt, act_clip_val, weight_clip_val, args)

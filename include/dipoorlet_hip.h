@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 6
+#define DPL_ABI_VERSION 7
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -220,6 +220,18 @@ int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha
                    const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
                    int64_t inner, const dpl_round_step_params* p, const dpl_round_sched* d_sched, float* d_qw_next,
                    float* d_grad_alpha, double* d_reg_loss, dpl_stream_t s);
+/* Sparse + quantised weight with a straight-through round (sparse_quant_layer.py:9-29, 61-66):
+ * qw = clamp?(rint(w * mask / scale)) * scale; d_mask (0 / 1 per weight) may be null. */
+int dpl_sparse_quant(const float* d_w, const float* d_mask, const float* d_scale, const float* d_qmin,
+                     const float* d_qmax, int64_t n, int64_t n_channels, int64_t inner, int clamp, float* d_qw,
+                     dpl_stream_t s);
+/* Its gradient fused with torch.optim.SGD's update (sparse_quant.py:107-109: momentum, weight decay):
+ * g = ((dL/dqw * grad_scale * scale) * clamp_pass) / scale * mask; d_grad_w (may be null) receives g; when `update`:
+ * g += weight_decay * w; buf = first ? g : momentum * buf + g; w -= lr * buf. */
+int dpl_sparse_step(const float* d_grad_qw, float* d_w, const float* d_mask, float* d_momentum_buf,
+                    const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
+                    int64_t inner, int clamp, float grad_scale, float lr, float momentum, float weight_decay, int first,
+                    int update, float* d_grad_w, dpl_stream_t s);
 /* *d_loss += sum((y - target)^2) * inv_m with y = relu ? max(z, 0) : z  (L2_norm: inv_m = 1 / (elements / dim 1));
  * d_grad (may be null) = grad_coef * (y - target), zero where the ReLU is closed. */
 int dpl_l2_loss(const float* d_z, const float* d_target, int64_t n, int relu, float grad_coef, double inv_m,

@@ -274,6 +274,66 @@ def bn_case(out, meta):
     meta["bn"] = {"dtype_mean": str(out["bn_mean1"].dtype), "dtype_var": str(out["bn_var1"].dtype)}
 
 
+def sparse_cases(out, meta):
+    """prune masks, quant_weight_wo_roundmask (value + straight-through gradient) and an SGD trajectory of
+    learning_sparse_quant (sparse_quant.py:107-130) on CPU torch, through the reference's own functions."""
+    import torch.nn.functional as F
+    import dipoorlet.weight_transform.sparse_quant_layer as sq
+    g = torch.Generator().manual_seed(123)
+    w4 = torch.randn((8, 8, 3, 3), generator=g) * 0.1
+    w2 = torch.randn((6, 16), generator=g) * 0.1
+    out["sp_w4"], out["sp_w2"] = w4.numpy(), w2.numpy()
+    out["sp_mask_unstr_w4"] = sq.create_unstruction_mask(w4, 0.5).numpy()
+    out["sp_mask_unstr_w2_30"] = sq.create_unstruction_mask(w2, 0.3).numpy()
+    out["sp_mask_nv24_w4"] = sq.create_nv24_mask(w4, 2, 4).numpy()
+    out["sp_mask_nv24_w2"] = sq.create_nv24_mask(w2, 2, 4).numpy()
+    rows = []
+    for key, w, per_channel in (("spq_pc", w4, True), ("spq_pt", w2, False)):
+        if per_channel:
+            scale = channel_view(w.abs().reshape(w.shape[0], -1).max(1).values / 200.0, w.dim())   # some values clamp
+            q_min, q_max = channel_view(torch.full((w.shape[0],), -127.0), w.dim()), channel_view(torch.full((w.shape[0],), 127.0), w.dim())
+        else:
+            scale, q_min, q_max = (w.abs().max() / 127.0).reshape(()), torch.tensor(-127.0), torch.tensor(127.0)
+        G = torch.randn(w.shape, generator=g)
+        wp = w.clone().requires_grad_(True)
+        info = {"pattern": "unstruction", "rate": 0.5}
+        qw = sq.quant_weight_wo_roundmask(sq.prune_weight(wp, info), scale, q_min, q_max, per_channel)
+        (qw * G).sum().backward()
+        out[key + "_scale"], out[key + "_G"] = scale.reshape(-1).numpy(), G.numpy()
+        out[key + "_qw"], out[key + "_grad"] = qw.detach().numpy(), wp.grad.numpy()
+        rows.append({"key": key, "per_channel": per_channel, "w": "sp_w4" if per_channel else "sp_w2"})
+    meta["sparse_quant"] = rows
+    # trajectory: conv 3x3 pad 1 + relu, per-channel grid, unstructured 50 %
+    n, bs, epochs = 16, 8, 12
+    w = torch.randn((6, 4, 3, 3), generator=g) * 0.1
+    b = torch.randn((6,), generator=g) * 0.1
+    x = torch.randn((n, 4, 8, 8), generator=g)
+    fp = F.relu(F.conv2d(x + torch.randn(x.shape, generator=g) * 0.05, w, b, 1, 1))
+    scale = channel_view(w.abs().reshape(6, -1).max(1).values / 127.0, 4)
+    q_min, q_max = channel_view(torch.full((6,), -127.0), 4), channel_view(torch.full((6,), 127.0), 4)
+    info = {"pattern": "unstruction", "rate": 0.5}
+    wp = torch.nn.Parameter(w.clone())
+    opt = torch.optim.SGD([wp], lr=0.001, momentum=0.9, weight_decay=1e-4)
+    sched = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer=opt, T_max=epochs)
+    losses = []
+    for ep in range(epochs):
+        for idx in range(n // bs):
+            xb = x[idx * bs:(idx + 1) * bs]
+            qw = sq.quant_weight_wo_roundmask(sq.prune_weight(wp, info), scale, q_min, q_max, True)
+            loss = sq.L2_norm(F.relu(F.conv2d(xb, qw, b, 1, 1)), fp[idx * bs:(idx + 1) * bs])
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss))
+        sched.step()
+    final = sq.quant_weight_wo_roundmask(sq.prune_weight(wp.detach(), info), scale, q_min, q_max, True)
+    out["sptraj_w"], out["sptraj_b"], out["sptraj_x"], out["sptraj_fp"] = w.numpy(), b.numpy(), x.numpy(), fp.numpy()
+    out["sptraj_scale"] = scale.reshape(-1).numpy()
+    out["sptraj_learned"], out["sptraj_final"] = wp.detach().numpy(), final.numpy()
+    out["sptraj_losses"] = np.array(losses)
+    meta["sparse_traj"] = {"n": n, "bs": bs, "epochs": epochs, "rate": 0.5}
+
+
 def main():
     aq = import_reference()
     torch.set_num_threads(1)
@@ -285,6 +345,7 @@ def main():
     acti_drop_case(aq, out, meta["drop"])
     trajectories(aq, out, meta["traj"])
     we_case(out, meta)
+    sparse_cases(out, meta)
     bn_case(out, meta)
     t = aq.TempDecay(1000)
     meta["temp_decay_1000"] = {str(i): float(t(i)) for i in (0, 199, 200, 500, 1000)}

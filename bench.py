@@ -57,8 +57,6 @@ def cpu_baseline(algo, bins, tensors, budget_s):
     restatement on one thread — what the reference's own Python does per image."""
     import warnings
 
-    import numpy as np
-
     from oracle import c_oracle as CO
     from oracle import np_oracle as O
     B = tensors[0].shape[0]

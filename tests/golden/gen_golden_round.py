@@ -226,7 +226,6 @@ def we_case(out, meta):
     -> conv4, plus a branch that must be left alone."""
     import types
     import dipoorlet.weight_transform.weight_equalization as we
-    import dipoorlet.weight_transform.utils as wu
     we.numpy_helper.to_array = lambda t: np.asarray(t)
     holder = {}
 

@@ -6,7 +6,6 @@ import types
 import warnings
 
 import numpy as np
-import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp

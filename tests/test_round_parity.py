@@ -5,7 +5,6 @@ trajectories as in tests/test_round_oracle_golden.py."""
 import ctypes as C
 import json
 import os
-import types
 
 import numpy as np
 import pytest

@@ -47,6 +47,8 @@ def build_parser():
     p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
     p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
     p.add_argument("--skip_profiling", default=False, action="store_true")
+    p.add_argument("--keep_bn", default=False, action="store_true",
+                   help="do not fold BatchNormalization into the preceding Conv / Gemm (the reference always simplifies)")
     return p
 
 
@@ -67,6 +69,10 @@ def main(argv=None):
     dist.barrier()
     start = time.time()
     onnx_graph = ONNXGraph.load(args.model, args.output_dir, args.deploy, args.model_type)
+    if not args.keep_bn and not args.update_bn:     # __main__.py:101 — onnxsim's Conv + BN fusion
+        n_folded = onnx_graph.fold_batchnorm()
+        if n_folded and rank == 0:
+            logger.info("Folded {} BatchNormalization nodes into their producers.".format(n_folded))
     args.rank, args.world_size = rank, world
     args.local_rank = rank % max(1, __import__("torch").cuda.device_count())
     if rank == 0:

@@ -170,6 +170,54 @@ class ONNXGraph:
             else:
                 setattr(self, k, copy.deepcopy(v))
 
+    # ------------------------------------------------------------------ simplification
+    def fold_batchnorm(self):
+        """The one rewrite of `onnxsim.simplify` (dipoorlet/__main__.py:101) that changes what gets calibrated:
+        a BatchNormalization whose input is produced by a Conv / ConvTranspose / Gemm with constant weights, and
+        consumed by nothing else, is folded into that layer (W' = W * g / sqrt(var + eps) per output channel,
+        b' = (b - mean) * g / sqrt(var + eps) + beta).  Returns the number of folded nodes."""
+        folded = 0
+        for bn in [n for n in self.graph.node if n.op_type == "BatchNormalization"]:
+            prev = self.get_tensor_producer(bn.input[0])
+            if isinstance(prev, str) or prev.op_type not in ("Conv", "ConvTranspose", "Gemm"):
+                continue
+            if len(self.get_tensor_consumer(bn.input[0])) != 1 or bn.input[0] in self.network_outputs:
+                continue
+            if prev.input[1] not in self.initializer or any(i not in self.initializer for i in bn.input[1:5]):
+                continue
+            if prev.op_type == "Gemm" and (not prev.attrs.get("transB", 0) or prev.attrs.get("alpha", 1.0) != 1.0
+                                           or prev.attrs.get("beta", 1.0) != 1.0):
+                continue
+            gamma, beta, mean, var = (np.asarray(self.initializer[i], np.float64) for i in bn.input[1:5])
+            k = gamma / np.sqrt(var + float(bn.attrs.get("epsilon", 1e-5)))
+            w = np.asarray(self.initializer[prev.input[1]], np.float64)
+            if prev.op_type == "ConvTranspose":      # [C_in, C_out / group, ...]: output channels on axis 1
+                group = int(prev.attrs.get("group", 1))
+                if group != 1:
+                    continue
+                w_new = w * k.reshape((1, -1) + (1,) * (w.ndim - 2))
+            else:
+                w_new = w * k.reshape((-1,) + (1,) * (w.ndim - 1))
+            has_bias = len(prev.input) > 2 and prev.input[2] != ""
+            b = np.asarray(self.initializer[prev.input[2]], np.float64) if has_bias else np.zeros_like(mean)
+            b_new = (b - mean) * k + beta
+            self.set_initializer(prev.input[1], w_new.astype(np.float32))
+            bname = prev.input[2] if has_bias else prev.name + "_bias"
+            self.set_initializer(bname, b_new.astype(np.float32))
+            if not has_bias:
+                prev.input = list(prev.input[:2]) + [bname]
+                if bname not in self.input:
+                    self.input.append(bname)
+            prev.output[0] = bn.output[0]            # the layer now produces what the BN produced
+            self.remove_node_purely(bn)
+            folded += 1
+        if folded:
+            used = {i for n in self.graph.node for i in n.input}
+            for name in [k for k in self.initializer if k not in used]:
+                self.del_initializer(name)
+            self.update_model()
+        return folded
+
     # ------------------------------------------------------------------ I/O
     def to_model(self, expand_fake_quant=True):
         m = onnx_io.Model()

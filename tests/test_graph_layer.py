@@ -139,3 +139,47 @@ def test_wire_format_scalar_and_attr_types(tmp_path):
     assert r.initializers["w"].shape == () and r.initializers["w"] == np.float32(3.25)
     assert r.initializers["h"].dtype == np.float16 and r.initializers["u"].tolist() == [1, 255]
     assert r.inputs == [("a", 1, [1, 0, 3])]
+
+
+def test_fold_batchnorm_keeps_the_function():
+    """ONNXGraph.fold_batchnorm (the Conv + BN fusion onnxsim performs for the reference): same outputs, no BN left,
+    a bias is created where the layer had none, a BN with a second consumer of its input is left alone."""
+    from dipoorlet_amd.models import _B
+    g = _B(9)
+
+    def bn(x, c, tag):
+        for nm, arr in ((f"{tag}.g", np.abs(g.rng.standard_normal(c)) + 0.5), (f"{tag}.b", g.rng.standard_normal(c) * 0.1),
+                        (f"{tag}.m", g.rng.standard_normal(c) * 0.2), (f"{tag}.v", np.abs(g.rng.standard_normal(c)) + 0.3)):
+            g.const(nm, arr.astype(np.float32))
+        return g.node("BatchNormalization", [x, f"{tag}.g", f"{tag}.b", f"{tag}.m", f"{tag}.v"], out=f"{tag}_out",
+                      epsilon=1e-3)
+    x = bn(g.conv("input", 3, 8, 3, 1, 1, "c1"), 8, "bn1")
+    x = g.node("Relu", [x], out="r1")
+    w = g.w("c2.weight", (6, 8, 1, 1))                                   # a Conv without bias
+    x = g.node("Conv", [x, w], out="c2_out", dilations=[1, 1], group=1, kernel_shape=[1, 1], pads=[0] * 4, strides=[1, 1])
+    x = bn(x, 6, "bn2")
+    side = g.conv(x, 6, 6, 1, 1, 0, "c3")                                # c3_out feeds a BN and an Add: not foldable
+    y = bn(side, 6, "bn3")
+    x = g.node("Add", [y, side], out="sum")
+    x = g.node("GlobalAveragePool", [x], out="gap")
+    x = g.node("Flatten", [x], out="flat", axis=1)
+    fw = g.w("fc.weight", (5, 6))
+    fb = g.b("fc.bias", 5)
+    x = bn_in = g.node("Gemm", [x, fw, fb], out="fc_out", transB=1)
+    for nm, arr in (("bn4.g", np.ones(5)), ("bn4.b", np.zeros(5)), ("bn4.m", g.rng.standard_normal(5) * 0.1), ("bn4.v", np.ones(5) * 0.7)):
+        g.const(nm, arr.astype(np.float32))
+    x = g.node("BatchNormalization", [bn_in, "bn4.g", "bn4.b", "bn4.m", "bn4.v"], out="output")
+    graph = g.finish("input", [1, 3, 12, 12], "output")
+    inp = {"input": torch.from_numpy(np.random.default_rng(0).standard_normal((3, 3, 12, 12)).astype(np.float32))}
+    ref = GraphSession(graph, device="cpu").run_named(inp, ["output", "sum"])
+    assert graph.fold_batchnorm() == 3
+    ops_left = [n.op_type for n in graph.graph.node]
+    assert ops_left.count("BatchNormalization") == 1 and "bn1.g" not in graph.initializer
+    c2 = next(n for n in graph.graph.node if len(n.input) > 1 and n.input[1] == "c2.weight")
+    assert len(c2.input) == 3 and c2.input[2] in graph.initializer and c2.output[0] == "bn2_out"
+    out = GraphSession(graph, device="cpu").run_named(inp, ["output", "sum"])
+    for a, b in zip(out, ref):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-5, atol=2e-6)
+    path = graph.save_onnx_model("/tmp/_folded_bn_test")                # round-trips through the writer / reader
+    again = GraphSession(ONNXGraph.load(path), device="cpu").run_named(inp, ["output"])[0]
+    np.testing.assert_allclose(again.numpy(), ref[0].numpy(), rtol=2e-5, atol=2e-6)

@@ -58,7 +58,7 @@ def test_we_cli_keeps_the_function_and_balances_ranges(tmp_path):
     d = str(tmp_path)
     _build(d)
     out = os.path.join(d, "out_we")
-    _cli(d, out, ["--we"])
+    _cli(d, out, ["--we", "--keep_bn"])       # with the BN in place only (c1, c2) is an equalisable pair
     g0, (y0,) = _forward(os.path.join(d, "model.onnx"), d, ["output"])
     g1, (y1,) = _forward(os.path.join(out, "weight_equal_model.onnx"), d, ["output"])
     np.testing.assert_allclose(y1, y0, rtol=2e-4, atol=2e-5)         # positive per-channel rescaling commutes with ReLU
@@ -116,3 +116,20 @@ def test_update_bn_cli_matches_the_reference_recurrence(tmp_path):
     for k in ("c1.weight", "c2.weight", "bn.scale", "bn.bias"):                    # nothing else moved
         assert np.array_equal(g1.get_initializer(k), g0.get_initializer(k))
     assert os.path.exists(os.path.join(out, "trt_clip_val.json"))
+
+
+def test_cli_folds_batchnorm_by_default(tmp_path):
+    """Like the reference (which always runs onnxsim), the CLI calibrates the BN-folded network: no BN output in the
+    ranges, and the folded network computes what the original did."""
+    d = str(tmp_path)
+    _build(d)
+    out = os.path.join(d, "out_fold")
+    _cli(d, out, ["--bc"])
+    act = json.load(open(os.path.join(out, "act_clip_val.json")))
+    assert "c2_out" not in act and "bn_out" in act and len(act) == 8
+    from dipoorlet_amd.graph import ONNXGraph
+    g1 = ONNXGraph.load(os.path.join(out, "update_bias_model.onnx"))
+    assert all(n.op_type != "BatchNormalization" for n in g1.graph.node)
+    _, (y0,) = _forward(os.path.join(d, "model.onnx"), d, ["output"])
+    _, (y1,) = _forward(os.path.join(out, "update_bias_model.onnx"), d, ["output"])
+    assert np.corrcoef(y0.ravel(), y1.ravel())[0, 1] > 0.999          # bias correction moves the biases a little

@@ -593,6 +593,9 @@ __global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* ou
 // per-pair kernel then runs the reference's exact iteration from (exact bin totals above the current bin) +
 // (gathered elements of the current bin).  Every iterate is verified to land in a marked bin; a pair that
 // fails (or whose bracket explodes: flat / degenerate distributions) takes the compaction path instead.
+#ifndef DPL_MARGIN0
+#define DPL_MARGIN0 0
+#endif
 constexpr int kLogNB = 2048;
 constexpr int kLogShift = 17;                               // 23 - 6: six mantissa bits per bin
 constexpr uint32_t kLogKey0 = (uint32_t)(127 - 18) << 6;    // key of 2^-18
@@ -854,15 +857,18 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
                     r = 1u;
                     break;
                 }
-                for (int w0 = (jl - 1) >> 5; w0 <= (jh + 1) >> 5; ++w0) {   // one LDS read-modify-write per word
-                    const int lo_b = max(jl - 1, w0 << 5) & 31, hi_b = min(jh + 1, (w0 << 5) + 31) & 31;
+                // s_0 is known exactly, so its evaluation needs its own bin only; later iterates are brackets and get
+                // one bin of margin on either side (the exact walk verifies every iterate anyway)
+                const int ml = jl - (itn == 0 ? DPL_MARGIN0 : 1), mh = jh + (itn == 0 ? DPL_MARGIN0 : 1);
+                for (int w0 = ml >> 5; w0 <= mh >> 5; ++w0) {   // one LDS read-modify-write per word
+                    const int lo_b = max(ml, w0 << 5) & 31, hi_b = min(mh, (w0 << 5) + 31) & 31;
                     const uint32_t mask = (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
                     const uint32_t old = bm[w0];
                     bm[w0] = old | mask;
                     marked += __popc(mask & ~old);
                 }
-                jmin_s = jl - 1 < jmin_s ? jl - 1 : jmin_s;
-                jmax_s = jh + 1 > jmax_s ? jh + 1 : jmax_s;
+                jmin_s = ml < jmin_s ? ml : jmin_s;
+                jmax_s = mh > jmax_s ? mh : jmax_s;
                 if (marked > kLogMaxMarked) {
                     r = 1u;
                     break;

@@ -70,6 +70,7 @@ SIGNATURES = {
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
+    "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),

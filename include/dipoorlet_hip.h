@@ -151,6 +151,10 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
                           uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
+/* TEST HOOK: makes the exact walk of dpl_octav_run_bracket reject every `every`-th pair (0 = off) so that the
+ * restart on the compaction route — taken in production only when an iterate leaves the bracket's bins — can be
+ * exercised; returns the previous setting. */
+int dpl_test_hook_exact_fail_every(int every);
 int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
 
 /* ---- per-output-channel weight ranges: replaces np.min/np.max(tensor.reshape(C,-1), -1)

@@ -371,3 +371,29 @@ def test_octav_bracket_routes(dev):
                 warnings.simplefilter("ignore")
                 s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
             assert _close(got[b, t, 0], s), (t, b, got[b, t], s)
+
+
+def test_octav_exact_walk_restart_path(dev):
+    """An iterate that leaves the bracket's bins makes the exact walk hand the pair to the compaction route.  That is
+    rare by construction, so the C-ABI test hook rejects every second pair on purpose: the results must not change."""
+    from dipoorlet_amd import _hip, ops
+    rng = np.random.default_rng(23)
+    B, sizes = 3, [150528, 40000, 802816, 1000]
+    tensors = [torch.from_numpy(np.stack([(rng.standard_normal(n) * (1 + t)).astype(np.float32) if t % 2 == 0 else
+                                          np.maximum(rng.standard_normal(n), 0).astype(np.float32) * 2.5
+                                          for _ in range(B)])).to(dev) for t, n in enumerate(sizes)]
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    want = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
+    old = _hip.lib().dpl_test_hook_exact_fail_every(2)
+    try:
+        states = torch.empty((plan.n_pairs + 1) * 80, dtype=torch.uint8, device=dev)
+        got = ops.octav_batch(plan, tensors, False, states, form="bracket").cpu().numpy()
+        ctl = states.cpu().numpy()[-80:].view(np.uint64)
+    finally:
+        _hip.lib().dpl_test_hook_exact_fail_every(old)
+    assert int(ctl[2]) == plan.n_pairs // 2                 # control block: pairs that took the compaction route
+    assert np.array_equal(got, want)
+    for t in range(len(sizes)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert _close(got[0, t, 0], O.octav_scale(tensors[t][0].cpu().numpy(), 1))

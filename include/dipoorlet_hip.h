@@ -138,7 +138,7 @@ int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const u
 /* Same iterate sequence in TWO reads of the data and no tail lists (init with list_mode = 2): pass 1 takes the
  * statistics and an exact log-scale histogram of |x| (64 bins per octave over 2^-18..2^14: per bin a count
  * and an integer sum of mantissas); a per-pair bracket walk over the bin edges marks the few dozen bins the
- * iterates can visit; pass 2 gathers only those elements (3-8 %) into d_list0; a per-pair kernel then runs the
+ * iterates can visit; pass 2 gathers only those elements (about 2 %) into d_list0; a per-pair kernel then runs the
  * exact iteration from (exact totals of the bins above) + (gathered elements of the current bin), verifying
  * that every iterate lands in a marked bin.  Pairs it cannot serve (bracket explodes on flat / degenerate
  * distributions, values >= 2^14, failed verification) are finished by the compaction route above.

@@ -589,7 +589,7 @@ __global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* ou
 // exact count and an exact integer sum of mantissas (all values of a bin share the exponent, so
 // sum = (sum of 24-bit mantissas) * 2^(e-150): order-independent, deterministic).  F(s) is then exact at every
 // bin edge.  A small per-pair kernel walks the iteration in BRACKET form over the edges and marks the few
-// dozen bins the true iterates can fall into (3-8 % of the elements); pass 2 gathers just those elements; a
+// dozen bins the true iterates can fall into (about 2 % of the elements); pass 2 gathers just those elements; a
 // per-pair kernel then runs the reference's exact iteration from (exact bin totals above the current bin) +
 // (gathered elements of the current bin).  Every iterate is verified to land in a marked bin; a pair that
 // fails (or whose bracket explodes: flat / degenerate distributions) takes the compaction path instead.
@@ -914,7 +914,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
 }
 
 // Pass 2: collect the elements that fall in marked bins (|x| values) into the pair's list 0.  Survivors are
-// sparse (3-8 %), so each lane appends to a private LDS queue (no cross-lane work per element); a wave flushes
+// sparse (about 2 %), so each lane appends to a private LDS queue (no cross-lane work per element); a wave flushes
 // its queues behind one scan + one returning atomic when any queue is half full.
 // The membership test is one LDS word + a bit extract per element: the pair's 2048 window marks are placed inside a
 // bitmap over the WHOLE key space (bits >> 17 of any non-negative float: 16384 keys = 2 KiB), so no clamping or

@@ -89,3 +89,15 @@ def test_ops_refuse_cpu_tensors(lib):
     from dipoorlet_amd import ops
     with pytest.raises(_hip.DipoorletHipError):
         ops.rowwise_minmax(torch.zeros(4, 4))
+
+
+def test_header_compiles_as_plain_c_and_cpp():
+    """include/dipoorlet_hip.h is the drop-in boundary: it must be consumable by a C compiler (cgo / JNI / ctypes
+    style FFI generators) as well as from C++."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "dipoorlet_hip.h")
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], check=True)
+    subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-Wall", "-Werror", hdr], check=True)

@@ -352,10 +352,53 @@ __global__ __launch_bounds__(kBlock) void k_fake_quant_tensor(const float* __res
     if (t < n) y[t] = fq_one(x[t], scale, zp, qlo, qhi);
 }
 
+// Per-channel form, x viewed as [outer, n_channels, inner].  The channel of a 16-byte vector is one 32-bit
+// division per FOUR elements when rows are a multiple of four long (every conv activation / weight but 7x7 maps),
+// and the loop keeps four vectors per lane in flight like the per-tensor kernel.
+template <bool kVec>
 __global__ __launch_bounds__(kBlock) void k_fake_quant_channel(const float* __restrict__ x, float* __restrict__ y,
-                                                                int64_t n, const float* __restrict__ scale_p,
-                                                                const int32_t* __restrict__ zp_p, int64_t n_channels,
-                                                                int64_t inner, float qlo, float qhi) {
+                                                                uint32_t n, const float* __restrict__ scale_p,
+                                                                const int32_t* __restrict__ zp_p, uint32_t n_channels,
+                                                                uint32_t inner, float qlo, float qhi) {
+    const uint32_t stride = gridDim.x * kBlock;
+    if (kVec) {
+        const uint32_t nvec = n >> 2, inner4 = inner >> 2;
+        const f4* xv = reinterpret_cast<const f4*>(x);
+        f4* yv = reinterpret_cast<f4*>(y);
+        for (uint32_t i0 = blockIdx.x * kBlock + threadIdx.x; i0 < nvec; i0 += 4 * stride) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * stride;
+                v[u] = i < nvec ? __builtin_nontemporal_load(xv + i) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + u * stride;
+                if (i < nvec) {
+                    const uint32_t c = (i / inner4) % n_channels;
+                    const float sc = scale_p[c], zp = (float)zp_p[c];
+                    v[u].x = fq_one(v[u].x, sc, zp, qlo, qhi);
+                    v[u].y = fq_one(v[u].y, sc, zp, qlo, qhi);
+                    v[u].z = fq_one(v[u].z, sc, zp, qlo, qhi);
+                    v[u].w = fq_one(v[u].w, sc, zp, qlo, qhi);
+                    __builtin_nontemporal_store(v[u], yv + i);
+                }
+            }
+        }
+    } else {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+            const uint32_t c = (i / inner) % n_channels;
+            y[i] = fq_one(x[i], scale_p[c], (float)zp_p[c], qlo, qhi);
+        }
+    }
+}
+
+// (tensors of 2^32 elements or more)
+__global__ __launch_bounds__(kBlock) void k_fake_quant_channel64(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int64_t n, const float* __restrict__ scale_p,
+                                                                  const int32_t* __restrict__ zp_p, int64_t n_channels,
+                                                                  int64_t inner, float qlo, float qhi) {
     const int64_t stride = (int64_t)gridDim.x * kBlock;
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const int64_t c = (i / inner) % n_channels;
@@ -372,12 +415,20 @@ __global__ __launch_bounds__(kBlock) void k_cos_acc(const float* __restrict__ a,
     const f4* av = reinterpret_cast<const f4*>(a);
     const f4* bv = reinterpret_cast<const f4*>(b);
     const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-        const f4 p = __builtin_nontemporal_load(av + i);
-        const f4 q = __builtin_nontemporal_load(bv + i);
-        ab += (double)p.x * q.x + (double)p.y * q.y + (double)p.z * q.z + (double)p.w * q.w;
-        aa += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z + (double)p.w * p.w;
-        bb += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+    for (int64_t i0 = (int64_t)blockIdx.x * kBlock + threadIdx.x; i0 < nvec; i0 += 4 * stride) {
+        f4 p[4], q[4];   // eight 16-byte loads in flight per lane
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            p[u] = i < nvec ? __builtin_nontemporal_load(av + i) : f4{0.f, 0.f, 0.f, 0.f};
+            q[u] = i < nvec ? __builtin_nontemporal_load(bv + i) : f4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ab += (double)p[u].x * q[u].x + (double)p[u].y * q[u].y + (double)p[u].z * q[u].z + (double)p[u].w * q[u].w;
+            aa += (double)p[u].x * p[u].x + (double)p[u].y * p[u].y + (double)p[u].z * p[u].z + (double)p[u].w * p[u].w;
+            bb += (double)q[u].x * q[u].x + (double)q[u].y * q[u].y + (double)q[u].z * q[u].z + (double)q[u].w * q[u].w;
+        }
     }
     const int64_t t = (nvec << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (t < n) {
@@ -655,8 +706,18 @@ int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale
         hipLaunchKernelGGL(k_fake_quant_tensor, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y, n,
                            d_scale, d_zp, (float)qlo, (float)qhi);
     } else {
-        hipLaunchKernelGGL(k_fake_quant_channel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y,
-                           n, d_scale, d_zp, n_channels, inner, (float)qlo, (float)qhi);
+        if (n >= 0xFFFFFFFFll) {
+            hipLaunchKernelGGL(k_fake_quant_channel64, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x,
+                               d_y, n, d_scale, d_zp, n_channels, inner, (float)qlo, (float)qhi);
+        } else if ((inner & 3) == 0 && ((((uintptr_t)d_x | (uintptr_t)d_y) & 15u) == 0)) {
+            hipLaunchKernelGGL(k_fake_quant_channel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x,
+                               d_y, (uint32_t)n, d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo,
+                               (float)qhi);
+        } else {
+            hipLaunchKernelGGL(k_fake_quant_channel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x,
+                               d_y, (uint32_t)n, d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo,
+                               (float)qhi);
+        }
     }
     DPL_LAUNCH_CHECK("k_fake_quant");
     return 0;

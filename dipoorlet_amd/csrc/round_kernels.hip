@@ -237,14 +237,26 @@ __global__ __launch_bounds__(kBlock) void k_l2_loss(const float* __restrict__ z,
         const f4* zv = reinterpret_cast<const f4*>(z);
         const f4* tv = reinterpret_cast<const f4*>(t);
         f4* gv = reinterpret_cast<f4*>(grad);
-        for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < nv; i += stride) {
-            const f4 a = __builtin_nontemporal_load(zv + i), b = __builtin_nontemporal_load(tv + i);
-            f4 g;
-            g.x = one(a.x, b.x);
-            g.y = one(a.y, b.y);
-            g.z = one(a.z, b.z);
-            g.w = one(a.w, b.w);
-            if (grad) gv[i] = g;
+        for (uint64_t i0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i0 < nv; i0 += 4 * stride) {
+            f4 a[4], b[4];   // eight 16-byte loads in flight per lane
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = i0 + u * stride;
+                a[u] = i < nv ? __builtin_nontemporal_load(zv + i) : f4{0.f, 0.f, 0.f, 0.f};
+                b[u] = i < nv ? __builtin_nontemporal_load(tv + i) : f4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint64_t i = i0 + u * stride;
+                if (i < nv) {
+                    f4 g;
+                    g.x = one(a[u].x, b[u].x);
+                    g.y = one(a[u].y, b[u].y);
+                    g.z = one(a[u].z, b[u].z);
+                    g.w = one(a[u].w, b[u].w);
+                    if (grad) __builtin_nontemporal_store(g, gv + i);
+                }
+            }
         }
         for (uint64_t i = (nv << 2) + (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
             const float g = one(z[i], t[i]);

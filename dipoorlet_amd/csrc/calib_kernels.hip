@@ -476,13 +476,46 @@ __global__ __launch_bounds__(kBlock) void k_cos_items(const dpl_work_item* __res
             const uint32_t nvec = n >> 2;
             gptr_f4 av = (gptr_f4)a;
             gptr_f4 bv = (gptr_f4)b;
-            for (uint32_t i = threadIdx.x; i < nvec; i += kBlock) {
-                const f4 p = __builtin_nontemporal_load(av + i);
-                const f4 q = __builtin_nontemporal_load(bv + i);
+            // two streams, software pipelined like stream_span: the next 2 + 2 vectors per lane are in flight while
+            // the current ones are consumed (ping-pong register sets, no register copy between them)
+            constexpr int kU = 2;
+            constexpr uint32_t kStride = kU * kBlock;
+            auto eat1 = [&](const f4& p, const f4& q) {
                 ab += (double)p.x * q.x + (double)p.y * q.y + (double)p.z * q.z + (double)p.w * q.w;
                 aa += (double)p.x * p.x + (double)p.y * p.y + (double)p.z * p.z + (double)p.w * p.w;
                 bbs += (double)q.x * q.x + (double)q.y * q.y + (double)q.z * q.z + (double)q.w * q.w;
+            };
+#define DPL_CLOAD(P, Q, base)                                      \
+    _Pragma("unroll") for (int u = 0; u < kU; ++u) {               \
+        P[u] = __builtin_nontemporal_load(av + (base) + u * kBlock); \
+        Q[u] = __builtin_nontemporal_load(bv + (base) + u * kBlock); \
+    }
+#define DPL_CEAT(P, Q) _Pragma("unroll") for (int u = 0; u < kU; ++u) eat1(P[u], Q[u])
+            uint32_t i = threadIdx.x;
+            if (i + (kU - 1) * kBlock < nvec) {
+                f4 PA[kU], QA[kU], PB[kU], QB[kU];
+                DPL_CLOAD(PA, QA, i);
+                i += kStride;
+                for (;;) {
+                    if (!(i + (kU - 1) * kBlock < nvec)) {
+                        DPL_CEAT(PA, QA);
+                        break;
+                    }
+                    DPL_CLOAD(PB, QB, i);
+                    i += kStride;
+                    DPL_CEAT(PA, QA);
+                    if (!(i + (kU - 1) * kBlock < nvec)) {
+                        DPL_CEAT(PB, QB);
+                        break;
+                    }
+                    DPL_CLOAD(PA, QA, i);
+                    i += kStride;
+                    DPL_CEAT(PB, QB);
+                }
             }
+#undef DPL_CLOAD
+#undef DPL_CEAT
+            for (; i < nvec; i += kBlock) eat1(__builtin_nontemporal_load(av + i), __builtin_nontemporal_load(bv + i));
             done = nvec << 2;
         }
         for (uint32_t i = done + threadIdx.x; i < n; i += kBlock) {

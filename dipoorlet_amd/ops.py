@@ -42,7 +42,7 @@ def _upload_struct_array(arr, n, device):
 
 # Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
 # faster from HBM than many small items; the histogram wants a little more latency hiding).
-DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024}
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512}   # measured optima per kernel family
 
 
 def _blocks_for(kind):
@@ -91,7 +91,7 @@ class TensorSetPlan:
         return [(t, 0, e * self.batch, t) for t, e in enumerate(self.elems)]
 
     def work(self, kind, per_image=False):
-        """WorkSet for kernel family `kind` in {'minmax', 'hist', 'octav'}."""
+        """WorkSet for kernel family `kind` in {'minmax', 'hist', 'octav', 'cos'}."""
         nb = None if self.chunk else max(1, min(_blocks_for(kind), (self.total + 4095) // 4096))
         key = (per_image, nb)
         w = self._work.get(key)
@@ -351,7 +351,7 @@ def cos_accumulate(a, b, acc, slot=0):
 def cos_per_image(plan, tensors_a, tensors_b):
     """Cosine partial sums for every (image, tensor) pair of two tensor sets with the same geometry ->
     fp64 device tensor [B, T, 3] = (sum a*b, sum a*a, sum b*b)."""
-    w = plan.work("minmax", per_image=True)
+    w = plan.work("cos", per_image=True)
     ta = plan.seg_table(tensors_a)
     tb = plan.seg_table(tensors_b)
     acc = torch.zeros(plan.batch, plan.T, 3, dtype=torch.float64, device=plan.device)

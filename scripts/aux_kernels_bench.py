@@ -46,3 +46,15 @@ for name, fn, nbytes in (
     t = timeit(fn)
     rows.append({"kernel": name, "ms": round(t * 1e3, 4), "GBps": round(nbytes / t / 1e9, 1), "of_8TBps": round(nbytes / t / 8e12, 3)})
     print(json.dumps(rows[-1]), flush=True)
+
+# the batched cosine kernel of the profiling flow: every (image, tensor) pair of two ResNet-50-shaped tensor sets
+from dipoorlet_amd.synthetic import resnet50_tensors, synth_activations  # noqa: E402
+spec = resnet50_tensors()
+elems = [e for _, e, _ in spec]
+B = 16
+plan = ops.TensorSetPlan(elems, B, dev)
+ta, tb = synth_activations(spec, B, dev, seed=1), synth_activations(spec, B, dev, seed=2)
+t = timeit(lambda: ops.cos_per_image(plan, ta, tb), iters=10)
+nbytes = 8 * sum(elems) * B
+print(json.dumps({"kernel": "cos_per_image (k_cos_items), ResNet-50 shapes, batch 16", "ms": round(t * 1e3, 4),
+                  "GBps": round(nbytes / t / 1e9, 1), "of_8TBps": round(nbytes / t / 8e12, 3)}), flush=True)

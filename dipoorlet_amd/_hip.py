@@ -14,7 +14,7 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_BINS = 16384
 
 
@@ -75,6 +75,7 @@ SIGNATURES = {
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
+    "dpl_channel_diff_sum": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
     "dpl_cos_items_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),
     "dpl_round_init": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "dpl_round_quant": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, C.c_int, _P, _P]),

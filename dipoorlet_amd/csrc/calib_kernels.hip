@@ -453,6 +453,54 @@ __global__ __launch_bounds__(kBlock) void k_cos_acc(const float* __restrict__ a,
     }
 }
 
+// ================================================================ N2: per-channel sum of (a - b)  (bias correction)
+// a, b viewed as [outer, C, inner] (Conv output [n, C, H, W]; Gemm output [n, C] with inner = 1):
+// acc[c] += sum over outer and inner of (a - b), in fp64.  One wave per (outer, channel) row, rows round-robin over
+// the waves of the launch; 16-byte loads when the rows allow it.
+__global__ __launch_bounds__(kBlock) void k_channel_diff_sum(const float* __restrict__ a, const float* __restrict__ b,
+                                                              uint64_t rows, uint32_t n_channels, uint32_t inner,
+                                                              int vec_ok, double* __restrict__ acc) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const uint64_t wave = (uint64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (kBlock / kWave);
+    if (inner == 1) {  // [n, C]: lanes over channels, waves over rows of 64 channels
+        const uint64_t chunks = (n_channels + kWave - 1) / kWave;
+        for (uint64_t t = wave; t < chunks; t += n_waves) {
+            const uint32_t c = (uint32_t)t * kWave + lane;
+            if (c >= n_channels) continue;
+            double d = 0.0;
+            for (uint64_t r = 0; r < rows / n_channels; ++r) d += (double)a[r * n_channels + c] - (double)b[r * n_channels + c];
+            atomicAdd(acc + c, d);
+        }
+        return;
+    }
+    for (uint64_t r = wave; r < rows; r += n_waves) {
+        const float* pa = a + r * inner;
+        const float* pb = b + r * inner;
+        double d = 0.0;
+        uint32_t i = 0;
+        if (vec_ok) {  // inner % 4 == 0 and both bases 16-byte aligned: every row starts aligned
+            const f4* va = reinterpret_cast<const f4*>(pa);
+            const f4* vb = reinterpret_cast<const f4*>(pb);
+            const uint32_t nv = inner >> 2;
+            for (uint32_t j = lane; j < nv; j += 2 * kWave) {
+                const f4 p0 = __builtin_nontemporal_load(va + j), q0 = __builtin_nontemporal_load(vb + j);
+                const bool two = j + kWave < nv;
+                const f4 p1 = two ? __builtin_nontemporal_load(va + j + kWave) : f4{0.f, 0.f, 0.f, 0.f};
+                const f4 q1 = two ? __builtin_nontemporal_load(vb + j + kWave) : f4{0.f, 0.f, 0.f, 0.f};
+                d += ((double)p0.x - (double)q0.x) + ((double)p0.y - (double)q0.y) + ((double)p0.z - (double)q0.z) +
+                     ((double)p0.w - (double)q0.w);
+                d += ((double)p1.x - (double)q1.x) + ((double)p1.y - (double)q1.y) + ((double)p1.z - (double)q1.z) +
+                     ((double)p1.w - (double)q1.w);
+            }
+            i = nv << 2;
+        }
+        for (uint32_t j = i + lane; j < inner; j += kWave) d += (double)pa[j] - (double)pb[j];
+        d = wave_sum(d);
+        if (lane == 0) atomicAdd(acc + (uint32_t)(r % n_channels), d);
+    }
+}
+
 // Per-slot cosine partial sums over work items: slot = (image, tensor) pair for the profiling flow
 // (profiling.py:57-64: one cosine per image per quantised layer output).  a and b come from two segment
 // tables with identical geometry (fp model vs fake-quantised model).
@@ -765,6 +813,22 @@ int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_
     hipLaunchKernelGGL(k_cos_acc, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_a, d_b, n,
                        d_acc + 3 * slot);
     DPL_LAUNCH_CHECK("k_cos_acc");
+    return 0;
+}
+
+int dpl_channel_diff_sum(const float* d_a, const float* d_b, int64_t outer, int64_t n_channels, int64_t inner,
+                         double* d_acc, dpl_stream_t s) {
+    if (outer <= 0 || n_channels <= 0 || inner <= 0) return 0;
+    if (n_channels > 0xFFFFFFFFll || inner > 0xFFFFFFFFll) return fail_msg("dpl_channel_diff_sum: extent out of range");
+    const uint64_t rows = (uint64_t)outer * (uint64_t)n_channels;
+    const int vec_ok = ((inner & 3) == 0) && ((((uintptr_t)d_a | (uintptr_t)d_b) & 15u) == 0);
+    uint64_t work = inner == 1 ? (uint64_t)(n_channels + kWave - 1) / kWave : rows;
+    uint64_t blocks = (work + kBlock / kWave - 1) / (kBlock / kWave);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_channel_diff_sum, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_a, d_b, rows,
+                       (uint32_t)n_channels, (uint32_t)inner, vec_ok, d_acc);
+    DPL_LAUNCH_CHECK("k_channel_diff_sum");
     return 0;
 }
 

@@ -348,6 +348,24 @@ def cos_accumulate(a, b, acc, slot=0):
     return acc
 
 
+def channel_diff_sum(a, b, acc=None):
+    """acc[c] += sum over every axis but the channel one of (a - b), fp64 (bias_correction.py:9-13).
+    a, b: [n, C, spatial...] (channel axis 1) or [n, C]; returns the fp64 device tensor [C]."""
+    _require_cuda(a, "a")
+    _require_cuda(b, "b")
+    if a.shape != b.shape or a.dim() < 2:
+        raise _hip.DipoorletHipError("channel_diff_sum: shapes must match and carry a channel axis")
+    n_ch = int(a.shape[1])
+    inner = 1
+    for d in a.shape[2:]:
+        inner *= int(d)
+    if acc is None:
+        acc = torch.zeros(n_ch, dtype=torch.float64, device=a.device)
+    _hip.check(_hip.lib().dpl_channel_diff_sum(_ptr(a), _ptr(b), int(a.shape[0]), n_ch, inner, _ptr(acc), _stream()),
+               "dpl_channel_diff_sum")
+    return acc
+
+
 def cos_per_image(plan, tensors_a, tensors_b):
     """Cosine partial sums for every (image, tensor) pair of two tensor sets with the same geometry ->
     fp64 device tensor [B, T, 3] = (sum a*b, sum a*a, sum b*b)."""

@@ -17,6 +17,7 @@ The fake-quant structure does not depend on bias values, so the quantised graph 
 import numpy as np
 import torch
 
+from .. import ops
 from ..executor import _OPS, GraphSession
 from ..forward_net import load_input_batch
 from ..graph import ONNXGraph
@@ -28,14 +29,14 @@ BIAS_CORRECTION_NODE_TYPE = ["Conv", "Gemm"]
 
 def _channel_mean_diff(fp_chunks, q_chunks, is_conv):
     """bias_correction.py:10-13 — mean(fp - q) over every axis but the channel one (axis 1 of a Conv output
-    [n, C, spatial...]; the last axis of a Gemm output [n, C]).  Accumulated in fp64 on the device."""
-    tot, cnt = None, 0
+    [n, C, spatial...]; the last axis of a Gemm output [n, C]): one fused kernel per chunk pair, fp64 sums."""
+    acc, cnt = None, 0
     for a, b in zip(fp_chunks, q_chunks):
-        d = a.double() - b.double()
-        d = d.transpose(0, 1).reshape(d.shape[1], -1) if is_conv else d.reshape(-1, d.shape[-1]).t()
-        tot = d.sum(1) if tot is None else tot + d.sum(1)
-        cnt += d.shape[1]
-    return (tot / cnt).float()
+        if not is_conv:
+            a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+        acc = ops.channel_diff_sum(a.contiguous(), b.contiguous(), acc)
+        cnt += a.numel() // a.shape[1]
+    return (acc / cnt).float()
 
 
 class _Frontier:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 7
+#define DPL_ABI_VERSION 8
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -171,6 +171,12 @@ int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale
 /* ---- cosine-similarity partial sums (utils.py:273-278): d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a),
  *      sum(b*b) in fp64. */
 int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_acc, int64_t slot, dpl_stream_t s);
+
+/* Bias correction (bias_correction.py:9-13: bias += mean(fp_out - q_out) over every axis but the channel one):
+ * a, b viewed as [outer, n_channels, inner] (Conv output [n, C, H, W]; Gemm output [n, C] with inner = 1);
+ * d_acc[c] += sum over outer and inner of (a - b), accumulated in fp64. */
+int dpl_channel_diff_sum(const float* d_a, const float* d_b, int64_t outer, int64_t n_channels, int64_t inner,
+                         double* d_acc, dpl_stream_t s);
 
 /* Same sums per work-item slot (slot = (image, tensor) pair in the profiling flow, profiling.py:57-64):
  * d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a), sum(b*b); a from d_seg_a, b from d_seg_b (same geometry). */

@@ -397,3 +397,24 @@ def test_octav_exact_walk_restart_path(dev):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             assert _close(got[0, t, 0], O.octav_scale(tensors[t][0].cpu().numpy(), 1))
+
+
+def test_channel_diff_sum(dev):
+    """dpl_channel_diff_sum (bias correction's mean(fp - q) per channel) against numpy in fp64: conv maps with rows of
+    every alignment class, a Gemm output, accumulation over several chunks."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(29)
+    for shape in ((5, 7, 14, 14), (3, 6, 7, 7), (2, 9, 5, 13), (4, 300), (2, 3, 64, 64), (1, 1, 3)):
+        a = rng.standard_normal(shape).astype(np.float32)
+        b = (a + rng.standard_normal(shape).astype(np.float32) * 1e-2).astype(np.float32)
+        axes = tuple(i for i in range(len(shape)) if i != 1)
+        want = (a.astype(np.float64) - b.astype(np.float64)).sum(axis=axes)
+        acc = ops.channel_diff_sum(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev))
+        np.testing.assert_allclose(acc.cpu().numpy(), want, rtol=1e-12, atol=1e-12)
+        acc = ops.channel_diff_sum(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev), acc)   # accumulates
+        np.testing.assert_allclose(acc.cpu().numpy(), 2 * want, rtol=1e-12, atol=1e-12)
+    # an unaligned view (rows not starting on 16 bytes)
+    flat = torch.from_numpy(rng.standard_normal(2 * 4 * 36 + 1).astype(np.float32)).to(dev)
+    a = flat[1:].reshape(2, 4, 36)
+    b = torch.zeros_like(a)
+    np.testing.assert_allclose(ops.channel_diff_sum(a, b).cpu().numpy(), a.double().sum((0, 2)).cpu().numpy(), rtol=1e-12)

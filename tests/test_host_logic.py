@@ -153,3 +153,35 @@ def test_world2_gloo_merge_equals_world1_reference(golden_dir, tmp_path):
         rows = r0["rows"][:, t].numpy()
         clip = O.octav_clip(rows[:, 0], rows[:, 1], rows[:, 2])
         assert [float(clip[0]), float(clip[1])] == oo[k]
+
+
+def _launcher_worker(kind, port, q):
+    """Runs in a fresh process: environment as OpenMPI / SLURM would set it -> the process group the helpers build."""
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    from dipoorlet_amd import dist_helper as dh
+    if kind == "mpi":
+        os.environ.update(OMPI_MCA_orte_hnp_uri="123.0;tcp://127.0.0.1:5555", OMPI_COMM_WORLD_SIZE="1",
+                          OMPI_COMM_WORLD_RANK="0", MASTER_PORT=str(port))
+        dh.init_from_mpi()
+    else:
+        os.environ.update(SLURM_JOB_ID=str(port - 24553), SLURM_NODELIST="HOST-AB-127-0-0-1", SLURM_NTASKS="1",
+                          SLURM_PROCID="0")
+        dh.init_from_slurm()
+    q.put((os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"], dist.get_rank(), dist.get_world_size(),
+           dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_mpi_and_slurm_bootstrap():
+    """dist_helper.py:8-49 — rank / size / master derived from the launcher's environment (gloo here: no GPU)."""
+    ctx = mp.get_context("spawn")
+    for kind, port in (("mpi", 29871), ("slurm", 24553 + 4321)):
+        q = ctx.Queue()
+        p = ctx.Process(target=_launcher_worker, args=(kind, port, q))
+        p.start()
+        addr, mport, rank, world, backend = q.get(timeout=120)
+        p.join(60)
+        assert p.exitcode == 0
+        assert (addr, rank, world, backend) == ("127.0.0.1", 0, 1, "gloo")
+        assert mport == str(port)

@@ -185,3 +185,63 @@ def test_mpi_and_slurm_bootstrap():
         assert p.exitcode == 0
         assert (addr, rank, world, backend) == ("127.0.0.1", 0, 1, "gloo")
         assert mport == str(port)
+
+
+def test_rv_and_stpu_emitters_match_the_reference_files(tmp_path, golden_dir):
+    """deploy.py's rv / stpu emitters against the files the reference's own emitters wrote for the same graph and
+    ranges (tests/golden/deploy_level.json, from gen_golden_deploy.py)."""
+    import yaml
+    from dipoorlet_amd.deploy import to_deploy
+    from dipoorlet_amd.graph import ONNXGraph
+    from dipoorlet_amd.onnx_io import Node
+    with open(os.path.join(golden_dir, "deploy_level.json")) as f:
+        G = json.load(f)
+
+    def graph():
+        g = ONNXGraph()
+        g.graph.node = [Node(op, i, o, name=n, attrs=a) for op, i, o, n, a in G["nodes"]]
+        g.initializer = {k: np.asarray(v, np.float32) for k, v in G["weights"].items()}
+        g.network_inputs, g.network_outputs = ["input"], ["output"]
+        g.tensor_name_shape_map = {k: list(v) for k, v in G["shapes"].items()}
+        g.update_model()
+        return g
+
+    def clips():
+        act = {k: [np.float64(v[0]), np.float64(v[1])] for k, v in G["act_clip"].items()}
+        wt = {k: [np.array(v[0]), np.array(v[1])] for k, v in G["weight_clip"].items()}
+        return act, wt
+
+    def close(a, b, path=""):
+        if isinstance(b, dict):
+            assert isinstance(a, dict) and list(a) == list(b), path      # same keys in the same order
+            for k in b:
+                close(a[k], b[k], path + "/" + str(k))
+        elif isinstance(b, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                close(x, y, f"{path}[{i}]")
+        elif isinstance(b, float):
+            assert a == pytest_approx(b), (path, a, b)
+        else:
+            assert a == b, (path, a, b)
+    for tag, deploy, wg in (("rv", "rv", False), ("stpu", "stpu", False), ("stpu_wg", "stpu", True)):
+        out = tmp_path / tag
+        os.makedirs(out)
+        act, wt = clips()
+        to_deploy(graph(), act, wt, types.SimpleNamespace(deploy=deploy, output_dir=str(out), stpu_wg=wg))
+        want = {k.split("/", 1)[1]: v for k, v in G["files"].items() if k.startswith(tag + "/")}
+        assert sorted(os.listdir(out)) == sorted(want)
+        for name, text in want.items():
+            got = open(out / name).read()
+            if name.endswith(".json"):
+                close(json.loads(got), json.loads(text), name)
+            else:
+                close(yaml.safe_load(got), yaml.safe_load(text), name)
+        if not wg and tag == "rv":      # without winograd nothing is tolerance-dependent: byte-identical files
+            for name, text in want.items():
+                assert open(out / name).read() == text, name
+
+
+def pytest_approx(v):
+    import pytest
+    return pytest.approx(v, rel=1e-6, abs=1e-12)

@@ -64,6 +64,7 @@ class _Graph:
                                                  for o, i, u, n, a in NODES])
         self.network_inputs = ["input"]
         self.initializer = {k: [v] for k, v in weights.items()}
+        self.initializer.update({b: [np.zeros(1, np.float32)] for b in ("b1", "b3", "b4", "b5")})
 
     def get_tensor_consumer(self, t):
         r = [n for n in self.graph.node if t in n.input]
@@ -98,10 +99,25 @@ def main():
         c = {k: [np.float64(v[0]), np.float64(v[1])] for k, v in act.items()}
         c.update({k: [np.array(v[0]), np.array(v[1])] for k, v in wclip.items()})
         return c
-    for tag, fn, wg in (("rv", rv.gen_rv_yaml, False), ("stpu", stpu.gen_stpu_minmax, False),
-                        ("stpu_wg", stpu.gen_stpu_minmax, True)):
+    import dipoorlet.deploy.deploy_atlas as atlas
+    import dipoorlet.deploy.deploy_imx as imx
+    import dipoorlet.deploy.deploy_magicmind as mm
+    import dipoorlet.deploy.deploy_snpe as snpe
+    import dipoorlet.deploy.deploy_ti as ti
+    import dipoorlet.deploy.deploy_trt as trt
+
+    def act_only():
+        return {k: [np.float64(v[0]), np.float64(v[1])] for k, v in act.items()}
+    emitters = (("rv", rv.gen_rv_yaml, False, clip), ("stpu", stpu.gen_stpu_minmax, False, clip),
+                ("stpu_wg", stpu.gen_stpu_minmax, True, clip), ("trt", trt.gen_trt_range, False, act_only),
+                ("snpe", snpe.gen_snpe_encodings, False, act_only), ("ti", ti.gen_ti_json, False, act_only),
+                ("imx", imx.gen_imx_range, False, clip), ("magicmind", mm.gen_magicmind_proto, False, act_only),
+                ("atlas", atlas.gen_atlas_quant_param, False, act_only))
+    for tag, fn, wg, mk in emitters:
         with tempfile.TemporaryDirectory() as td:
-            fn(_Graph(weights), clip(), types.SimpleNamespace(output_dir=td, stpu_wg=wg))
+            g = _Graph(weights)
+            g.network_outputs = ["output"]
+            fn(g, mk(), types.SimpleNamespace(output_dir=td, stpu_wg=wg, deploy=tag))
             for f in sorted(os.listdir(td)):
                 out["files"][f"{tag}/{f}"] = open(os.path.join(td, f)).read()
     with open(os.path.join(HERE, "deploy_level.json"), "w") as f:

@@ -187,9 +187,9 @@ def test_mpi_and_slurm_bootstrap():
         assert mport == str(port)
 
 
-def test_rv_and_stpu_emitters_match_the_reference_files(tmp_path, golden_dir):
-    """deploy.py's rv / stpu emitters against the files the reference's own emitters wrote for the same graph and
-    ranges (tests/golden/deploy_level.json, from gen_golden_deploy.py)."""
+def test_deploy_emitters_match_the_reference_files(tmp_path, golden_dir):
+    """Every deploy.py emitter against the files the reference's own emitters wrote for the same graph and ranges
+    (tests/golden/deploy_level.json, from gen_golden_deploy.py)."""
     import yaml
     from dipoorlet_amd.deploy import to_deploy
     from dipoorlet_amd.graph import ONNXGraph
@@ -201,6 +201,7 @@ def test_rv_and_stpu_emitters_match_the_reference_files(tmp_path, golden_dir):
         g = ONNXGraph()
         g.graph.node = [Node(op, i, o, name=n, attrs=a) for op, i, o, n, a in G["nodes"]]
         g.initializer = {k: np.asarray(v, np.float32) for k, v in G["weights"].items()}
+        g.initializer.update({b: np.zeros(1, np.float32) for b in ("b1", "b3", "b4", "b5")})
         g.network_inputs, g.network_outputs = ["input"], ["output"]
         g.tensor_name_shape_map = {k: list(v) for k, v in G["shapes"].items()}
         g.update_model()
@@ -224,7 +225,9 @@ def test_rv_and_stpu_emitters_match_the_reference_files(tmp_path, golden_dir):
             assert a == pytest_approx(b), (path, a, b)
         else:
             assert a == b, (path, a, b)
-    for tag, deploy, wg in (("rv", "rv", False), ("stpu", "stpu", False), ("stpu_wg", "stpu", True)):
+    for tag, deploy, wg in (("rv", "rv", False), ("stpu", "stpu", False), ("stpu_wg", "stpu", True), ("trt", "trt", False),
+                            ("snpe", "snpe", False), ("ti", "ti", False), ("imx", "imx", False),
+                            ("magicmind", "magicmind", False), ("atlas", "atlas", False)):
         out = tmp_path / tag
         os.makedirs(out)
         act, wt = clips()
@@ -235,9 +238,11 @@ def test_rv_and_stpu_emitters_match_the_reference_files(tmp_path, golden_dir):
             got = open(out / name).read()
             if name.endswith(".json"):
                 close(json.loads(got), json.loads(text), name)
-            else:
+            elif name.endswith(".yaml"):
                 close(yaml.safe_load(got), yaml.safe_load(text), name)
-        if not wg and tag == "rv":      # without winograd nothing is tolerance-dependent: byte-identical files
+            else:
+                assert got == text, name
+        if tag != "stpu_wg":            # without winograd nothing is tolerance-dependent: byte-identical files
             for name, text in want.items():
                 assert open(out / name).read() == text, name
 

@@ -63,6 +63,9 @@ def main(argv=None):
     rank, world = dist.get_rank(), dist.get_world_size()
     if args.output_dir is None:
         args.output_dir = os.path.join(os.path.abspath(os.path.dirname(args.model)), "results")
+    if args.model_type is not None:      # __main__.py:71-73 (the onnxruntime transformer optimiser step is not run:
+        args.optim_transformer = True    # the graph is executed as it is)
+        args.skip_prof_layer = True
     if rank == 0:
         os.makedirs(args.output_dir, exist_ok=True)
         setup_logger(args)
@@ -93,12 +96,12 @@ def main(argv=None):
                                                                                   weight_clip_val, args)
     dist.barrier()
     if not args.skip_profiling:
-        from .profiling import (quantize_profiling_multipass, show_model_profiling_res, show_model_ranges,
-                                weight_need_perchannel)
+        from .profiling import (quantize_profiling_multipass, quantize_profiling_transformer, show_model_profiling_res,
+                                show_model_ranges, weight_need_perchannel)
         if rank == 0:
             logger.info("Profiling...")
-        layer_cos, model_cos, qnodes = quantize_profiling_multipass(graph_after_wt, graph_ori, act_clip_val,
-                                                                    weight_clip_val, args)
+        prof = quantize_profiling_transformer if args.model_type is not None else quantize_profiling_multipass   # :141-146
+        layer_cos, model_cos, qnodes = prof(graph_after_wt, graph_ori, act_clip_val, weight_clip_val, args)
         if rank == 0:
             show_model_profiling_res(graph_after_wt, layer_cos, model_cos, qnodes, args)
             show_model_ranges(graph_after_wt, act_clip_val, weight_clip_val, args)

@@ -303,10 +303,21 @@ class ActivationCache:
         return [t[k] for t in self.chunks(tensor_name) for k in range(t.shape[0])]
 
 
+def forward_get_tensor(graph, net, index, args):
+    """forward_net.py:467-485 — every tensor of calibration image `index`, by name, as device tensors [1, ...]
+    (`net`, the reference's ModelProto argument, is not needed: the graph makes its own session)."""
+    from collections import OrderedDict
+    sess = graph.make_session(args)
+    dev = sess.device if hasattr(sess, "device") else torch.device("cuda", torch.cuda.current_device())
+    shapes = {n: graph.get_tensor_shape(n) for n in graph.network_inputs}
+    inputs = load_input_batch(args.input_dir, graph.network_inputs, shapes, index, index + 1, dev)
+    return OrderedDict(zip(sess.tensor_names, sess.run(inputs)))
+
+
 def log_forward_time(seconds):
     logger.info("Forward time: {:.2f} seconds".format(seconds))
 
 
 __all__ = ["ActivationSession", "ActivationCache", "CalibrationRun", "input_data_generator", "load_input_batch", "forward_get_minmax",
-           "forward_get_hist", "forward_net_octav", "forward_get_minmax_transformer", "forward_get_hist_transformer",
+           "forward_get_hist", "forward_net_octav", "forward_get_tensor", "forward_get_minmax_transformer", "forward_get_hist_transformer",
            "forward_net_octav_transformer", "hist_pass", "DEFAULT_BATCH"]

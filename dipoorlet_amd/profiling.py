@@ -107,6 +107,15 @@ def quantize_profiling_multipass(graph_after_wt, graph_ori, act_clip_val, weight
     return layer_cosine, model_cosine, quant_node_list
 
 
+def quantize_profiling_transformer(graph_after_wt, graph_ori, act_clip_val, weight_clip_val, args):
+    """profiling.py:102-156 — the `--model_type` / `--optim_transformer` variant: network-output cosines only (its
+    layer dictionary stays empty).  The reference needs a separate node-by-node executor for large transformer
+    graphs; here the same batched pass serves both, so this is the multipass result without the per-layer part."""
+    _, model_cosine, quant_node_list = quantize_profiling_multipass(graph_after_wt, graph_ori, act_clip_val,
+                                                                    weight_clip_val, args)
+    return {}, model_cosine, quant_node_list
+
+
 def show_model_profiling_res(graph_after_wt, layer_cosine_dict, model_cosine_dict, quant_node_list, args):
     """profiling.py:246-264 — log per-layer cosines, the 10 worst layers, and the output cosines."""
     import heapq

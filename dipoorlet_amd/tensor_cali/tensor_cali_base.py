@@ -1,9 +1,10 @@
-"""Entry point of the calibration phase (dipoorlet/tensor_cali/tensor_cali_base.py:4-7): weight ranges,
-then the activation algorithm selected by args.act_quant through the dispatcher."""
-from .basic_algorithm import find_clip_val_minmax_weight, tensor_cali_dispatcher
+"""Entry point of the calibration phase (counterpart of dipoorlet/tensor_cali/tensor_cali_base.py:4-7)."""
+from . import basic_algorithm as _algo
 
 
 def tensor_calibration(onnx_graph, args):
-    weight_clip_val = find_clip_val_minmax_weight(onnx_graph, args)
-    act_clip_val = tensor_cali_dispatcher(args.act_quant, onnx_graph, args)
-    return act_clip_val, weight_clip_val
+    """-> (activation clip ranges from the algorithm registered under args.act_quant, per-channel weight ranges).
+    Every rank calls this; the activation statistics are merged over ranks inside the algorithm."""
+    ranges = {"weight": _algo.find_clip_val_minmax_weight(onnx_graph, args)}
+    ranges["act"] = _algo.tensor_cali_dispatcher(args.act_quant, onnx_graph, args)
+    return ranges["act"], ranges["weight"]

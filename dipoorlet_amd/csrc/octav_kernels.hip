@@ -925,7 +925,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
 #define DPL_QUEUE_CAP 32
 #endif
 constexpr int kQueueCap = DPL_QUEUE_CAP;     // a tile adds at most 16: flush once a queue holds more than cap - 16
-constexpr int kQueueStride = kQueueCap + 1;  // odd stride: lanes with equal fill hit different banks
+constexpr int kQueueStride = kQueueCap + 1;  // entries per lane (+1: the branch-free append writes one past the fill)
 constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;   // 512
 constexpr int kKeyWord0 = (int)(kLogKey0 >> 5);           // word of the window's first bin (kLogKey0 is a multiple of 32)
 static_assert((kLogKey0 & 31u) == 0u, "the window must start on a bitmap word");
@@ -937,11 +937,12 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
                                                           const uint32_t* __restrict__ bitmap,
                                                           const uint64_t* __restrict__ pair_base,
                                                           float* __restrict__ list0) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t queues[];  // [waves][64][kQueueStride]
+    extern __shared__ __attribute__((aligned(16))) uint32_t queues[];  // [waves][kQueueStride][64]: entry j of lane l
+    // sits at [j][l], so the bank of every queue access depends on the lane alone (no conflicts whatever the fills)
     __shared__ uint32_t bm[kKeyWords];
     const int w = threadIdx.x / kWave;
     const uint32_t lane = threadIdx.x & (kWave - 1);
-    uint32_t* q = queues + ((size_t)w * kWave + lane) * kQueueStride;
+    uint32_t* q = queues + (size_t)w * kWave * kQueueStride + lane;
     uint32_t k0, k1;
     block_items(bb, k0, k1);
     for (uint32_t k = k0; k < k1; ++k) {
@@ -968,7 +969,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
             uint32_t base = 0;
             if (lane == kWave - 1) base = atomicAdd(&me->len[0], total);
             base = __shfl(base, kWave - 1, kWave) + inc - cnt;
-            for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j];
+            for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j * kWave];
             cnt = 0;
         };
         for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t, bool) {
@@ -993,7 +994,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
             if (__any(any != 0u)) {
 #pragma unroll
                 for (int j = 0; j < 16; ++j) {
-                    q[cnt] = u[j];
+                    q[cnt * kWave] = u[j];
                     cnt += hit[j];
                 }
             }

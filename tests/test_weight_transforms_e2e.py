@@ -133,3 +133,22 @@ def test_cli_folds_batchnorm_by_default(tmp_path):
     _, (y0,) = _forward(os.path.join(d, "model.onnx"), d, ["output"])
     _, (y1,) = _forward(os.path.join(out, "update_bias_model.onnx"), d, ["output"])
     assert np.corrcoef(y0.ravel(), y1.ravel())[0, 1] > 0.999          # bias correction moves the biases a little
+
+
+def test_transform_chain_we_bn_adaround(tmp_path):
+    """All transforms in one run, in the reference's order (--bc --we --update_bn --adaround): every stage writes its
+    model, equalised layers are skipped by AdaRound (adaround.py:36-37), the run ends with the deploy file."""
+    d = str(tmp_path)
+    _build(d)
+    out = os.path.join(d, "out_chain")
+    _cli(d, out, ["--bc", "--we", "--update_bn", "--adaround", "--ada_bs", "4", "--ada_epoch", "3"])
+    for f in ("update_bias_model.onnx", "weight_equal_model.onnx", "update_bn_model.onnx", "adaround.onnx",
+              "trt_clip_val.json", "act_clip_val.json"):
+        assert os.path.exists(os.path.join(out, f)), f
+    from dipoorlet_amd.graph import ONNXGraph
+    g_bn = ONNXGraph.load(os.path.join(out, "update_bn_model.onnx"))
+    g_ada = ONNXGraph.load(os.path.join(out, "adaround.onnx"))
+    assert np.array_equal(g_ada.get_initializer("c1.weight"), g_bn.get_initializer("c1.weight"))      # c1 -> c2 equalised: skipped
+    assert not np.array_equal(g_ada.get_initializer("c3.weight"), g_bn.get_initializer("c3.weight"))  # c3 learned
+    log = open(os.path.join(out, "log.txt")).read()
+    assert "Cross Layer WE: " in log and "Update BN for node" in log and "Adaround for: " in log

@@ -418,3 +418,50 @@ def test_channel_diff_sum(dev):
     a = flat[1:].reshape(2, 4, 36)
     b = torch.zeros_like(a)
     np.testing.assert_allclose(ops.channel_diff_sum(a, b).cpu().numpy(), a.double().sum((0, 2)).cpu().numpy(), rtol=1e-12)
+
+
+def test_octav_randomised_shapes_and_distributions(dev):
+    """A seeded sweep over odd sizes (not multiples of 4, below / above the small-pair threshold, split over several
+    workgroups) and distributions (discrete-valued, sparse, constant, huge / tiny scale, heavy tails): the three forms
+    agree with each other and with the numpy oracle, for both `dynamic_sym` settings, in batched launches."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(20260)
+    sizes = [1, 3, 17, 1023, 1025, 4099, 16383, 16385, 50001, 131071, 300003, 1200007]
+
+    def draw(kind, n):
+        if kind == 0:
+            return rng.standard_normal(n) * 10 ** rng.uniform(-3, 3)
+        if kind == 1:
+            return np.maximum(rng.standard_normal(n) - rng.uniform(-1, 1), 0) * 10 ** rng.uniform(-2, 2)
+        if kind == 2:
+            return rng.integers(-8, 9, n) * 0.25                         # discrete values: many ties
+        if kind == 3:
+            return np.where(rng.random(n) < 0.02, rng.standard_normal(n) * 5, 0.0)
+        if kind == 4:
+            return np.full(n, rng.uniform(0.1, 3.0))                     # constant
+        if kind == 5:
+            return rng.standard_t(2.5, n)                                # heavy tails
+        if kind == 6:
+            return np.abs(rng.standard_normal(n)) + 1e-7                 # |min| < 1e-6: dynamic_sym trigger
+        return rng.lognormal(0, 2.0, n) * rng.choice([-1, 1], n)
+    B = 2
+    elems, tensors, raw = [], [], []
+    for t, n in enumerate(sizes):
+        data = np.stack([draw((t + b) % 8, n) for b in range(B)]).astype(np.float32)
+        raw.append(data)
+        elems.append(n)
+        tensors.append(torch.from_numpy(data).to(dev))
+    plan = ops.TensorSetPlan(elems, B, dev)
+    for dyn in (False, True):
+        got = {form: ops.octav_batch(plan, tensors, dyn, form=form).cpu().numpy() for form in ("bracket", "compact", "full")}
+        assert np.array_equal(got["bracket"], got["compact"], equal_nan=True)
+        assert np.array_equal(got["bracket"], got["full"], equal_nan=True)
+        for t, n in enumerate(sizes):
+            for b in range(B):
+                x = raw[t][b]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    s = O.octav_scale(x, O.octav_unsigned(x.min(), dyn))
+                g = got["bracket"][b, t]
+                assert _close(g[0], s), (n, b, dyn, g, s)
+                assert g[1] == x.min() and g[2] == x.max()

@@ -12,9 +12,10 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
+# DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
+LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_BINS = 16384
 
 
@@ -70,6 +71,11 @@ SIGNATURES = {
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
+    "dpl_octav_slice_cap": (C.c_uint32, []),
+    "dpl_octav_resident_occupancy": (C.c_int, []),
+    "dpl_build_octav_slices": (_I64, [_P, _I64, C.c_int, _P, _I64, _P]),
+    "dpl_octav_run_resident": (C.c_int, [_P, _I64, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P,
+                                         _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
@@ -149,6 +155,22 @@ def build_balanced_items(spans, n_blocks):
     n2 = lib().dpl_build_balanced_items(C.addressof(arr), ns, n_blocks, C.addressof(out), n, C.addressof(bb))
     assert n2 == n
     return out, int(n), bb
+
+
+def build_octav_slices(spans, n_queues):
+    """HOST: spans (one per (image, tensor) pair) -> (WorkItem array, n_slices, queue_begin array), or None when a pair
+    is too large for the resident form (more than 64 slices)."""
+    arr, ns = _span_array(spans)
+    n = lib().dpl_build_octav_slices(C.addressof(arr), ns, n_queues, None, 0, None)
+    if n == -3:
+        return None
+    if n < 0:
+        check(int(n), "dpl_build_octav_slices")
+    out = (WorkItem * max(n, 1))()
+    qb = (C.c_uint32 * (n_queues + 1))()
+    n2 = lib().dpl_build_octav_slices(C.addressof(arr), ns, n_queues, C.addressof(out), n, C.addressof(qb))
+    assert n2 == n
+    return out, int(n), qb
 
 
 def build_work_items(spans, chunk_elems):

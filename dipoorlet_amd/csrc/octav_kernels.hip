@@ -2,6 +2,7 @@
 // Three forms of the same iterate sequence: full re-reads, tail compaction, and the two-read bracket form over an
 // exact log-scale histogram (the default).  Shared helpers: common.hpp.
 #include "common.hpp"
+#include "octav_common.hpp"
 
 #pragma clang fp contract(off)
 
@@ -117,29 +118,6 @@ __global__ __launch_bounds__(kBlock) void k_octav_pass(const dpl_work_item* __re
         }
         __syncthreads();
     }
-}
-
-// One fixed-point step (forward_net.py:326-330): s' = fl32(sum) / fl32(c/unsigned * cnt_le + cnt_gt) — the python-float
-// denominator is cast to float32 for the divide (NEP 50); |s' - s| < 1e-6 stops KEEPING the previous s.
-struct OctavStep {
-    float s;
-    uint32_t iters, done, decreased;
-};
-__device__ __forceinline__ OctavStep octav_step(double sum, unsigned long long cnt_gt, unsigned long long cnt_le,
-                                                float unsigned_div, float s, uint32_t iters, int max_iters) {
-    const double c = 1.0 / 65536.0 / 3.0 / (double)unsigned_div;
-    const double denom = c * (double)(long long)cnt_le + (double)(long long)cnt_gt;
-    const float s1 = __fdiv_rn((float)sum, (float)denom);
-    OctavStep r{s, iters, 0u, 0u};
-    if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
-        r.done = 1u;
-    } else {
-        r.decreased = !(s1 >= s) ? 1u : 0u;
-        r.s = s1;
-        r.iters = iters + 1u;
-        if ((int)r.iters >= max_iters || s1 != s1) r.done = 1u;
-    }
-    return r;
 }
 
 template <bool kFirst>
@@ -577,7 +555,8 @@ __global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* ou
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool bad = st[i].nan_seen != 0u || st[i].min_enc == 0xFFFFFFFFu;
-    out[3 * i + 0] = st[i].s;
+    // control block bit 1: a workgroup of the resident form gave up waiting for its cluster (never expected)
+    out[3 * i + 0] = (st[n].nan_seen & 2u) ? __uint_as_float(0x7FC00000u) : st[i].s;
     out[3 * i + 1] = bad ? NAN : dec_f32(st[i].min_enc);
     out[3 * i + 2] = bad ? NAN : dec_f32(st[i].max_enc);
 }
@@ -593,34 +572,6 @@ __global__ void k_octav_finalize(const dpl_octav_state* st, int64_t n, float* ou
 // per-pair kernel then runs the reference's exact iteration from (exact bin totals above the current bin) +
 // (gathered elements of the current bin).  Every iterate is verified to land in a marked bin; a pair that
 // fails (or whose bracket explodes: flat / degenerate distributions) takes the compaction path instead.
-#ifndef DPL_MARGIN0
-#define DPL_MARGIN0 0
-#endif
-#ifndef DPL_MARGIN
-#define DPL_MARGIN 0
-#endif
-constexpr int kLogNB = 2048;
-constexpr int kLogShift = 17;                               // 23 - 6: six mantissa bits per bin
-constexpr uint32_t kLogKey0 = (uint32_t)(127 - 18) << 6;    // key of 2^-18
-constexpr int kLogWords = kLogNB / 32;
-constexpr int kBitmapRow = kLogWords + 2;                   // + the gather range [lo, hi) as float bits
-constexpr int kLogMaxMarked = 256;
-constexpr uint32_t kSmallPair = 16384;                      // pairs this small are gathered whole
-
-__device__ __forceinline__ int log_bin(float a) {
-    const int b = (int)(__float_as_uint(a) >> kLogShift) - (int)kLogKey0;
-    return b < 0 ? 0 : (b > kLogNB - 1 ? kLogNB - 1 : b);
-}
-__device__ __forceinline__ double log_bin_scale(int b) {   // 2^(e - 150) for the exponent field e of bin b
-    const int e = (int)(((uint32_t)b + kLogKey0) >> 6);
-    return __longlong_as_double((long long)(e - 150 + 1023) << 52);
-}
-
-// One 64-bit LDS atomic per element: the bin word holds the count in bits 44..63 and the mantissa sum in bits
-// 0..43 (a sub-span has < 2^20 elements, an explicit mantissa is < 2^23: neither field can overflow into the other).
-constexpr int kPackShift = 44;
-constexpr unsigned long long kPackMask = (1ull << kPackShift) - 1ull;
-
 struct LogHistOp {
     unsigned long long* packed;
     float mn, mx;
@@ -792,10 +743,6 @@ __device__ __forceinline__ void build_suffix(uint32_t* gc, unsigned long long* g
     __syncthreads();
 }
 
-__device__ __forceinline__ float log_edge(int b) {  // lower edge of bin b (bin 0 starts at 0)
-    return b <= 0 ? 0.0f : __uint_as_float(((uint32_t)b + kLogKey0) << kLogShift);
-}
-
 // Per pair: s_0, then the bracket walk over the bin edges; marks the bins the iterates can visit.
 __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __restrict__ st,
                                                            dpl_octav_state* __restrict__ ctl,
@@ -822,15 +769,10 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
     // histogram rows hold the suffix totals  N_ge[j] (u32)  and  S_ge[j] (fp64 bits)
     build_suffix(gc, gs, n_ge, s_ge, scr_s, scr_n, true);
     if (threadIdx.x == 0) {
-        const float mn = dec_f32(me->min_enc);
-        const float ud = (dynamic_sym && fabsf(mn) < 1e-6f && !me->nan_seen) ? 4.0f : 1.0f;
-        // sum(|x|) and count(|x| > 0): exact window totals + the directly accumulated out-of-window part
-        const float s0 = me->nan_seen ? __uint_as_float(0x7FC00000u)
-                                      : __fdiv_rn((float)(me->sum + s_ge[1]), (float)(long long)(me->cnt_gt + n_ge[1]));
-        const float max_abs = fmaxf(fabsf(mn), fabsf(dec_f32(me->max_enc)));
-        const unsigned long long n = me->n_elems;
-        me->unsigned_div = ud;
-        me->s = s0;
+        const BracketResult br = bracket_walk(n_ge, s_ge, bm, dec_f32(me->min_enc), dec_f32(me->max_enc), me->nan_seen != 0u,
+                                              me->sum, me->cnt_gt, me->n_elems, dynamic_sym, max_iters);
+        me->unsigned_div = br.unsigned_div;
+        me->s = br.s0;
         me->iters = 0u;
         me->sum = 0.0;
         me->cnt_gt = 0ull;
@@ -838,68 +780,16 @@ __global__ __launch_bounds__(kBlock) void k_octav_bracket(dpl_octav_state* __res
         me->len[0] = 0u;
         me->len[1] = 0u;
         me->cur = 2u;
-        uint32_t r = 2u;
-        if (s0 != s0 || max_iters <= 0) {
-            me->done = 1u;  // NaN is a fixed point of the iteration
-            r = 0u;
-        } else if (!(max_abs < log_edge(kLogNB))) {
-            r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
-        } else if (n <= (unsigned long long)kSmallPair) {
-            for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair's window
-            jmin_s = 0;
-            jmax_s = kLogNB - 1;
-        } else {
-            const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
-            double lo = (double)s0, hi = (double)s0;
-            int marked = 0;
-            jmin_s = kLogNB;
-            jmax_s = -1;
-            for (int itn = 0; itn < 20 && r == 2u; ++itn) {
-                const int jl = log_bin((float)lo), jh = log_bin((float)hi);
-                if (jl <= 1 || jh >= kLogNB - 2 || !(lo == lo) || !(hi == hi)) {
-                    r = 1u;
-                    break;
-                }
-                // Mark exactly the bins of the bracket, no margin.  Within a bin F(s) moves monotonically between its
-                // values at the two edges unless the bin contains F itself (dropping a value v raises F iff v < F),
-                // i.e. only at the fixed point, where the excursion beyond the edge values is second order; together
-                // with the fp32 rounding of the true iterate that can put an iterate one bin outside the bracket
-                // with a probability of order 1e-4 per pair.  The exact walk verifies every iterate and such a pair
-                // simply finishes on the compaction route; a margin bin on either side (DPL_MARGIN=1) would more
-                // than double the values gathered (2.2 % -> 4.9 % on ResNet-50 activations) to avoid that.
-                const int ml = jl - (itn == 0 ? DPL_MARGIN0 : DPL_MARGIN), mh = jh + (itn == 0 ? DPL_MARGIN0 : DPL_MARGIN);
-                for (int w0 = ml >> 5; w0 <= mh >> 5; ++w0) {   // one LDS read-modify-write per word
-                    const int lo_b = max(ml, w0 << 5) & 31, hi_b = min(mh, (w0 << 5) + 31) & 31;
-                    const uint32_t mask = (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
-                    const uint32_t old = bm[w0];
-                    bm[w0] = old | mask;
-                    marked += __popc(mask & ~old);
-                }
-                jmin_s = ml < jmin_s ? ml : jmin_s;
-                jmax_s = mh > jmax_s ? mh : jmax_s;
-                if (marked > kLogMaxMarked) {
-                    r = 1u;
-                    break;
-                }
-                double nlo = INFINITY, nhi = -INFINITY;
-                for (int j = jl; j <= jh + 1; ++j) {  // F with everything in bins >= j counted as "above"
-                    const double ng = (double)n_ge[j];
-                    const double f = s_ge[j] / (c * ((double)(long long)n - ng) + ng);
-                    nlo = fmin(nlo, f);
-                    nhi = fmax(nhi, f);
-                }
-                if (nlo == lo && nhi == hi) break;  // the bracket stopped moving
-                lo = nlo;
-                hi = nhi;
-            }
-        }
-        if (r == 1u) {  // compaction route (k_octav_compact_full and friends)
+        jmin_s = br.jmin;
+        jmax_s = br.jmax;
+        if (br.route == 0u) me->done = 1u;  // NaN is a fixed point of the iteration
+        if (br.route == 1u) {  // compaction route (k_octav_compact_full and friends)
             me->mode = 1u;
             atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
         } else {
             me->mode = 2u;
         }
-        route = r;
+        route = br.route;
     }
     __syncthreads();
     // bitmap row: kLogWords words of marks + [lowest marked edge, edge above the highest marked bin] as float bits
@@ -1231,6 +1121,25 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
 
 int g_exact_fail_every = 0;   // dpl_test_hook_exact_fail_every
 
+// The compaction route on its own, for the pairs a histogram form marked mode 1 (shared with octav_resident.hip).
+int dpl_octav_fallback_route(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                             const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                             const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                             float* d_list0, float* d_list1, int dynamic_sym, int max_iters, hipStream_t st) {
+    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock), pairs((unsigned)n_pairs);
+    dpl_octav_state* ctl = d_states + n_pairs;
+    const size_t stage_bytes = (size_t)(kBlock / kWave) * kStageCap * sizeof(float);
+    hipLaunchKernelGGL(k_octav_compact_full, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
+                       ctl, d_pair_base, d_list0);
+    hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
+    hipLaunchKernelGGL(k_octav_iterate_lists, pairs, dim3(kIterBlock),
+                       (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
+                       d_pair_base, d_list0, d_list1, max_iters);
+    hipLaunchKernelGGL(k_octav_iterate_full, pairs, pb, 0, st, d_states, ctl, d_pair_spans, d_seg_ptrs, max_iters);
+    DPL_LAUNCH_CHECK("k_octav_fallback_route");
+    return 0;
+}
+
 extern "C" {
 
 int dpl_test_hook_exact_fail_every(int every) {
@@ -1320,13 +1229,9 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                            d_lh_cnt, reinterpret_cast<const unsigned long long*>(d_lh_sum), d_bitmap, d_pair_base,
                            d_list0, d_list1, max_iters, g_exact_fail_every);
         // 5. pairs the bracket could not serve (flat / degenerate distributions, values >= 2^14): compaction route
-        hipLaunchKernelGGL(k_octav_compact_full, pg, pb, stage_bytes, st, d_items, d_block_begin, d_seg_ptrs, d_states,
-                           ctl, d_pair_base, d_list0);
-        hipLaunchKernelGGL(k_octav_update<false>, ug, ub, 0, st, d_states, n_pairs, dynamic_sym, max_iters, ctl);
-        hipLaunchKernelGGL(k_octav_iterate_lists, pairs, dim3(kIterBlock),
-                           (size_t)(kIterBlock / kWave) * kIterStageCap * sizeof(float), st, d_states, ctl, d_pair_order,
-                           d_pair_base, d_list0, d_list1, max_iters);
-        hipLaunchKernelGGL(k_octav_iterate_full, pairs, pb, 0, st, d_states, ctl, d_pair_spans, d_seg_ptrs, max_iters);
+        if (int e = dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs,
+                                             d_pair_spans, d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, st))
+            return e;
     }
     DPL_LAUNCH_CHECK("k_octav_bracket");
     return 0;

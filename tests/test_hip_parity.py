@@ -118,9 +118,10 @@ def test_hist_prepare_flags_bad_ranges(dev):
     assert acc.range_status()["status"][0] == 2
 
 
-@pytest.mark.parametrize("form", ["bracket", "compact", "full"])
+@pytest.mark.parametrize("form", ["resident", "bracket", "compact", "full"])
 def test_octav_golden(dev, kl, form):
-    """All three forms (log-histogram bracket, tail compaction, full re-reads): same iterate sequence."""
+    """All four forms (single-read register-resident, two-read bracket, tail compaction, full re-reads): same iterate
+    sequence."""
     from dipoorlet_amd import ops
     meta, g = kl
     for c in meta["cases"]:
@@ -156,12 +157,14 @@ def test_octav_non_monotone_pairs_fall_back_to_full_passes(dev):
     a = ops.octav_batch(plan, tensors, False, form="compact").cpu().numpy()
     f = ops.octav_batch(plan, tensors, False, form="full").cpu().numpy()
     k = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
+    r = ops.octav_batch(plan, tensors, False, form="resident").cpu().numpy()
     for t in range(len(sizes)):
         for b in range(B):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
-            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s), (t, b, a[b, t], f[b, t], k[b, t], s)
+            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s) and _close(r[b, t, 0], s), \
+                (t, b, a[b, t], f[b, t], k[b, t], r[b, t], s)
 
 
 def test_batched_tensor_set_vs_golden_pipeline_stats(dev, golden_dir):
@@ -350,8 +353,9 @@ def test_empty_and_tiny_spans(dev):
                 assert _close(oc[b, t, 0], s), (t, b, oc[b, t], s)
 
 
-def test_octav_bracket_routes(dev):
-    """The bracket form on data that exercises each route: ordinary tensors (bracket), a flat distribution whose
+@pytest.mark.parametrize("form", ["resident", "bracket"])
+def test_octav_bracket_routes(dev, form):
+    """The histogram forms on data that exercises each route: ordinary tensors (bracket), a flat distribution whose
     bracket explodes, values beyond the 2^14 window, a huge dynamic range, all in one batched launch."""
     from dipoorlet_amd import ops
     rng = np.random.default_rng(17)
@@ -364,7 +368,7 @@ def test_octav_bracket_routes(dev):
           lambda: np.where(rng.random(n) < 0.999, 0, rng.standard_normal(n)).astype(np.float32)]
     tensors = [torch.from_numpy(np.stack([f() for _ in range(B)])).to(dev) for f in mk]
     plan = ops.TensorSetPlan([n] * len(mk), B, dev)
-    got = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
+    got = ops.octav_batch(plan, tensors, False, form=form).cpu().numpy()
     for t in range(len(mk)):
         for b in range(B):
             with warnings.catch_warnings():
@@ -373,7 +377,8 @@ def test_octav_bracket_routes(dev):
             assert _close(got[b, t, 0], s), (t, b, got[b, t], s)
 
 
-def test_octav_exact_walk_restart_path(dev):
+@pytest.mark.parametrize("form", ["resident", "bracket"])
+def test_octav_exact_walk_restart_path(dev, form):
     """An iterate that leaves the bracket's bins makes the exact walk hand the pair to the compaction route.  That is
     rare by construction, so the C-ABI test hook rejects every second pair on purpose: the results must not change."""
     from dipoorlet_amd import _hip, ops
@@ -383,11 +388,11 @@ def test_octav_exact_walk_restart_path(dev):
                                           np.maximum(rng.standard_normal(n), 0).astype(np.float32) * 2.5
                                           for _ in range(B)])).to(dev) for t, n in enumerate(sizes)]
     plan = ops.TensorSetPlan(sizes, B, dev)
-    want = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
+    want = ops.octav_batch(plan, tensors, False, form=form).cpu().numpy()
     old = _hip.lib().dpl_test_hook_exact_fail_every(2)
     try:
         states = torch.empty((plan.n_pairs + 1) * 80, dtype=torch.uint8, device=dev)
-        got = ops.octav_batch(plan, tensors, False, states, form="bracket").cpu().numpy()
+        got = ops.octav_batch(plan, tensors, False, states, form=form).cpu().numpy()
         ctl = states.cpu().numpy()[-80:].view(np.uint64)
     finally:
         _hip.lib().dpl_test_hook_exact_fail_every(old)
@@ -453,7 +458,8 @@ def test_octav_randomised_shapes_and_distributions(dev):
         tensors.append(torch.from_numpy(data).to(dev))
     plan = ops.TensorSetPlan(elems, B, dev)
     for dyn in (False, True):
-        got = {form: ops.octav_batch(plan, tensors, dyn, form=form).cpu().numpy() for form in ("bracket", "compact", "full")}
+        got = {form: ops.octav_batch(plan, tensors, dyn, form=form).cpu().numpy() for form in ("resident", "bracket", "compact", "full")}
+        assert np.array_equal(got["bracket"], got["resident"], equal_nan=True)
         assert np.array_equal(got["bracket"], got["compact"], equal_nan=True)
         assert np.array_equal(got["bracket"], got["full"], equal_nan=True)
         for t, n in enumerate(sizes):

@@ -72,10 +72,10 @@ SIGNATURES = {
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
     "dpl_octav_slice_cap": (C.c_uint32, []),
-    "dpl_octav_resident_occupancy": (C.c_int, []),
+    "dpl_octav_oneread_occupancy": (C.c_int, []),
     "dpl_build_octav_slices": (_I64, [_P, _I64, C.c_int, _P, _I64, _P]),
-    "dpl_octav_run_resident": (C.c_int, [_P, _I64, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P,
-                                         _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dpl_octav_run_oneread": (C.c_int, [_P, _I64, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _I64, _P, _I64, _P,
+                                        _I64, _P, _P, _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
@@ -159,7 +159,7 @@ def build_balanced_items(spans, n_blocks):
 
 def build_octav_slices(spans, n_queues):
     """HOST: spans (one per (image, tensor) pair) -> (WorkItem array, n_slices, queue_begin array), or None when a pair
-    is too large for the resident form (more than 64 slices)."""
+    is too large for the one-read form (more than 64 slices)."""
     arr, ns = _span_array(spans)
     n = lib().dpl_build_octav_slices(C.addressof(arr), ns, n_queues, None, 0, None)
     if n == -3:

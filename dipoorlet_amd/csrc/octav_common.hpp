@@ -77,75 +77,154 @@ struct BracketResult {
     uint32_t route;
     int jmin, jmax;
 };
+// The bracket walk proper: from s_0 (finite) over the bin edges, marking in bm[kLogWords] (zeroed by the caller) the bins
+// the true iterates can fall into.  Returns route 2 (marks valid, bins [jmin, jmax]) or 1 (the bracket leaves the window
+// or marks more than kLogMaxMarked bins: such a pair belongs on the compaction route).
+__device__ __forceinline__ BracketResult bracket_marks(const uint32_t* n_ge, const double* s_ge, uint32_t* bm, float s0,
+                                                       float ud, unsigned long long n) {
+    BracketResult out;
+    out.s0 = s0;
+    out.unsigned_div = ud;
+    out.jmin = kLogNB;
+    out.jmax = -1;
+    uint32_t r = 2u;
+    const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
+    double lo = (double)s0, hi = (double)s0;
+    int marked = 0;
+    for (int itn = 0; itn < 20 && r == 2u; ++itn) {
+        const int jl = log_bin((float)lo), jh = log_bin((float)hi);
+        if (jl <= 1 || jh >= kLogNB - 2 || !(lo == lo) || !(hi == hi)) {
+            r = 1u;
+            break;
+        }
+        // Mark exactly the bins of the bracket, no margin.  Within a bin F(s) moves monotonically between its
+        // values at the two edges unless the bin contains F itself (dropping a value v raises F iff v < F),
+        // i.e. only at the fixed point, where the excursion beyond the edge values is second order; together
+        // with the fp32 rounding of the true iterate that can put an iterate one bin outside the bracket
+        // with a probability of order 1e-4 per pair.  The exact walk verifies every iterate and such a pair
+        // simply finishes on the compaction route; a margin bin on either side (DPL_MARGIN=1) would more
+        // than double the values gathered (2.2 % -> 4.9 % on ResNet-50 activations) to avoid that.
+        const int ml = jl - (itn == 0 ? DPL_MARGIN0 : DPL_MARGIN), mh = jh + (itn == 0 ? DPL_MARGIN0 : DPL_MARGIN);
+        for (int w0 = ml >> 5; w0 <= mh >> 5; ++w0) {   // one LDS read-modify-write per word
+            const int lo_b = max(ml, w0 << 5) & 31, hi_b = min(mh, (w0 << 5) + 31) & 31;
+            const uint32_t mask = (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
+            const uint32_t old = bm[w0];
+            bm[w0] = old | mask;
+            marked += __popc(mask & ~old);
+        }
+        out.jmin = ml < out.jmin ? ml : out.jmin;
+        out.jmax = mh > out.jmax ? mh : out.jmax;
+        if (marked > kLogMaxMarked) {
+            r = 1u;
+            break;
+        }
+        double nlo = INFINITY, nhi = -INFINITY;
+        for (int j = jl; j <= jh + 1; ++j) {  // F with everything in bins >= j counted as "above"
+            const double ng = (double)n_ge[j];
+            const double f = s_ge[j] / (c * ((double)(long long)n - ng) + ng);
+            nlo = fmin(nlo, f);
+            nhi = fmax(nhi, f);
+        }
+        if (nlo == lo && nhi == hi) break;  // the bracket stopped moving
+        lo = nlo;
+        hi = nhi;
+    }
+    out.route = r;
+    return out;
+}
+
 __device__ __forceinline__ BracketResult bracket_walk(const uint32_t* n_ge, const double* s_ge, uint32_t* bm, float mn,
                                                       float mx, bool nan_seen, double sum_out,
                                                       unsigned long long nz_out, unsigned long long n, int dynamic_sym,
                                                       int max_iters) {
-    BracketResult out;
     // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
     const float ud = (dynamic_sym && fabsf(mn) < 1e-6f && !nan_seen) ? 4.0f : 1.0f;
     // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
     const float s0 = nan_seen ? __uint_as_float(0x7FC00000u)
                               : __fdiv_rn((float)(sum_out + s_ge[1]), (float)(long long)(nz_out + n_ge[1]));
     const float max_abs = fmaxf(fabsf(mn), fabsf(mx));
+    BracketResult out;
     out.s0 = s0;
     out.unsigned_div = ud;
     out.jmin = kLogNB;
     out.jmax = -1;
-    uint32_t r = 2u;
+    out.route = 2u;
     if (s0 != s0 || max_iters <= 0) {
-        r = 0u;  // NaN is a fixed point of the iteration
+        out.route = 0u;  // NaN is a fixed point of the iteration
     } else if (!(max_abs < log_edge(kLogNB))) {
-        r = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
+        out.route = 1u;  // values at or above 2^14 (or inf): outside the exactly-summed window
     } else if (n <= (unsigned long long)kSmallPair) {
         for (int q = 0; q < kLogWords; ++q) bm[q] = 0xFFFFFFFFu;  // gather the whole (small) pair's window
         out.jmin = 0;
         out.jmax = kLogNB - 1;
     } else {
-        const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
-        double lo = (double)s0, hi = (double)s0;
-        int marked = 0;
-        for (int itn = 0; itn < 20 && r == 2u; ++itn) {
-            const int jl = log_bin((float)lo), jh = log_bin((float)hi);
-            if (jl <= 1 || jh >= kLogNB - 2 || !(lo == lo) || !(hi == hi)) {
-                r = 1u;
-                break;
-            }
-            // Mark exactly the bins of the bracket, no margin.  Within a bin F(s) moves monotonically between its
-            // values at the two edges unless the bin contains F itself (dropping a value v raises F iff v < F),
-            // i.e. only at the fixed point, where the excursion beyond the edge values is second order; together
-            // with the fp32 rounding of the true iterate that can put an iterate one bin outside the bracket
-            // with a probability of order 1e-4 per pair.  The exact walk verifies every iterate and such a pair
-            // simply finishes on the compaction route; a margin bin on either side (DPL_MARGIN=1) would more
-            // than double the values gathered (2.2 % -> 4.9 % on ResNet-50 activations) to avoid that.
-            const int ml = jl - (itn == 0 ? DPL_MARGIN0 : DPL_MARGIN), mh = jh + (itn == 0 ? DPL_MARGIN0 : DPL_MARGIN);
-            for (int w0 = ml >> 5; w0 <= mh >> 5; ++w0) {   // one LDS read-modify-write per word
-                const int lo_b = max(ml, w0 << 5) & 31, hi_b = min(mh, (w0 << 5) + 31) & 31;
-                const uint32_t mask = (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
-                const uint32_t old = bm[w0];
-                bm[w0] = old | mask;
-                marked += __popc(mask & ~old);
-            }
-            out.jmin = ml < out.jmin ? ml : out.jmin;
-            out.jmax = mh > out.jmax ? mh : out.jmax;
-            if (marked > kLogMaxMarked) {
-                r = 1u;
-                break;
-            }
-            double nlo = INFINITY, nhi = -INFINITY;
-            for (int j = jl; j <= jh + 1; ++j) {  // F with everything in bins >= j counted as "above"
-                const double ng = (double)n_ge[j];
-                const double f = s_ge[j] / (c * ((double)(long long)n - ng) + ng);
-                nlo = fmin(nlo, f);
-                nhi = fmax(nhi, f);
-            }
-            if (nlo == lo && nhi == hi) break;  // the bracket stopped moving
-            lo = nlo;
-            hi = nhi;
-        }
+        out = bracket_marks(n_ge, s_ge, bm, s0, ud, n);
     }
-    out.route = r;
     return out;
 }
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ p_generic, uint32_t base, uint32_t n, bool aligned,
+                                          f4 (&v)[4]) {
+    gptr_f32 p = (gptr_f32)p_generic;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t idx = base + u * 256 + lane * 4;
+        if (aligned && idx + 3 < n) {
+            v[u] = __builtin_nontemporal_load((gptr_f4)(p + idx));
+        } else {  // zeros never survive (s >= 0)
+            v[u].x = idx + 0 < n ? p[idx + 0] : 0.0f;
+            v[u].y = idx + 1 < n ? p[idx + 1] : 0.0f;
+            v[u].z = idx + 2 < n ? p[idx + 2] : 0.0f;
+            v[u].w = idx + 3 < n ? p[idx + 3] : 0.0f;
+        }
+    }
+}
+
+// Tile walker for the compaction-style kernels: wave w of the workgroup takes the 1024-element tiles
+// w, w + waves, ... of p[0..n).  Full tiles of an aligned span go through a branch-free, software-pipelined
+// loop (two register sets; the next tile's four 16-byte loads are in flight while the current tile is
+// consumed); the ragged end (< one workgroup tile) or an unaligned span uses the bounds-checked loader, which
+// pads with zeros.  eat(v, tile_base, full): `full` tells the consumer that no element is padding.
+template <int kThreads, class Eat>
+__device__ __forceinline__ void for_each_tile(const float* __restrict__ p, uint32_t n, Eat&& eat) {
+    const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
+    constexpr uint32_t kStep = kThreads * 16;
+    const bool aligned = (((uintptr_t)p) & 15u) == 0;
+    const uint32_t n_main = aligned ? (n / kStep) * kStep : 0u;
+    gptr_f4 pv = (gptr_f4)p;
+#define DPL_TLOAD(buf, t0)                                                                  \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[u] = __builtin_nontemporal_load(pv + ((t0) >> 2) + u * 64 + lane)
+    uint32_t tile = w * 1024;
+    if (tile < n_main) {
+        f4 A[4], B[4];
+        DPL_TLOAD(A, tile);
+        for (;;) {
+            uint32_t nxt = tile + kStep;
+            if (nxt >= n_main) {
+                eat(A, tile, true);
+                break;
+            }
+            DPL_TLOAD(B, nxt);
+            eat(A, tile, true);
+            tile = nxt;
+            nxt = tile + kStep;
+            if (nxt >= n_main) {
+                eat(B, tile, true);
+                break;
+            }
+            DPL_TLOAD(A, nxt);
+            eat(B, tile, true);
+            tile = nxt;
+        }
+    }
+#undef DPL_TLOAD
+    for (uint32_t t2 = n_main + w * 1024; t2 < n; t2 += kStep) {
+        f4 v[4];
+        load_tile(p, t2, n, aligned, v);
+        eat(v, t2, false);
+    }
+}
+
 
 }  // namespace

@@ -204,69 +204,6 @@ __device__ __forceinline__ void tail_tile(const f4 (&v)[4], float s, float* stag
     acc.sum += (double)part;
 }
 
-__device__ __forceinline__ void load_tile(const float* __restrict__ p_generic, uint32_t base, uint32_t n, bool aligned,
-                                          f4 (&v)[4]) {
-    gptr_f32 p = (gptr_f32)p_generic;
-    const uint32_t lane = threadIdx.x & (kWave - 1);
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t idx = base + u * 256 + lane * 4;
-        if (aligned && idx + 3 < n) {
-            v[u] = __builtin_nontemporal_load((gptr_f4)(p + idx));
-        } else {  // zeros never survive (s >= 0)
-            v[u].x = idx + 0 < n ? p[idx + 0] : 0.0f;
-            v[u].y = idx + 1 < n ? p[idx + 1] : 0.0f;
-            v[u].z = idx + 2 < n ? p[idx + 2] : 0.0f;
-            v[u].w = idx + 3 < n ? p[idx + 3] : 0.0f;
-        }
-    }
-}
-
-// Tile walker for the compaction-style kernels: wave w of the workgroup takes the 1024-element tiles
-// w, w + waves, ... of p[0..n).  Full tiles of an aligned span go through a branch-free, software-pipelined
-// loop (two register sets; the next tile's four 16-byte loads are in flight while the current tile is
-// consumed); the ragged end (< one workgroup tile) or an unaligned span uses the bounds-checked loader, which
-// pads with zeros.  eat(v, tile_base, full): `full` tells the consumer that no element is padding.
-template <int kThreads, class Eat>
-__device__ __forceinline__ void for_each_tile(const float* __restrict__ p, uint32_t n, Eat&& eat) {
-    const uint32_t w = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-    constexpr uint32_t kStep = kThreads * 16;
-    const bool aligned = (((uintptr_t)p) & 15u) == 0;
-    const uint32_t n_main = aligned ? (n / kStep) * kStep : 0u;
-    gptr_f4 pv = (gptr_f4)p;
-#define DPL_TLOAD(buf, t0)                                                                  \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[u] = __builtin_nontemporal_load(pv + ((t0) >> 2) + u * 64 + lane)
-    uint32_t tile = w * 1024;
-    if (tile < n_main) {
-        f4 A[4], B[4];
-        DPL_TLOAD(A, tile);
-        for (;;) {
-            uint32_t nxt = tile + kStep;
-            if (nxt >= n_main) {
-                eat(A, tile, true);
-                break;
-            }
-            DPL_TLOAD(B, nxt);
-            eat(A, tile, true);
-            tile = nxt;
-            nxt = tile + kStep;
-            if (nxt >= n_main) {
-                eat(B, tile, true);
-                break;
-            }
-            DPL_TLOAD(A, nxt);
-            eat(B, tile, true);
-            tile = nxt;
-        }
-    }
-#undef DPL_TLOAD
-    for (uint32_t t2 = n_main + w * 1024; t2 < n; t2 += kStep) {
-        f4 v[4];
-        load_tile(p, t2, n, aligned, v);
-        eat(v, t2, false);
-    }
-}
-
 // First evaluation: full data -> list 0, several workgroups per pair (global cursor + atomics).
 __global__ __launch_bounds__(kBlock) void k_octav_compact_full(const dpl_work_item* __restrict__ items,
                                                                 const uint32_t* __restrict__ bb,

@@ -1,0 +1,781 @@
+// OCTAV ('-A mse', forward_net.py:284-342) in ONE read of the activations, one launch per batch.
+//
+// Why not two reads: measured on MI355X (scripts/mall_probe.hip, profiles/r02/mall_probe.txt) a re-read of recently
+// streamed data costs the same whether HBM or the 256 MiB Infinity Cache serves it (6.1-6.9 TB/s either way, one
+// shared fabric), so the two-read bracket form of octav_kernels.hip cannot pass ~40 % of the roofline.  And a form that
+// keeps a pair on chip until a leader has walked its bracket (tried first: k_octav_resident, round 2) spends its time
+// waiting — three cross-workgroup round trips per slice against ~16 us of residency a CU can afford at HBM rate.
+//
+// So nothing waits here.  The values the exact iteration needs are the ones in the histogram bins its iterates fall
+// into; WHICH bins is predicted from the previous batches (the bins the same tensor's iterates visited, OR-ed over the
+// images of the last two batches, cheap neighbours added) and every iterate of the exact walk is VERIFIED against the
+// set that was gathered.  A pair whose iterate leaves the gathered bins (first batch of a run, a distribution shift)
+// publishes its bracket for the next batch and finishes on the compaction route of octav_kernels.hip.  Results are the
+// reference's iterate sequence either way; only the speed depends on the prediction.
+//
+// Persistent 256-thread workgroups pull SLICES (<= kCap = 128 Ki elements of one (image, tensor) pair) from per-XCD queues:
+//   1  the slice's only HBM read, straight into registers (buffer loads: zero fill past the end, all in flight);
+//   2  per element: min / max, exact log-scale histogram of |x| in LDS (64 bins per octave: count + integer mantissa
+//      sum, as in the bracket form) and — values of predicted bins only — a branch-free append to per-lane LDS queues;
+//   3  queues -> the pair's list (one returning atomic per wave), LDS histogram -> the pair's row (agent-scope
+//      atomics), statistics -> the pair's state; ONE ticket;
+//   4  the last slice of a pair: suffix totals of the merged row, s_0, then the exact walk — totals of the bins above
+//      the iterate's bin (exact integers) + the listed values of that bin (integer mantissa sums: the result does not
+//      depend on arrival order) — verifying each iterate's bin against the gathered set, and recording the bins it
+//      visited for the next batch.
+// A pair that fits one slice never leaves its workgroup: no list, no row, no prediction — the walk runs on the
+// registers that still hold the slice.
+// Cross-workgroup traffic is agent-scope atomics and sc1 (write-through) stores read by sc1 loads: no L2 write-back
+// fences (MI355X_MICROARCH.md, inter-workgroup visibility).  No workgroup ever waits for another.
+#include "common.hpp"
+#include "octav_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// keeps the scheduler from interleaving the unrolled per-vector bodies (their temporaries would not fit beside the slice)
+#define DPL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+#ifndef DPL_RES_VEC
+#define DPL_RES_VEC 20
+#endif
+#ifndef DPL_RES_OCC
+#define DPL_RES_OCC 4
+#endif
+#ifndef DPL_WALK_OCC
+#define DPL_WALK_OCC 4
+#endif
+constexpr int kVec = DPL_RES_VEC;                               // 16-byte vectors per thread the walk keeps a list in
+constexpr uint32_t kWalkCap = (uint32_t)kThreads * kVec * 4;    // list values the walk holds in registers (20 480)
+#ifndef DPL_SLICE_CAP
+#define DPL_SLICE_CAP 131072
+#endif
+constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
+static_assert(kCap < (1u << 20) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed 20-bit field");
+constexpr int kQueueCap = 12;                                   // per-lane survivor queue; flushed above cap - 4
+constexpr int kQueueStride = kQueueCap + 1;
+constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;         // bitmap over every 14-bit key: 512 words
+constexpr int kKeyWord0 = (int)(kLogKey0 >> 5);
+constexpr uint32_t kBigCluster = (1u << 20) / kCap + 1;         // clusters this large may overflow the packed count field
+constexpr uint32_t kMaxCluster = 64;
+
+// LDS: [A: packed histogram 16 KiB | later S_ge fp64][B: survivor queues 13 KiB | later N_ge 8 KiB][key bitmap 2 KiB]
+constexpr int kLdsA = kLogNB * 8;
+constexpr int kLdsB = kWaves * kWave * kQueueStride * 4;
+constexpr int kLdsKey = kKeyWords * 4;
+static_assert(kLdsB >= kLogNB * 4, "N_ge must fit the queue region");
+
+template <class T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ T add_agent(T* p, T v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#ifdef DPL_RES_PROF
+// phase cycle counters of a tuning build (scripts/res_prof.py): [workgroup][8] u64, accumulated by thread 0
+__device__ unsigned long long g_res_prof[4096 * 8];
+#define DPL_PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define DPL_PROF_ADD(slot, a, b) do { if (threadIdx.x == 0) g_res_prof[(blockIdx.x & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
+__device__ __forceinline__ void g_prof_iters_add(uint32_t b, uint32_t it) { g_res_prof[(b & 4095u) * 8 + 7] += it; }
+#else
+__device__ __forceinline__ void g_prof_iters_add(uint32_t, uint32_t) {}
+#define DPL_PROF_T(var) do {} while (0)
+#define DPL_PROF_ADD(slot, a, b) do {} while (0)
+#endif
+
+struct Shared {
+    double red_d[kWaves];
+    unsigned long long red_q[kWaves];
+    uint32_t red_a[kWaves], red_b[kWaves];
+    unsigned long long part_m[2][kWaves];   // walk: the waves' partial (count, mantissa sum), two alternating slots
+    uint32_t part_c[2][kWaves];
+    float red_mn[kWaves], red_mx[kWaves];
+    uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
+    uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
+    uint32_t item, last, any_pred, fetched;
+    OctavStep step;
+    int jb;
+    uint32_t bad, route;
+    float s0, ud;
+    double s_above;
+    unsigned long long n_above, n_elems;
+};
+
+// Raw per-bin (count, scaled sum) in n_ge / s_ge -> suffix totals in place (N_ge[j], S_ge[j] = everything in bins >= j).
+// Thread t owns the 8 bins below 2047 - 8 t; all 256 threads; the raw values were written by their owners.
+__device__ __forceinline__ void suffix_in_place(uint32_t* n_ge, double* s_ge, Shared& sh) {
+    constexpr int kPerT = kLogNB / kThreads;
+    const int hi = kLogNB - 1 - (int)threadIdx.x * kPerT;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    uint32_t ln = 0;
+    double ls = 0.0;
+    for (int q = 0; q < kPerT; ++q) {
+        ln += n_ge[hi - q];
+        ls += s_ge[hi - q];
+    }
+    double is = ls;
+    uint32_t in = ln;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double ts = __shfl_up(is, o, kWave);
+        const uint32_t tn = __shfl_up(in, o, kWave);
+        if (lane >= (uint32_t)o) {
+            is += ts;
+            in += tn;
+        }
+    }
+    if (lane == kWave - 1) {
+        sh.red_d[w] = is;
+        sh.red_a[w] = in;
+    }
+    __syncthreads();
+    double rs = is - ls;
+    uint32_t rn = in - ln;
+    for (int q = 0; q < w; ++q) {
+        rs += sh.red_d[q];
+        rn += sh.red_a[q];
+    }
+    for (int q = 0; q < kPerT; ++q) {
+        const int b = hi - q;
+        rn += n_ge[b];
+        rs += s_ge[b];
+        n_ge[b] = rn;
+        s_ge[b] = rs;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double bin_sum(unsigned long long mant_explicit, uint32_t count, int b) {
+    return (double)(mant_explicit + ((unsigned long long)count << 23)) * log_bin_scale(b);   // full 24-bit mantissas
+}
+
+// One slice, streamed: per element min / max, the LDS histogram, and a queue append for the values of marked bins
+// (queues -> the pair's list behind one returning atomic per wave flush).  Leaves the per-wave statistics in sh.red_*.
+// Its own function (not inlined): the register allocator otherwise spills the tile buffers of this hot loop to make
+// room for values that only the walk needs.
+__device__ __attribute__((noinline)) void stream_slice(const float* __restrict__ pg, uint32_t cnt,
+                                                       unsigned long long* __restrict__ l_packed,
+                                                       const uint32_t* __restrict__ keybm, uint32_t* __restrict__ queues,
+                                                       uint32_t* __restrict__ dst, uint32_t* __restrict__ cursor, Shared& sh) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    float mn = INFINITY, mx = -INFINITY;
+    uint32_t nan = 0u, nz = 0u;
+    double sum = 0.0;
+    uint32_t* myq = queues + (size_t)w * kWave * kQueueStride + lane;   // entry j of lane l at [j][l]
+    uint32_t qn = 0u;
+    auto flush = [&]() {
+        uint32_t inc = qn;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, kWave);
+            if (lane >= (uint32_t)o) inc += t;
+        }
+        const uint32_t total = __shfl(inc, kWave - 1, kWave);
+        uint32_t base = 0u;
+        if (lane == kWave - 1) base = add_agent(cursor, total);
+        base = __shfl(base, kWave - 1, kWave) + inc - qn;
+        for (uint32_t j = 0; j < qn; ++j) st_agent(dst + base + j, myq[j * kWave]);
+        qn = 0u;
+    };
+    // one element: key = 14 bits of exponent and top mantissa (shared by the histogram bin and the bitmap lookup)
+    auto one = [&](float x, uint32_t& hit, uint32_t& a) {
+        const uint32_t bits = __float_as_uint(x);
+        a = bits & 0x7FFFFFFFu;
+        const uint32_t key = a >> kLogShift;
+        const uint32_t t = key - (kLogKey0 + 1u);
+        hit = (keybm[key >> 5] >> (key & 31u)) & 1u;
+        if (t < (uint32_t)(kLogNB - 1)) {
+            // window bins 1 .. kLogNB-1 carry {count, 23 explicit mantissa bits} (as LogHistOp, octav_kernels.hip)
+            atomicAdd(l_packed + t + 1u, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu));
+        } else if (__any(a != 0u)) {   // nonzero values outside the window (rare) are accumulated directly
+            const float f = __uint_as_float(a);
+            if (f > 0.0f) {
+                sum += (double)f;
+                ++nz;
+            }
+            nan |= (f != f);
+        }
+    };
+    auto eat4 = [&](const f4& t4) {
+        uint32_t h0, h1, h2, h3, a0, a1, a2, a3;
+        one(t4.x, h0, a0);
+        one(t4.y, h1, a1);
+        one(t4.z, h2, a2);
+        one(t4.w, h3, a3);
+        if (__any((h0 | h1 | h2 | h3) != 0u)) {   // branch-free append: the tail only advances for a survivor
+            myq[qn * kWave] = a0;
+            qn += h0;
+            myq[qn * kWave] = a1;
+            qn += h1;
+            myq[qn * kWave] = a2;
+            qn += h2;
+            myq[qn * kWave] = a3;
+            qn += h3;
+            if (__any(qn > (uint32_t)(kQueueCap - 4))) flush();
+        }
+    };
+    for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (full) {
+                mn = fminf(mn, fminf(fminf(t[u].x, t[u].y), fminf(t[u].z, t[u].w)));
+                mx = fmaxf(mx, fmaxf(fmaxf(t[u].x, t[u].y), fmaxf(t[u].z, t[u].w)));
+            } else {   // padding is +0.0: in no histogram bin, in no marked bin; only min / max must skip it
+                const uint32_t e = base + (uint32_t)u * 256u + lane * 4u;
+                if (e + 0 < cnt) mn = fminf(mn, t[u].x), mx = fmaxf(mx, t[u].x);
+                if (e + 1 < cnt) mn = fminf(mn, t[u].y), mx = fmaxf(mx, t[u].y);
+                if (e + 2 < cnt) mn = fminf(mn, t[u].z), mx = fmaxf(mx, t[u].z);
+                if (e + 3 < cnt) mn = fminf(mn, t[u].w), mx = fmaxf(mx, t[u].w);
+            }
+            eat4(t[u]);
+        }
+    });
+    if (__any(qn != 0u)) flush();
+    // per-wave totals of the directly accumulated statistics
+    const float wmn = wave_min(mn), wmx = wave_max(mx);
+    const uint32_t wnz = wave_sum(nz);
+    const double wsum = wave_sum(sum);
+    const uint32_t wnan = __any(nan) ? 1u : 0u;
+    if (lane == 0) {
+        sh.red_mn[w] = wmn;
+        sh.red_mx[w] = wmx;
+        sh.red_a[w] = wnz;
+        sh.red_b[w] = wnan;
+        sh.red_d[w] = wsum;
+    }
+}
+
+// K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
+// then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
+__global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
+    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
+    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ vis_a,
+    const uint32_t* __restrict__ vis_b, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
+    uint32_t* queues = reinterpret_cast<uint32_t*>(lds_raw + kLdsA);
+    uint32_t* keybm = reinterpret_cast<uint32_t*>(lds_raw + kLdsA + kLdsB);
+    __shared__ Shared sh;
+
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    const uint32_t pair = it.slot, n_sl = it.reserved, cnt = it.count;
+    dpl_octav_state* me = st + pair;
+    const float* pg = segs[it.seg] + it.offset;
+    const bool small = n_sl == 1u && cnt <= kWalkCap;    // the walk can hold the pair's whole window: no prediction
+    const bool big = n_sl >= kBigCluster;
+    const uint32_t tensor = pair % n_tensors;
+    for (int b = tid; b < kLogNB; b += kThreads) l_packed[b] = 0ull;
+    for (int i = tid; i < kKeyWords; i += kThreads) {   // the bins to gather: what this tensor's iterates visited lately
+        const int j = i - kKeyWord0;
+        keybm[i] = (j >= 0 && j < kLogWords)
+                       ? (small ? 0xFFFFFFFFu : (vis_a[tensor * kLogWords + j] | vis_b[tensor * kLogWords + j]))
+                       : 0u;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
+    stream_slice(pg, cnt, l_packed, keybm, queues, reinterpret_cast<uint32_t*>(list0 + pair_base[pair]), &me->len[0], sh);
+    __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
+
+    // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
+    unsigned long long* row = lh + (uint64_t)pair * kLogNB;
+    uint32_t* row_cnt = lh_cnt + (uint64_t)pair * kLogNB;
+    if (tid == 0) {
+        float tmn = INFINITY, tmx = -INFINITY;
+        uint32_t tnz = 0u, tnan = 0u;
+        double tsum = 0.0;
+        for (int j = 0; j < kWaves; ++j) {
+            tmn = fminf(tmn, sh.red_mn[j]);
+            tmx = fmaxf(tmx, sh.red_mx[j]);
+            tnz += sh.red_a[j];
+            tnan |= sh.red_b[j];
+            tsum += sh.red_d[j];
+        }
+        if (tnz) {
+            atomicAdd(&me->sum, tsum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)cnt);
+        if (tmn <= tmx) {
+            atomicMin(&me->min_enc, enc_f32(tmn));
+            atomicMax(&me->max_enc, enc_f32(tmx));
+        }
+        if (tnan) atomicOr(&me->nan_seen, 1u);
+    }
+    for (int b = tid; b < kLogNB; b += kThreads) {
+        const unsigned long long hv = l_packed[b];
+        if (hv) {
+            if (big) {
+                add_agent(row + b, hv & kPackMask);
+                add_agent(row_cnt + b, (uint32_t)(hv >> kPackShift));
+            } else {
+                add_agent(row + b, hv);
+            }
+        }
+    }
+}
+
+// The values of ONE histogram bin of a pair (bit patterns of |x| whose 14-bit key equals `want`), appended at out[*counter ...]:
+// the walk's answer to a bin the prediction missed.  Not inlined: it must not cost the walk loop any registers.
+__device__ __attribute__((noinline)) void fetch_bin_values(const float* __restrict__ p, uint32_t n, uint32_t want,
+                                                            uint32_t* __restrict__ out, uint32_t* counter) {
+    for_each_tile<kThreads>(p, n, [&](const f4 (&t)[4], uint32_t, bool) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t a0 = __float_as_uint(t[u].x) & 0x7FFFFFFFu, a1 = __float_as_uint(t[u].y) & 0x7FFFFFFFu,
+                           a2 = __float_as_uint(t[u].z) & 0x7FFFFFFFu, a3 = __float_as_uint(t[u].w) & 0x7FFFFFFFu;
+            if ((a0 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a0;
+            if ((a1 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a1;
+            if ((a2 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a2;
+            if ((a3 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a3;
+        }
+    });
+}
+
+// The exact walk of one pair (one workgroup per pair, largest pairs first): suffix totals of the pair's merged row (the row is
+// handed back zeroed), s_0, then the reference's iteration — totals of the bins above the iterate's bin (exact integers)
+// + the listed values of that bin (integer mantissa sums) — verifying that every iterate lands in a gathered bin.  Records
+// the bins it stepped into (or, when it left the gathered set, the pair's bracket) for the next batches.
+__global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
+    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ vis_a,
+    const uint32_t* __restrict__ vis_b, uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
+    float* __restrict__ list0, const dpl_span* __restrict__ pair_spans, const float* const* __restrict__ segs, int dynamic_sym,
+    int max_iters, int fail_every) {
+    __shared__ double s_ge[kLogNB];
+    __shared__ uint32_t n_ge[kLogNB];
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
+    dpl_octav_state* me = st + pair;
+    const unsigned long long n_pair = me->n_elems;
+    if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
+    const bool small = n_pair <= (unsigned long long)kWalkCap;
+    const bool big = n_pair > (unsigned long long)(kBigCluster - 1u) * kCap;   // as the slices decided (cluster size)
+    const uint32_t tensor = pair % n_tensors;
+    unsigned long long* row = lh + (uint64_t)pair * kLogNB;
+    uint32_t* row_cnt = lh_cnt + (uint64_t)pair * kLogNB;
+    DPL_PROF_T(w0);
+    if (tid == 0) sh.any_pred = 0u;
+    // merged per-bin totals -> LDS (own bins per thread); the pair's row is handed back zeroed
+    {
+        constexpr int kPerT = kLogNB / kThreads;
+        const int hi = kLogNB - 1 - (int)tid * kPerT;
+        unsigned long long raw[kPerT];
+        uint32_t rc[kPerT];
+#pragma unroll
+        for (int qq = 0; qq < kPerT; ++qq) {
+            const int b = hi - qq;
+            raw[qq] = row[b];
+            rc[qq] = big ? row_cnt[b] : 0u;
+            if (raw[qq]) row[b] = 0ull;
+            if (big && rc[qq]) row_cnt[b] = 0u;
+        }
+#pragma unroll
+        for (int qq = 0; qq < kPerT; ++qq) {
+            const int b = hi - qq;
+            const uint32_t c = big ? rc[qq] : (uint32_t)(raw[qq] >> kPackShift);
+            const unsigned long long m = big ? raw[qq] : (raw[qq] & kPackMask);
+            n_ge[b] = c;
+            s_ge[b] = bin_sum(m, c, b);
+        }
+        suffix_in_place(n_ge, s_ge, sh);
+    }
+    DPL_PROF_T(w1);
+    DPL_PROF_ADD(0, w0, w1);   // row -> suffix totals
+    // the bins whose values were gathered (the walk may only step into these)
+    if (tid < (uint32_t)kLogWords) {
+        sh.bm[tid] = small ? 0xFFFFFFFFu : (vis_a[tensor * kLogWords + tid] | vis_b[tensor * kLogWords + tid]);
+        sh.pub[tid] = 0u;
+        if (sh.bm[tid]) sh.any_pred = 1u;
+    }
+    if (tid == 0) {
+        const double sum_out = me->sum;
+        const unsigned long long nz_out = me->cnt_gt;
+        const unsigned long long n = me->n_elems;
+        const float gmn = dec_f32(me->min_enc), gmx = dec_f32(me->max_enc);
+        const bool nanseen = me->nan_seen != 0u;
+        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+        const float ud = (dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+        // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
+        const float s0 = nanseen ? __uint_as_float(0x7FC00000u)
+            : __fdiv_rn((float)(sum_out + s_ge[1]), (float)(long long)(nz_out + n_ge[1]));
+        uint32_t route = 2u;                                         // 2: walk
+        if (s0 != s0 || max_iters <= 0) route = 0u;                  // 0: finished (NaN is a fixed point)
+        else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB))) route = 1u;   // 1: values >= 2^14 / inf: compaction route
+        sh.s0 = s0;
+        sh.ud = ud;
+        sh.n_elems = n;
+        sh.route = route;
+        me->s = s0;
+        me->unsigned_div = ud;
+        me->iters = 0u;
+        me->sum = 0.0;
+        me->cnt_gt = 0ull;
+        me->cnt_le = 0ull;
+        me->len[1] = 0u;
+        me->cur = 2u;
+    }
+    __syncthreads();
+    const uint32_t route = __builtin_amdgcn_readfirstlane(sh.route);
+    uint32_t bad = route == 1u ? 1u : 0u;
+    float s = sh.s0;
+    uint32_t iters = 0u;
+    if (route == 2u) {
+        const float ud = sh.ud;
+        const unsigned long long n_elems = sh.n_elems;
+        uint32_t L = __builtin_amdgcn_readfirstlane(me->len[0]);
+        // the pair's list (bit patterns of |x|) goes into registers; a list longer than they hold is re-read in
+        // pieces every iteration
+        f4 v[kVec];
+        uint32_t n_chunks = (L + kWalkCap - 1u) / kWalkCap;
+        float* lp = list0 + pair_base[pair];
+        auto load_chunk = [&](uint32_t c0) {
+            // buffer loads: zero fill past the list's end (one descriptor per row: the range check leaves the SGPR
+            // offset out, so the row offset goes into the base)
+            const int nbytes = (int)(min(L - c0, kWalkCap) << 2);
+            const uint32_t voff = tid << 4;
+#pragma unroll
+            for (int u = 0; u < kVec; ++u) {
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)(lp + c0 + u * kThreads * 4), 0, max(nbytes - u * kThreads * 16, 0), 0x00020000);
+                v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+            }
+        };
+        if (n_chunks == 1u) load_chunk(0u);
+        DPL_PROF_T(w2);
+        DPL_PROF_ADD(1, w1, w2);   // state, s_0, list load issued
+        auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
+        // A bin the prediction missed: this workgroup fetches it — one more read of the PAIR (not of the batch), its values of
+        // bin j appended to the list — and the walk goes on.  Three misses, or a tensor with no prediction at all (the first
+        // batch of a run), send the pair to the compaction route instead.
+        uint32_t misses = sh.any_pred ? 0u : 3u;
+        auto fetch_bin = [&](int j) {
+            const dpl_span sp = pair_spans[pair];
+            const uint32_t want = (uint32_t)j + kLogKey0;
+            if (tid == 0) sh.fetched = 0u;
+            __syncthreads();
+            fetch_bin_values(segs[sp.seg] + sp.offset, (uint32_t)sp.count, want, reinterpret_cast<uint32_t*>(lp) + L, &sh.fetched);
+            if (tid == 0) sh.bm[j >> 5] |= 1u << (j & 31);
+            __threadfence_block();
+            drain_vmem();
+            __syncthreads();
+            L += sh.fetched;
+            n_chunks = (L + kWalkCap - 1u) / kWalkCap;
+            if (n_chunks == 1u) load_chunk(0u);
+            ++misses;
+        };
+        // every thread carries the (uniform) walk state and takes the step itself from the four wave partials: one barrier
+        // per iteration, no broadcast; the partials alternate between two slots so that no second barrier is needed
+        int jb = log_bin(s);
+        bad = (jb > 0 && jb < kLogNB - 1) ? 0u : 1u;
+        if (!bad && !marked(jb)) {
+            if (misses < 3u) fetch_bin(jb);
+            else bad = 1u;
+        }
+        if (fail_every > 0 && pair % (uint32_t)fail_every == 0u) bad = 1u;   // test hook: the restart path
+        unsigned long long n_above = 0ull;
+        double s_above = 0.0;
+        auto enter = [&](int j) {   // exact totals of the bins above bin j; bin j goes on record
+            n_above = (j + 1 < kLogNB) ? (unsigned long long)n_ge[j + 1] : 0ull;
+            s_above = (j + 1 < kLogNB) ? s_ge[j + 1] : 0.0;
+            if (tid == 0) sh.pub[j >> 5] |= 1u << (j & 31);
+        };
+        if (!bad) enter(jb);
+        uint32_t done = 0u, par = 0u;
+        while (!done && !bad) {
+            // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1)
+            const uint32_t lo = __float_as_uint(s), hi = ((uint32_t)(jb + 1) + kLogKey0) << kLogShift;
+            uint32_t c = 0u, ms = 0u;
+            auto in1 = [&](float f) {
+                const uint32_t u = __float_as_uint(f);
+                const bool in = u > lo && u < hi;
+                c += (uint32_t)in;
+                ms += in ? (u & 0x7FFFFFu) : 0u;
+            };
+            unsigned long long msum = 0ull;
+            for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+                if (n_chunks > 1u) load_chunk(ch * kWalkCap);
+                const uint32_t lvec = (min(L - ch * kWalkCap, kWalkCap) + 3u) >> 2;
+                ms = 0u;
+#pragma unroll
+                for (int u = 0; u < kVec; ++u) {
+                    if ((uint32_t)u * kThreads < lvec) {   // uniform
+                        in1(v[u].x);
+                        in1(v[u].y);
+                        in1(v[u].z);
+                        in1(v[u].w);
+                    }
+                }
+                msum += (unsigned long long)ms;
+            }
+            c = wave_sum(c);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) msum += __shfl_xor(msum, o, kWave);
+            if (lane == 0) {
+                sh.part_c[par][w] = c;
+                sh.part_m[par][w] = msum;
+            }
+            __syncthreads();
+            unsigned long long tc = 0ull, tm = 0ull;
+#pragma unroll
+            for (int j = 0; j < kWaves; ++j) {
+                tc += sh.part_c[par][j];
+                tm += sh.part_m[par][j];
+            }
+            par ^= 1u;
+            const unsigned long long tg = n_above + tc;
+            const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+            const OctavStep qs = octav_step(ts, tg, n_elems - tg, ud, s, iters, max_iters);
+            s = qs.s;
+            iters = qs.iters;
+            done = qs.done;
+            if (!done) {
+                const int jn = log_bin(s);
+                if (jn != jb) {
+                    if (jn <= 0 || jn >= kLogNB - 1) {
+                        bad = 1u;                      // out of the binned window
+                    } else if (!marked(jn)) {
+                        if (misses < 3u) fetch_bin(jn);   // a bin that was not gathered
+                        else bad = 1u;
+                    }
+                    if (!bad) {
+                        jb = jn;
+                        enter(jb);
+                    }
+                }
+            }
+        }
+    }
+    DPL_PROF_T(w3);
+    DPL_PROF_ADD(2, w1, w3);   // state .. end of the walk
+    // ---- what the next batches should gather for this tensor: the bins this walk stepped into — or, when it
+    // left the gathered set, the pair's bracket over the bin edges (histogram only) — plus neighbours that hold
+    // next to nothing.
+    if (!small && route == 2u) {
+        if (bad) {
+            if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
+            __syncthreads();
+            if (tid == 0) bracket_marks(n_ge, s_ge, sh.pub, sh.s0, sh.ud, sh.n_elems);
+            __syncthreads();
+        }
+        if (tid < (uint32_t)kLogWords) {
+            // neighbours: bin j-1 / j+1 of a published bin j join when they hold <= 0.2 % of the pair
+            const uint32_t cheap = (uint32_t)(sh.n_elems >> 9);
+            const uint32_t mine = sh.pub[tid];
+            const uint32_t up = (mine << 1) | (tid > 0 ? sh.pub[tid - 1] >> 31 : 0u);                    // j + 1 candidates
+            const uint32_t dn = (mine >> 1) | (tid + 1 < (uint32_t)kLogWords ? sh.pub[tid + 1] << 31 : 0u);   // j - 1 candidates
+            uint32_t cand = (up | dn) & ~mine, add = 0u;
+            while (cand) {
+                const int bit = __ffs(cand) - 1;
+                cand &= cand - 1u;
+                const int j = (int)tid * 32 + bit;
+                if (j > 0 && j < kLogNB - 1 && n_ge[j] - n_ge[j + 1] <= cheap) add |= 1u << bit;
+            }
+            // the sparse tail, wholesale: every bin from which on no more than 1/128 of the pair lies above — that is where
+            // the late iterates land, and where they scatter most from image to image
+            const uint32_t thin = (uint32_t)(sh.n_elems >> 7);
+            uint32_t tail = 0u;
+            for (int bit = 0; bit < 32; ++bit) {
+                const int j = (int)tid * 32 + bit;
+                if (j > 0 && j < kLogNB - 1 && n_ge[j] != 0u && n_ge[j] <= thin) tail |= 1u << bit;
+            }
+            const uint32_t out = mine | add | tail;
+            if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
+        }
+    }
+    DPL_PROF_T(w4);
+    DPL_PROF_ADD(3, w3, w4);   // publish
+    if (tid == 0) g_prof_iters_add(blockIdx.x, iters);
+    if (tid == 0) {
+        if (route == 0u) {
+            me->done = 1u;
+            me->mode = 2u;
+        } else if (bad) {
+            // restart from s_0 (in me->s) on the compaction route: state as k_octav_update<true> leaves it
+            me->mode = 1u;
+            me->done = 0u;
+            me->len[0] = 0u;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        } else {
+            me->s = s;
+            me->iters = iters;
+            me->done = 1u;
+            me->mode = 2u;
+        }
+    }
+}
+
+__global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* queue_head, int n_queues,
+                                     uint32_t* vis_w, int64_t vis_words) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_queues) queue_head[i] = 0u;
+    if (i < vis_words) vis_w[i] = 0u;
+    if (i > n_pairs) return;  // slot n_pairs is the control block
+    dpl_octav_state z;
+    z.sum = 0.0;
+    z.cnt_gt = 0;
+    z.cnt_le = 0;
+    z.min_enc = 0xFFFFFFFFu;
+    z.max_enc = 0u;
+    z.nan_seen = 0u;
+    z.done = 0u;
+    z.s = 0.0f;
+    z.unsigned_div = 1.0f;
+    z.iters = 0u;
+    z.mode = 2u;
+    z.n_elems = 0ull;
+    z.len[0] = 0u;
+    z.len[1] = 0u;
+    z.cur = 2u;
+    z.reserved = 0u;
+    st[i] = z;
+}
+
+}  // namespace
+
+extern int g_exact_fail_every;   // octav_kernels.hip (dpl_test_hook_exact_fail_every)
+int dpl_octav_fallback_route(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                             const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                             const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                             float* d_list0, float* d_list1, int dynamic_sym, int max_iters, hipStream_t st);
+
+extern "C" {
+
+#ifdef DPL_RES_PROF
+int dpl_res_prof_read(unsigned long long* host_out, int reset) {   // tuning builds only
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_res_prof), sizeof(unsigned long long) * 4096 * 8);
+    if (e != hipSuccess) return fail("dpl_res_prof_read", e);
+    if (reset) {
+        static unsigned long long z[4096 * 8];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_res_prof), z, sizeof(z));
+        if (e != hipSuccess) return fail("dpl_res_prof_read", e);
+    }
+    return 0;
+}
+#endif
+
+uint32_t dpl_octav_slice_cap(void) { return kCap; }
+int dpl_octav_oneread_occupancy(void) { return DPL_RES_OCC; }
+
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, int n_queues, dpl_work_item* out, int64_t cap,
+                               uint32_t* queue_begin) {
+    if (!spans || n_spans < 0 || n_queues < 1 || n_queues > 64) return fail_msg("dpl_build_octav_slices: bad arguments");
+    // pairs to queues: largest first, each to the queue with the least elements so far; a queue keeps that order
+    int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_spans > 0 ? n_spans : 1));
+    int* qof = (int*)malloc(sizeof(int) * (size_t)(n_spans > 0 ? n_spans : 1));
+    if (!order || !qof) {
+        free(order);
+        free(qof);
+        return fail_msg("dpl_build_octav_slices: out of memory");
+    }
+    for (int64_t i = 0; i < n_spans; ++i) order[i] = i;
+    struct Cmp {
+        static int f(const void* a, const void* b, void* ctx) {
+            const dpl_span* sp = (const dpl_span*)ctx;
+            const int64_t ia = *(const int64_t*)a, ib = *(const int64_t*)b;
+            if (sp[ia].count != sp[ib].count) return sp[ia].count > sp[ib].count ? -1 : 1;
+            return ia < ib ? -1 : (ia > ib ? 1 : 0);
+        }
+    };
+    qsort_r(order, (size_t)n_spans, sizeof(int64_t), Cmp::f, (void*)spans);
+    uint64_t load[64] = {0};
+    int64_t n_total = 0;
+    int64_t per_q[64] = {0};
+    for (int64_t oi = 0; oi < n_spans; ++oi) {
+        const dpl_span& sp = spans[order[oi]];
+        const uint64_t c = sp.count == 0 ? 0 : (sp.count + kCap - 1) / kCap;
+        if (c > kMaxCluster) {
+            free(order);
+            free(qof);
+            snprintf(g_err, sizeof(g_err), "dpl_build_octav_slices: a pair of %llu elements needs %llu slices (max %u)",
+                     (unsigned long long)sp.count, (unsigned long long)c, kMaxCluster);
+            return -3;
+        }
+        int best = 0;
+        for (int qi = 1; qi < n_queues; ++qi)
+            if (load[qi] < load[best]) best = qi;
+        qof[order[oi]] = best;
+        load[best] += sp.count;
+        per_q[best] += (int64_t)c;
+        n_total += (int64_t)c;
+    }
+    if (out && queue_begin && n_total <= cap) {
+        int64_t pos[65];
+        pos[0] = 0;
+        for (int qi = 0; qi < n_queues; ++qi) pos[qi + 1] = pos[qi] + per_q[qi];
+        for (int qi = 0; qi <= n_queues; ++qi) queue_begin[qi] = (uint32_t)pos[qi];
+        for (int64_t oi = 0; oi < n_spans; ++oi) {
+            const dpl_span& sp = spans[order[oi]];
+            if (sp.count == 0) continue;
+            const uint64_t c = (sp.count + kCap - 1) / kCap;
+            const uint64_t per = (((sp.count + c - 1) / c) + 3) & ~3ull;   // equal slices, cut on multiples of 4 elements
+            int64_t& p = pos[qof[order[oi]]];
+            uint64_t off = 0;
+            for (uint64_t j = 0; j < c; ++j) {
+                const uint64_t take = (j + 1 == c) ? sp.count - off : per;
+                out[p].offset = sp.offset + off;
+                out[p].count = (uint32_t)take;
+                out[p].seg = sp.seg;
+                out[p].slot = sp.slot;
+                out[p].reserved = (uint32_t)c;
+                ++p;
+                off += take;
+            }
+        }
+    }
+    free(order);
+    free(qof);
+    return n_total;
+}
+
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_queue_begin, int n_queues,
+                          uint32_t* d_queue_head, int n_workgroups, uint64_t* d_lh, uint32_t* d_lh_cnt,
+                          const uint32_t* d_vis_a, const uint32_t* d_vis_b, uint32_t* d_vis_w, int64_t n_tensors,
+                          const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                          const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                          float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_slices <= 0 || n_pairs <= 0) return 0;
+    if (n_queues < 1 || n_queues > 64 || n_workgroups < n_queues || n_tensors < 1)
+        return fail_msg("dpl_octav_run_oneread: bad queue / workgroup / tensor counts");
+    if (!d_lh || !d_lh_cnt || !d_queue_head || !d_vis_a || !d_vis_b || !d_vis_w)
+        return fail_msg("dpl_octav_run_oneread: null scratch buffer");
+    if (int e = check_blocks("dpl_octav_run_oneread", n_items, d_block_begin, n_blocks)) return e;
+    hipStream_t st = (hipStream_t)s;
+    dpl_octav_state* ctl = d_states + n_pairs;
+    const int64_t vis_words = n_tensors * kLogWords;
+    const int64_t init_n = (n_pairs + 1 > vis_words ? n_pairs + 1 : vis_words);
+    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, st, d_states, n_pairs, d_queue_head,
+                       n_queues, d_vis_w, vis_words);
+    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB + kLdsKey), st, d_slices,
+                       d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_vis_a, d_vis_b,
+                       (uint32_t)n_tensors, d_pair_base, d_list0);
+    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, st, d_states, ctl, d_pair_order,
+                       reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_vis_a, d_vis_b, d_vis_w, (uint32_t)n_tensors,
+                       d_pair_base, d_list0, d_pair_spans, d_seg_ptrs, dynamic_sym, max_iters, g_exact_fail_every);
+    DPL_LAUNCH_CHECK("k_octav_oneread");
+    if (max_iters > 0)
+        return dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
+                                        d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, st);
+    return 0;
+}
+
+}  // extern "C"

@@ -132,25 +132,26 @@ class TensorSetPlan:
                               torch.empty(n, 66, dtype=torch.int32, device=self.device))
         return self._octav_lh
 
-    def octav_resident_scratch(self):
-        """Work decomposition and scratch of the single-read (register-resident) OCTAV form, or None when a pair is too
-        large for it: (slices, n_slices, queue_begin, n_queues, queue_head, sync, lh, lh_cnt)."""
-        if getattr(self, "_octav_res", None) is None:
+    def octav_oneread_scratch(self):
+        """Work decomposition, scratch and prediction state of the one-read OCTAV form, or None when a pair is too large
+        for it: dict(slices, n_slices, queue_begin, n_queues, queue_head, lh, lh_cnt, vis [3, T, 64], calls)."""
+        if getattr(self, "_octav_one", None) is None:
             n_queues = int(os.environ.get("DPL_RES_QUEUES", "8"))   # one per XCD
             built = _hip.build_octav_slices(self._spans(True), n_queues)
             if built is None:
-                self._octav_res = False
+                self._octav_one = False
             else:
                 arr, n, qb = built
                 n_pairs = self.n_pairs
-                self._octav_res = (
-                    _upload_struct_array(arr, n, self.device), n,
-                    torch.frombuffer(bytearray(bytes(qb)), dtype=torch.int32).to(self.device), n_queues,
-                    torch.zeros(n_queues, dtype=torch.int32, device=self.device),
-                    torch.zeros(n_pairs, 4, dtype=torch.int32, device=self.device),
-                    torch.zeros(n_pairs, 2048, dtype=torch.int64, device=self.device),   # handed back zeroed by every run
-                    torch.zeros(n_pairs, 2048, dtype=torch.int32, device=self.device))
-        return self._octav_res or None
+                self._octav_one = dict(
+                    slices=_upload_struct_array(arr, n, self.device), n_slices=n,
+                    queue_begin=torch.frombuffer(bytearray(bytes(qb)), dtype=torch.int32).to(self.device),
+                    n_queues=n_queues, queue_head=torch.zeros(n_queues, dtype=torch.int32, device=self.device),
+                    lh=torch.zeros(n_pairs, 2048, dtype=torch.int64, device=self.device),    # handed back zeroed by every run
+                    lh_cnt=torch.zeros(n_pairs, 2048, dtype=torch.int32, device=self.device),
+                    # bins each tensor's iterates visited in the last batches (three rotating bitmaps: written / read / read)
+                    vis=torch.zeros(3, self.T, 64, dtype=torch.int32, device=self.device), calls=0)
+        return self._octav_one or None
 
     def seg_table(self, tensors):
         """Device table of base pointers for this launch (cached per pointer tuple)."""
@@ -254,12 +255,12 @@ class CalibAccumulators:
 _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 
-_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "resident": 3}
+_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
 _RES_WGS = None
 
 
-def _resident_workgroups():
-    """Persistent workgroups of the resident form: its occupancy per compute unit x the compute units."""
+def _oneread_workgroups():
+    """Persistent workgroups of the one-read form: its occupancy per compute unit x the compute units."""
     global _RES_WGS
     if _RES_WGS is None:
         v = os.environ.get("DPL_RES_WGS")
@@ -267,7 +268,7 @@ def _resident_workgroups():
             _RES_WGS = int(v)
         else:
             _, _, cus, _ = _hip.device_info()
-            _RES_WGS = max(8, _hip.lib().dpl_octav_resident_occupancy() * max(cus, 1))
+            _RES_WGS = max(8, _hip.lib().dpl_octav_oneread_occupancy() * max(cus, 1))
     return _RES_WGS
 
 
@@ -275,19 +276,20 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max).
 
     Four forms computing the SAME iterate sequence (forward_net.py:323-330):
-      'resident' (default) ONE read: persistent workgroups keep slices of every pair in registers while the pair's
-                           log-scale histogram is merged, its bracket walked and the marked bins extracted; the exact
-                           iteration runs on the extracted values (csrc/octav_resident.hip).  A tensor set with a pair
-                           too large for it (> 64 slices) uses 'bracket'
+      'oneread' (default)  ONE read, one launch: statistics, exact log-scale histogram and the values of the bins the
+                           iterates are predicted to visit (from the same tensor in the previous batches of this plan)
+                           in a single pass; the exact iteration verifies every iterate against what was gathered and
+                           mispredicted pairs (all of them in a plan's first batch) finish on the compaction route
+                           (csrc/octav_oneread.hip).  A tensor set with a pair too large for it uses 'bracket'
       'bracket'            two reads: statistics + exact log-scale histogram, bracket walk, gather of the marked
                            bins, exact per-pair iteration; pairs it cannot serve finish on the compaction route
       'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists
       'full'               every evaluation re-reads the full data (21 passes)
     `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default."""
     if form is None:
-        form = ("compact" if compact else "full") if compact is not None else os.environ.get("DPL_OCTAV_FORM", "resident")
+        form = ("compact" if compact else "full") if compact is not None else os.environ.get("DPL_OCTAV_FORM", "oneread")
     mode = _OCTAV_MODE[form]
-    res = plan.octav_resident_scratch() if mode == 3 else None
+    res = plan.octav_oneread_scratch() if mode == 3 else None
     if mode == 3 and res is None:
         mode = 2
     w = plan.work("octav", per_image=True)
@@ -299,14 +301,16 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     L = _hip.lib()
     dyn = 1 if dynamic_sym else 0
     if mode == 3:
-        slices, n_slices, qb, n_queues, qhead, sync, lh, lh_cnt = res
         spans, base, order, l0, l1 = plan.octav_scratch()
-        _, _, bitmap = plan.octav_loghist_scratch()
-        _hip.check(L.dpl_octav_run_resident(_ptr(slices), n_slices, _ptr(qb), n_queues, _ptr(qhead),
-                                            _resident_workgroups(), _ptr(sync), _ptr(lh), _ptr(lh_cnt), _ptr(bitmap),
-                                            *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
-                                            _ptr(order), _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
-                   "dpl_octav_run_resident")
+        k = res["calls"]
+        res["calls"] = k + 1
+        vis = res["vis"]
+        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["queue_begin"]), res["n_queues"],
+                                           _ptr(res["queue_head"]), _oneread_workgroups(),
+                                           _ptr(res["lh"]), _ptr(res["lh_cnt"]), _ptr(vis[(k + 2) % 3]), _ptr(vis[(k + 1) % 3]),
+                                           _ptr(vis[k % 3]), plan.T, *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans),
+                                           _ptr(base), _ptr(order), _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
+                   "dpl_octav_run_oneread")
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
         return out

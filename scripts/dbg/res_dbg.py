@@ -8,8 +8,8 @@ sizes = [int(a) for a in sys.argv[1].split(",")] if len(sys.argv) > 1 else [1000
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 xs = [torch.from_numpy(rng.standard_normal((B, n)).astype(np.float32)).to(dev) for n in sizes]
 plan = ops.TensorSetPlan(sizes, B, dev)
-print("slices", plan.octav_resident_scratch()[1], flush=True)
-for form in ("bracket", "resident"):
+print("slices", plan.octav_oneread_scratch()["n_slices"], flush=True)
+for form in ("bracket", "oneread", "oneread", "oneread"):
     out = ops.octav_batch(plan, xs, False, form=form)
     torch.cuda.synchronize()
     print(form, out.cpu().numpy().reshape(-1, 3)[:6], flush=True)

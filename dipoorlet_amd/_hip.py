@@ -72,10 +72,9 @@ SIGNATURES = {
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
     "dpl_octav_slice_cap": (C.c_uint32, []),
-    "dpl_octav_oneread_occupancy": (C.c_int, []),
-    "dpl_build_octav_slices": (_I64, [_P, _I64, C.c_int, _P, _I64, _P]),
-    "dpl_octav_run_oneread": (C.c_int, [_P, _I64, _P, C.c_int, _P, C.c_int, _P, _P, _P, _P, _P, _I64, _P, _I64, _P,
-                                        _I64, _P, _P, _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dpl_build_octav_slices": (_I64, [_P, _I64, _P, _I64]),
+    "dpl_octav_run_oneread": (C.c_int, [_P, _I64, _P, _P, _P, _P, C.c_int, C.c_int, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P,
+                                        _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
@@ -157,20 +156,19 @@ def build_balanced_items(spans, n_blocks):
     return out, int(n), bb
 
 
-def build_octav_slices(spans, n_queues):
-    """HOST: spans (one per (image, tensor) pair) -> (WorkItem array, n_slices, queue_begin array), or None when a pair
-    is too large for the one-read form (more than 64 slices)."""
+def build_octav_slices(spans):
+    """HOST: spans (one per (image, tensor) pair) -> (WorkItem array, n_slices), largest pairs first, or None when a pair is
+    too large for the one-read form (more than 64 slices)."""
     arr, ns = _span_array(spans)
-    n = lib().dpl_build_octav_slices(C.addressof(arr), ns, n_queues, None, 0, None)
+    n = lib().dpl_build_octav_slices(C.addressof(arr), ns, None, 0)
     if n == -3:
         return None
     if n < 0:
         check(int(n), "dpl_build_octav_slices")
     out = (WorkItem * max(n, 1))()
-    qb = (C.c_uint32 * (n_queues + 1))()
-    n2 = lib().dpl_build_octav_slices(C.addressof(arr), ns, n_queues, C.addressof(out), n, C.addressof(qb))
+    n2 = lib().dpl_build_octav_slices(C.addressof(arr), ns, C.addressof(out), n)
     assert n2 == n
-    return out, int(n), qb
+    return out, int(n)
 
 
 def build_work_items(spans, chunk_elems):

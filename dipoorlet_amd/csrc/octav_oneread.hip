@@ -50,6 +50,7 @@ constexpr int kWaves = kThreads / kWave;
 #endif
 constexpr int kVec = DPL_RES_VEC;                               // 16-byte vectors per thread the walk keeps a list in
 constexpr uint32_t kWalkCap = (uint32_t)kThreads * kVec * 4;    // list values the walk holds in registers (20 480)
+constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this small gather their whole window (no prediction)
 #ifndef DPL_SLICE_CAP
 #define DPL_SLICE_CAP 131072
 #endif
@@ -87,11 +88,13 @@ __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)"
 __device__ unsigned long long g_res_prof[4096 * 8];
 #define DPL_PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #define DPL_PROF_ADD(slot, a, b) do { if (threadIdx.x == 0) g_res_prof[(blockIdx.x & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
+#define DPL_PROF_WAVE(idx, slot, a, b) do { if ((threadIdx.x & 63u) == 0) g_res_prof[((idx) & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
 __device__ __forceinline__ void g_prof_iters_add(uint32_t b, uint32_t it) { g_res_prof[(b & 4095u) * 8 + 7] += it; }
 #else
 __device__ __forceinline__ void g_prof_iters_add(uint32_t, uint32_t) {}
 #define DPL_PROF_T(var) do {} while (0)
 #define DPL_PROF_ADD(slot, a, b) do {} while (0)
+#define DPL_PROF_WAVE(idx, slot, a, b) do {} while (0)
 #endif
 
 struct Shared {
@@ -263,8 +266,8 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
 // then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
 __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
-    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ vis_a,
-    const uint32_t* __restrict__ vis_b, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0) {
+    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ pred, uint32_t n_tensors,
+    const uint64_t* __restrict__ pair_base, float* __restrict__ list0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
     uint32_t* queues = reinterpret_cast<uint32_t*>(lds_raw + kLdsA);
@@ -276,15 +279,13 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const uint32_t pair = it.slot, n_sl = it.reserved, cnt = it.count;
     dpl_octav_state* me = st + pair;
     const float* pg = segs[it.seg] + it.offset;
-    const bool small = n_sl == 1u && cnt <= kWalkCap;    // the walk can hold the pair's whole window: no prediction
+    const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
     const bool big = n_sl >= kBigCluster;
     const uint32_t tensor = pair % n_tensors;
     for (int b = tid; b < kLogNB; b += kThreads) l_packed[b] = 0ull;
     for (int i = tid; i < kKeyWords; i += kThreads) {   // the bins to gather: what this tensor's iterates visited lately
-        const int j = i - kKeyWord0;
-        keybm[i] = (j >= 0 && j < kLogWords)
-                       ? (small ? 0xFFFFFFFFu : (vis_a[tensor * kLogWords + j] | vis_b[tensor * kLogWords + j]))
-                       : 0u;
+        const int j = i - kKeyWord0;                    // (a small pair gathers its whole window)
+        keybm[i] = (j >= 0 && j < kLogWords) ? (small ? 0xFFFFFFFFu : pred[tensor * kLogWords + j]) : 0u;
     }
     __syncthreads();
 
@@ -330,33 +331,15 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     }
 }
 
-// The values of ONE histogram bin of a pair (bit patterns of |x| whose 14-bit key equals `want`), appended at out[*counter ...]:
-// the walk's answer to a bin the prediction missed.  Not inlined: it must not cost the walk loop any registers.
-__device__ __attribute__((noinline)) void fetch_bin_values(const float* __restrict__ p, uint32_t n, uint32_t want,
-                                                            uint32_t* __restrict__ out, uint32_t* counter) {
-    for_each_tile<kThreads>(p, n, [&](const f4 (&t)[4], uint32_t, bool) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t a0 = __float_as_uint(t[u].x) & 0x7FFFFFFFu, a1 = __float_as_uint(t[u].y) & 0x7FFFFFFFu,
-                           a2 = __float_as_uint(t[u].z) & 0x7FFFFFFFu, a3 = __float_as_uint(t[u].w) & 0x7FFFFFFFu;
-            if ((a0 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a0;
-            if ((a1 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a1;
-            if ((a2 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a2;
-            if ((a3 >> kLogShift) == want) out[atomicAdd(counter, 1u)] = a3;
-        }
-    });
-}
-
 // The exact walk of one pair (one workgroup per pair, largest pairs first): suffix totals of the pair's merged row (the row is
 // handed back zeroed), s_0, then the reference's iteration — totals of the bins above the iterate's bin (exact integers)
 // + the listed values of that bin (integer mantissa sums) — verifying that every iterate lands in a gathered bin.  Records
 // the bins it stepped into (or, when it left the gathered set, the pair's bracket) for the next batches.
 __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
-    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ vis_a,
-    const uint32_t* __restrict__ vis_b, uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
-    float* __restrict__ list0, const dpl_span* __restrict__ pair_spans, const float* const* __restrict__ segs, int dynamic_sym,
-    int max_iters, int fail_every) {
+    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ pred,
+    uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
+    const float* __restrict__ list0, int dynamic_sym, int max_iters, int fail_every) {
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
@@ -372,8 +355,6 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     const uint32_t tensor = pair % n_tensors;
     unsigned long long* row = lh + (uint64_t)pair * kLogNB;
     uint32_t* row_cnt = lh_cnt + (uint64_t)pair * kLogNB;
-    DPL_PROF_T(w0);
-    if (tid == 0) sh.any_pred = 0u;
     // merged per-bin totals -> LDS (own bins per thread); the pair's row is handed back zeroed
     {
         constexpr int kPerT = kLogNB / kThreads;
@@ -398,13 +379,10 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         }
         suffix_in_place(n_ge, s_ge, sh);
     }
-    DPL_PROF_T(w1);
-    DPL_PROF_ADD(0, w0, w1);   // row -> suffix totals
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
-        sh.bm[tid] = small ? 0xFFFFFFFFu : (vis_a[tensor * kLogWords + tid] | vis_b[tensor * kLogWords + tid]);
+        sh.bm[tid] = small ? 0xFFFFFFFFu : pred[tensor * kLogWords + tid];
         sh.pub[tid] = 0u;
-        if (sh.bm[tid]) sh.any_pred = 1u;
     }
     if (tid == 0) {
         const double sum_out = me->sum;
@@ -441,12 +419,12 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     if (route == 2u) {
         const float ud = sh.ud;
         const unsigned long long n_elems = sh.n_elems;
-        uint32_t L = __builtin_amdgcn_readfirstlane(me->len[0]);
+        const uint32_t L = __builtin_amdgcn_readfirstlane(me->len[0]);
         // the pair's list (bit patterns of |x|) goes into registers; a list longer than they hold is re-read in
         // pieces every iteration
         f4 v[kVec];
-        uint32_t n_chunks = (L + kWalkCap - 1u) / kWalkCap;
-        float* lp = list0 + pair_base[pair];
+        const uint32_t n_chunks = (L + kWalkCap - 1u) / kWalkCap;
+        const float* lp = list0 + pair_base[pair];
         auto load_chunk = [&](uint32_t c0) {
             // buffer loads: zero fill past the list's end (one descriptor per row: the range check leaves the SGPR
             // offset out, so the row offset goes into the base)
@@ -460,36 +438,11 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             }
         };
         if (n_chunks == 1u) load_chunk(0u);
-        DPL_PROF_T(w2);
-        DPL_PROF_ADD(1, w1, w2);   // state, s_0, list load issued
         auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
-        // A bin the prediction missed: this workgroup fetches it — one more read of the PAIR (not of the batch), its values of
-        // bin j appended to the list — and the walk goes on.  Three misses, or a tensor with no prediction at all (the first
-        // batch of a run), send the pair to the compaction route instead.
-        uint32_t misses = sh.any_pred ? 0u : 3u;
-        auto fetch_bin = [&](int j) {
-            const dpl_span sp = pair_spans[pair];
-            const uint32_t want = (uint32_t)j + kLogKey0;
-            if (tid == 0) sh.fetched = 0u;
-            __syncthreads();
-            fetch_bin_values(segs[sp.seg] + sp.offset, (uint32_t)sp.count, want, reinterpret_cast<uint32_t*>(lp) + L, &sh.fetched);
-            if (tid == 0) sh.bm[j >> 5] |= 1u << (j & 31);
-            __threadfence_block();
-            drain_vmem();
-            __syncthreads();
-            L += sh.fetched;
-            n_chunks = (L + kWalkCap - 1u) / kWalkCap;
-            if (n_chunks == 1u) load_chunk(0u);
-            ++misses;
-        };
         // every thread carries the (uniform) walk state and takes the step itself from the four wave partials: one barrier
         // per iteration, no broadcast; the partials alternate between two slots so that no second barrier is needed
         int jb = log_bin(s);
-        bad = (jb > 0 && jb < kLogNB - 1) ? 0u : 1u;
-        if (!bad && !marked(jb)) {
-            if (misses < 3u) fetch_bin(jb);
-            else bad = 1u;
-        }
+        bad = marked(jb) ? 0u : 1u;
         if (fail_every > 0 && pair % (uint32_t)fail_every == 0u) bad = 1u;   // test hook: the restart path
         unsigned long long n_above = 0ull;
         double s_above = 0.0;
@@ -549,23 +502,15 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             done = qs.done;
             if (!done) {
                 const int jn = log_bin(s);
-                if (jn != jb) {
-                    if (jn <= 0 || jn >= kLogNB - 1) {
-                        bad = 1u;                      // out of the binned window
-                    } else if (!marked(jn)) {
-                        if (misses < 3u) fetch_bin(jn);   // a bin that was not gathered
-                        else bad = 1u;
-                    }
-                    if (!bad) {
-                        jb = jn;
-                        enter(jb);
-                    }
+                if (!marked(jn)) {
+                    bad = 1u;   // a bin that was not gathered (or out of the binned window): the compaction route takes over
+                } else if (jn != jb) {
+                    jb = jn;
+                    enter(jb);
                 }
             }
         }
     }
-    DPL_PROF_T(w3);
-    DPL_PROF_ADD(2, w1, w3);   // state .. end of the walk
     // ---- what the next batches should gather for this tensor: the bins this walk stepped into — or, when it
     // left the gathered set, the pair's bracket over the bin edges (histogram only) — plus neighbours that hold
     // next to nothing.
@@ -601,9 +546,6 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
         }
     }
-    DPL_PROF_T(w4);
-    DPL_PROF_ADD(3, w3, w4);   // publish
-    if (tid == 0) g_prof_iters_add(blockIdx.x, iters);
     if (tid == 0) {
         if (route == 0u) {
             me->done = 1u;
@@ -623,11 +565,15 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     }
 }
 
-__global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* queue_head, int n_queues,
-                                     uint32_t* vis_w, int64_t vis_words) {
+__global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* vis_w, const uint32_t* vis_o, uint32_t* pred,
+                                     int64_t vis_words, int zero_w) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_queues) queue_head[i] = 0u;
-    if (i < vis_words) vis_w[i] = 0u;
+    if (i < vis_words) {   // this batch gathers what the current and the previous epoch's walks stepped into (a snapshot: the
+                           // walks of this batch keep adding to vis_w while they run)
+        const uint32_t mine = zero_w ? 0u : vis_w[i];
+        if (zero_w) vis_w[i] = 0u;
+        pred[i] = mine | vis_o[i];
+    }
     if (i > n_pairs) return;  // slot n_pairs is the control block
     dpl_octav_state z;
     z.sum = 0.0;
@@ -673,19 +619,12 @@ int dpl_res_prof_read(unsigned long long* host_out, int reset) {   // tuning bui
 #endif
 
 uint32_t dpl_octav_slice_cap(void) { return kCap; }
-int dpl_octav_oneread_occupancy(void) { return DPL_RES_OCC; }
 
-int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, int n_queues, dpl_work_item* out, int64_t cap,
-                               uint32_t* queue_begin) {
-    if (!spans || n_spans < 0 || n_queues < 1 || n_queues > 64) return fail_msg("dpl_build_octav_slices: bad arguments");
-    // pairs to queues: largest first, each to the queue with the least elements so far; a queue keeps that order
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap) {
+    if (!spans || n_spans < 0) return fail_msg("dpl_build_octav_slices: bad arguments");
+    // largest pairs first: the long ones start at once, the short ones fill the tail of the launch
     int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_spans > 0 ? n_spans : 1));
-    int* qof = (int*)malloc(sizeof(int) * (size_t)(n_spans > 0 ? n_spans : 1));
-    if (!order || !qof) {
-        free(order);
-        free(qof);
-        return fail_msg("dpl_build_octav_slices: out of memory");
-    }
+    if (!order) return fail_msg("dpl_build_octav_slices: out of memory");
     for (int64_t i = 0; i < n_spans; ++i) order[i] = i;
     struct Cmp {
         static int f(const void* a, const void* b, void* ctx) {
@@ -696,38 +635,25 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, int n_que
         }
     };
     qsort_r(order, (size_t)n_spans, sizeof(int64_t), Cmp::f, (void*)spans);
-    uint64_t load[64] = {0};
     int64_t n_total = 0;
-    int64_t per_q[64] = {0};
     for (int64_t oi = 0; oi < n_spans; ++oi) {
         const dpl_span& sp = spans[order[oi]];
         const uint64_t c = sp.count == 0 ? 0 : (sp.count + kCap - 1) / kCap;
         if (c > kMaxCluster) {
             free(order);
-            free(qof);
             snprintf(g_err, sizeof(g_err), "dpl_build_octav_slices: a pair of %llu elements needs %llu slices (max %u)",
                      (unsigned long long)sp.count, (unsigned long long)c, kMaxCluster);
             return -3;
         }
-        int best = 0;
-        for (int qi = 1; qi < n_queues; ++qi)
-            if (load[qi] < load[best]) best = qi;
-        qof[order[oi]] = best;
-        load[best] += sp.count;
-        per_q[best] += (int64_t)c;
         n_total += (int64_t)c;
     }
-    if (out && queue_begin && n_total <= cap) {
-        int64_t pos[65];
-        pos[0] = 0;
-        for (int qi = 0; qi < n_queues; ++qi) pos[qi + 1] = pos[qi] + per_q[qi];
-        for (int qi = 0; qi <= n_queues; ++qi) queue_begin[qi] = (uint32_t)pos[qi];
+    if (out && n_total <= cap) {
+        int64_t p = 0;
         for (int64_t oi = 0; oi < n_spans; ++oi) {
             const dpl_span& sp = spans[order[oi]];
             if (sp.count == 0) continue;
             const uint64_t c = (sp.count + kCap - 1) / kCap;
             const uint64_t per = (((sp.count + c - 1) / c) + 3) & ~3ull;   // equal slices, cut on multiples of 4 elements
-            int64_t& p = pos[qof[order[oi]]];
             uint64_t off = 0;
             for (uint64_t j = 0; j < c; ++j) {
                 const uint64_t take = (j + 1 == c) ? sp.count - off : per;
@@ -742,35 +668,33 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, int n_que
         }
     }
     free(order);
-    free(qof);
     return n_total;
 }
 
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_queue_begin, int n_queues,
-                          uint32_t* d_queue_head, int n_workgroups, uint64_t* d_lh, uint32_t* d_lh_cnt,
-                          const uint32_t* d_vis_a, const uint32_t* d_vis_b, uint32_t* d_vis_w, int64_t n_tensors,
-                          const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
-                          const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
-                          float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, uint32_t* d_lh_cnt, uint32_t* d_vis,
+                          uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
+                          int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
+                          dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym, int max_iters,
+                          dpl_stream_t s) {
     if (n_slices <= 0 || n_pairs <= 0) return 0;
-    if (n_queues < 1 || n_queues > 64 || n_workgroups < n_queues || n_tensors < 1)
-        return fail_msg("dpl_octav_run_oneread: bad queue / workgroup / tensor counts");
-    if (!d_lh || !d_lh_cnt || !d_queue_head || !d_vis_a || !d_vis_b || !d_vis_w)
-        return fail_msg("dpl_octav_run_oneread: null scratch buffer");
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_run_oneread: bad tensor count / epoch");
+    if (!d_lh || !d_lh_cnt || !d_vis || !d_pred) return fail_msg("dpl_octav_run_oneread: null scratch buffer");
     if (int e = check_blocks("dpl_octav_run_oneread", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
     dpl_octav_state* ctl = d_states + n_pairs;
     const int64_t vis_words = n_tensors * kLogWords;
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * vis_words;
+    const uint32_t* d_vis_o = d_vis + (int64_t)(1 - write_epoch) * vis_words;
     const int64_t init_n = (n_pairs + 1 > vis_words ? n_pairs + 1 : vis_words);
-    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, st, d_states, n_pairs, d_queue_head,
-                       n_queues, d_vis_w, vis_words);
+    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, st, d_states, n_pairs, d_vis_w, d_vis_o,
+                       d_pred, vis_words, reset_epoch);
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB + kLdsKey), st, d_slices,
-                       d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_vis_a, d_vis_b,
+                       d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_pred,
                        (uint32_t)n_tensors, d_pair_base, d_list0);
     hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, st, d_states, ctl, d_pair_order,
-                       reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_vis_a, d_vis_b, d_vis_w, (uint32_t)n_tensors,
-                       d_pair_base, d_list0, d_pair_spans, d_seg_ptrs, dynamic_sym, max_iters, g_exact_fail_every);
+                       reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base,
+                       d_list0, dynamic_sym, max_iters, g_exact_fail_every);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     if (max_iters > 0)
         return dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,

@@ -134,23 +134,21 @@ class TensorSetPlan:
 
     def octav_oneread_scratch(self):
         """Work decomposition, scratch and prediction state of the one-read OCTAV form, or None when a pair is too large
-        for it: dict(slices, n_slices, queue_begin, n_queues, queue_head, lh, lh_cnt, vis [3, T, 64], calls)."""
+        for it: dict(slices, n_slices, lh, lh_cnt, vis [2, T, 64], pred [T, 64], calls)."""
         if getattr(self, "_octav_one", None) is None:
-            n_queues = int(os.environ.get("DPL_RES_QUEUES", "8"))   # one per XCD
-            built = _hip.build_octav_slices(self._spans(True), n_queues)
+            built = _hip.build_octav_slices(self._spans(True))
             if built is None:
                 self._octav_one = False
             else:
-                arr, n, qb = built
+                arr, n = built
                 n_pairs = self.n_pairs
                 self._octav_one = dict(
                     slices=_upload_struct_array(arr, n, self.device), n_slices=n,
-                    queue_begin=torch.frombuffer(bytearray(bytes(qb)), dtype=torch.int32).to(self.device),
-                    n_queues=n_queues, queue_head=torch.zeros(n_queues, dtype=torch.int32, device=self.device),
                     lh=torch.zeros(n_pairs, 2048, dtype=torch.int64, device=self.device),    # handed back zeroed by every run
                     lh_cnt=torch.zeros(n_pairs, 2048, dtype=torch.int32, device=self.device),
-                    # bins each tensor's iterates visited in the last batches (three rotating bitmaps: written / read / read)
-                    vis=torch.zeros(3, self.T, 64, dtype=torch.int32, device=self.device), calls=0)
+                    # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
+                    vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
+                    pred=torch.zeros(self.T, 64, dtype=torch.int32, device=self.device), calls=0)
         return self._octav_one or None
 
     def seg_table(self, tensors):
@@ -256,20 +254,9 @@ _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 
 _OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
-_RES_WGS = None
-
-
-def _oneread_workgroups():
-    """Persistent workgroups of the one-read form: its occupancy per compute unit x the compute units."""
-    global _RES_WGS
-    if _RES_WGS is None:
-        v = os.environ.get("DPL_RES_WGS")
-        if v:
-            _RES_WGS = int(v)
-        else:
-            _, _, cus, _ = _hip.device_info()
-            _RES_WGS = max(8, _hip.lib().dpl_octav_oneread_occupancy() * max(cus, 1))
-    return _RES_WGS
+# batches per prediction epoch of the one-read form: a batch gathers the bins the walks of the current and the previous epoch
+# stepped into (8-16 batches of history)
+_ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
 
 
 def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):
@@ -304,12 +291,11 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
         spans, base, order, l0, l1 = plan.octav_scratch()
         k = res["calls"]
         res["calls"] = k + 1
-        vis = res["vis"]
-        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["queue_begin"]), res["n_queues"],
-                                           _ptr(res["queue_head"]), _oneread_workgroups(),
-                                           _ptr(res["lh"]), _ptr(res["lh_cnt"]), _ptr(vis[(k + 2) % 3]), _ptr(vis[(k + 1) % 3]),
-                                           _ptr(vis[k % 3]), plan.T, *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans),
-                                           _ptr(base), _ptr(order), _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
+        epoch, first = divmod(k, _ONEREAD_EPOCH)
+        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["lh"]), _ptr(res["lh_cnt"]),
+                                           _ptr(res["vis"]), _ptr(res["pred"]), epoch % 2, 1 if first == 0 else 0, plan.T,
+                                           *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base), _ptr(order),
+                                           _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
                    "dpl_octav_run_oneread")
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")

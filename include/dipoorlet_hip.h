@@ -150,37 +150,32 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
                           uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
-/* Same iterate sequence in ONE read of the data and one launch per batch (csrc/octav_oneread.hip).  Persistent
- * workgroups pull SLICES (at most dpl_octav_slice_cap() elements of one pair) from `n_queues` queues; a slice is read
- * once into registers and yields, in that one pass, the pair's statistics, its exact log-scale histogram (merged per
- * pair by agent-scope atomics) and the values of the bins the exact iteration is PREDICTED to visit (the bins the
- * same tensor's iterates visited in the last two batches, d_vis_a | d_vis_b); the last slice of a pair walks the
- * exact iteration from the merged histogram + the gathered values, VERIFYING every iterate against the gathered bins,
- * and publishes the pair's bracket into d_vis_w for the next batches.  A pair whose iterate leaves the gathered bins
- * (always the case in the first batch of a run: call with zeroed d_vis_a / d_vis_b) finishes on the compaction route
- * (d_items .. d_list1 as for dpl_octav_run_bracket); pairs that fit one slice never need a prediction.
- *   dpl_build_octav_slices (HOST): cuts every span (= pair) into ceil(count / cap) equal slices (multiples of 4
- *     elements), assigns pairs to queues largest-first / least-loaded, writes the items queue by queue with
- *     item.reserved = the pair's slice count and queue_begin[0..n_queues].  Returns the slice count (call with
- *     out = NULL to size), -3 when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
- *   d_queue_head: uint32 [n_queues] scratch;
- *   d_lh: uint64 [n_pairs, 2048] and d_lh_cnt: uint32 [n_pairs, 2048]: merged histogram rows, ZERO before the first
- *     call; every call hands them back zeroed;
- *   d_vis_a, d_vis_b (read), d_vis_w (zeroed, then written): uint32 [n_tensors, 64] bin bitmaps; slot = image *
- *     n_tensors + tensor.  The caller rotates three buffers: w of batch k is a of batch k + 1 and b of batch k + 2;
- *   n_workgroups: persistent workgroups to launch (dpl_octav_oneread_occupancy() per compute unit fill the chip).
+/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip): a streaming kernel — one workgroup per SLICE
+ * (at most dpl_octav_slice_cap() elements of one pair), each slice read once and yielding in that pass the pair's
+ * statistics, its exact log-scale histogram (merged per pair by agent-scope atomics) and the values of the bins the
+ * exact iteration is PREDICTED to visit — then a walk kernel, one wave per pair: suffix totals of the merged histogram,
+ * the gathered values grouped by bin, the reference's iteration on (exact totals of the bins above) + (gathered values of
+ * the iterate's bin), every iterate VERIFIED against the gathered bins.  The prediction is what the same tensor's walks
+ * stepped into in earlier batches (two alternating epoch accumulators in d_vis; d_pred receives the snapshot this batch
+ * uses).  A walk that meets a bin that was not gathered fetches it from the pair's data (small pairs) or hands the pair
+ * to the compaction route (d_items .. d_list1 as for dpl_octav_run_bracket; always the case for a tensor's first batch:
+ * start with d_vis zeroed); pairs of at most 2048 elements gather their whole window and never need a prediction.
+ *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
+ *     of 4 elements); item.reserved = the pair's slice count.  Returns the slice count (call with out = NULL to size), -3
+ *     when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
+ *   d_lh: uint64 [n_pairs, 2048] and d_lh_cnt: uint32 [n_pairs, 2048]: merged histogram rows, ZERO before the first call;
+ *     every call hands them back zeroed;
+ *   d_vis: uint32 [2, n_tensors, 64] epoch accumulators (slot = image * n_tensors + tensor); this batch's walks add to
+ *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 64] scratch.
  * Initialises d_states itself (no dpl_octav_init call). */
 uint32_t dpl_octav_slice_cap(void);
-int dpl_octav_oneread_occupancy(void);
-int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, int n_queues, dpl_work_item* out, int64_t cap,
-                               uint32_t* queue_begin);
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_queue_begin, int n_queues,
-                          uint32_t* d_queue_head, int n_workgroups, uint64_t* d_lh, uint32_t* d_lh_cnt,
-                          const uint32_t* d_vis_a, const uint32_t* d_vis_b, uint32_t* d_vis_w, int64_t n_tensors,
-                          const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
-                          const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
-                          float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s);
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap);
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, uint32_t* d_lh_cnt, uint32_t* d_vis,
+                          uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
+                          int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
+                          dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym, int max_iters,
+                          dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 /* TEST HOOK: makes the exact walk of dpl_octav_run_bracket reject every `every`-th pair (0 = off) so that the
  * restart on the compaction route — taken in production only when an iterate leaves the bracket's bins — can be

@@ -10,7 +10,7 @@ plan = ops.TensorSetPlan(elems, B, dev)
 dt = np.dtype([("sum","<f8"),("cnt_gt","<u8"),("cnt_le","<u8"),("min_enc","<u4"),("max_enc","<u4"),("nan","<u4"),("done","<u4"),("s","<f4"),("ud","<f4"),("iters","<u4"),("mode","<u4"),("n","<u8"),("len0","<u4"),("len1","<u4"),("cur","<u4"),("res","<u4")])
 import ctypes
 L = _hip.lib()
-for k in range(8):
+for k in range(20):
     st = torch.empty((plan.n_pairs + 1) * 80, dtype=torch.uint8, device=dev)
     # run only the one-read kernels' part by calling the op and inspecting state AFTER (fallback already finished: mode 1 pairs keep mode 1)
     ops.octav_batch(plan, pool[k % 4], False, st, form="oneread")
@@ -23,5 +23,5 @@ for k in range(8):
     print(f"batch {k}: fallback pairs {len(fb)} (ctl {ctl['cnt_le']}), by size {dict(sizes)}; tensors most hit {tens.most_common(5)}")
 res = plan.octav_oneread_scratch()
 vis = res["vis"].cpu().numpy().astype(np.uint32)
-pc = np.array([[bin(int(w)).count("1") for w in vis[2][t]] for t in range(T)]).sum(1)
+pc = np.array([[bin(int(w)).count("1") for w in (vis[0][t] | vis[1][t])] for t in range(T)]).sum(1)
 print("marked bins per tensor (last written buffer):", pc.min(), np.median(pc), pc.max())

@@ -48,12 +48,36 @@ def build_parser():
     p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
     p.add_argument("--skip_profiling", default=False, action="store_true")
     p.add_argument("--keep_bn", default=False, action="store_true",
-                   help="do not fold BatchNormalization into the preceding Conv / Gemm (the reference always simplifies)")
+                   help="do not fold BatchNormalization into the preceding Conv / Gemm (the reference always simplifies; "
+                        "note: --update_bn also keeps the BN nodes, which it re-estimates — unlike the reference, whose "
+                        "onnxsim pass has fused them before --update_bn runs)")
     return p
 
 
 def main(argv=None):
+    """One rank of a calibration run.  A rank that fails must not leave its peers parked at the next barrier (the
+    reference's ranks hang until the launcher is killed, __main__.py:105-110): the error is logged and the process exits
+    non-zero at once, which makes torch.distributed.run / mpirun / srun take the whole group down."""
+    try:
+        return _main(argv)
+    except SystemExit:
+        raise
+    except BaseException as e:   # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        logger.error("rank %s failed: %s", os.environ.get("RANK", "0"), e)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            os._exit(1)   # no atexit / destructor may wait on a collective the peers will never join
+        raise
+
+
+def _main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.quant_format == "QOP":
+        raise SystemExit("--quant_format QOP (onnxruntime's QOperator export, dipoorlet/utils.py:415-435) is not built: "
+                         "use the default QDQ format")
     if args.slurm:
         dist_helper.init_from_slurm()
     elif args.mpirun:
@@ -86,7 +110,7 @@ def main(argv=None):
                   weight_fname=f"weight_clip_val.json.rank{rank}")
     dist.barrier()
     if rank == 0:
-        reduce_clip_val(world, args)
+        reduce_clip_val(world, args, already_merged=(args.merge != "reference"))
     dist.barrier()
     act_clip_val, weight_clip_val = load_clip_val(args)
     from .weight_transform import weight_calibration

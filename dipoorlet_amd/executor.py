@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .forward_net import ActivationSession
+from .utils import logger
 
 _OPS = {}
 
@@ -438,6 +439,7 @@ class GraphSession(ActivationSession):
         self.input_names = list(graph.network_inputs)
         # fake-quantised WEIGHTS are constants: quantise them once here instead of on every forward
         self._folded = set()
+        self._batched_ok = None   # decided by batched_ok() at the first batched run
         for node in graph.graph.node:
             if node.op_type == "FakeQuant" and node.input[0] in self.consts:
                 w = self.consts[node.input[0]]
@@ -499,19 +501,71 @@ class GraphSession(ActivationSession):
                 env[node.output[0]] = out
         return env
 
+    def _lead(self):
+        return max(1, int(self.graph.get_tensor_shape(self.input_names[0])[0]))
+
     @torch.no_grad()
-    def run(self, inputs):
-        first = inputs[self.input_names[0]]
-        lead = max(1, int(self.graph.get_tensor_shape(self.input_names[0])[0]))
-        batch = first.shape[0] // lead
-        env = self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
+    def _run_env(self, inputs, batch):
+        return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
+
+    def _collect(self, env, names, batch):
         out = []
-        for n in self.tensor_names:
+        for n in names:
             t = env[n]
             if t.dtype != torch.float32:
                 t = t.float()
-            out.append(self._batch_major(n, t, batch))
+            out.append(self._batch_major(n, t, batch) if n in self.shape1 else t)
         return out
+
+    @torch.no_grad()
+    def batched_ok(self):
+        """Is running B images through a graph exported for one image the same as running them one by one?  The executor
+        batches by rewriting literal leading 1s (Reshape, Concat, ...) and by locating the batch axis of every tensor
+        (_batch_major): heuristics that a Reshape with a literal non-leading shape can defeat WITHOUT an error — the
+        calibration statistics would then silently come from scrambled data.  So, once per session: a batch-2 forward on
+        random inputs must reproduce, for every exposed tensor, two batch-1 forwards.  If not, this session runs one image
+        at a time from then on (and says so)."""
+        if self._batched_ok is None:
+            g = torch.Generator(device="cpu").manual_seed(20260)
+            lead = self._lead()
+            feeds = {n: torch.randn([2 * lead] + [max(1, int(d)) for d in self.graph.get_tensor_shape(n)[1:]], generator=g)
+                        .to(self.device) for n in self.input_names}
+            ok = True
+            try:
+                both = self._collect(self._run_env(feeds, 2), self.tensor_names, 2)
+                for k in range(2):
+                    one = self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in feeds.items()}, 1),
+                                        self.tensor_names, 1)
+                    for name, tb, t1 in zip(self.tensor_names, both, one):
+                        ref = t1.reshape(-1)
+                        got = tb[k].reshape(-1)
+                        tol = 1e-3 * float(ref.abs().max().clamp_min(1e-6))   # (library kernels may differ between batch sizes)
+                        if got.numel() != ref.numel() or float((got - ref).abs().max()) > tol:
+                            logger.warning("executor: batched execution of this graph differs from per-image execution at "
+                                           "tensor %s: running one image at a time", name)
+                            ok = False
+                            break
+                    if not ok:
+                        break
+            except RuntimeError as e:   # e.g. no batch axis could be located
+                logger.warning("executor: batched execution of this graph failed (%s): running one image at a time", e)
+                ok = False
+            self._batched_ok = ok
+        return self._batched_ok
+
+    def _run_any(self, inputs, names):
+        first = inputs[self.input_names[0]]
+        lead = self._lead()
+        batch = first.shape[0] // lead
+        if batch > 1 and not self.batched_ok():
+            per = [self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in inputs.items()}, 1), names, 1)
+                   for k in range(batch)]
+            return [torch.cat([p[i] for p in per]) for i in range(len(names))]
+        return self._collect(self._run_env(inputs, batch), names, batch)
+
+    @torch.no_grad()
+    def run(self, inputs):
+        return self._run_any(inputs, self.tensor_names)
 
     def _batch_major(self, name, t, batch):
         """Calibration tensors are handed on as [B, per-image...] contiguous.  A graph may carry the batch on
@@ -534,8 +588,5 @@ class GraphSession(ActivationSession):
 
     @torch.no_grad()
     def run_named(self, inputs, names):
-        first = inputs[self.input_names[0]]
-        lead = max(1, int(self.graph.get_tensor_shape(self.input_names[0])[0]))
-        env = self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names},
-                            first.shape[0] // lead)
-        return [env[n] for n in names]
+        """Chosen tensors by name, laid out like run()'s ([B, per-image ...], checked batching)."""
+        return self._run_any(inputs, list(names))

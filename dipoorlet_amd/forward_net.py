@@ -273,28 +273,59 @@ class ActivationCache:
         self.ed = args.data_num if ed is None else ed
         self.activation_cache = {}     # name -> [per-batch device tensors]
         self._filled = False
+        self._selective = False        # over the HBM budget: keep only the tensors asked for (one forward each)
+        self._sess = None
 
     def reset(self):
         self.activation_cache.clear()
         self._filled = False
 
-    def _fill(self):
-        sess = self.graph.make_session(self.args)
+    def _session(self):
+        if self._sess is None:
+            self._sess = self.graph.make_session(self.args)
+        return self._sess
+
+    def _sweep(self, keep):
+        """One batched forward of the shard; returns {name: [per-batch tensors]} for the names in `keep`."""
+        sess = self._session()
         dev = sess.device if hasattr(sess, "device") else torch.device("cuda", torch.cuda.current_device())
         shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
         batch = int(getattr(self.args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
-        per_name = {n: [] for n in sess.tensor_names}
+        per_name = {n: [] for n in sess.tensor_names if n in keep}
         for i in range(self.st, self.ed, batch):
             j = min(i + batch, self.ed)
             inputs = load_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, dev)
             for n, t in zip(sess.tensor_names, sess.run(inputs)):
-                per_name[n].append(t)
-        self.activation_cache = per_name
+                if n in per_name:
+                    per_name[n].append(t)
+        return per_name
+
+    def _fill(self):
+        """Everything resident if it fits the budget (args.resident_gb, default 160 GB of the 288) — else SELECTIVE mode:
+        a tensor's activations are produced when first asked for by one more forward of the shard that keeps only that
+        tensor (slower, bounded memory, same values)."""
+        sess = self._session()
+        need = 4.0 * sum(sess.elems_per_image) * max(0, self.ed - self.st)
+        budget = float(getattr(self.args, "resident_gb", 160.0) or 160.0) * 1e9
+        self._selective = need > budget
+        if self._selective:
+            logger.warning("ActivationCache: %.1f GB of activations exceed the %.0f GB budget: keeping tensors on demand",
+                           need / 1e9, budget / 1e9)
+            self.activation_cache = {}
+        else:
+            self.activation_cache = self._sweep(set(sess.tensor_names))
         self._filled = True
 
     def chunks(self, tensor_name):
         if not self._filled:
             self._fill()
+        if self._selective and tensor_name not in self.activation_cache:
+            one = 4.0 * self._session().elems_per_image[self._session().tensor_names.index(tensor_name)] * (self.ed - self.st)
+            held = sum(4.0 * t.numel() for v in self.activation_cache.values() for t in v)
+            budget = float(getattr(self.args, "resident_gb", 160.0) or 160.0) * 1e9
+            if held + one > budget:
+                self.activation_cache.clear()   # make room: the evicted tensors are re-produced if asked for again
+            self.activation_cache.update(self._sweep({tensor_name}))
         return self.activation_cache[tensor_name]
 
     def __getitem__(self, tensor_name):

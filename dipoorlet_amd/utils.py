@@ -82,10 +82,15 @@ def load_clip_val(args, act_fname="act_clip_val.json", weight_fname="weight_clip
     return act, wt
 
 
-def reduce_clip_val(rank_size, args, act_fname="act_clip_val.json", weight_fname="weight_clip_val.json"):
+def reduce_clip_val(rank_size, args, act_fname="act_clip_val.json", weight_fname="weight_clip_val.json", already_merged=False):
     """Rank-0 merge of the per-rank files `<fname>.rank<r>` (utils.py:326-345): minmax -> elementwise
-    min / max; hist and mse -> sum over ranks of value / rank_size (rank order); weights from rank 0."""
+    min / max; hist and mse -> sum over ranks of value / rank_size (rank order); weights from rank 0.
+    already_merged: every rank already holds the clips of the WHOLE calibration set (statistics merged over RCCL): rank 0's
+    files are the result as they are — averaging W identical values would only perturb the last fp64 bit (v / 6 * 6 != v)."""
     act, wt = load_clip_val(args, act_fname + ".rank0", weight_fname + ".rank0")
+    if already_merged:
+        save_clip_val(act, wt, args)
+        return
     mean_mode = args.act_quant != "minmax"
     w = float(rank_size)
     if mean_mode:
@@ -102,6 +107,39 @@ def reduce_clip_val(rank_size, args, act_fname="act_clip_val.json", weight_fname
             else:
                 act[k] = [np.array(min(v[0], act[k][0])), np.array(max(v[1], act[k][1]))]
     save_clip_val(act, wt, args)
+
+
+# ------------------------------------------------------------------ profiling result exchange (utils.py:371-412)
+def save_profiling_res(layer_cosine_dict, model_cosine_dict, args, layer_res_fname="layer_res.json",
+                       model_res_fname="model_res.json"):
+    """utils.py:371-383 — this rank's cosine tables as `<fname>.rank<r>` (the layer table only without --model_type)."""
+    rank = getattr(args, "rank", 0)
+    if getattr(args, "model_type", None) is None:
+        with open(os.path.join(args.output_dir, f"{layer_res_fname}.rank{rank}"), "w") as f:
+            json.dump(layer_cosine_dict, f, indent=4)
+    with open(os.path.join(args.output_dir, f"{model_res_fname}.rank{rank}"), "w") as f:
+        json.dump(model_cosine_dict, f, indent=4)
+
+
+def reduce_profiling_res(rank_size, args, layer_res_fname="layer_res.json", model_res_fname="model_res.json"):
+    """utils.py:386-412 — mean over ranks of the per-rank layer cosines and of the network outputs' mean cosine (each rank
+    weighted 1 / rank_size, summed in rank order), minimum over ranks of the outputs' worst cosine."""
+    def read(fname, r):
+        with open(os.path.join(args.output_dir, f"{fname}.rank{r}")) as f:
+            return json.load(f)
+    w = float(rank_size)
+    layer = {}
+    if getattr(args, "model_type", None) is None:
+        layer = {k: v / w for k, v in read(layer_res_fname, 0).items()}
+        for r in range(1, rank_size):
+            for k, v in read(layer_res_fname, r).items():
+                layer[k] += v / w
+    model = {k: [v[0] / w, v[1]] for k, v in read(model_res_fname, 0).items()}
+    for r in range(1, rank_size):
+        for k, v in read(model_res_fname, r).items():
+            model[k][0] += v[0] / w
+            model[k][1] = min(model[k][1], v[1])
+    return layer, model
 
 
 def setup_logger(args=None, level=logging.INFO):

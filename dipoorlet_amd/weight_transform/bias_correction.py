@@ -39,6 +39,57 @@ def _channel_mean_diff(fp_chunks, q_chunks, is_conv):
     return (acc / cnt).float()
 
 
+def update_conv_node_bias(graph_bc, node, fp_activations, q_activations):
+    """bias_correction.py:9-31 on device tensors: bias += mean(fp - q) over every axis but the channel one (Conv output
+    chunks [n, C, H, W], Gemm output chunks [n, C]); a node without a bias input gets `<node>_bias`.  Returns the
+    per-channel difference (fp32 device tensor) that was added.  `*_activations`: lists of per-chunk device tensors."""
+    diff = _channel_mean_diff(fp_activations, q_activations, node.op_type == "Conv")
+    bc_node = next(n for n in graph_bc.graph.node if n.name == node.name)
+    if len(bc_node.input) > 2:
+        bname = bc_node.input[2]
+        new_bias = graph_bc.get_initializer(bname).astype(np.float32) + diff.cpu().numpy()
+    else:
+        bname = node.name + "_bias"
+        new_bias = diff.cpu().numpy()
+        bc_node.input.append(bname)
+        graph_bc.input.append(bname)
+    graph_bc.set_initializer(bname, new_bias.astype(np.float32))
+    return diff
+
+
+def _frontier_peak_elems(graph, session):
+    """Largest number of live activation elements per image during a node-major walk (reference-count simulation over
+    the per-image tensor sizes the session inferred)."""
+    size = dict(zip(session.tensor_names, session.elems_per_image))
+    ref = {}
+    for node in graph.graph.node:
+        if node.name in session._folded:
+            continue
+        for i in node.input:
+            if i != "" and i not in session.consts:
+                ref[i] = ref.get(i, 0) + 1
+    for o in graph.network_outputs:
+        ref[o] = ref.get(o, 0) + 1
+    live = {n: size.get(n, 0) for n in graph.network_inputs}
+    peak = sum(live.values())
+    for node in graph.graph.node:
+        if node.name in session._folded:
+            continue
+        for o in node.output:
+            if o != "":
+                live[o] = size.get(o, size.get(node.input[0], 0) if node.input else 0)
+        peak = max(peak, sum(live.values()))
+        for i in node.input:
+            if i in ref:
+                ref[i] -= 1
+                if ref[i] == 0:
+                    live.pop(i, None)
+        for o in node.output:
+            if o not in ref:
+                live.pop(o, None)
+    return peak
+
+
 class _Frontier:
     """Activations of every live tensor for the whole calibration set, as lists of per-chunk tensors."""
 
@@ -97,6 +148,14 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
     bounds = [(i, min(i + chunk, N)) for i in range(0, N, chunk)]
     sizes = [j - i for i, j in bounds]
     shapes = {n: graph.get_tensor_shape(n) for n in graph.network_inputs}
+    # HBM budget: the two frontiers hold the WHOLE set's live activations.  Refuse up front with a plain message rather than
+    # die in the allocator halfway through (the other ranks would be left at the next barrier).
+    need = 4.0 * N * (_frontier_peak_elems(graph, s_fp) + _frontier_peak_elems(graph_q, s_q))
+    budget = float(getattr(args, "resident_gb", 160.0) or 160.0) * 1e9
+    if need > budget:
+        raise MemoryError(f"--bc keeps the live activations of all {N} images of both networks in HBM: about {need / 1e9:.0f} GB "
+                          f"at the widest point of this graph, over the {budget / 1e9:.0f} GB budget (--resident_gb); "
+                          f"lower -N for --bc or raise --resident_gb")
     fp, qf = _Frontier(s_fp, graph), _Frontier(s_q, graph_q)
     for n in graph.network_inputs:
         chunks = [load_input_batch(args.input_dir, [n], shapes, i, j, dev)[n] for i, j in bounds]
@@ -106,28 +165,19 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
     for node in graph_q.graph.node:
         if node.name in s_q._folded:
             continue
-        qf.run(node, len(bounds), sizes)
         if node.name not in fp_nodes:
+            qf.run(node, len(bounds), sizes)
             continue  # a FakeQuant node
         fp_node = fp_nodes[node.name]
         keep_fp = fp.env  # outputs needed below are still referenced until their consumers ran
-        fp.ref[fp_node.output[0]] = fp.ref.get(fp_node.output[0], 0) + 1  # hold the output for the diff
-        qf.ref[node.output[0]] = qf.ref.get(node.output[0], 0) + 1
+        fp.ref[fp_node.output[0]] = fp.ref.get(fp_node.output[0], 0) + 1  # hold both outputs for the diff BEFORE the nodes
+        qf.ref[node.output[0]] = qf.ref.get(node.output[0], 0) + 1        # run: an output nobody consumes is dropped at once
+        qf.run(node, len(bounds), sizes)
         fp.run(fp_node, len(bounds), sizes)
         out = node.output[0]
         if node.op_type in BIAS_CORRECTION_NODE_TYPE:
             logger.info("Update bias for node: {}".format(node.name))
-            diff = _channel_mean_diff(keep_fp[out], qf.env[out], node.op_type == "Conv")
-            bc_node = next(n for n in graph_bc.graph.node if n.name == node.name)
-            if len(bc_node.input) > 2:
-                bname = bc_node.input[2]
-                new_bias = graph_bc.get_initializer(bname).astype(np.float32) + diff.cpu().numpy()
-            else:  # bias_correction.py:24-31 — the node had no bias: add one
-                bname = node.name + "_bias"
-                new_bias = diff.cpu().numpy()
-                bc_node.input.append(bname)
-                graph_bc.input.append(bname)
-            graph_bc.set_initializer(bname, new_bias.astype(np.float32))
+            diff = update_conv_node_bias(graph_bc, node, keep_fp[out], qf.env[out])
             shape = [1, -1] + [1] * (qf.env[out][0].dim() - 2)
             for t in qf.env[out]:  # the bias is additive in the output: fix the computed q output in place
                 t.add_(diff.reshape(shape))

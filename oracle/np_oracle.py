@@ -259,6 +259,31 @@ def cos_similarity(a, b):
     return d / np.sqrt(np.square(a).sum()) / np.sqrt(np.square(b).sum())
 
 
+def bias_correction_delta(fp_stack, q_stack, is_conv):
+    """bias_correction.py:10-13 — stacks of per-image outputs [N, 1, C, H, W] (Conv) or [N, 1, C] (Gemm):
+    np.squeeze(fp - q, axis=1).mean(axis=(0, 2, 3) or 0)."""
+    d = np.stack(fp_stack, axis=0) - np.stack(q_stack, axis=0)
+    return np.squeeze(d, axis=1).mean(axis=(0, 2, 3) if is_conv else 0)
+
+
+def reduce_profiling_res(per_rank_layer, per_rank_model):
+    """utils.py:386-412 — per_rank_layer: list of {tensor: cos} (or None with --model_type); per_rank_model: list of
+    {output: [mean cos, min cos]}.  Ranks are weighted 1 / W in rank order; the minimum is taken over ranks."""
+    w = float(len(per_rank_model))
+    layer = {}
+    if per_rank_layer is not None:
+        layer = {k: v / w for k, v in per_rank_layer[0].items()}
+        for d in per_rank_layer[1:]:
+            for k, v in d.items():
+                layer[k] += v / w
+    model = {k: [v[0] / w, v[1]] for k, v in per_rank_model[0].items()}
+    for d in per_rank_model[1:]:
+        for k, v in d.items():
+            model[k][0] += v[0] / w
+            model[k][1] = min(model[k][1], v[1])
+    return layer, model
+
+
 # ------------------------------------------------------------------ a15: shard + merge
 def shard_range(data_num, rank, world_size):
     """forward_net.py:207-209 — contiguous floor split; the remainder images are dropped."""

@@ -82,3 +82,63 @@ def mini_net_activations(image_idx):
             x = make_tensor("relu", n, 77)
         out.append((name, x))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ auxiliary fixtures
+# (tests/golden/gen_golden_aux.py records what the REFERENCE computes for these; the tests rebuild the same inputs)
+def aux_cos_pair(i):
+    """Tensor pairs for cos_similarity (utils.py:273-278), incl. an exactly-zero dot product and an all-zero tensor."""
+    rng = np.random.default_rng(900 + i)
+    if i == 0:
+        a = rng.standard_normal(1000).astype(np.float32)
+        return a, (a + rng.standard_normal(1000).astype(np.float32) * np.float32(0.05)).astype(np.float32)
+    if i == 1:
+        a = rng.standard_normal((3, 4, 5)).astype(np.float32)
+        return a, (a * np.float32(0.9) + np.float32(0.01)).astype(np.float32)
+    if i == 2:
+        return np.array([1.0, 0.0, 2.0, 0.0], np.float32), np.array([0.0, 3.0, 0.0, -1.0], np.float32)   # dot == 0
+    if i == 3:
+        return np.zeros(64, np.float32), rng.standard_normal(64).astype(np.float32)
+    if i == 4:
+        a = rng.standard_normal(4096).astype(np.float32)
+        return a, a.copy()
+    if i == 5:
+        a = np.maximum(rng.standard_normal(150528), 0).astype(np.float32) * np.float32(3.0)
+        return a, (np.round(a / np.float32(0.05)) * np.float32(0.05)).astype(np.float32)
+    a = rng.standard_normal(2048).astype(np.float32)
+    return a, (-a + rng.standard_normal(2048).astype(np.float32) * np.float32(0.3)).astype(np.float32)
+
+
+def aux_stack(i, n, C, hw):
+    """fp / quantised activation stacks of one node over n images, each [1, C, H, W] (Conv) or [1, C] (Gemm)."""
+    rng = np.random.default_rng(700 + i)
+    shape = (n, 1, C) + (tuple(hw) if hw else ())
+    fp = rng.standard_normal(shape).astype(np.float32) * np.float32(2.0)
+    q = (fp + rng.standard_normal(shape).astype(np.float32) * np.float32(0.03) + np.float32(0.01)).astype(np.float32)
+    return fp, q
+
+
+# A 13-node graph that exercises every selection rule of quantize.py:20-108: merge-ReLU behind Conv / Add, a tensor
+# feeding two quantised nodes (dedupe), TensorRT's first-Conv-branch-of-an-Add rule, ConvTranspose weights, a two-input
+# Mul (RELU_TYPE but not merged), a PRelu fed by the network input (skipped), bias inputs, two network outputs.
+AUX_GRAPH = {
+    "inputs": ["data"],
+    "outputs": ["prob", "pr"],
+    "initializers": {"w1": 4, "b1": 4, "w2": 4, "w3": 4, "b3": 4, "wt": 4, "wf": 3, "bf": 3, "slope": 1},
+    "tensors": ["data", "c1", "r1", "p1", "c2", "c3", "a1", "r2", "d1", "m1", "g1", "logits", "prob", "pr"],
+    "nodes": [
+        {"name": "conv1", "op": "Conv", "in": ["data", "w1", "b1"], "out": ["c1"]},
+        {"name": "relu1", "op": "Relu", "in": ["c1"], "out": ["r1"]},
+        {"name": "pool", "op": "MaxPool", "in": ["r1"], "out": ["p1"]},
+        {"name": "conv2", "op": "Conv", "in": ["p1", "w2"], "out": ["c2"]},
+        {"name": "conv3", "op": "Conv", "in": ["p1", "w3", "b3"], "out": ["c3"]},
+        {"name": "add", "op": "Add", "in": ["c2", "c3"], "out": ["a1"]},
+        {"name": "relu_b", "op": "Relu", "in": ["a1"], "out": ["r2"]},
+        {"name": "deconv", "op": "ConvTranspose", "in": ["r2", "wt"], "out": ["d1"]},
+        {"name": "mul", "op": "Mul", "in": ["d1", "r2"], "out": ["m1"]},
+        {"name": "gap", "op": "AveragePool", "in": ["m1"], "out": ["g1"]},
+        {"name": "fc", "op": "Gemm", "in": ["g1", "wf", "bf"], "out": ["logits"]},
+        {"name": "sig", "op": "Sigmoid", "in": ["logits"], "out": ["prob"]},
+        {"name": "prelu", "op": "PRelu", "in": ["data", "slope"], "out": ["pr"]},
+    ],
+}

@@ -537,10 +537,13 @@ class GraphSession(ActivationSession):
                     one = self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in feeds.items()}, 1),
                                         self.tensor_names, 1)
                     for name, tb, t1 in zip(self.tensor_names, both, one):
-                        ref = t1.reshape(-1)
-                        got = tb[k].reshape(-1)
-                        tol = 1e-3 * float(ref.abs().max().clamp_min(1e-6))   # (library kernels may differ between batch sizes)
-                        if got.numel() != ref.numel() or float((got - ref).abs().max()) > tol:
+                        ref = t1.reshape(-1).double()
+                        got = tb[k].reshape(-1).double()
+                        # scrambled data is wrong by O(1); different library kernels for the two batch sizes by ~1e-4
+                        bad = got.numel() != ref.numel()
+                        if not bad:
+                            bad = float((got - ref).norm()) > 2e-2 * float(ref.norm()) + 1e-6
+                        if bad:
                             logger.warning("executor: batched execution of this graph differs from per-image execution at "
                                            "tensor %s: running one image at a time", name)
                             ok = False
@@ -560,7 +563,9 @@ class GraphSession(ActivationSession):
         if batch > 1 and not self.batched_ok():
             per = [self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in inputs.items()}, 1), names, 1)
                    for k in range(batch)]
-            return [torch.cat([p[i] for p in per]) for i in range(len(names))]
+            # [B, per-image ...] like the batched path: images stack on the leading 1 of the per-image shape, or on a new axis
+            return [torch.cat([p[i] for p in per]) if (per[0][i].dim() > 0 and per[0][i].shape[0] == 1)
+                    else torch.stack([p[i] for p in per]) for i in range(len(names))]
         return self._collect(self._run_env(inputs, batch), names, batch)
 
     @torch.no_grad()

@@ -183,3 +183,33 @@ def test_fold_batchnorm_keeps_the_function():
     path = graph.save_onnx_model("/tmp/_folded_bn_test")                # round-trips through the writer / reader
     again = GraphSession(ONNXGraph.load(path), device="cpu").run_named(inp, ["output"])[0]
     np.testing.assert_allclose(again.numpy(), ref[0].numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_batched_execution_is_verified_against_per_image():
+    """A graph exported for one image whose Reshape carries a literal NON-leading shape ([4, -1]) mixes the images of a
+    batch without raising.  The session notices (batch-2 forward != two batch-1 forwards), runs one image at a time from
+    then on, and a batched run() / run_named() returns what the per-image runs return; a well-behaved graph keeps batching."""
+    from dipoorlet_amd.onnx_io import Node
+    g = ONNXGraph()
+    g.graph.node = [Node("Relu", ["x"], ["r"], name="relu"),
+                    Node("Reshape", ["r", "shp"], ["y"], name="reshape"),
+                    Node("Mul", ["y", "k"], ["z"], name="mul")]
+    g.initializer = {"shp": np.array([4, -1], np.int64), "k": np.array(2.0, np.float32)}
+    g.network_inputs, g.network_outputs = ["x"], ["z"]
+    g.input = ["x", "shp", "k"]
+    g.tensor_name_shape_map = {"x": [1, 4, 6], "z": [4, 6]}
+    g.topologize_graph()
+    g.set_index()
+    s = GraphSession(g, device="cpu")
+    x = torch.randn(3, 4, 6)
+    outs = s.run({"x": x})
+    assert s._batched_ok is False
+    for k in range(3):
+        one = s.run({"x": x[k:k + 1]})
+        for name, tb, t1 in zip(s.tensor_names, outs, one):
+            assert torch.equal(tb[k:k + 1].reshape(t1.shape), t1), name
+    named = s.run_named({"x": x}, ["z"])[0]
+    assert torch.equal(named, torch.stack([s.run_named({"x": x[k:k + 1]}, ["z"])[0] for k in range(3)]))
+    ok = GraphSession(models.resnet18(), device="cpu")
+    ok.run({n: torch.randn(2, *ok.graph.get_tensor_shape(n)[1:]) for n in ok.input_names})
+    assert ok._batched_ok is True

@@ -1,0 +1,156 @@
+"""GPU: BASELINE.json's configurations at their STATED sizes.
+
+  configs[0]  ResNet-18 ONNX at 224 x 224, -A minmax, N = 32 .bin images, through the CLI; clips against the oracle on the
+              activations the run's own forward produced.
+  configs[1]  ResNet-50 activation set, -A hist --bins 2048, N = 1024: both passes accumulated over 32 batches of 32 (+ a
+              ragged last batch variant), size-independent properties in u64 and oracle spot checks.
+  configs[2]  ResNet-50 activation set, -A mse, N = 256 + a ragged batch through ops.octav_batch (one-read form with its
+              prediction warming up over the batches): min / max exact, OCTAV rows against the oracle on sampled pairs.
+(configs[3] / [4] need 8 GPUs: not available to the test box; tests/test_multirank_gpu.py covers two ranks.)"""
+import json
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b):
+    return np.allclose(a, b, rtol=1e-5, atol=1e-5, equal_nan=True)
+
+
+def test_config0_resnet18_224_minmax_n32_cli(tmp_path):
+    from dipoorlet_amd import models
+    from dipoorlet_amd.__main__ import main
+    from dipoorlet_amd.executor import GraphSession
+    N = 32
+    g = models.resnet18(seed=3, image=224)
+    g.output_dir = str(tmp_path)
+    g.save_onnx_model("r18")
+    os.makedirs(tmp_path / "calib" / "input")
+    rng = np.random.default_rng(18)
+    for i in range(N):
+        rng.standard_normal(3 * 224 * 224).astype(np.float32).tofile(tmp_path / "calib" / "input" / f"{i}.bin")
+    lo, hi = {}, {}
+    orig = GraphSession.run
+
+    def spy(self, inputs):   # running oracle min / max of exactly what the calibration forward produced
+        res = orig(self, inputs)
+        for n, t in zip(self.tensor_names, res):
+            x = t.cpu().numpy()
+            a, b = O.minmax(x.reshape(-1))
+            lo[n] = min(lo.get(n, a), a)
+            hi[n] = max(hi.get(n, b), b)
+        return res
+    GraphSession.run = spy
+    try:
+        rc = main(["-M", str(tmp_path / "r18.onnx"), "-I", str(tmp_path / "calib"), "-N", str(N), "-A", "minmax", "-D", "trt",
+                   "-O", str(tmp_path / "out"), "--calib_batch", "16", "--skip_profiling"])
+    finally:
+        GraphSession.run = orig
+    assert rc == 0
+    act = json.load(open(tmp_path / "out" / "act_clip_val.json"))
+    assert len(act) == 50 and set(act) == set(lo)                      # 50 tensors per image
+    for n in act:
+        assert act[n] == [float(lo[n]), float(hi[n])], n              # bit exact
+    trt = json.load(open(tmp_path / "out" / "trt_clip_val.json"))["blob_range"]
+    assert all(trt[n] == max(-act[n][0], act[n][1]) for n in act)
+
+
+@pytest.fixture(scope="module")
+def r50_pool():
+    from dipoorlet_amd.synthetic import resnet50_tensors, synth_activations
+    dev = torch.device("cuda:0")
+    spec = resnet50_tensors()
+    pool = [synth_activations(spec, 32, dev, seed=4242 + j) for j in range(3)]     # 3 x 3.4 GB
+    return dev, spec, pool
+
+
+def test_config1_resnet50_hist_n1024(r50_pool):
+    from dipoorlet_amd import ops
+    dev, spec, pool = r50_pool
+    elems = [e for _, e, _ in spec]
+    T, E = len(elems), sum(elems)
+    plan = ops.TensorSetPlan(elems, 32, dev)
+    n_batches = 32                                                   # N = 1024
+    acc = ops.CalibAccumulators(T, dev, 2048)
+    for b in range(n_batches):
+        acc.minmax_accumulate(plan, pool[b % 3])
+    gmin, gmax = acc.finalize_minmax()
+    # ranges against torch's own reductions over the pool
+    tmin = torch.stack([torch.stack([p[t].min() for p in pool]).min() for t in range(T)])
+    tmax = torch.stack([torch.stack([p[t].max() for p in pool]).max() for t in range(T)])
+    assert torch.equal(gmin, tmin) and torch.equal(gmax, tmax)
+    acc.hist_prepare()
+    for b in range(n_batches):
+        acc.abs_hist_accumulate(plan, pool[b % 3])
+    hist = acc.hist.cpu().numpy().astype(np.uint64)
+    per_tensor = hist.sum(1)
+    assert [int(v) for v in per_tensor] == [e * 32 * n_batches for e in elems]          # nothing dropped, nothing doubled
+    assert int(per_tensor.sum()) == E * 1024                                            # checksum of checksums
+    # linearity: 32 batches cycle a 3-batch pool = 11 x pool[0] + 11 x pool[1] + 10 x pool[2]
+    for t in (0, 5, 60, 122):
+        lo, hi = float(gmin[t]), float(gmax[t])
+        one = [O.abs_hist(pool[j][t].cpu().numpy().reshape(-1), 2048, O.hist_dmax(np.float32(lo), np.float32(hi))) for j in range(3)]
+        want = 11 * one[0].astype(np.uint64) + 11 * one[1].astype(np.uint64) + 10 * one[2].astype(np.uint64)
+        assert np.array_equal(hist[t], want), t
+    clip = acc.hist_percentile(0.99999).cpu().numpy()
+    for t in (0, 5, 60, 122):
+        want = O.hist_percentile(hist[t].astype(np.int64), np.float32(gmin[t].item()), np.float32(gmax[t].item()), 2048, 0.99999)
+        assert clip[t].view(np.uint32).tolist() == np.asarray(want, np.float32).view(np.uint32).tolist(), t
+    # ragged last batch at this scale: 7 more images through a second plan on the same accumulators' ranges
+    plan7 = ops.TensorSetPlan(elems, 7, dev)
+    before = acc.hist.clone()
+    acc.abs_hist_accumulate(plan7, [x[:7].contiguous() for x in pool[1]])
+    delta = (acc.hist - before).sum(1).cpu().numpy()
+    assert [int(v) for v in delta] == [e * 7 for e in elems]
+
+
+def test_config2_resnet50_mse_n256_plus_ragged(r50_pool):
+    from dipoorlet_amd import ops
+    dev, spec, pool = r50_pool
+    elems = [e for _, e, _ in spec]
+    T = len(elems)
+    plan = ops.TensorSetPlan(elems, 32, dev)
+    rows = []
+    for b in range(8):                                              # N = 256: the prediction warms up over the batches
+        rows.append(ops.octav_batch(plan, pool[b % 3], False).clone())
+    plan5 = ops.TensorSetPlan(elems, 5, dev)
+    rows.append(ops.octav_batch(plan5, [x[10:15].contiguous() for x in pool[2]], False).clone())
+    allr = torch.cat(rows).cpu().numpy()
+    assert allr.shape == (261, T, 3) and np.isfinite(allr).all()
+    # the same batch seen again (b = 0, 3, 6 are pool[0]): batch 0 had no prediction (every multi-slice pair took the
+    # compaction route, fp32 partial sums), batches 3 and 6 walked from the gathered bins (exact integer sums).  Both follow
+    # the reference's iterate sequence; an iterate may differ in its last bit, the fixed point it lands on hardly ever does.
+    assert np.array_equal(allr[96:128], allr[192:224])
+    assert np.array_equal(allr[0:32, :, 1:], allr[96:128, :, 1:])
+    rel = np.abs(allr[0:32, :, 0] - allr[96:128, :, 0]) / np.abs(allr[96:128, :, 0])
+    assert rel.max() <= 2e-7 and (rel > 0).mean() < 0.01, (rel.max(), (rel > 0).mean())
+    # min / max exact against torch for every pair of one late batch
+    late = pool[7 % 3]
+    got = allr[7 * 32:8 * 32]
+    for t in range(T):
+        assert np.array_equal(got[:, t, 1], late[t].min(1).values.cpu().numpy()), t
+        assert np.array_equal(got[:, t, 2], late[t].max(1).values.cpu().numpy()), t
+    # OCTAV scale against the oracle: every tensor size class, early (no prediction), late and ragged batches
+    rng = np.random.default_rng(3)
+    picks = [(0, 0), (0, 1), (0, 122), (7, 1), (7, 30), (7, 77)] + [(int(rng.integers(1, 8)), int(rng.integers(0, T))) for _ in range(10)]
+    for b, t in picks:
+        k = int(rng.integers(0, 32))
+        x = pool[b % 3][t][k].cpu().numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = O.octav_scale(x, 1)
+        assert _close(allr[b * 32 + k, t, 0], s), (b, t, k, allr[b * 32 + k, t], s)
+    for t in (2, 50, 121):
+        for k in range(5):
+            x = pool[2][t][10 + k].cpu().numpy()
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                s = O.octav_scale(x, 1)
+            assert _close(allr[256 + k, t, 0], s), (t, k)

@@ -225,14 +225,30 @@ def test_vit_calibration_mse_and_cli_bc(tmp_path):
         x.tofile(tmp_path / "calib" / "input" / f"{i}.bin")
     args = types.SimpleNamespace(input_dir=str(tmp_path / "calib"), data_num=6, rank=0, local_rank=0, world_size=1,
                                  deploy="trt", calib_batch=4)
-    stats = forward_net_octav(g, args)
-    s1 = g.make_session()
-    for i, x in enumerate(imgs):  # image by image, batch 1: the reference's own schedule
-        outs = s1.run({"input": torch.from_numpy(x).reshape(1, 3, 32, 32).cuda()})
-        for n, t in zip(s1.tensor_names, outs):
-            ref_s = O.octav_scale(t.cpu().numpy(), 1)
-            assert np.isclose(stats[n]["optimal_s"][i], ref_s, rtol=2e-4, atol=1e-5), (n, i)
-            assert np.isclose(stats[n]["max"][i], t.max().item(), rtol=1e-4, atol=1e-5)
+    # record, on the host, exactly the activations the calibration forward produced (batch 4 then batch 2): OCTAV is then
+    # held to the north-star tolerance, 1e-5, instead of absorbing the difference between a batched and a batch-1 forward
+    from dipoorlet_amd.executor import GraphSession
+    rec = {}
+    orig = GraphSession.run
+
+    def spy(self, inputs):
+        res = orig(self, inputs)
+        for n, t in zip(self.tensor_names, res):
+            rec.setdefault(n, []).extend(x.reshape(-1) for x in t.cpu().numpy())
+        return res
+    GraphSession.run = spy
+    try:
+        stats = forward_net_octav(g, args)
+    finally:
+        GraphSession.run = orig
+    assert all(len(v) == 6 for v in rec.values())
+    for n, per_img in rec.items():
+        for i, x in enumerate(per_img):
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                ref_s = O.octav_scale(x, 1)
+            assert np.isclose(stats[n]["optimal_s"][i], ref_s, rtol=1e-5, atol=1e-5), (n, i, stats[n]["optimal_s"][i], ref_s)
+            assert stats[n]["max"][i] == x.max() and stats[n]["min"][i] == x.min(), (n, i)
     rc = main(["-M", str(tmp_path / "vit.onnx"), "-I", str(tmp_path / "calib"), "-N", "6", "-A", "mse", "-D", "trt", "-O",
                str(tmp_path / "out"), "--calib_batch", "4", "--bc"])
     assert rc == 0

@@ -276,16 +276,24 @@ def main():
     # ------------------------------------------------------------------ the line
     kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once
     achieved = kernel_bytes / (hist_kern_ms * 1e-3) / 1e9 if hist_kern_ms > 0 else 0.0
-    traffic = None                                             # measured by scripts/profile_gpu.sh (rocprofv3 --pmc), never a constant
-    tj = os.environ.get("DPL_TRAFFIC_JSON")
-    if tj and os.path.exists(tj):
+    # HBM bytes per launch by the PMC counters (scripts/profile_gpu.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    # this very script).  Quoted only when the record was measured on the kernel sources this run uses (sha over csrc/), else null.
+    def measured_traffic(kernel):
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r02", "traffic.json"))
         try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from summarize_prof import source_sha
             with open(tj) as f:
                 tr = json.load(f)
-            if tr.get("kernel") == "k_abs_hist" and tr.get("batch") == B:
-                traffic = tr.get("hbm_bytes_per_launch")
+            if tr.get("source_sha") == source_sha() and tr.get("batch") == B:
+                return tr["kernels"][kernel]["hbm_bytes_per_launch"]
         except Exception:
-            traffic = None
+            pass
+        return None
+    traffic = measured_traffic("k_abs_hist")
+    if mse is not None:
+        t1, t2 = measured_traffic("k_octav_oneread"), measured_traffic("k_octav_walk")
+        mse["roofline"]["traffic"] = (t1 + t2) if (t1 is not None and t2 is not None) else None
     images = N_HIST * world * a.steps
     hist_rate = images / dt_hist
     headline_mse = a.algo == "mse" and mse is not None

@@ -52,7 +52,7 @@ constexpr int kVec = DPL_RES_VEC;                               // 16-byte vecto
 constexpr uint32_t kWalkCap = (uint32_t)kThreads * kVec * 4;    // list values the walk holds in registers (20 480)
 constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this small gather their whole window (no prediction)
 #ifndef DPL_SLICE_CAP
-#define DPL_SLICE_CAP 131072
+#define DPL_SLICE_CAP 262144
 #endif
 constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
 static_assert(kCap < (1u << 20) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed 20-bit field");
@@ -191,7 +191,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
         uint32_t base = 0u;
         if (lane == kWave - 1) base = add_agent(cursor, total);
         base = __shfl(base, kWave - 1, kWave) + inc - qn;
-        for (uint32_t j = 0; j < qn; ++j) st_agent(dst + base + j, myq[j * kWave]);
+        for (uint32_t j = 0; j < qn; ++j) dst[base + j] = myq[j * kWave];   // plain stores: the walk is a later launch, L2 may combine the lines
         qn = 0u;
     };
     // one element: key = 14 bits of exponent and top mantissa (shared by the histogram bin and the bitmap lookup)
@@ -329,6 +329,22 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
             }
         }
     }
+}
+
+// wave64 sum by DPP (row-local butterflies, then the two row broadcasts): ~6 VALU instead of six dependent ds_bpermute round
+// trips; the total arrives in lane 63 and is broadcast from there
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {   // per-lane values below 2^56
+    const uint32_t lo = wave_sum_dpp((uint32_t)v & 0xFFFFFFu), hi = wave_sum_dpp((uint32_t)(v >> 24));
+    return (unsigned long long)lo + ((unsigned long long)hi << 24);
 }
 
 // The exact walk of one pair (one workgroup per pair, largest pairs first): suffix totals of the pair's merged row (the row is
@@ -479,9 +495,8 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
                 }
                 msum += (unsigned long long)ms;
             }
-            c = wave_sum(c);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) msum += __shfl_xor(msum, o, kWave);
+            c = wave_sum_dpp(c);
+            msum = wave_sum64(msum);
             if (lane == 0) {
                 sh.part_c[par][w] = c;
                 sh.part_m[par][w] = msum;

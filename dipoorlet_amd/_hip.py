@@ -72,7 +72,7 @@ SIGNATURES = {
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
     "dpl_octav_slice_cap": (C.c_uint32, []),
-    "dpl_build_octav_slices": (_I64, [_P, _I64, _P, _I64]),
+    "dpl_build_octav_slices": (_I64, [_P, _I64, _P, _I64, _P]),
     "dpl_octav_run_oneread": (C.c_int, [_P, _I64, _P, _P, _P, _P, C.c_int, C.c_int, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P,
                                         _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
@@ -157,18 +157,19 @@ def build_balanced_items(spans, n_blocks):
 
 
 def build_octav_slices(spans):
-    """HOST: spans (one per (image, tensor) pair) -> (WorkItem array, n_slices), largest pairs first, or None when a pair is
-    too large for the one-read form (more than 64 slices)."""
+    """HOST: spans (one per (image, tensor) pair, slots 0 .. n-1) -> (WorkItem array, n_slices, pair_slice0 uint32 [n, 2]),
+    largest pairs first, or None when a pair is too large for the one-read form (more than 64 slices)."""
     arr, ns = _span_array(spans)
-    n = lib().dpl_build_octav_slices(C.addressof(arr), ns, None, 0)
+    n = lib().dpl_build_octav_slices(C.addressof(arr), ns, None, 0, None)
     if n == -3:
         return None
     if n < 0:
         check(int(n), "dpl_build_octav_slices")
     out = (WorkItem * max(n, 1))()
-    n2 = lib().dpl_build_octav_slices(C.addressof(arr), ns, C.addressof(out), n)
+    ps = (C.c_uint32 * (2 * max(ns, 1)))()
+    n2 = lib().dpl_build_octav_slices(C.addressof(arr), ns, C.addressof(out), n, C.addressof(ps))
     assert n2 == n
-    return out, int(n)
+    return out, int(n), ps
 
 
 def build_work_items(spans, chunk_elems):

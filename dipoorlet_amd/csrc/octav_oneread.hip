@@ -266,7 +266,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
 // then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
 __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
-    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ pred, uint32_t n_tensors,
+    unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pred, uint32_t n_tensors,
     const uint64_t* __restrict__ pair_base, float* __restrict__ list0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
@@ -280,7 +280,6 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     dpl_octav_state* me = st + pair;
     const float* pg = segs[it.seg] + it.offset;
     const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
-    const bool big = n_sl >= kBigCluster;
     const uint32_t tensor = pair % n_tensors;
     for (int b = tid; b < kLogNB; b += kThreads) l_packed[b] = 0ull;
     for (int i = tid; i < kKeyWords; i += kThreads) {   // the bins to gather: what this tensor's iterates visited lately
@@ -294,8 +293,6 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
 
     // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
-    unsigned long long* row = lh + (uint64_t)pair * kLogNB;
-    uint32_t* row_cnt = lh_cnt + (uint64_t)pair * kLogNB;
     if (tid == 0) {
         float tmn = INFINITY, tmx = -INFINITY;
         uint32_t tnz = 0u, tnan = 0u;
@@ -318,17 +315,10 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
         }
         if (tnan) atomicOr(&me->nan_seen, 1u);
     }
-    for (int b = tid; b < kLogNB; b += kThreads) {
-        const unsigned long long hv = l_packed[b];
-        if (hv) {
-            if (big) {
-                add_agent(row + b, hv & kPackMask);
-                add_agent(row_cnt + b, (uint32_t)(hv >> kPackShift));
-            } else {
-                add_agent(row + b, hv);
-            }
-        }
-    }
+    // the slice's histogram goes out as ONE row of plain, coalesced stores (16 KiB, empty bins included: nothing to zero
+    // beforehand, no read-modify-write at the memory side); the walk adds up the rows of a pair's slices
+    unsigned long long* row = lh + (uint64_t)blockIdx.x * kLogNB;
+    for (int b = tid; b < kLogNB; b += kThreads) row[b] = l_packed[b];
 }
 
 // wave64 sum by DPP (row-local butterflies, then the two row broadcasts): ~6 VALU instead of six dependent ds_bpermute round
@@ -353,7 +343,7 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 // the bins it stepped into (or, when it left the gathered set, the pair's bracket) for the next batches.
 __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
-    unsigned long long* __restrict__ lh, uint32_t* __restrict__ lh_cnt, const uint32_t* __restrict__ pred,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, int dynamic_sym, int max_iters, int fail_every) {
     __shared__ double s_ge[kLogNB];
@@ -367,31 +357,33 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     const unsigned long long n_pair = me->n_elems;
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const bool small = n_pair <= (unsigned long long)kWalkCap;
-    const bool big = n_pair > (unsigned long long)(kBigCluster - 1u) * kCap;   // as the slices decided (cluster size)
     const uint32_t tensor = pair % n_tensors;
-    unsigned long long* row = lh + (uint64_t)pair * kLogNB;
-    uint32_t* row_cnt = lh_cnt + (uint64_t)pair * kLogNB;
-    // merged per-bin totals -> LDS (own bins per thread); the pair's row is handed back zeroed
+    // per-bin totals = the sum of the pair's slice rows -> LDS (own bins per thread)
     {
         constexpr int kPerT = kLogNB / kThreads;
         const int hi = kLogNB - 1 - (int)tid * kPerT;
-        unsigned long long raw[kPerT];
-        uint32_t rc[kPerT];
+        const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
+        uint32_t cnt[kPerT];
+        unsigned long long mant[kPerT];
 #pragma unroll
         for (int qq = 0; qq < kPerT; ++qq) {
-            const int b = hi - qq;
-            raw[qq] = row[b];
-            rc[qq] = big ? row_cnt[b] : 0u;
-            if (raw[qq]) row[b] = 0ull;
-            if (big && rc[qq]) row_cnt[b] = 0u;
+            cnt[qq] = 0u;
+            mant[qq] = 0ull;
+        }
+        for (uint32_t sl = sl0; sl < sl1; ++sl) {
+            const unsigned long long* row = lh + (uint64_t)sl * kLogNB;
+#pragma unroll
+            for (int qq = 0; qq < kPerT; ++qq) {
+                const unsigned long long v = row[hi - qq];
+                cnt[qq] += (uint32_t)(v >> kPackShift);
+                mant[qq] += v & kPackMask;
+            }
         }
 #pragma unroll
         for (int qq = 0; qq < kPerT; ++qq) {
             const int b = hi - qq;
-            const uint32_t c = big ? rc[qq] : (uint32_t)(raw[qq] >> kPackShift);
-            const unsigned long long m = big ? raw[qq] : (raw[qq] & kPackMask);
-            n_ge[b] = c;
-            s_ge[b] = bin_sum(m, c, b);
+            n_ge[b] = cnt[qq];
+            s_ge[b] = bin_sum(mant[qq], cnt[qq], b);
         }
         suffix_in_place(n_ge, s_ge, sh);
     }
@@ -635,7 +627,7 @@ int dpl_res_prof_read(unsigned long long* host_out, int reset) {   // tuning bui
 
 uint32_t dpl_octav_slice_cap(void) { return kCap; }
 
-int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap) {
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0) {
     if (!spans || n_spans < 0) return fail_msg("dpl_build_octav_slices: bad arguments");
     // largest pairs first: the long ones start at once, the short ones fill the tail of the launch
     int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_spans > 0 ? n_spans : 1));
@@ -664,11 +656,18 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_
     }
     if (out && n_total <= cap) {
         int64_t p = 0;
+        // pair_slice0[2 slot], [2 slot + 1]: first and one-past-last slice of the pair in slot `slot` (slots 0 .. n_spans-1)
+        if (pair_slice0)
+            for (int64_t i = 0; i < 2 * n_spans; ++i) pair_slice0[i] = 0u;
         for (int64_t oi = 0; oi < n_spans; ++oi) {
             const dpl_span& sp = spans[order[oi]];
             if (sp.count == 0) continue;
             const uint64_t c = (sp.count + kCap - 1) / kCap;
             const uint64_t per = (((sp.count + c - 1) / c) + 3) & ~3ull;   // equal slices, cut on multiples of 4 elements
+            if (pair_slice0 && sp.slot < (uint64_t)n_spans) {
+                pair_slice0[2 * sp.slot] = (uint32_t)p;
+                pair_slice0[2 * sp.slot + 1] = (uint32_t)(p + (int64_t)c);
+            }
             uint64_t off = 0;
             for (uint64_t j = 0; j < c; ++j) {
                 const uint64_t take = (j + 1 == c) ? sp.count - off : per;
@@ -686,7 +685,7 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_
     return n_total;
 }
 
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, uint32_t* d_lh_cnt, uint32_t* d_vis,
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh, uint32_t* d_vis,
                           uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
                           int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
                           dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
@@ -694,7 +693,7 @@ int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, uint6
                           dpl_stream_t s) {
     if (n_slices <= 0 || n_pairs <= 0) return 0;
     if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_run_oneread: bad tensor count / epoch");
-    if (!d_lh || !d_lh_cnt || !d_vis || !d_pred) return fail_msg("dpl_octav_run_oneread: null scratch buffer");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred) return fail_msg("dpl_octav_run_oneread: null scratch buffer");
     if (int e = check_blocks("dpl_octav_run_oneread", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
     dpl_octav_state* ctl = d_states + n_pairs;
@@ -705,10 +704,10 @@ int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, uint6
     hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, st, d_states, n_pairs, d_vis_w, d_vis_o,
                        d_pred, vis_words, reset_epoch);
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB + kLdsKey), st, d_slices,
-                       d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_pred,
+                       d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_pred,
                        (uint32_t)n_tensors, d_pair_base, d_list0);
     hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, st, d_states, ctl, d_pair_order,
-                       reinterpret_cast<unsigned long long*>(d_lh), d_lh_cnt, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base,
+                       reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base,
                        d_list0, dynamic_sym, max_iters, g_exact_fail_every);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     if (max_iters > 0)

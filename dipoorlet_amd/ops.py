@@ -134,18 +134,17 @@ class TensorSetPlan:
 
     def octav_oneread_scratch(self):
         """Work decomposition, scratch and prediction state of the one-read OCTAV form, or None when a pair is too large
-        for it: dict(slices, n_slices, lh, lh_cnt, vis [2, T, 64], pred [T, 64], calls)."""
+        for it: dict(slices, n_slices, pair_slice0, lh, vis [2, T, 64], pred [T, 64], calls)."""
         if getattr(self, "_octav_one", None) is None:
             built = _hip.build_octav_slices(self._spans(True))
             if built is None:
                 self._octav_one = False
             else:
-                arr, n = built
-                n_pairs = self.n_pairs
+                arr, n, ps = built
                 self._octav_one = dict(
                     slices=_upload_struct_array(arr, n, self.device), n_slices=n,
-                    lh=torch.zeros(n_pairs, 2048, dtype=torch.int64, device=self.device),    # handed back zeroed by every run
-                    lh_cnt=torch.zeros(n_pairs, 2048, dtype=torch.int32, device=self.device),
+                    pair_slice0=torch.frombuffer(bytearray(bytes(ps)), dtype=torch.int32).to(self.device),
+                    lh=torch.empty(n, 2048, dtype=torch.int64, device=self.device),    # one histogram row per slice
                     # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
                     vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
                     pred=torch.zeros(self.T, 64, dtype=torch.int32, device=self.device), calls=0)
@@ -292,7 +291,7 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
         k = res["calls"]
         res["calls"] = k + 1
         epoch, first = divmod(k, _ONEREAD_EPOCH)
-        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["lh"]), _ptr(res["lh_cnt"]),
+        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["lh"]),
                                            _ptr(res["vis"]), _ptr(res["pred"]), epoch % 2, 1 if first == 0 else 0, plan.T,
                                            *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base), _ptr(order),
                                            _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),

@@ -161,16 +161,17 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  * to the compaction route (d_items .. d_list1 as for dpl_octav_run_bracket; always the case for a tensor's first batch:
  * start with d_vis zeroed); pairs of at most 2048 elements gather their whole window and never need a prediction.
  *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
- *     of 4 elements); item.reserved = the pair's slice count.  Returns the slice count (call with out = NULL to size), -3
- *     when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
- *   d_lh: uint64 [n_pairs, 2048] and d_lh_cnt: uint32 [n_pairs, 2048]: merged histogram rows, ZERO before the first call;
- *     every call hands them back zeroed;
+ *     of 4 elements); item.reserved = the pair's slice count; pair_slice0[2 slot], [2 slot + 1] = first / one-past-last
+ *     slice of the pair in slot `slot` (spans carry slots 0 .. n_spans-1).  Returns the slice count (call with out = NULL
+ *     to size), -3 when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
+ *   d_lh: uint64 [n_slices, 2048] scratch: every slice writes its histogram row in full (plain coalesced stores, no
+ *     read-modify-write, nothing to zero); the walk adds up the rows of a pair's slices;
  *   d_vis: uint32 [2, n_tensors, 64] epoch accumulators (slot = image * n_tensors + tensor); this batch's walks add to
  *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 64] scratch.
  * Initialises d_states itself (no dpl_octav_init call). */
 uint32_t dpl_octav_slice_cap(void);
-int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap);
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, uint32_t* d_lh_cnt, uint32_t* d_vis,
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh, uint32_t* d_vis,
                           uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
                           int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
                           dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,

@@ -56,6 +56,7 @@ constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this sm
 #endif
 constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
 static_assert(kCap < (1u << 20) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed 20-bit field");
+constexpr int kRareTiles = (int)(kCap / (kWaves * 1024u)) + 1;   // tiles of a slice one wave walks (+ the ragged one)
 constexpr int kQueueCap = 12;                                   // per-lane survivor queue; flushed above cap - 4
 constexpr int kQueueStride = kQueueCap + 1;
 constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;         // bitmap over every 14-bit key: 512 words
@@ -90,7 +91,9 @@ __device__ unsigned long long g_res_prof[4096 * 8];
 #define DPL_PROF_ADD(slot, a, b) do { if (threadIdx.x == 0) g_res_prof[(blockIdx.x & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
 #define DPL_PROF_WAVE(idx, slot, a, b) do { if ((threadIdx.x & 63u) == 0) g_res_prof[((idx) & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
 __device__ __forceinline__ void g_prof_iters_add(uint32_t b, uint32_t it) { g_res_prof[(b & 4095u) * 8 + 7] += it; }
+#define DPL_PROF_L(len) g_res_prof[(blockIdx.x & 4095u) * 8 + 6] += (len)
 #else
+#define DPL_PROF_L(len) do {} while (0)
 __device__ __forceinline__ void g_prof_iters_add(uint32_t, uint32_t) {}
 #define DPL_PROF_T(var) do {} while (0)
 #define DPL_PROF_ADD(slot, a, b) do {} while (0)
@@ -104,13 +107,14 @@ struct Shared {
     unsigned long long part_m[2][kWaves];   // walk: the waves' partial (count, mantissa sum), two alternating slots
     uint32_t part_c[2][kWaves];
     float red_mn[kWaves], red_mx[kWaves];
+    uint32_t rare_tiles[kWaves * kRareTiles];   // streaming kernel: tiles holding a non-zero value outside the window
     uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
     uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
     uint32_t item, last, any_pred, fetched;
     OctavStep step;
     int jb;
     uint32_t bad, route;
-    float s0, ud;
+    float s0, ud, w_s;
     double s_above;
     unsigned long long n_above, n_elems;
 };
@@ -188,37 +192,41 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
             if (lane >= (uint32_t)o) inc += t;
         }
         const uint32_t total = __shfl(inc, kWave - 1, kWave);
+        // global (address space 1) accesses, not flat ones: a pending FLAT operation may complete out of order with the tile
+        // loads and then the compiler can only wait with vmcnt(0) — i.e. for the NEXT tile's loads it has just issued — before
+        // it touches the current tile: the software pipeline of for_each_tile would be gone
+#ifdef DPL_FLUSH_FLAT
+        typedef uint32_t* gptr_u32;
+#else
+        typedef __attribute__((address_space(1))) uint32_t* gptr_u32;
+#endif
+        gptr_u32 gdst = (gptr_u32)dst;
         uint32_t base = 0u;
-        if (lane == kWave - 1) base = add_agent(cursor, total);
+        if (lane == kWave - 1) base = __hip_atomic_fetch_add((gptr_u32)cursor, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base = __shfl(base, kWave - 1, kWave) + inc - qn;
-        for (uint32_t j = 0; j < qn; ++j) dst[base + j] = myq[j * kWave];   // plain stores: the walk is a later launch, L2 may combine the lines
+        for (uint32_t j = 0; j < qn; ++j) gdst[base + j] = myq[j * kWave];   // plain stores: the walk is a later launch, L2 may combine the lines
         qn = 0u;
     };
-    // one element: key = 14 bits of exponent and top mantissa (shared by the histogram bin and the bitmap lookup)
-    auto one = [&](float x, uint32_t& hit, uint32_t& a) {
-        const uint32_t bits = __float_as_uint(x);
-        a = bits & 0x7FFFFFFFu;
-        const uint32_t key = a >> kLogShift;
-        const uint32_t t = key - (kLogKey0 + 1u);
-        hit = (keybm[key >> 5] >> (key & 31u)) & 1u;
-        if (t < (uint32_t)(kLogNB - 1)) {
-            // window bins 1 .. kLogNB-1 carry {count, 23 explicit mantissa bits} (as LogHistOp, octav_kernels.hip)
-            atomicAdd(l_packed + t + 1u, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu));
-        } else if (__any(a != 0u)) {   // nonzero values outside the window (rare) are accumulated directly
-            const float f = __uint_as_float(a);
-            if (f > 0.0f) {
-                sum += (double)f;
-                ++nz;
-            }
-            nan |= (f != f);
-        }
-    };
+    // Four elements at a time, straight-line: the four bitmap words are requested first (one wait for all of them, after the
+    // histogram atomics have been issued), the histogram atomic is predicated per lane, and the rare non-zero value outside the
+    // window (or NaN) only leaves a per-lane mark that is looked at once per tile (`rare_tile`).
+    // key = 14 bits of exponent and top mantissa, shared by the histogram bin and the bitmap lookup.
+    uint32_t rare = 0u;
     auto eat4 = [&](const f4& t4) {
-        uint32_t h0, h1, h2, h3, a0, a1, a2, a3;
-        one(t4.x, h0, a0);
-        one(t4.y, h1, a1);
-        one(t4.z, h2, a2);
-        one(t4.w, h3, a3);
+        const uint32_t b0 = __float_as_uint(t4.x), b1 = __float_as_uint(t4.y), b2 = __float_as_uint(t4.z), b3 = __float_as_uint(t4.w);
+        const uint32_t a0 = b0 & 0x7FFFFFFFu, a1 = b1 & 0x7FFFFFFFu, a2 = b2 & 0x7FFFFFFFu, a3 = b3 & 0x7FFFFFFFu;
+        const uint32_t k0 = a0 >> kLogShift, k1 = a1 >> kLogShift, k2 = a2 >> kLogShift, k3 = a3 >> kLogShift;
+        const uint32_t w0 = keybm[k0 >> 5], w1 = keybm[k1 >> 5], w2 = keybm[k2 >> 5], w3 = keybm[k3 >> 5];
+        const uint32_t t0 = k0 - (kLogKey0 + 1u), t1 = k1 - (kLogKey0 + 1u), t2 = k2 - (kLogKey0 + 1u), t3 = k3 - (kLogKey0 + 1u);
+        // window bins 1 .. kLogNB-1 carry {count, 23 explicit mantissa bits} (as LogHistOp, octav_kernels.hip)
+        constexpr uint32_t kWin = (uint32_t)(kLogNB - 1);
+        if (t0 < kWin) atomicAdd(l_packed + t0 + 1u, (1ull << kPackShift) | (unsigned long long)(b0 & 0x7FFFFFu));
+        if (t1 < kWin) atomicAdd(l_packed + t1 + 1u, (1ull << kPackShift) | (unsigned long long)(b1 & 0x7FFFFFu));
+        if (t2 < kWin) atomicAdd(l_packed + t2 + 1u, (1ull << kPackShift) | (unsigned long long)(b2 & 0x7FFFFFu));
+        if (t3 < kWin) atomicAdd(l_packed + t3 + 1u, (1ull << kPackShift) | (unsigned long long)(b3 & 0x7FFFFFu));
+        rare |= (t0 < kWin ? 0u : a0) | (t1 < kWin ? 0u : a1) | (t2 < kWin ? 0u : a2) | (t3 < kWin ? 0u : a3);
+        const uint32_t h0 = (w0 >> (k0 & 31u)) & 1u, h1 = (w1 >> (k1 & 31u)) & 1u, h2 = (w2 >> (k2 & 31u)) & 1u,
+                       h3 = (w3 >> (k3 & 31u)) & 1u;
         if (__any((h0 | h1 | h2 | h3) != 0u)) {   // branch-free append: the tail only advances for a survivor
             myq[qn * kWave] = a0;
             qn += h0;
@@ -231,6 +239,10 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
             if (__any(qn > (uint32_t)(kQueueCap - 4))) flush();
         }
     };
+    // A tile in which some lane marked such a value is only noted (its base, per wave) and looked at again after the
+    // slice has been streamed — the hot loop carries no code for it.  A wave has at most kCap / (waves * 1024) tiles.
+    uint32_t* rare_list = sh.rare_tiles + (size_t)w * kRareTiles;
+    uint32_t rare_n = 0u;
     for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -246,7 +258,36 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
             }
             eat4(t[u]);
         }
+        if (__any(rare != 0u)) {
+            if (lane == 0) rare_list[rare_n] = base;
+            ++rare_n;
+            rare = 0u;
+        }
     });
+    // the noted tiles again (cold): non-zero values outside the window, and NaNs, are accumulated directly
+    for (uint32_t r = 0; r < rare_n; ++r) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(rare_list[r]);
+        const bool aligned = (((uintptr_t)pg) & 15u) == 0;
+        f4 t[4];
+        load_tile(pg, base, cnt, aligned, t);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xs[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t a = __float_as_uint(xs[e]) & 0x7FFFFFFFu;
+                const uint32_t tt = (a >> kLogShift) - (kLogKey0 + 1u);
+                if (!(tt < (uint32_t)(kLogNB - 1)) && a != 0u) {
+                    const float f = __uint_as_float(a);
+                    if (f > 0.0f) {
+                        sum += (double)f;
+                        ++nz;
+                    }
+                    nan |= (f != f);
+                }
+            }
+        }
+    }
     if (__any(qn != 0u)) flush();
     // per-wave totals of the directly accumulated statistics
     const float wmn = wave_min(mn), wmx = wave_max(mx);
@@ -358,6 +399,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const bool small = n_pair <= (unsigned long long)kWalkCap;
     const uint32_t tensor = pair % n_tensors;
+    DPL_PROF_T(pt0);
     // per-bin totals = the sum of the pair's slice rows -> LDS (own bins per thread)
     {
         constexpr int kPerT = kLogNB / kThreads;
@@ -420,6 +462,8 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         me->cur = 2u;
     }
     __syncthreads();
+    DPL_PROF_T(pt1);
+    DPL_PROF_ADD(0, pt0, pt1);
     const uint32_t route = __builtin_amdgcn_readfirstlane(sh.route);
     uint32_t bad = route == 1u ? 1u : 0u;
     float s = sh.s0;
@@ -447,8 +491,11 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         };
         if (n_chunks == 1u) load_chunk(0u);
         auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
-        // every thread carries the (uniform) walk state and takes the step itself from the four wave partials: one barrier
-        // per iteration, no broadcast; the partials alternate between two slots so that no second barrier is needed
+        // all waves count their share of the list; ONE wave takes the step (fp64 totals, the division, the bin look-ups — some
+        // hundred instructions that would otherwise issue four times over on a CU whose issue slots are what this kernel runs
+        // out of) and hands the next iterate to the others through LDS: two barriers per iteration.  Which wave: by workgroup,
+        // so that the stepping waves of the workgroups sharing a CU do not all sit on the same SIMD
+        const int stepper = (int)(blockIdx.x & (kWaves - 1));
         int jb = log_bin(s);
         bad = marked(jb) ? 0u : 1u;
         if (fail_every > 0 && pair % (uint32_t)fail_every == 0u) bad = 1u;   // test hook: the restart path
@@ -457,10 +504,16 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         auto enter = [&](int j) {   // exact totals of the bins above bin j; bin j goes on record
             n_above = (j + 1 < kLogNB) ? (unsigned long long)n_ge[j + 1] : 0ull;
             s_above = (j + 1 < kLogNB) ? s_ge[j + 1] : 0.0;
-            if (tid == 0) sh.pub[j >> 5] |= 1u << (j & 31);
+            if (lane == 0) sh.pub[j >> 5] |= 1u << (j & 31);   // (only the stepping wave enters bins)
         };
-        if (!bad) enter(jb);
-        uint32_t done = 0u, par = 0u;
+        if (!bad && w == stepper) enter(jb);
+        uint32_t done = 0u;
+        DPL_PROF_T(pt2);
+        DPL_PROF_ADD(1, pt1, pt2);
+        if (tid == 0) {
+            g_prof_iters_add(blockIdx.x, 0u);
+            DPL_PROF_L(L);
+        }
         while (!done && !bad) {
             // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1)
             const uint32_t lo = __float_as_uint(s), hi = ((uint32_t)(jb + 1) + kLogKey0) << kLogShift;
@@ -490,34 +543,52 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             c = wave_sum_dpp(c);
             msum = wave_sum64(msum);
             if (lane == 0) {
-                sh.part_c[par][w] = c;
-                sh.part_m[par][w] = msum;
+                sh.part_c[0][w] = c;
+                sh.part_m[0][w] = msum;
             }
             __syncthreads();
-            unsigned long long tc = 0ull, tm = 0ull;
+            if (w == stepper) {
+                unsigned long long tc = 0ull, tm = 0ull;
 #pragma unroll
-            for (int j = 0; j < kWaves; ++j) {
-                tc += sh.part_c[par][j];
-                tm += sh.part_m[par][j];
-            }
-            par ^= 1u;
-            const unsigned long long tg = n_above + tc;
-            const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
-            const OctavStep qs = octav_step(ts, tg, n_elems - tg, ud, s, iters, max_iters);
-            s = qs.s;
-            iters = qs.iters;
-            done = qs.done;
-            if (!done) {
-                const int jn = log_bin(s);
-                if (!marked(jn)) {
-                    bad = 1u;   // a bin that was not gathered (or out of the binned window): the compaction route takes over
-                } else if (jn != jb) {
-                    jb = jn;
-                    enter(jb);
+                for (int j = 0; j < kWaves; ++j) {
+                    tc += sh.part_c[0][j];
+                    tm += sh.part_m[0][j];
+                }
+                const unsigned long long tg = n_above + tc;
+                const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+                const OctavStep qs = octav_step(ts, tg, n_elems - tg, ud, s, iters, max_iters);
+                s = qs.s;
+                iters = qs.iters;
+                done = qs.done;
+                if (!done) {
+                    const int jn = log_bin(s);
+                    if (!marked(jn)) {
+                        bad = 1u;   // a bin that was not gathered (or out of the binned window): the compaction route takes over
+                    } else if (jn != jb) {
+                        jb = jn;
+                        enter(jb);
+                    }
+                }
+                if (lane == 0) {
+                    sh.w_s = s;
+                    sh.jb = jb;
+                    sh.bad = done | (bad << 1);
                 }
             }
+            __syncthreads();
+            if (w != stepper) {
+                s = sh.w_s;
+                jb = sh.jb;
+                const uint32_t fl = sh.bad;
+                done = fl & 1u;
+                bad = fl >> 1;
+            }
         }
+        DPL_PROF_T(pt3);
+        DPL_PROF_ADD(2, pt2, pt3);
+        if (tid == 0) g_prof_iters_add(blockIdx.x, iters);
     }
+    DPL_PROF_T(pt4);
     // ---- what the next batches should gather for this tensor: the bins this walk stepped into — or, when it
     // left the gathered set, the pair's bracket over the bin edges (histogram only) — plus neighbours that hold
     // next to nothing.
@@ -553,6 +624,8 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
         }
     }
+    DPL_PROF_T(pt5);
+    DPL_PROF_ADD(3, pt4, pt5);
     if (tid == 0) {
         if (route == 0u) {
             me->done = 1u;
@@ -685,6 +758,59 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_
     return n_total;
 }
 
+int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
+                              dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s) {
+    if (n_pairs <= 0) return 0;
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_prepare: bad tensor count / epoch");
+    if (!d_vis || !d_pred || !d_states) return fail_msg("dpl_octav_oneread_prepare: null buffer");
+    const int64_t vis_words = n_tensors * kLogWords;
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * vis_words;
+    const uint32_t* d_vis_o = d_vis + (int64_t)(1 - write_epoch) * vis_words;
+    const int64_t init_n = (n_pairs + 1 > vis_words ? n_pairs + 1 : vis_words);
+    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs, d_vis_w,
+                       d_vis_o, d_pred, vis_words, reset_epoch);
+    DPL_LAUNCH_CHECK("k_octav_oneread_init");
+    return 0;
+}
+
+int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, const uint32_t* d_pred,
+                             int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                             const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s) {
+    if (n_slices <= 0 || n_pairs <= 0) return 0;
+    if (n_tensors < 1) return fail_msg("dpl_octav_oneread_stream: bad tensor count");
+    if (!d_lh || !d_pred) return fail_msg("dpl_octav_oneread_stream: null scratch buffer");
+    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB + kLdsKey), (hipStream_t)s,
+                       d_slices, d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_pred, (uint32_t)n_tensors,
+                       d_pair_base, d_list0);
+    DPL_LAUNCH_CHECK("k_octav_oneread");
+    return 0;
+}
+
+int dpl_octav_oneread_walk(const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred,
+                           int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+                           const uint64_t* d_pair_base, const uint32_t* d_pair_order, const float* d_list0, int dynamic_sym,
+                           int max_iters, dpl_stream_t s) {
+    if (n_pairs <= 0) return 0;
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_walk: bad tensor count / epoch");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred) return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
+    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                       d_pair_order, reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w,
+                       (uint32_t)n_tensors, d_pair_base, d_list0, dynamic_sym, max_iters, g_exact_fail_every);
+    DPL_LAUNCH_CHECK("k_octav_walk");
+    return 0;
+}
+
+int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                               const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                               const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                               float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_pairs <= 0 || max_iters <= 0) return 0;
+    if (int e = check_blocks("dpl_octav_oneread_fallback", n_items, d_block_begin, n_blocks)) return e;
+    return dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
+                                    d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, (hipStream_t)s);
+}
+
 int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh, uint32_t* d_vis,
                           uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
                           int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
@@ -692,28 +818,15 @@ int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym, int max_iters,
                           dpl_stream_t s) {
     if (n_slices <= 0 || n_pairs <= 0) return 0;
-    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_run_oneread: bad tensor count / epoch");
-    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred) return fail_msg("dpl_octav_run_oneread: null scratch buffer");
-    if (int e = check_blocks("dpl_octav_run_oneread", n_items, d_block_begin, n_blocks)) return e;
-    hipStream_t st = (hipStream_t)s;
-    dpl_octav_state* ctl = d_states + n_pairs;
-    const int64_t vis_words = n_tensors * kLogWords;
-    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * vis_words;
-    const uint32_t* d_vis_o = d_vis + (int64_t)(1 - write_epoch) * vis_words;
-    const int64_t init_n = (n_pairs + 1 > vis_words ? n_pairs + 1 : vis_words);
-    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, st, d_states, n_pairs, d_vis_w, d_vis_o,
-                       d_pred, vis_words, reset_epoch);
-    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB + kLdsKey), st, d_slices,
-                       d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_pred,
-                       (uint32_t)n_tensors, d_pair_base, d_list0);
-    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, st, d_states, ctl, d_pair_order,
-                       reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base,
-                       d_list0, dynamic_sym, max_iters, g_exact_fail_every);
-    DPL_LAUNCH_CHECK("k_octav_oneread");
-    if (max_iters > 0)
-        return dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
-                                        d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, st);
-    return 0;
+    if (int e = dpl_octav_oneread_prepare(d_vis, d_pred, write_epoch, reset_epoch, n_tensors, d_states, n_pairs, s)) return e;
+    if (int e = dpl_octav_oneread_stream(d_slices, n_slices, d_lh, d_pred, n_tensors, d_seg_ptrs, d_states, n_pairs, d_pair_base,
+                                         d_list0, s))
+        return e;
+    if (int e = dpl_octav_oneread_walk(d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs, d_pair_base,
+                                       d_pair_order, d_list0, dynamic_sym, max_iters, s))
+        return e;
+    return dpl_octav_oneread_fallback(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
+                                      d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, s);
 }
 
 }  // extern "C"

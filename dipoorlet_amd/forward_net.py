@@ -241,8 +241,10 @@ def forward_net_octav(onnx_graph, args, run=None):
     run = _run_of(onnx_graph, args, run)
     dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
     rows = []
+    pipe = ops.OctavPipeline(dynamic_sym, run.device)    # the walk of batch i runs beside the forward / streaming pass of batch i + 1
     for b, tensors in run.forward():
-        rows.append(ops.octav_batch(run.plan(b), tensors, dynamic_sym).clone())
+        rows.append(pipe.submit(run.plan(b), tensors))
+    pipe.sync()
     run.octav_rows = torch.cat(rows) if rows else torch.zeros(0, run.T, 3, device=run.device)
     r = _np32(run.octav_rows)
     return {n: {"optimal_s": list(r[:, t, 0]), "min": list(r[:, t, 1]), "max": list(r[:, t, 2])}

@@ -319,6 +319,135 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     return out
 
 
+class OctavPipeline:
+    """OCTAV over a RUN of batches in the one-read form with the two halves of a batch on two HIP streams: the streaming
+    kernel of batch i + 1 (HBM-bound, the caller's stream) runs beside the per-pair walk of batch i (latency-bound: ~20
+    dependent iterations per pair, a side stream).  Same kernels, same results as octav_batch(form='oneread').
+
+        pipe = OctavPipeline(dynamic_sym)
+        rows = [pipe.submit(plan, tensors) for ...]     # [B, T, 3] each, NOT valid yet
+        pipe.sync()                                     # rows are valid for work on the caller's stream
+
+    Each plan keeps two sets of per-batch scratch (states, histogram rows, prediction snapshot, gather list) so that
+    batch i + 1 can stream while batch i walks.  The walk leaves the number of pairs it could not finish (a bin outside the
+    prediction: every multi-slice pair of a plan's first batch, rare afterwards) in the set's control block; that count is
+    copied to pinned memory and read when the set comes up for reuse two submits later (or in sync()), and only then, if it
+    is non-zero, is the compaction route launched for that batch — in steady state no no-op launches queue up behind the
+    streaming kernel.  The activations of a batch, its pointer table and its result stay referenced from the set until
+    then.  The host therefore runs at most two batches ahead of the device.
+    A tensor set the one-read form cannot take (a pair above 64 slices) runs octav_batch on the caller's stream instead."""
+
+    def __init__(self, dynamic_sym, device=None):
+        self.dyn = 1 if dynamic_sym else 0
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
+        self._touched = []
+
+    @staticmethod
+    def _sets(plan, res):
+        sets = getattr(plan, "_octav_pipe_sets", None)
+        if sets is None:
+            _, _, _, l0, _ = plan.octav_scratch()
+            nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
+            off = plan.n_pairs * C.sizeof(_hip.OctavState) + _hip.OctavState.cnt_le.offset
+            # four state arrays in rotation (call k uses k % 4): the array for call k + 2 is initialised at the end of call k's
+            # side-stream work, while the one of call k must survive until the host has read k's count of unfinished pairs
+            plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(4)]
+            plan._octav_pipe_failed = [x[off:off + 8].view(torch.int64) for x in plan._octav_pipe_states]
+            sets = []
+            for j in range(2):
+                sets.append(dict(failed=torch.zeros(1, dtype=torch.int64).pin_memory(),
+                                 lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
+                                 pred=res["pred"] if j == 0 else torch.zeros_like(res["pred"]),
+                                 l0=l0 if j == 0 else torch.empty_like(l0), done=None, refs=None, pending=False, k=-1))
+            plan._octav_pipe_sets = sets
+        return sets
+
+    def _prepare(self, plan, res, st, k, stream):
+        """State array + prediction snapshot (in set `st`) for the plan's call number k."""
+        ep, first = divmod(k, _ONEREAD_EPOCH)
+        _hip.check(_hip.lib().dpl_octav_oneread_prepare(_ptr(res["vis"]), _ptr(st["pred"]), ep % 2, 1 if first == 0 else 0, plan.T,
+                                                        _ptr(plan._octav_pipe_states[k % 4]), plan.n_pairs, stream),
+                   "dpl_octav_oneread_prepare")
+        st["prepared"] = k
+
+    def _finish(self, plan, res, st):
+        """Side stream: results of the set's batch -> its output rows, the set made ready for its next use, completion event."""
+        side = self.side.cuda_stream
+        _hip.check(_hip.lib().dpl_octav_finalize(_ptr(st["states"]), plan.n_pairs, _ptr(st["refs"][2]), side), "dpl_octav_finalize")
+        self._prepare(plan, res, st, st["k"] + 2, side)    # off the caller's stream: the set's next use is two calls away
+        st["done"] = torch.cuda.Event()
+        st["done"].record(self.side)
+
+    def _settle(self, plan, res, st):
+        """HOST wait for the set's walk; the compaction route for its batch if some pair needs it."""
+        if not st["pending"]:
+            return
+        st["pending"] = False
+        st["done"].synchronize()
+        if int(st["failed"][0]) == 0:
+            return
+        tensors, tab, out = st["refs"]
+        spans, base, order, _, l1 = plan.octav_scratch()
+        w = plan.work("octav", per_image=True)
+        _hip.check(_hip.lib().dpl_octav_oneread_fallback(*w.args(), _ptr(tab), _ptr(st["states"]), plan.n_pairs, _ptr(spans),
+                                                         _ptr(base), _ptr(order), _ptr(st["l0"]), _ptr(l1), self.dyn,
+                                                         _OCTAV_MAX_ITERS, self.side.cuda_stream), "dpl_octav_oneread_fallback")
+        self._finish(plan, res, st)
+
+    def submit(self, plan, tensors):
+        form = os.environ.get("DPL_OCTAV_FORM", "oneread")
+        res = plan.octav_oneread_scratch() if form == "oneread" else None
+        if res is None:
+            return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form == "oneread" else form)
+        main = torch.cuda.current_stream(plan.device)
+        sets = self._sets(plan, res)
+        k = res["calls"]
+        res["calls"] = k + 1
+        cur = sets[k % 2]
+        self._settle(plan, res, cur)
+        if cur["done"] is not None:
+            main.wait_event(cur["done"])        # everything that last used this set has finished
+        _, base, order, _, _ = plan.octav_scratch()
+        tab = plan.seg_table(tensors)
+        out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+        cur["refs"] = (list(tensors), tab, out)
+        cur["k"] = k
+        cur["states"] = plan._octav_pipe_states[k % 4]
+        L = _hip.lib()
+        if cur.get("prepared") != k:
+            self._prepare(plan, res, cur, k, main.cuda_stream)
+        _hip.check(L.dpl_octav_oneread_stream(_ptr(res["slices"]), res["n_slices"], _ptr(cur["lh"]), _ptr(cur["pred"]), plan.T,
+                                              _ptr(tab), _ptr(cur["states"]), plan.n_pairs, _ptr(base), _ptr(cur["l0"]),
+                                              main.cuda_stream), "dpl_octav_oneread_stream")
+        streamed = torch.cuda.Event()
+        streamed.record(main)
+        self.side.wait_event(streamed)
+        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
+                                            (k // _ONEREAD_EPOCH) % 2, plan.T, _ptr(cur["states"]), plan.n_pairs, _ptr(base),
+                                            _ptr(order), _ptr(cur["l0"]), self.dyn, _OCTAV_MAX_ITERS, self.side.cuda_stream),
+                   "dpl_octav_oneread_walk")
+        with torch.cuda.stream(self.side):
+            cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)
+        self._finish(plan, res, cur)
+        cur["pending"] = True
+        if all(p is not plan for p, _ in self._touched):
+            self._touched.append((plan, res))
+        return out
+
+    def sync(self):
+        """Settle every outstanding batch (host waits for the walks), order the caller's stream after the side stream and
+        let go of the batches' tensors."""
+        for plan, res in self._touched:
+            for st in sorted(plan._octav_pipe_sets, key=lambda q: q["k"]):
+                self._settle(plan, res, st)
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+        for plan, _ in self._touched:
+            for st in plan._octav_pipe_sets:
+                st["refs"] = None
+        self._touched = []
+
+
 # ------------------------------------------------------------------------------- single-tensor conveniences
 def minmax(x):
     """(min, max) of one device tensor as a fp32 device tensor [2] (NaN if x holds a NaN)."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 9
+#define DPL_ABI_VERSION 10
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -150,16 +150,18 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
                           uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
-/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip): a streaming kernel — one workgroup per SLICE
- * (at most dpl_octav_slice_cap() elements of one pair), each slice read once and yielding in that pass the pair's
- * statistics, its exact log-scale histogram (merged per pair by agent-scope atomics) and the values of the bins the
- * exact iteration is PREDICTED to visit — then a walk kernel, one wave per pair: suffix totals of the merged histogram,
- * the gathered values grouped by bin, the reference's iteration on (exact totals of the bins above) + (gathered values of
- * the iterate's bin), every iterate VERIFIED against the gathered bins.  The prediction is what the same tensor's walks
- * stepped into in earlier batches (two alternating epoch accumulators in d_vis; d_pred receives the snapshot this batch
- * uses).  A walk that meets a bin that was not gathered fetches it from the pair's data (small pairs) or hands the pair
- * to the compaction route (d_items .. d_list1 as for dpl_octav_run_bracket; always the case for a tensor's first batch:
- * start with d_vis zeroed); pairs of at most 2048 elements gather their whole window and never need a prediction.
+/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip), two kernels per batch:
+ *   k_octav_oneread — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one pair): the slice's only HBM
+ *     read yields the pair's statistics, the slice's exact log-scale histogram row and the values of the bins the exact
+ *     iteration is PREDICTED to visit (appended to the pair's list);
+ *   k_octav_walk — one workgroup per pair: per-bin totals = the sum of the pair's slice rows, suffix totals, s_0, then the
+ *     reference's iteration on (exact totals of the bins above) + (listed values of the iterate's bin), every iterate
+ *     VERIFIED to lie in a gathered bin.
+ * The prediction is what the same tensor's walks stepped into in earlier batches (two alternating epoch accumulators in
+ * d_vis; d_pred receives the snapshot this batch uses).  A walk that meets a bin that was not gathered publishes the pair's
+ * bracket for the following batches and hands the pair to the compaction route (d_items .. d_list1 as for
+ * dpl_octav_run_bracket; always the case for a tensor's first batch: start with d_vis zeroed); pairs of at most 20480
+ * elements gather their whole window and never need a prediction.
  *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
  *     of 4 elements); item.reserved = the pair's slice count; pair_slice0[2 slot], [2 slot + 1] = first / one-past-last
  *     slice of the pair in slot `slot` (spans carry slots 0 .. n_spans-1).  Returns the slice count (call with out = NULL
@@ -168,9 +170,28 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  *     read-modify-write, nothing to zero); the walk adds up the rows of a pair's slices;
  *   d_vis: uint32 [2, n_tensors, 64] epoch accumulators (slot = image * n_tensors + tensor); this batch's walks add to
  *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 64] scratch.
- * Initialises d_states itself (no dpl_octav_init call). */
+ * dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot d_pred (and the
+ * epoch reset); dpl_octav_oneread_stream = k_octav_oneread; dpl_octav_oneread_walk = k_octav_walk, which leaves the number
+ * of pairs that need the compaction route in the control block (d_states[n_pairs].cnt_le); dpl_octav_oneread_fallback = that
+ * route (every kernel of it is a no-op when the count is 0, but a launch still has to be scheduled: a caller that can read
+ * the count skips the call); dpl_octav_run_oneread = all four on one stream.  stream and walk may run on different streams (the walk of batch i beside the streaming kernel of batch i + 1: the walk is
+ * latency-bound, the streaming kernel HBM-bound) when the caller orders walk(i) after stream(i) and gives concurrently
+ * live batches their own d_states / d_lh / d_pred / d_list0 / d_list1; d_vis is shared (bits are only ever OR-ed in). */
 uint32_t dpl_octav_slice_cap(void);
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
+int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
+                              dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
+int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, const uint32_t* d_pred,
+                             int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                             const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s);
+int dpl_octav_oneread_walk(const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred,
+                           int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+                           const uint64_t* d_pair_base, const uint32_t* d_pair_order, const float* d_list0, int dynamic_sym,
+                           int max_iters, dpl_stream_t s);
+int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                               const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                               const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                               float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s);
 int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh, uint32_t* d_vis,
                           uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
                           int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,

@@ -41,12 +41,14 @@ ops.octav_batch(plan, pool[0], False, st, form="oneread")
 print("pairs on the compaction route in a steady-state batch:", int(st.cpu().numpy()[-80:].view(np.uint64)[2]), "of", plan.n_pairs)
 p = buf.reshape(4096, 8).astype(np.float64)
 wgs = int((p.sum(1) > 0).sum())
-names = ["scan (row -> suffix)", "s_0 + bucket pass", "s_0 .. end of walk", "publish + clean"]
+names = ["rows -> suffix totals, s_0", "list -> registers", "walk", "publish"]
 tot = p.sum(0) / n
 wgs = int((p[:, 0] > 0).sum())
-print(f"batch {B}: {ms:.3f} ms per batch (all kernels); walk kernel: {wgs} waves, mean iterations {tot[7] / wgs:.1f}")
+print(f"batch {B}: {ms:.3f} ms per batch (all kernels); walk kernel: {wgs} workgroups, mean iterations {tot[7] / wgs:.1f}, "
+      f"mean list {tot[6] / wgs:.0f}")
 for i, nm in enumerate(names):
-    print(f"  {nm:24s} mean {tot[i] / wgs:9.0f} cycles per wave   max {p[:, i].max() / n:9.0f}")
+    print(f"  {nm:28s} mean {tot[i] / wgs:9.0f} ticks per workgroup   max {p[:, i].max() / n:9.0f}")
 for lo, hi in ((0, 384), (384, 864), (864, 1952), (1952, 3936)):
     q = p[lo:hi] / n
-    print(f"  slots {lo:4d}-{hi:4d}: scan {q[:, 0].mean():8.0f}  bucket {q[:, 1].mean():8.0f}  walk {(q[:, 2] - q[:, 1]).mean():8.0f}  finish {q[:, 3].mean():8.0f}  iters {q[:, 7].mean():.1f}")
+    print(f"  slots {lo:4d}-{hi:4d}: rows {q[:, 0].mean():8.0f}  list {q[:, 1].mean():8.0f}  walk {q[:, 2].mean():8.0f}  publish {q[:, 3].mean():8.0f}  "
+          f"iters {q[:, 7].mean():.1f}  list {q[:, 6].mean():.0f}")

@@ -482,3 +482,42 @@ def test_octav_randomised_shapes_and_distributions(dev):
                 g = got["bracket"][b, t]
                 assert _close(g[0], s), (n, b, dyn, g, s)
                 assert g[1] == x.min() and g[2] == x.max()
+
+
+def test_octav_pipeline_matches_single_stream(dev, kl):
+    """OctavPipeline (walk of batch i on a side stream beside the streaming kernel of batch i + 1, double-buffered
+    scratch) returns what octav_batch returns batch by batch — including the first batches, where every multi-slice pair
+    takes the compaction route on the side stream — and the oracle's scales."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(41)
+    B, sizes = 4, [401408, 30000, 802816, 777, 200704]
+    batches = []
+    for k in range(7):
+        batches.append([torch.from_numpy(np.stack([
+            ((rng.standard_normal(n) * (1 + 0.3 * k + t)).astype(np.float32) if t % 2 == 0 else
+             np.maximum(rng.standard_normal(n), 0).astype(np.float32) * (2.5 + k)) for _ in range(B)])).to(dev)
+            for t, n in enumerate(sizes)])
+    want = [ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), x, False, form="bracket").cpu().numpy() for x in batches]
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    pipe = ops.OctavPipeline(False, dev)
+    outs = [pipe.submit(plan, x) for x in batches]
+    del batches                                   # the pipeline keeps what its side stream still reads
+    pipe.sync()
+    for k, (o, w) in enumerate(zip(outs, want)):
+        got = o.cpu().numpy()
+        assert np.array_equal(got[:, :, 1:], w[:, :, 1:]), k
+        assert np.allclose(got[:, :, 0], w[:, :, 0], rtol=2e-7, atol=0), k
+    # a second run on the same plan (prediction warmed up), interleaved with a ragged plan
+    plan2 = ops.TensorSetPlan(sizes, 2, dev)
+    x = [torch.from_numpy(np.stack([(rng.standard_normal(n) * (1 + t)).astype(np.float32) for _ in range(B)])).to(dev)
+         for t, n in enumerate(sizes)]
+    a = pipe.submit(plan, x)
+    b = pipe.submit(plan2, [v[:2].contiguous() for v in x])
+    c = pipe.submit(plan, x)
+    pipe.sync()
+    assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
+    assert np.array_equal(a.cpu().numpy()[:2], b.cpu().numpy())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(len(sizes)):
+            assert _close(a[1, t, 0].item(), O.octav_scale(x[t][1].cpu().numpy(), 1))

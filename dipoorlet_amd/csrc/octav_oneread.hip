@@ -55,20 +55,27 @@ constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this sm
 #define DPL_SLICE_CAP 262144
 #endif
 constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
-static_assert(kCap < (1u << 20) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed 20-bit field");
+static_assert(kCap < (1u << 19) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed field below the flag bit");
 constexpr int kRareTiles = (int)(kCap / (kWaves * 1024u)) + 1;   // tiles of a slice one wave walks (+ the ragged one)
-constexpr int kQueueCap = 12;                                   // per-lane survivor queue; flushed above cap - 4
-constexpr int kQueueStride = kQueueCap + 1;
-constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;         // bitmap over every 14-bit key: 512 words
-constexpr int kKeyWord0 = (int)(kLogKey0 >> 5);
+#ifndef DPL_QUEUE_CAP
+#define DPL_QUEUE_CAP 832
+#endif
+constexpr int kQueueCap = DPL_QUEUE_CAP;                        // entries of a WAVE's dense survivor queue; flushed above cap - 256
+static_assert(kQueueCap > 256, "a vector of four elements per lane may add 256 survivors");
+#ifndef DPL_QUEUE_TOP
+#define DPL_QUEUE_TOP 256
+#endif
+constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a tile's drain point, above this many entries
+#ifndef DPL_APPEND_LAG
+#define DPL_APPEND_LAG 1
+#endif
+constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
 constexpr uint32_t kBigCluster = (1u << 20) / kCap + 1;         // clusters this large may overflow the packed count field
 constexpr uint32_t kMaxCluster = 64;
 
-// LDS: [A: packed histogram 16 KiB | later S_ge fp64][B: survivor queues 13 KiB | later N_ge 8 KiB][key bitmap 2 KiB]
-constexpr int kLdsA = kLogNB * 8;
-constexpr int kLdsB = kWaves * kWave * kQueueStride * 4;
-constexpr int kLdsKey = kKeyWords * 4;
-static_assert(kLdsB >= kLogNB * 4, "N_ge must fit the queue region");
+// LDS: [A: packed histogram 16 KiB, bit 63 of a word = gather flag | one dummy word per lane][B: the waves' survivor queues 13 KiB]
+constexpr int kLdsA = kLogNB * 8 + kWave * 8;                   // + the lanes' dummy words
+constexpr int kLdsB = kWaves * kQueueCap * 4;
 
 template <class T>
 __device__ __forceinline__ T ld_agent(const T* p) {
@@ -110,7 +117,8 @@ struct Shared {
     uint32_t rare_tiles[kWaves * kRareTiles];   // streaming kernel: tiles holding a non-zero value outside the window
     uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
     uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
-    uint32_t item, last, any_pred, fetched;
+    uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
+    uint32_t seg_off[kMaxCluster], seg_len[kMaxCluster];   // walk: the pair's list segments (one per slice)
     OctavStep step;
     int jb;
     uint32_t bad, route;
@@ -168,82 +176,122 @@ __device__ __forceinline__ double bin_sum(unsigned long long mant_explicit, uint
     return (double)(mant_explicit + ((unsigned long long)count << 23)) * log_bin_scale(b);   // full 24-bit mantissas
 }
 
+// wave64 inclusive prefix sum by DPP (Hillis-Steele inside each row of 16, then the two row broadcasts): VALU only — the
+// ds_bpermute form is six dependent LDS round trips
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
 // One slice, streamed: per element min / max, the LDS histogram, and a queue append for the values of marked bins
-// (queues -> the pair's list behind one returning atomic per wave flush).  Leaves the per-wave statistics in sh.red_*.
+// (queues -> the slice's own region of the pair's list; the region's cursor lives in LDS).  Leaves the per-wave statistics
+// in sh.red_*.
 // Its own function (not inlined): the register allocator otherwise spills the tile buffers of this hot loop to make
-// room for values that only the walk needs.
-__device__ __attribute__((noinline)) void stream_slice(const float* __restrict__ pg, uint32_t cnt,
-                                                       unsigned long long* __restrict__ l_packed,
-                                                       const uint32_t* __restrict__ keybm, uint32_t* __restrict__ queues,
-                                                       uint32_t* __restrict__ dst, uint32_t* __restrict__ cursor, Shared& sh) {
+// room for values that only the walk needs.  The dynamic LDS block is addressed through address-space-3 pointers taken
+// here (not handed in): ds_ instructions with constant offsets, nothing reloaded.
+typedef __attribute__((address_space(3))) unsigned long long* lptr_u64;
+typedef __attribute__((address_space(3))) uint32_t* lptr_u32;
+__device__ __attribute__((noinline)) void stream_slice(const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
+                                                       Shared& sh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const lptr_u64 l_packed = (lptr_u64)(lds_raw);
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const int w = tid / kWave;
     float mn = INFINITY, mx = -INFINITY;
     uint32_t nan = 0u, nz = 0u;
     double sum = 0.0;
-    uint32_t* myq = queues + (size_t)w * kWave * kQueueStride + lane;   // entry j of lane l at [j][l]
-    uint32_t qn = 0u;
+    // the wave's survivor queue: dense (ballot + mbcnt positions), `tail` entries in use (wave-uniform)
+    const lptr_u32 wq = (lptr_u32)(lds_raw + kLdsA) + (uint32_t)w * kQueueCap;
+    uint32_t tail = 0u;
+    // A flush touches no global atomic: the slice owns the part of the pair's list that starts at the slice's offset in the
+    // pair (as many entries as the slice has elements), and the position inside it comes from a cursor in LDS.  Flushes
+    // need care: gfx950 has ONE in-order counter for loads and stores (vmcnt), and the waits for tile data are counts the
+    // compiler fixes statically — a store issued between a tile's loads and the wait for them makes that wait also wait
+    // for the store's acknowledgement (measured, round 2: per-lane queues flushed in mid-tile every ~7 tiles cost 56 us
+    // of 634; dropping a returning global atomic from the flush changed nothing).  So the regular flush (queue more than
+    // kQueueTop full) happens at the START of a tile's consumption, once the whole tile has arrived: the only loads
+    // outstanding then are the next tile's, and by the time those are waited for — a tile's worth of work later — the
+    // stores have long been acknowledged.  A flush in the middle of a tile remains for the case that one tile brings more
+    // than the rest of the queue holds (a small pair gathering its whole window).  The queue is dense, so the stores are
+    // full 256-byte instructions.
     auto flush = [&]() {
-        uint32_t inc = qn;
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o, kWave);
-            if (lane >= (uint32_t)o) inc += t;
-        }
-        const uint32_t total = __shfl(inc, kWave - 1, kWave);
-        // global (address space 1) accesses, not flat ones: a pending FLAT operation may complete out of order with the tile
-        // loads and then the compiler can only wait with vmcnt(0) — i.e. for the NEXT tile's loads it has just issued — before
-        // it touches the current tile: the software pipeline of for_each_tile would be gone
-#ifdef DPL_FLUSH_FLAT
-        typedef uint32_t* gptr_u32;
-#else
-        typedef __attribute__((address_space(1))) uint32_t* gptr_u32;
-#endif
+        typedef __attribute__((address_space(1))) uint32_t* gptr_u32;   // global, not flat: see for_each_tile
         gptr_u32 gdst = (gptr_u32)dst;
         uint32_t base = 0u;
-        if (lane == kWave - 1) base = __hip_atomic_fetch_add((gptr_u32)cursor, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base = __shfl(base, kWave - 1, kWave) + inc - qn;
-        for (uint32_t j = 0; j < qn; ++j) gdst[base + j] = myq[j * kWave];   // plain stores: the walk is a later launch, L2 may combine the lines
-        qn = 0u;
+        if (lane == 0) base = __hip_atomic_fetch_add((lptr_u32)&sh.cursor, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < tail; i += kWave) gdst[base + i] = wq[i] & 0x7FFFFFFFu;   // |x|; the walk is a later launch
+        tail = 0u;
     };
-    // Four elements at a time, straight-line: the four bitmap words are requested first (one wait for all of them, after the
-    // histogram atomics have been issued), the histogram atomic is predicated per lane, and the rare non-zero value outside the
-    // window (or NaN) only leaves a per-lane mark that is looked at once per tile (`rare_tile`).
-    // key = 14 bits of exponent and top mantissa, shared by the histogram bin and the bitmap lookup.
+    // Four elements at a time, straight-line and branch-free.  ONE LDS operation per element does both jobs: the histogram
+    // word of a bin the walk is predicted to visit carries a flag in bit 63 (set when the workgroup initialises its
+    // histogram), and the RETURNING 64-bit add {count += 1, mantissa sum += 23 explicit bits} hands the flag back — there is
+    // no separate look-up of the predicted set (measured, round 2: that look-up — address, ds_read, bit extract, ~7 of ~21
+    // VALU instructions per element — cost 95 us of a 680 us kernel that is bound by instruction issue; the atomics
+    // themselves 4 us).  A zero or a value outside the window adds to a per-LANE dummy word behind the histogram instead of
+    // being masked off (no exec juggling, no same-address pile-up: lane l's dummy lies in bank pair l); its flag is never
+    // set.  The rare non-zero value outside the window (or NaN) leaves a per-lane mark that is looked at once per tile.
+    // `issue` starts the four adds of a vector; `append` (a vector later: the returns have arrived by then) puts the flagged
+    // elements at the wave's queue tail (position = tail + the number of flagged lanes below: ballot + v_mbcnt).
     uint32_t rare = 0u;
-    auto eat4 = [&](const f4& t4) {
-        const uint32_t b0 = __float_as_uint(t4.x), b1 = __float_as_uint(t4.y), b2 = __float_as_uint(t4.z), b3 = __float_as_uint(t4.w);
-        const uint32_t a0 = b0 & 0x7FFFFFFFu, a1 = b1 & 0x7FFFFFFFu, a2 = b2 & 0x7FFFFFFFu, a3 = b3 & 0x7FFFFFFFu;
-        const uint32_t k0 = a0 >> kLogShift, k1 = a1 >> kLogShift, k2 = a2 >> kLogShift, k3 = a3 >> kLogShift;
-        const uint32_t w0 = keybm[k0 >> 5], w1 = keybm[k1 >> 5], w2 = keybm[k2 >> 5], w3 = keybm[k3 >> 5];
-        const uint32_t t0 = k0 - (kLogKey0 + 1u), t1 = k1 - (kLogKey0 + 1u), t2 = k2 - (kLogKey0 + 1u), t3 = k3 - (kLogKey0 + 1u);
-        // window bins 1 .. kLogNB-1 carry {count, 23 explicit mantissa bits} (as LogHistOp, octav_kernels.hip)
-        constexpr uint32_t kWin = (uint32_t)(kLogNB - 1);
-        if (t0 < kWin) atomicAdd(l_packed + t0 + 1u, (1ull << kPackShift) | (unsigned long long)(b0 & 0x7FFFFFu));
-        if (t1 < kWin) atomicAdd(l_packed + t1 + 1u, (1ull << kPackShift) | (unsigned long long)(b1 & 0x7FFFFFu));
-        if (t2 < kWin) atomicAdd(l_packed + t2 + 1u, (1ull << kPackShift) | (unsigned long long)(b2 & 0x7FFFFFu));
-        if (t3 < kWin) atomicAdd(l_packed + t3 + 1u, (1ull << kPackShift) | (unsigned long long)(b3 & 0x7FFFFFu));
-        rare |= (t0 < kWin ? 0u : a0) | (t1 < kWin ? 0u : a1) | (t2 < kWin ? 0u : a2) | (t3 < kWin ? 0u : a3);
-        const uint32_t h0 = (w0 >> (k0 & 31u)) & 1u, h1 = (w1 >> (k1 & 31u)) & 1u, h2 = (w2 >> (k2 & 31u)) & 1u,
-                       h3 = (w3 >> (k3 & 31u)) & 1u;
-        if (__any((h0 | h1 | h2 | h3) != 0u)) {   // branch-free append: the tail only advances for a survivor
-            myq[qn * kWave] = a0;
-            qn += h0;
-            myq[qn * kWave] = a1;
-            qn += h1;
-            myq[qn * kWave] = a2;
-            qn += h2;
-            myq[qn * kWave] = a3;
-            qn += h3;
-            if (__any(qn > (uint32_t)(kQueueCap - 4))) flush();
-        }
+    struct Ret4 {
+        uint32_t h[4];   // high words of the returned histogram entries (bit 31 = the flag)
+    };
+    constexpr uint32_t kWin = (uint32_t)(kLogNB - 1);   // window bins 1 .. kLogNB-1 (as LogHistOp, octav_kernels.hip)
+    const lptr_u64 dummy = l_packed + kLogNB + lane;
+    auto add1 = [&](uint32_t bits) {
+        const uint32_t t = ((bits >> kLogShift) & 0x3FFFu) - (kLogKey0 + 1u);   // key = 14 bits of exponent and top mantissa
+        const bool in = t < kWin;
+        const lptr_u64 slot = in ? l_packed + t + 1u : dummy;
+        rare |= in ? 0u : bits;
+        return (uint32_t)(__hip_atomic_fetch_add(slot, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+    };
+    auto issue = [&](const f4& t4) {
+        Ret4 r;
+        r.h[0] = add1(__float_as_uint(t4.x));
+        r.h[1] = add1(__float_as_uint(t4.y));
+        r.h[2] = add1(__float_as_uint(t4.z));
+        r.h[3] = add1(__float_as_uint(t4.w));
+        return r;
+    };
+    auto put = [&](uint32_t bits, uint32_t hi) {
+        const bool f = (int32_t)hi < 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, tail));
+        if (f) wq[pos] = bits;
+        tail += (uint32_t)__builtin_popcountll(m);
+    };
+    auto append = [&](const f4& t4, const Ret4& r) {
+#if defined(DPL_ABL_NOAPPEND)      // ablation builds (timing only): the returns are not looked at, nothing is queued
+#else
+        put(__float_as_uint(t4.x), r.h[0]);
+        put(__float_as_uint(t4.y), r.h[1]);
+        put(__float_as_uint(t4.z), r.h[2]);
+        put(__float_as_uint(t4.w), r.h[3]);
+        if (tail > (uint32_t)(kQueueCap - 256)) flush();   // (rare: see flush)
+#endif
     };
     // A tile in which some lane marked such a value is only noted (its base, per wave) and looked at again after the
     // slice has been streamed — the hot loop carries no code for it.  A wave has at most kCap / (waves * 1024) tiles.
     uint32_t* rare_list = sh.rare_tiles + (size_t)w * kRareTiles;
     uint32_t rare_n = 0u;
     for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
+        if (tail > (uint32_t)kQueueTop) {   // the regular flush: BEFORE the tile is consumed, AFTER all of it has arrived
+            asm volatile("" ::"v"(t[3].w));   // (a use of the tile's last register: the compiler waits for the whole tile here)
+#if defined(DPL_ABL_NOFLUSH)       // ablation builds (timing only): a full queue is simply dropped
+            tail = 0u;
+#else
+            flush();
+#endif
+        }
+        Ret4 r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (full) {
@@ -256,13 +304,16 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
                 if (e + 2 < cnt) mn = fminf(mn, t[u].z), mx = fmaxf(mx, t[u].z);
                 if (e + 3 < cnt) mn = fminf(mn, t[u].w), mx = fmaxf(mx, t[u].w);
             }
-            eat4(t[u]);
+            r[u] = issue(t[u]);
+            if (u >= kAppendLag) append(t[u - kAppendLag], r[u - kAppendLag]);
         }
-        if (__any(rare != 0u)) {
+#pragma unroll
+        for (int u = 4 - kAppendLag; u < 4; ++u) append(t[u], r[u]);
+        if (__any((rare & 0x7FFFFFFFu) != 0u)) {   // (a lone sign bit is -0.0: nothing to account for)
             if (lane == 0) rare_list[rare_n] = base;
             ++rare_n;
-            rare = 0u;
         }
+        rare = 0u;
     });
     // the noted tiles again (cold): non-zero values outside the window, and NaNs, are accumulated directly
     for (uint32_t r = 0; r < rare_n; ++r) {
@@ -288,7 +339,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
             }
         }
     }
-    if (__any(qn != 0u)) flush();
+    if (tail != 0u) flush();
     // per-wave totals of the directly accumulated statistics
     const float wmn = wave_min(mn), wmx = wave_max(mx);
     const uint32_t wnz = wave_sum(nz);
@@ -308,11 +359,9 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
 __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
     unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pred, uint32_t n_tensors,
-    const uint64_t* __restrict__ pair_base, float* __restrict__ list0) {
+    const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
-    uint32_t* queues = reinterpret_cast<uint32_t*>(lds_raw + kLdsA);
-    uint32_t* keybm = reinterpret_cast<uint32_t*>(lds_raw + kLdsA + kLdsB);
     __shared__ Shared sh;
 
     const uint32_t tid = threadIdx.x;
@@ -322,15 +371,20 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const float* pg = segs[it.seg] + it.offset;
     const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
     const uint32_t tensor = pair % n_tensors;
-    for (int b = tid; b < kLogNB; b += kThreads) l_packed[b] = 0ull;
-    for (int i = tid; i < kKeyWords; i += kThreads) {   // the bins to gather: what this tensor's iterates visited lately
-        const int j = i - kKeyWord0;                    // (a small pair gathers its whole window)
-        keybm[i] = (j >= 0 && j < kLogWords) ? (small ? 0xFFFFFFFFu : pred[tensor * kLogWords + j]) : 0u;
+    // empty histogram; bit 63 of a bin's word = "gather this bin's values": what this tensor's iterates visited lately
+    // (a small pair gathers its whole window)
+    for (int b = tid; b < kLogNB; b += kThreads) {
+        const uint32_t f = small ? 1u : (pred[tensor * kLogWords + (b >> 5)] >> (b & 31)) & 1u;
+        l_packed[b] = (unsigned long long)f << 63;
     }
+    if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
+    if (tid == 0) sh.cursor = 0u;
     __syncthreads();
 
     // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
-    stream_slice(pg, cnt, l_packed, keybm, queues, reinterpret_cast<uint32_t*>(list0 + pair_base[pair]), &me->len[0], sh);
+    // the slice's region of the pair's list: at the slice's element offset inside the pair
+    const uint64_t in_pair = it.offset - slices[pair_slice0[2 * pair]].offset;
+    stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh);
     __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
 
     // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
@@ -359,7 +413,8 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     // the slice's histogram goes out as ONE row of plain, coalesced stores (16 KiB, empty bins included: nothing to zero
     // beforehand, no read-modify-write at the memory side); the walk adds up the rows of a pair's slices
     unsigned long long* row = lh + (uint64_t)blockIdx.x * kLogNB;
-    for (int b = tid; b < kLogNB; b += kThreads) row[b] = l_packed[b];
+    // (bin 0 holds no element: its word carries the length of the slice's list segment)
+    for (int b = tid; b < kLogNB; b += kThreads) row[b] = b == 0 ? (unsigned long long)sh.cursor : l_packed[b] & ~(1ull << 63);
 }
 
 // wave64 sum by DPP (row-local butterflies, then the two row broadcasts): ~6 VALU instead of six dependent ds_bpermute round
@@ -386,7 +441,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
-    const float* __restrict__ list0, int dynamic_sym, int max_iters, int fail_every) {
+    const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every) {
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
@@ -424,8 +479,14 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
 #pragma unroll
         for (int qq = 0; qq < kPerT; ++qq) {
             const int b = hi - qq;
+            if (b == 0) cnt[qq] = 0u, mant[qq] = 0ull;   // bin 0 holds no element (its row words are the segment lengths)
             n_ge[b] = cnt[qq];
             s_ge[b] = bin_sum(mant[qq], cnt[qq], b);
+        }
+        // the pair's gathered values: one list segment per slice, at the slice's element offset inside the pair
+        if (tid < sl1 - sl0) {
+            sh.seg_off[tid] = (uint32_t)(slices[sl0 + tid].offset - slices[sl0].offset);
+            sh.seg_len[tid] = (uint32_t)lh[(uint64_t)(sl0 + tid) * kLogNB];
         }
         suffix_in_place(n_ge, s_ge, sh);
     }
@@ -458,6 +519,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         me->sum = 0.0;
         me->cnt_gt = 0ull;
         me->cnt_le = 0ull;
+        me->len[0] = 0u;
         me->len[1] = 0u;
         me->cur = 2u;
     }
@@ -471,21 +533,45 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     if (route == 2u) {
         const float ud = sh.ud;
         const unsigned long long n_elems = sh.n_elems;
-        const uint32_t L = __builtin_amdgcn_readfirstlane(me->len[0]);
-        // the pair's list (bit patterns of |x|) goes into registers; a list longer than they hold is re-read in
-        // pieces every iteration
+        // the list (bit patterns of |x|) goes into registers, 1024 values per ROW (one 16-byte vector per thread); every
+        // segment starts a new row; a list of more rows than the registers hold is re-read in pieces every iteration
+        const uint32_t n_seg = __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
+        uint32_t n_rows = 0u, L = 0u;
+        for (uint32_t j = 0; j < n_seg; ++j) {
+            const uint32_t len = __builtin_amdgcn_readfirstlane(sh.seg_len[j]);
+            n_rows += (len + 1023u) >> 10;
+            L += len;
+        }
         f4 v[kVec];
-        const uint32_t n_chunks = (L + kWalkCap - 1u) / kWalkCap;
+        const uint32_t n_chunks = (n_rows + (uint32_t)kVec - 1u) / (uint32_t)kVec;
         const float* lp = list0 + pair_base[pair];
-        auto load_chunk = [&](uint32_t c0) {
-            // buffer loads: zero fill past the list's end (one descriptor per row: the range check leaves the SGPR
-            // offset out, so the row offset goes into the base)
-            const int nbytes = (int)(min(L - c0, kWalkCap) << 2);
+        auto load_chunk = [&](uint32_t row0) {
+            uint32_t j = 0u, r = row0;   // segment and row inside it of row `row0`
+            while (j < n_seg) {
+                const uint32_t rows_j = (__builtin_amdgcn_readfirstlane(sh.seg_len[j]) + 1023u) >> 10;
+                if (r < rows_j) break;
+                r -= rows_j;
+                ++j;
+            }
             const uint32_t voff = tid << 4;
 #pragma unroll
             for (int u = 0; u < kVec; ++u) {
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    (void*)(lp + c0 + u * kThreads * 4), 0, max(nbytes - u * kThreads * 16, 0), 0x00020000);
+                uint32_t len = j < n_seg ? __builtin_amdgcn_readfirstlane(sh.seg_len[j]) : 0u;
+                while (j < n_seg && (r << 10) >= len) {   // past the segment's end (or an empty segment): the next one
+                    ++j;
+                    r = 0u;
+                    len = j < n_seg ? __builtin_amdgcn_readfirstlane(sh.seg_len[j]) : 0u;
+                }
+                // buffer loads: zero fill past the segment's end (one descriptor per row: the range check leaves the SGPR
+                // offset out, so the row offset goes into the base)
+                const float* p = lp;
+                int nbytes = 0;
+                if (j < n_seg) {
+                    p = lp + __builtin_amdgcn_readfirstlane(sh.seg_off[j]) + (r << 10);
+                    nbytes = (int)(min(len - (r << 10), 1024u) << 2);
+                    ++r;
+                }
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nbytes, 0x00020000);
                 v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
             }
         };
@@ -526,12 +612,12 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             };
             unsigned long long msum = 0ull;
             for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-                if (n_chunks > 1u) load_chunk(ch * kWalkCap);
-                const uint32_t lvec = (min(L - ch * kWalkCap, kWalkCap) + 3u) >> 2;
+                if (n_chunks > 1u) load_chunk(ch * (uint32_t)kVec);
+                const uint32_t rows = min(n_rows - ch * (uint32_t)kVec, (uint32_t)kVec);
                 ms = 0u;
 #pragma unroll
                 for (int u = 0; u < kVec; ++u) {
-                    if ((uint32_t)u * kThreads < lvec) {   // uniform
+                    if ((uint32_t)u < rows) {   // uniform
                         in1(v[u].x);
                         in1(v[u].y);
                         in1(v[u].z);
@@ -773,30 +859,30 @@ int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch
     return 0;
 }
 
-int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, const uint32_t* d_pred,
-                             int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                             const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s) {
+int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
+                             const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                             int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s) {
     if (n_slices <= 0 || n_pairs <= 0) return 0;
     if (n_tensors < 1) return fail_msg("dpl_octav_oneread_stream: bad tensor count");
-    if (!d_lh || !d_pred) return fail_msg("dpl_octav_oneread_stream: null scratch buffer");
-    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB + kLdsKey), (hipStream_t)s,
+    if (!d_lh || !d_pred || !d_pair_slice0) return fail_msg("dpl_octav_oneread_stream: null scratch buffer");
+    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
                        d_slices, d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_pred, (uint32_t)n_tensors,
-                       d_pair_base, d_list0);
+                       d_pair_base, d_pair_slice0, d_list0);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
 }
 
-int dpl_octav_oneread_walk(const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred,
-                           int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+int dpl_octav_oneread_walk(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
+                           const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
                            const uint64_t* d_pair_base, const uint32_t* d_pair_order, const float* d_list0, int dynamic_sym,
                            int max_iters, dpl_stream_t s) {
     if (n_pairs <= 0) return 0;
     if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_walk: bad tensor count / epoch");
-    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred) return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices) return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
     uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
     hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
                        d_pair_order, reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w,
-                       (uint32_t)n_tensors, d_pair_base, d_list0, dynamic_sym, max_iters, g_exact_fail_every);
+                       (uint32_t)n_tensors, d_pair_base, d_list0, d_slices, dynamic_sym, max_iters, g_exact_fail_every);
     DPL_LAUNCH_CHECK("k_octav_walk");
     return 0;
 }
@@ -819,10 +905,10 @@ int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const
                           dpl_stream_t s) {
     if (n_slices <= 0 || n_pairs <= 0) return 0;
     if (int e = dpl_octav_oneread_prepare(d_vis, d_pred, write_epoch, reset_epoch, n_tensors, d_states, n_pairs, s)) return e;
-    if (int e = dpl_octav_oneread_stream(d_slices, n_slices, d_lh, d_pred, n_tensors, d_seg_ptrs, d_states, n_pairs, d_pair_base,
-                                         d_list0, s))
+    if (int e = dpl_octav_oneread_stream(d_slices, n_slices, d_pair_slice0, d_lh, d_pred, n_tensors, d_seg_ptrs, d_states, n_pairs,
+                                         d_pair_base, d_list0, s))
         return e;
-    if (int e = dpl_octav_oneread_walk(d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs, d_pair_base,
+    if (int e = dpl_octav_oneread_walk(d_slices, d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs, d_pair_base,
                                        d_pair_order, d_list0, dynamic_sym, max_iters, s))
         return e;
     return dpl_octav_oneread_fallback(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,

@@ -417,13 +417,13 @@ class OctavPipeline:
         L = _hip.lib()
         if cur.get("prepared") != k:
             self._prepare(plan, res, cur, k, main.cuda_stream)
-        _hip.check(L.dpl_octav_oneread_stream(_ptr(res["slices"]), res["n_slices"], _ptr(cur["lh"]), _ptr(cur["pred"]), plan.T,
+        _hip.check(L.dpl_octav_oneread_stream(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(cur["pred"]), plan.T,
                                               _ptr(tab), _ptr(cur["states"]), plan.n_pairs, _ptr(base), _ptr(cur["l0"]),
                                               main.cuda_stream), "dpl_octav_oneread_stream")
         streamed = torch.cuda.Event()
         streamed.record(main)
         self.side.wait_event(streamed)
-        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
+        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["slices"]), _ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
                                             (k // _ONEREAD_EPOCH) % 2, plan.T, _ptr(cur["states"]), plan.n_pairs, _ptr(base),
                                             _ptr(order), _ptr(cur["l0"]), self.dyn, _OCTAV_MAX_ITERS, self.side.cuda_stream),
                    "dpl_octav_oneread_walk")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 10
+#define DPL_ABI_VERSION 11
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -181,11 +181,11 @@ uint32_t dpl_octav_slice_cap(void);
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
 int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
                               dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
-int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, uint64_t* d_lh, const uint32_t* d_pred,
-                             int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                             const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s);
-int dpl_octav_oneread_walk(const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred,
-                           int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
+                             const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                             int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s);
+int dpl_octav_oneread_walk(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
+                           const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
                            const uint64_t* d_pair_base, const uint32_t* d_pair_order, const float* d_list0, int dynamic_sym,
                            int max_iters, dpl_stream_t s);
 int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,

@@ -7,7 +7,8 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 rm -f /tmp/sq_rows.jsonl
-for GROUP in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY"; do
+IFS=';' read -ra GROUPS_ <<< "${SQ_GROUPS:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS;SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY}"
+for GROUP in "${GROUPS_[@]}"; do
   rm -rf /tmp/sq_run
   rocprofv3 --pmc $GROUP --output-format csv -d /tmp/sq_run -o b -- python3 bench.py --cpu-seconds 0 --steps 6 --warmup 2 "$@" > /dev/null 2> /tmp/sq_err.txt || tail -3 /tmp/sq_err.txt
   python3 - <<'PY'
@@ -38,5 +39,5 @@ for k, v in t.items():
     if v.get("SQ_WAVE_CYCLES"):
         v["valu_insts_per_wave_cycle"] = round(v.get("SQ_INSTS_VALU", 0) / v["SQ_WAVE_CYCLES"], 4)
 json.dump(t, open(sys.argv[1], "w"), indent=1, sort_keys=True)
-print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("lds_bank_conflict_rate", "valu_insts_per_wave_cycle", "SQ_INSTS_VALU", "SQ_INSTS_LDS")} for k, v in t.items() if k in ("k_abs_hist", "k_minmax", "k_octav_loghist", "k_octav_gather", "k_octav_exact", "k_octav_bracket")}, indent=1))
+print(json.dumps({k: v for k, v in t.items() if k in ("k_abs_hist", "k_minmax", "k_octav_oneread", "k_octav_walk")}, indent=1))
 PY

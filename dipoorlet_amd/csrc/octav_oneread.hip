@@ -601,20 +601,23 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             DPL_PROF_L(L);
         }
         while (!done && !bad) {
-            // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1)
-            const uint32_t lo = __float_as_uint(s), hi = ((uint32_t)(jb + 1) + kLogKey0) << kLogShift;
-            uint32_t c = 0u, ms = 0u;
-            auto in1 = [&](float f) {
-                const uint32_t u = __float_as_uint(f);
-                const bool in = u > lo && u < hi;
-                c += (uint32_t)in;
-                ms += in ? (u & 0x7FFFFFu) : 0u;
-            };
-            unsigned long long msum = 0ull;
+            // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1), i.e. d = u - bits(s) - 1 below
+            // `span` (unsigned: anything at or below s wraps around).  Four VALU instructions per value — the count is a
+            // population count of the compare mask on the scalar unit — and the mantissa sum follows from the sum of d.
+            const uint32_t lo1 = __float_as_uint(s) + 1u;
+            const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
+            uint32_t c = 0u;   // (wave-uniform)
+            unsigned long long dsum = 0ull;
             for (uint32_t ch = 0; ch < n_chunks; ++ch) {
                 if (n_chunks > 1u) load_chunk(ch * (uint32_t)kVec);
                 const uint32_t rows = min(n_rows - ch * (uint32_t)kVec, (uint32_t)kVec);
-                ms = 0u;
+                uint32_t ds = 0u;   // per thread: at most 80 values below 2^17
+                auto in1 = [&](float f) {
+                    const uint32_t d = __float_as_uint(f) - lo1;
+                    const bool in = d < span;
+                    c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                    ds += in ? d : 0u;
+                };
 #pragma unroll
                 for (int u = 0; u < kVec; ++u) {
                     if ((uint32_t)u < rows) {   // uniform
@@ -624,13 +627,11 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
                         in1(v[u].w);
                     }
                 }
-                msum += (unsigned long long)ms;
+                dsum += (unsigned long long)wave_sum_dpp(ds);   // < 64 * 80 * 2^17
             }
-            c = wave_sum_dpp(c);
-            msum = wave_sum64(msum);
             if (lane == 0) {
                 sh.part_c[0][w] = c;
-                sh.part_m[0][w] = msum;
+                sh.part_m[0][w] = dsum + (unsigned long long)c * (unsigned long long)(lo1 & 0x7FFFFFu);   // sum of explicit mantissas
             }
             __syncthreads();
             if (w == stepper) {

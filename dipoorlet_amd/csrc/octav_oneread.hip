@@ -13,7 +13,7 @@
 // publishes its bracket for the next batch and finishes on the compaction route of octav_kernels.hip.  Results are the
 // reference's iterate sequence either way; only the speed depends on the prediction.
 //
-// Persistent 256-thread workgroups pull SLICES (<= kCap = 128 Ki elements of one (image, tensor) pair) from per-XCD queues:
+// One 256-thread workgroup per SLICE (<= kCap elements of one (image, tensor) pair):
 //   1  the slice's only HBM read, straight into registers (buffer loads: zero fill past the end, all in flight);
 //   2  per element: min / max, exact log-scale histogram of |x| in LDS (64 bins per octave: count + integer mantissa
 //      sum, as in the bracket form) and — values of predicted bins only — a branch-free append to per-lane LDS queues;
@@ -52,7 +52,7 @@ constexpr int kVec = DPL_RES_VEC;                               // 16-byte vecto
 constexpr uint32_t kWalkCap = (uint32_t)kThreads * kVec * 4;    // list values the walk holds in registers (20 480)
 constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this small gather their whole window (no prediction)
 #ifndef DPL_SLICE_CAP
-#define DPL_SLICE_CAP 262144
+#define DPL_SLICE_CAP 520192
 #endif
 constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
 static_assert(kCap < (1u << 19) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed field below the flag bit");

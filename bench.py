@@ -172,7 +172,9 @@ def main():
     elems = [e for _, e, _ in spec]
     T, E = len(elems), sum(elems)
     B = BATCH
-    pool = [synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j) for j in range(max(1, a.pool))]
+    # DPL_BENCH_JITTER (a tuning aid, not the headline workload): per-image contrast jitter of the synthetic activations
+    jitter = float(os.environ.get("DPL_BENCH_JITTER", "0"))
+    pool = [synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j, image_jitter=jitter) for j in range(max(1, a.pool))]
     plan = ops.TensorSetPlan(elems, B, dev)
 
     def fence():
@@ -281,6 +283,10 @@ def main():
                             "achieved": mse_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mse_ach / HBM_PEAK_GBPS,
                             "traffic": None, "bytes_per_launch": mse_bytes, "avg_batch_ms": mse_ms},
                "clip_checksum": float(mclip.double().abs().sum().item())}
+        if pipe is not None:   # prediction misses (pairs finished on the compaction route), warm-up sweeps included
+            mse["prediction"] = {"batches": pipe.batches, "batches_with_a_miss": pipe.fallback_batches,
+                                 "pairs_missed": pipe.fallback_pairs, "pairs_per_batch": plan.n_pairs,
+                                 "listed_share_of_elements": pipe.list_share, "switched_to_two_read_form": bool(pipe.switched)}
 
     # ------------------------------------------------------------------ the line
     kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once

@@ -255,6 +255,7 @@ _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 _OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
 # batches per prediction epoch of the one-read form: a batch gathers the bins the walks of the current and the previous epoch
 # stepped into (8-16 batches of history)
+_ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.10"))
 _ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
 
 
@@ -342,6 +343,9 @@ class OctavPipeline:
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
         self._touched = []
+        # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
+        self.batches = self.fallback_batches = self.fallback_pairs = self.switched = 0
+        self.list_share = 0.0    # gathered values / elements (running mean over the settled batches)
 
     @staticmethod
     def _sets(plan, res):
@@ -349,14 +353,14 @@ class OctavPipeline:
         if sets is None:
             _, _, _, l0, _ = plan.octav_scratch()
             nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
-            off = plan.n_pairs * C.sizeof(_hip.OctavState) + _hip.OctavState.cnt_le.offset
+            off = plan.n_pairs * C.sizeof(_hip.OctavState) + _hip.OctavState.sum.offset    # control block: sum, cnt_gt, cnt_le
             # four state arrays in rotation (call k uses k % 4): the array for call k + 2 is initialised at the end of call k's
             # side-stream work, while the one of call k must survive until the host has read k's count of unfinished pairs
             plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(4)]
-            plan._octav_pipe_failed = [x[off:off + 8].view(torch.int64) for x in plan._octav_pipe_states]
+            plan._octav_pipe_failed = [x[off:off + 24] for x in plan._octav_pipe_states]
             sets = []
             for j in range(2):
-                sets.append(dict(failed=torch.zeros(1, dtype=torch.int64).pin_memory(),
+                sets.append(dict(failed=torch.zeros(24, dtype=torch.uint8).pin_memory(),
                                  lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
                                  pred=res["pred"] if j == 0 else torch.zeros_like(res["pred"]),
                                  l0=l0 if j == 0 else torch.empty_like(l0), done=None, refs=None, pending=False, k=-1))
@@ -385,8 +389,24 @@ class OctavPipeline:
             return
         st["pending"] = False
         st["done"].synchronize()
-        if int(st["failed"][0]) == 0:
+        ctl = st["failed"].numpy()
+        listed, failed = float(ctl[0:8].view(np.float64)[0]), int(ctl[16:24].view(np.int64)[0])
+        self.batches += 1
+        # The one-read form is only as good as its prediction: images that differ (contrast, content) widen the set of bins
+        # a tensor's walks visit, the gathered lists grow with it and both kernels slow down (measured on ResNet-50 shapes:
+        # 4 % of the elements listed at 0.59 of the roofline; 10 % image-to-image contrast jitter: 0.20).  Beyond
+        # _ONEREAD_MAX_SHARE on two batches in a row the plan switches to the two-read bracket form, which needs no
+        # prediction, for the rest of its life.
+        share = listed / max(1, plan.batch * sum(plan.elems))
+        self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
+        plan._octav_wide = plan.__dict__.get("_octav_wide", 0) + 1 if share > _ONEREAD_MAX_SHARE else 0
+        if plan._octav_wide >= 2 and not plan.__dict__.get("_octav_two_read"):
+            plan._octav_two_read = True
+            self.switched += 1
+        if failed == 0:
             return
+        self.fallback_pairs += failed
+        self.fallback_batches += 1
         tensors, tab, out = st["refs"]
         spans, base, order, _, l1 = plan.octav_scratch()
         w = plan.work("octav", per_image=True)
@@ -397,7 +417,7 @@ class OctavPipeline:
 
     def submit(self, plan, tensors):
         form = os.environ.get("DPL_OCTAV_FORM", "oneread")
-        res = plan.octav_oneread_scratch() if form == "oneread" else None
+        res = plan.octav_oneread_scratch() if form == "oneread" and not plan.__dict__.get("_octav_two_read") else None
         if res is None:
             return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form == "oneread" else form)
         main = torch.cuda.current_stream(plan.device)

@@ -68,8 +68,10 @@ def resnet50_tensor_elems():
     return [e for _, e, _ in resnet50_tensors()]
 
 
-def synth_activations(spec, batch, device, seed=1234):
-    """One batched tensor set on the device.  `spec`: list of (name, elems, kind) or of bare elems."""
+def synth_activations(spec, batch, device, seed=1234, image_jitter=0.0):
+    """One batched tensor set on the device.  `spec`: list of (name, elems, kind) or of bare elems.
+    image_jitter > 0 scales every image of every tensor by its own factor in [1 - jitter, 1 + jitter] (images of real
+    calibration sets differ in contrast; used to stress the one-read OCTAV form's bin prediction)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     out = []
@@ -80,6 +82,8 @@ def synth_activations(spec, batch, device, seed=1234):
             e, kind = int(s), ("relu" if t % 2 else "pre")
         x = torch.randn(batch, e, generator=g, device=device, dtype=torch.float32)
         x.mul_(1.0 + 0.1 * t)
+        if image_jitter > 0.0:
+            x.mul_(1.0 + image_jitter * (2.0 * torch.rand(batch, 1, generator=g, device=device) - 1.0))
         if kind == "relu":
             x.clamp_(min=0)
         out.append(x)

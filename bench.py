@@ -286,7 +286,7 @@ def main():
         if pipe is not None:   # prediction misses (pairs finished on the compaction route), warm-up sweeps included
             mse["prediction"] = {"batches": pipe.batches, "batches_with_a_miss": pipe.fallback_batches,
                                  "pairs_missed": pipe.fallback_pairs, "pairs_per_batch": plan.n_pairs,
-                                 "listed_share_of_elements": pipe.list_share, "switched_to_two_read_form": bool(pipe.switched)}
+                                 "listed_share_of_elements": pipe.list_share, "switched_to_two_read_form": bool(pipe.switched), "batches_walked_sorted": pipe.sorted_batches}
 
     # ------------------------------------------------------------------ the line
     kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_BINS = 16384
 
 
@@ -72,13 +72,17 @@ SIGNATURES = {
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
     "dpl_octav_slice_cap": (C.c_uint32, []),
+    "dpl_octav_sort_chunk": (C.c_uint32, []),
+    "dpl_octav_dir_row": (C.c_uint32, []),
+    "dpl_octav_small_pair": (C.c_uint32, []),
     "dpl_build_octav_slices": (_I64, [_P, _I64, _P, _I64, _P]),
     "dpl_octav_oneread_prepare": (C.c_int, [_P, _P, C.c_int, C.c_int, _I64, _P, _I64, _P]),
     "dpl_octav_oneread_stream": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _P, _P, _P]),
-    "dpl_octav_oneread_walk": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _I64, _P, _I64, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dpl_octav_oneread_walk": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, C.c_int, _I64, _P, _I64, _P, _P, _I64, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "dpl_octav_oneread_missed": (C.c_int, [_P, _P, _P, _P, _P, C.c_int, _I64, _P, _I64, _P, _P, _I64, _P, C.c_int, C.c_int, _P]),
     "dpl_octav_oneread_fallback": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
-    "dpl_octav_run_oneread": (C.c_int, [_P, _I64, _P, _P, _P, _P, C.c_int, C.c_int, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P,
-                                        _P, _P, _P, _P, C.c_int, C.c_int, _P]),
+    "dpl_octav_run_oneread": (C.c_int, [_P, _I64, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _I64, _P, _I64, _P, _I64, _P, _P, _I64,
+                                        _P, _P, _P, _I64, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),

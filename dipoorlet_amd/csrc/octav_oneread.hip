@@ -27,6 +27,7 @@
 // registers that still hold the slice.
 // Cross-workgroup traffic is agent-scope atomics and sc1 (write-through) stores read by sc1 loads: no L2 write-back
 // fences (MI355X_MICROARCH.md, inter-workgroup visibility).  No workgroup ever waits for another.
+#include <type_traits>
 #include "common.hpp"
 #include "octav_common.hpp"
 
@@ -50,6 +51,9 @@ constexpr int kWaves = kThreads / kWave;
 #endif
 #ifndef DPL_THIN_SHIFT
 #define DPL_THIN_SHIFT 9    // ... and so is every bin above which at most n >> 9 elements lie (measured: 7 / 9 -> 9 / 11: +3 %, no more misses)
+#endif
+#ifndef DPL_SORTED_OCC
+#define DPL_SORTED_OCC 4   // waves per SIMD of k_octav_walk_sorted: every pair of a batch resident at once (15 per CU at 32 x 123 pairs)
 #endif
 #ifndef DPL_WALK_OCC
 #define DPL_WALK_OCC 4
@@ -78,6 +82,14 @@ constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a
 constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
 constexpr uint32_t kBigCluster = (1u << 20) / kCap + 1;         // clusters this large may overflow the packed count field
 constexpr uint32_t kMaxCluster = 64;
+// The prediction row of a tensor (d_pred): the bitmap of the bins to gather (kLogWords words, at most kMaxFlag bits set) and,
+// per word, the number of set bits in the words below it — the RANK of a gathered bin is a table index everywhere below.
+constexpr int kMaxFlag = 256;
+constexpr int kPredRow = 2 * kLogWords;
+// Sorted runs (k_octav_sort): a slice's list is sorted, kChunk values at a time, by the rank of the values' bins; the
+// directory row of a chunk holds, per rank, the position of the rank's first value in the chunk (+ the chunk's length).
+constexpr uint32_t kChunk = 8192;
+constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows are 16-byte aligned
 
 // LDS: [A: packed histogram 16 KiB, bit 63 of a word = gather flag | one dummy word per lane][B: the waves' survivor queues 13 KiB]
 constexpr int kLdsA = kLogNB * 8 + kWave * 8;                   // + the lanes' dummy words
@@ -380,7 +392,7 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     // empty histogram; bit 63 of a bin's word = "gather this bin's values": what this tensor's iterates visited lately
     // (a small pair gathers its whole window)
     for (int b = tid; b < kLogNB; b += kThreads) {
-        const uint32_t f = small ? 1u : (pred[tensor * kLogWords + (b >> 5)] >> (b & 31)) & 1u;
+        const uint32_t f = small ? 1u : (pred[tensor * kPredRow + (b >> 5)] >> (b & 31)) & 1u;
         l_packed[b] = (unsigned long long)f << 63;
     }
     if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
@@ -447,7 +459,8 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
-    const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every) {
+    const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
+    int only_missed) {
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
@@ -456,6 +469,10 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     const int w = tid / kWave;
     const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
     dpl_octav_state* me = st + pair;
+    // only_missed: the pass behind k_octav_walk_sorted — the pairs that kernel could not finish (mode 1) are walked again
+    // here up to the bin that was not gathered, for the sake of what this kernel does THEN: publish the pair's bracket for
+    // the next batches and leave the state the compaction route starts from.  No pair missed (the steady state): nothing to do.
+    if (only_missed && (ctl->cnt_le == 0ull || me->mode != 1u)) return;
     const unsigned long long n_pair = me->n_elems;
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const bool small = n_pair <= (unsigned long long)kWalkCap;
@@ -498,7 +515,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
-        sh.bm[tid] = small ? 0xFFFFFFFFu : pred[tensor * kLogWords + tid];
+        sh.bm[tid] = small ? 0xFFFFFFFFu : pred[tensor * kPredRow + tid];
         sh.pub[tid] = 0u;
     }
     if (tid == 0) {
@@ -605,7 +622,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         if (tid == 0) {
             g_prof_iters_add(blockIdx.x, 0u);
             DPL_PROF_L(L);
-            atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values (control block): what the caller's form choice looks at
+            if (!only_missed) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
         }
         while (!done && !bad) {
             // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1), i.e. d = u - bits(s) - 1 below
@@ -729,7 +746,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             me->mode = 1u;
             me->done = 0u;
             me->len[0] = 0u;
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+            if (!only_missed) atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
         } else {
             me->s = s;
             me->iters = iters;
@@ -739,14 +756,414 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sorted runs.  k_octav_sort: one workgroup per slice; the slice's list (as gathered: arrival order) is sorted IN PLACE,
+// kChunk values at a time, by the rank of the values' bins — a counting sort staged in LDS: the rank's counter hands out
+// the position inside the rank (returning LDS add), an exclusive scan of the counters the rank's start, the values are
+// placed in the LDS stage and leave as full 16-byte stores; the starts go to the chunk's directory row.  Random placement
+// happens in LDS only (64 lanes to 64 global lines would cost 64 cycles per store instruction).
+// k_octav_walk_sorted then needs, per iteration, the directory entries of ONE rank and the few hundred values behind them —
+// one WAVE walks a pair, no list in registers, no barrier, and a wide prediction costs bandwidth here instead of scan time.
+__global__ __launch_bounds__(kThreads) void k_octav_sort(
+    const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ pair_slice0, const unsigned long long* __restrict__ lh,
+    const uint32_t* __restrict__ pred, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0,
+    const uint32_t* __restrict__ slice_chunk0, uint16_t* __restrict__ dir) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kChunk];
+    __shared__ uint32_t cnt[kMaxFlag], off[kMaxFlag + 1];
+    __shared__ unsigned long long bp[kLogWords];   // per word: bitmap (low half) | ranks below the word (high half)
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    if (it.reserved == 1u && it.count <= kSmallCap) return;   // a small pair (whole window gathered): walked from registers
+    const uint32_t len = (uint32_t)lh[(uint64_t)blockIdx.x * kLogNB];
+    if (len == 0u) return;
+    const uint32_t pair = it.slot, tensor = pair % n_tensors;
+    uint32_t* region = reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + (it.offset - slices[pair_slice0[2 * pair]].offset));
+    if (tid < (uint32_t)kLogWords)
+        bp[tid] = (unsigned long long)pred[tensor * kPredRow + tid] | ((unsigned long long)pred[tensor * kPredRow + kLogWords + tid] << 32);
+    constexpr int kPer = (int)(kChunk / kThreads / 4);   // 16-byte vectors per thread and chunk
+    for (uint32_t c0 = 0; c0 < len; c0 += kChunk) {
+        const uint32_t n = min(len - c0, kChunk);
+        if (tid < (uint32_t)kMaxFlag) cnt[tid] = 0u;
+        // the chunk -> registers (zero fill past its end: a zero is no entry)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(region + c0), 0, (int)(n << 2), 0x00020000);
+        uint32_t val[kPer * 4], rp[kPer * 4];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const f4 x = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + (uint32_t)k * kThreads) << 4, 0, 0));
+            val[4 * k + 0] = __float_as_uint(x.x);
+            val[4 * k + 1] = __float_as_uint(x.y);
+            val[4 * k + 2] = __float_as_uint(x.z);
+            val[4 * k + 3] = __float_as_uint(x.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer * 4; ++e) {   // rank of the value's bin, position inside the rank
+            const uint32_t u = val[e];
+            rp[e] = 0xFFFFFFFFu;
+            if (u != 0u) {
+                const uint32_t b = (u >> kLogShift) - kLogKey0;
+                const unsigned long long wv = bp[(b >> 5) & (uint32_t)(kLogWords - 1)];
+                const uint32_t r = (uint32_t)(wv >> 32) + (uint32_t)__popc((uint32_t)wv & ((1u << (b & 31u)) - 1u));
+                rp[e] = (min(r, (uint32_t)(kMaxFlag - 1)) << 16) | atomicAdd(&cnt[min(r, (uint32_t)(kMaxFlag - 1))], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < (uint32_t)kWave) {   // exclusive scan of the counters: four per lane
+            const uint32_t a0 = cnt[4 * tid], a1 = cnt[4 * tid + 1], a2 = cnt[4 * tid + 2], a3 = cnt[4 * tid + 3];
+            const uint32_t incl = wave_incl_scan_dpp(a0 + a1 + a2 + a3), base = incl - (a0 + a1 + a2 + a3);
+            off[4 * tid] = base;
+            off[4 * tid + 1] = base + a0;
+            off[4 * tid + 2] = base + a0 + a1;
+            off[4 * tid + 3] = base + a0 + a1 + a2;
+            if (tid == kWave - 1) off[kMaxFlag] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer * 4; ++e)
+            if (rp[e] != 0xFFFFFFFFu) stage[off[rp[e] >> 16] + (rp[e] & 0xFFFFu)] = val[e];
+        __syncthreads();
+        // the sorted chunk back over itself (every thread has long read its part), the starts into the directory
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t i = (tid + (uint32_t)k * kThreads) * 4u;
+            if (i + 3u < n) {
+                *reinterpret_cast<uint4*>(region + c0 + i) = *reinterpret_cast<const uint4*>(stage + i);
+            } else {
+                for (uint32_t q = i; q < n; ++q) region[c0 + q] = stage[q];
+            }
+        }
+        uint16_t* drow = dir + (uint64_t)(slice_chunk0[blockIdx.x] + c0 / kChunk) * kDirRow;
+        for (uint32_t i = tid; i <= (uint32_t)kMaxFlag; i += kThreads) drow[i] = (uint16_t)off[i];
+        __syncthreads();
+    }
+}
+
+// wave64 inclusive prefix sum of doubles by DPP (the two halves moved separately; lanes a step does not reach add +0.0)
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+#define DPL_SCAN_STEP(ctrl, rmask, bound)                                                                              \
+    {                                                                                                                  \
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);                                      \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, ctrl, rmask, 0xF, bound);       \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), ctrl, rmask, 0xF, bound); \
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                                   \
+    }
+    DPL_SCAN_STEP(0x111, 0xF, true)
+    DPL_SCAN_STEP(0x112, 0xF, true)
+    DPL_SCAN_STEP(0x114, 0xF, true)
+    DPL_SCAN_STEP(0x118, 0xF, true)
+    DPL_SCAN_STEP(0x142, 0xA, false)
+    DPL_SCAN_STEP(0x143, 0xC, false)
+#undef DPL_SCAN_STEP
+    return v;
+}
+
+constexpr int kMaxRuns = kWave;   // sorted chunks of a pair one wave handles (one per lane); more: the compaction route
+
+// The exact walk of one pair by ONE WAVE over the pair's sorted runs (all pairs but the small ones, largest first).
+//   1  the pair's slice rows -> per-bin totals -> totals ABOVE every gathered bin, by rank, in LDS (lane l owns 16 bins per
+//      half of the window, highest bins in lane 0: two passes, a DPP prefix scan over the lanes each); the bins that hold
+//      next to nothing and the sparse tail, for what is published afterwards;
+//   2  s_0, then the reference's iteration: per step the directory entries of the iterate's rank (lane = run), a flat
+//      index over the runs' segments, up to four values per lane and round in flight, count / offset sum as in k_octav_walk;
+//      every iterate is verified to lie in a gathered bin;
+//   3  the bins stepped into (+ neighbours holding next to nothing, + the sparse tail) are published for the next batches.
+// A pair that cannot finish here (a bin that was not gathered, values beyond the window, more than kMaxRuns runs) is only
+// MARKED (mode 1, counted in the control block): k_octav_walk(only_missed) publishes its bracket and prepares its state.
+__global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
+    const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ slice_chunk0, const uint16_t* __restrict__ dir,
+    int dynamic_sym, int max_iters, int fail_every) {
+    __shared__ double t_s[kMaxFlag + 1];
+    __shared__ uint32_t t_n[kMaxFlag + 1];
+    __shared__ uint32_t bm[kLogWords], pre[kLogWords], cheapw[kLogWords], thinw[kLogWords], pub[kLogWords];
+    __shared__ double s1_sum;
+    __shared__ uint32_t s1_cnt;
+    constexpr int kLdsRuns = 4;   // directory rows kept in LDS (requested before phase 1, there when the walk starts)
+    __shared__ __attribute__((aligned(16))) uint16_t dirl[kLdsRuns][kDirRow];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
+    dpl_octav_state* me = st + pair;
+    const unsigned long long n_pair = me->n_elems;
+    if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
+    const uint32_t tensor = pair % n_tensors;
+    const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
+    bm[lane] = pred[tensor * kPredRow + lane];
+    pre[lane] = pred[tensor * kPredRow + kLogWords + lane];
+    cheapw[lane] = 0u;
+    thinw[lane] = 0u;
+    pub[lane] = 0u;
+    // the pair's runs: lane r holds run r (its first value relative to the pair's list, its directory row)
+    uint32_t my_addr = 0u, my_dir = 0u, n_runs = 0u, listed = 0u;
+    for (uint32_t sl = sl0; sl < sl1; ++sl) {
+        const uint32_t len = __builtin_amdgcn_readfirstlane((uint32_t)lh[(uint64_t)sl * kLogNB]);
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(slices[sl].offset - slices[sl0].offset));
+        const uint32_t ch0 = __builtin_amdgcn_readfirstlane(slice_chunk0[sl]);
+        listed += len;
+        for (uint32_t c = 0; c * kChunk < len; ++c) {
+            if (lane == n_runs) {
+                my_addr = off + c * kChunk;
+                my_dir = ch0 + c;
+            }
+            ++n_runs;
+        }
+    }
+    if (lane == 0) atomicAdd(&ctl->sum, (double)listed);   // the batch's gathered values: what the caller's form choice looks at
+    {   // the first runs' directory rows -> LDS (16 bytes per lane and run: kDirRow / 8 lanes)
+        uint4 dv[kLdsRuns];
+#pragma unroll
+        for (int j = 0; j < kLdsRuns; ++j) {
+            const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)my_dir, j);
+            dv[j] = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)j < n_runs && lane < (uint32_t)(kDirRow / 8))
+                dv[j] = reinterpret_cast<const uint4*>(dir + (uint64_t)dj * kDirRow)[lane];
+        }
+#pragma unroll
+        for (int j = 0; j < kLdsRuns; ++j)
+            if (lane < (uint32_t)(kDirRow / 8)) reinterpret_cast<uint4*>(dirl[j])[lane] = dv[j];
+    }
+    __syncthreads();
+    DPL_PROF_T(qt0);
+    // ---- 1. totals above every gathered bin
+    const uint32_t cheap_n = (uint32_t)(n_pair >> DPL_CHEAP_SHIFT), thin_n = (uint32_t)(n_pair >> DPL_THIN_SHIFT);
+    uint32_t carry_n = 0u;
+    double carry_s = 0.0;
+    // All 16 bins of a lane — a quarter octave — share the exponent, so sums stay INTEGERS (explicit mantissas + count * 2^23,
+    // below 2^51 per octave) inside an octave: a conversion to fp64 happens once per octave (its total) and once per
+    // gathered bin (the integer part above it inside its octave), not once per bin (fp64 conversions run at a quarter of the
+    // rate and were most of this phase: 41 us per pair with one per bin and sweep).
+    for (int half = 1; half >= 0; --half) {
+        const int hb = half * (kLogNB / 2) + (int)(kWave - 1 - lane) * 16;   // the lane's 16 bins; lane 0: the highest
+        uint32_t cnt[16];
+        unsigned long long m[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            cnt[q] = 0u;
+            m[q] = 0ull;
+        }
+        for (uint32_t sl = sl0; sl < sl1; ++sl) {
+            const unsigned long long* row = lh + (uint64_t)sl * kLogNB + hb;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const unsigned long long v = row[q];
+                cnt[q] += (uint32_t)(v >> kPackShift);
+                m[q] += v & kPackMask;
+            }
+        }
+        if (hb == 0) {   // bin 0 holds no element (its row words are the segment lengths)
+            cnt[0] = 0u;
+            m[0] = 0ull;
+        }
+        uint32_t tot_n = 0u;
+        unsigned long long tot_m = 0ull;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            m[q] += (unsigned long long)cnt[q] << 23;   // full 24-bit mantissas
+            tot_n += cnt[q];
+            tot_m += m[q];
+        }
+        const uint32_t incl_n = wave_incl_scan_dpp(tot_n);
+        // inside the octave (four lanes): the integer total of the lanes above, and the octave's total
+        const uint32_t pos = lane & 3u;
+        const unsigned long long p1 = __shfl_up(tot_m, 1, 4), p2 = __shfl_up(tot_m, 2, 4), p3 = __shfl_up(tot_m, 3, 4);
+        const unsigned long long above_m = (pos >= 1u ? p1 : 0ull) + (pos >= 2u ? p2 : 0ull) + (pos >= 3u ? p3 : 0ull);
+        unsigned long long oct_m = tot_m + __shfl_xor(tot_m, 1, 4);
+        oct_m += __shfl_xor(oct_m, 2, 4);
+        const double scale = log_bin_scale(hb);
+        const double incl_s = wave_incl_scan_f64(pos == 3u ? (double)oct_m * scale : 0.0);   // octave totals, at the octaves' last lanes
+        const double excl_s = __shfl_up(incl_s, 1, kWave);
+        const double base_s = carry_s + (lane == 0 ? 0.0 : excl_s);   // everything in the octaves above the lane's
+        uint32_t run_n = carry_n + incl_n - tot_n;                    // everything in the bins above the lane's
+        unsigned long long run_m = above_m;
+        const uint32_t word = (uint32_t)hb >> 5, sh16 = (uint32_t)hb & 16u;
+        const uint32_t bits = (bm[word] >> sh16) & 0xFFFFu;
+        const uint32_t below = pre[word] + (uint32_t)__popc(bm[word] & ((1u << sh16) - 1u));
+        uint32_t cheap_bits = 0u, thin_bits = 0u;
+#pragma unroll
+        for (int q = 15; q >= 0; --q) {
+            if ((bits >> q) & 1u) {   // a gathered bin: totals above it, by rank
+                const uint32_t r = below + (uint32_t)__popc(bits & ((1u << q) - 1u));
+                t_n[r] = run_n;
+                t_s[r] = base_s + (double)run_m * scale;
+            }
+            run_n += cnt[q];
+            run_m += m[q];
+            cheap_bits |= (cnt[q] <= cheap_n ? 1u : 0u) << q;
+            thin_bits |= (run_n != 0u && run_n <= thin_n ? 1u : 0u) << q;
+            if (hb + q == 1) {   // forward_net.py:324 — the window's part of sum(|x|) and count(|x| > 0)
+                s1_sum = base_s + (double)run_m * scale;
+                s1_cnt = run_n;
+            }
+        }
+        atomicOr(&cheapw[word], cheap_bits << sh16);
+        atomicOr(&thinw[word], thin_bits << sh16);
+        carry_n += (uint32_t)__builtin_amdgcn_readlane((int)incl_n, kWave - 1);
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(incl_s);
+        carry_s += __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb >> 32), kWave - 1) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb, kWave - 1)));
+    }
+    __syncthreads();
+    DPL_PROF_T(qt1);
+    DPL_PROF_ADD(0, qt0, qt1);
+    // ---- 2. s_0 and the walk (every lane carries the same state)
+    const double sum_out = me->sum;
+    const unsigned long long nz_out = me->cnt_gt;
+    const float gmn = dec_f32(me->min_enc), gmx = dec_f32(me->max_enc);
+    const bool nanseen = me->nan_seen != 0u;
+    // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+    const float ud = (dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+    const float s0 = nanseen ? __uint_as_float(0x7FC00000u) : __fdiv_rn((float)(sum_out + s1_sum), (float)(long long)(nz_out + s1_cnt));
+    uint32_t route = 2u;                                         // 2: walk
+    if (s0 != s0 || max_iters <= 0) route = 0u;                  // 0: finished (NaN is a fixed point)
+    else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB)) || n_runs > (uint32_t)kMaxRuns) route = 1u;   // 1: the compaction route
+    auto gathered = [&](int j) { return j > 0 && j < kLogNB - 1 && ((bm[j >> 5] >> (j & 31)) & 1u); };
+    uint32_t bad = route == 1u ? 1u : 0u;
+    float s = s0;
+    uint32_t iters = 0u;
+    if (route == 2u) {
+        const uint32_t* lp = reinterpret_cast<const uint32_t*>(list0 + pair_base[pair]);
+        int jb = log_bin(s);
+        bad = gathered(jb) ? 0u : 1u;
+        if (fail_every > 0 && pair % (uint32_t)fail_every == 0u) bad = 1u;   // test hook: the restart path
+        if (!bad && lane == 0) pub[jb >> 5] |= 1u << (jb & 31);
+        uint32_t done = 0u;
+        while (!done && !bad) {
+            const uint32_t r = __builtin_amdgcn_readfirstlane(pre[jb >> 5] + (uint32_t)__popc(bm[jb >> 5] & ((1u << (jb & 31)) - 1u)));
+            const unsigned long long n_above = t_n[r];
+            const double s_above = t_s[r];
+            // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1): d = u - bits(s) - 1 below `span`
+            const uint32_t lo1 = __float_as_uint(s) + 1u;
+            const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
+            uint32_t d0 = 0u, d1 = 0u;
+            if (lane < n_runs) {
+                if (lane < (uint32_t)kLdsRuns) {
+                    d0 = dirl[lane][r];
+                    d1 = dirl[lane][r + 1u];
+                } else {
+                    const uint16_t* drow = dir + (uint64_t)my_dir * kDirRow;
+                    d0 = drow[r];
+                    d1 = drow[r + 1u];
+                }
+            }
+            const uint32_t cj = d1 - d0, aj = my_addr + d0;
+            const uint32_t incl = wave_incl_scan_dpp(cj);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+            const uint32_t nr = min(n_runs, (uint32_t)kMaxRuns);
+            uint32_t c = 0u;   // (wave-uniform)
+            unsigned long long dsum = 0ull;
+            // one ROUND: flat indices f0 + 64 k + lane, k < kFl — all of a round's loads are in flight together (a dense bin
+            // of a large pair holds thousands of values: sixteen per lane and round; the bins of the late iterates: four)
+            auto round = [&](auto kfl, uint32_t f0) {
+                constexpr int kFl = decltype(kfl)::value;
+                uint32_t a[kFl];
+#pragma unroll
+                for (int k = 0; k < kFl; ++k) a[k] = 0u;
+                for (uint32_t j = 0; j < nr; ++j) {   // which run holds a flat index
+                    const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)j);
+                    const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)cj, (int)j);
+                    if (ej <= f0 || ej - nj >= f0 + (uint32_t)kFl * kWave) continue;   // (uniform) not in this round
+                    const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)aj, (int)j);
+#pragma unroll
+                    for (int k = 0; k < kFl; ++k) {
+                        const uint32_t rel = f0 + (uint32_t)k * kWave + lane - (ej - nj);
+                        if (rel < nj) a[k] = bj + rel;
+                    }
+                }
+                uint32_t u[kFl];
+#pragma unroll
+                for (int k = 0; k < kFl; ++k) u[k] = f0 + (uint32_t)k * kWave + lane < total ? lp[a[k]] : 0u;
+                uint32_t ds = 0u;
+#pragma unroll
+                for (int k = 0; k < kFl; ++k) {
+                    const uint32_t d = u[k] - lo1;   // (a zero wraps far beyond span)
+                    const bool in = d < span;
+                    c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                    ds += in ? d : 0u;
+                }
+                dsum += (unsigned long long)wave_sum_dpp(ds);
+            };
+            if (total <= 4u * kWave) {
+                if (total != 0u) round(std::integral_constant<int, 4>{}, 0u);
+            } else {
+                for (uint32_t f0 = 0; f0 < total; f0 += 16u * kWave) round(std::integral_constant<int, 16>{}, f0);
+            }
+            const unsigned long long tc = c, tm = dsum + (unsigned long long)c * (unsigned long long)(lo1 & 0x7FFFFFu);
+            const unsigned long long tg = n_above + tc;
+            const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+            const OctavStep qs = octav_step(ts, tg, n_pair - tg, ud, s, iters, max_iters);
+            s = qs.s;
+            iters = qs.iters;
+            done = qs.done;
+            if (!done) {
+                const int jn = log_bin(s);
+                if (!gathered(jn)) {
+                    bad = 1u;   // a bin that was not gathered (or out of the binned window): the compaction route takes over
+                } else if (jn != jb) {
+                    jb = jn;
+                    if (lane == 0) pub[jb >> 5] |= 1u << (jb & 31);
+                }
+            }
+        }
+    }
+    DPL_PROF_T(qt2);
+    DPL_PROF_ADD(2, qt1, qt2);
+    if (lane == 0) g_prof_iters_add(blockIdx.x, iters);
+    __syncthreads();
+    // ---- 3. what the next batches should gather for this tensor: the bins stepped into, neighbours that hold next to
+    // nothing, the sparse tail.  (A pair that missed is published by k_octav_walk(only_missed): its bracket.)
+    if (route == 2u && !bad) {
+        const uint32_t mine = pub[lane];
+        const uint32_t up = (mine << 1) | (lane > 0 ? pub[lane - 1] >> 31 : 0u);                                  // j + 1 candidates
+        const uint32_t dn = (mine >> 1) | (lane + 1 < (uint32_t)kLogWords ? pub[lane + 1] << 31 : 0u);           // j - 1 candidates
+        uint32_t valid = 0xFFFFFFFFu;
+        if (lane == 0) valid &= ~1u;                               // bins 1 .. kLogNB - 2
+        if (lane == (uint32_t)kLogWords - 1u) valid &= ~(1u << 31);
+        const uint32_t out = mine | (((up | dn) & ~mine & cheapw[lane]) | thinw[lane]) & valid;
+        if (out) atomicOr(vis_w + tensor * kLogWords + lane, out);
+    }
+    if (lane == 0) {
+        if (route == 0u || !bad) {
+            me->s = route == 0u ? s0 : s;
+            me->unsigned_div = ud;
+            me->iters = route == 0u ? 0u : iters;
+            me->sum = 0.0;
+            me->cnt_gt = 0ull;
+            me->cnt_le = 0ull;
+            me->len[0] = 0u;
+            me->len[1] = 0u;
+            me->cur = 2u;
+            me->done = 1u;
+            me->mode = 2u;
+        } else {
+            me->mode = 1u;   // missed: k_octav_walk(only_missed) takes it from here (the streamed statistics stay in place)
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        }
+    }
+}
+
 __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* vis_w, const uint32_t* vis_o, uint32_t* pred,
                                      int64_t vis_words, int zero_w) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < vis_words) {   // this batch gathers what the current and the previous epoch's walks stepped into (a snapshot: the
-                           // walks of this batch keep adding to vis_w while they run)
+                           // walks of this batch keep adding to vis_w while they run).  One wave = one tensor, lane = word.
         const uint32_t mine = zero_w ? 0u : vis_w[i];
         if (zero_w) vis_w[i] = 0u;
-        pred[i] = mine | vis_o[i];
+        uint32_t x = mine | vis_o[i];
+        // at most kMaxFlag - 1 bins (lowest first): ranks are table indices; a walk that needs a dropped bin finishes on the
+        // compaction route like any other miss
+        const uint32_t lane = threadIdx.x & (kWave - 1);
+        uint32_t incl = wave_incl_scan_dpp((uint32_t)__popc(x));
+        uint32_t below = incl - (uint32_t)__popc(x);
+        if (incl > (uint32_t)(kMaxFlag - 1)) {
+            const uint32_t keep = below < (uint32_t)(kMaxFlag - 1) ? (uint32_t)(kMaxFlag - 1) - below : 0u;
+            while ((uint32_t)__popc(x) > keep) x &= ~(1u << (31 - __clz(x)));
+            below = min(below, (uint32_t)(kMaxFlag - 1));
+        }
+        const int64_t t = i / kLogWords;
+        pred[t * kPredRow + lane] = x;
+        pred[t * kPredRow + kLogWords + lane] = below;
     }
     if (i > n_pairs) return;  // slot n_pairs is the control block
     dpl_octav_state z;
@@ -793,6 +1210,9 @@ int dpl_res_prof_read(unsigned long long* host_out, int reset) {   // tuning bui
 #endif
 
 uint32_t dpl_octav_slice_cap(void) { return kCap; }
+uint32_t dpl_octav_sort_chunk(void) { return kChunk; }
+uint32_t dpl_octav_dir_row(void) { return (uint32_t)kDirRow; }
+uint32_t dpl_octav_small_pair(void) { return kSmallCap; }
 
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0) {
     if (!spans || n_spans < 0) return fail_msg("dpl_build_octav_slices: bad arguments");
@@ -880,18 +1300,56 @@ int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, co
     return 0;
 }
 
-int dpl_octav_oneread_walk(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
-                           const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
-                           const uint64_t* d_pair_base, const uint32_t* d_pair_order, const float* d_list0, int dynamic_sym,
+int dpl_octav_oneread_walk(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                           uint16_t* d_dir, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred, int write_epoch,
+                           int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs, const uint64_t* d_pair_base,
+                           const uint32_t* d_pair_order, int64_t n_small, float* d_list0, int sorted, int dynamic_sym,
                            int max_iters, dpl_stream_t s) {
     if (n_pairs <= 0) return 0;
     if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_walk: bad tensor count / epoch");
-    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices) return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices || !d_slice_chunk0 || !d_dir || !d_pair_order)
+        return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
+    if (n_small < 0 || n_small > n_pairs || n_slices < 0) return fail_msg("dpl_octav_oneread_walk: bad counts");
     uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
-    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
-                       d_pair_order, reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w,
-                       (uint32_t)n_tensors, d_pair_base, d_list0, d_slices, dynamic_sym, max_iters, g_exact_fail_every);
-    DPL_LAUNCH_CHECK("k_octav_walk");
+    const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(d_lh);
+    if (!sorted) {   // every pair walked from registers by one workgroup (misses handled inside)
+        hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                           d_pair_order, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
+                           dynamic_sym, max_iters, g_exact_fail_every, 0);
+        DPL_LAUNCH_CHECK("k_octav_walk");
+        return 0;
+    }
+    const int64_t n_big = n_pairs - n_small;   // d_pair_order: largest first, so the small pairs are its last n_small entries
+    if (n_big > 0) {
+        hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)n_slices), dim3(kThreads), 0, (hipStream_t)s, d_slices, d_pair_slice0, lh, d_pred,
+                           (uint32_t)n_tensors, d_pair_base, d_list0, d_slice_chunk0, d_dir);
+        DPL_LAUNCH_CHECK("k_octav_sort");
+        hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                           d_pair_order, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
+                           d_slice_chunk0, d_dir, dynamic_sym, max_iters, g_exact_fail_every);
+        DPL_LAUNCH_CHECK("k_octav_walk_sorted");
+    }
+    if (n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
+        hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_small), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                           d_pair_order + n_big, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
+                           dynamic_sym, max_iters, g_exact_fail_every, 0);
+        DPL_LAUNCH_CHECK("k_octav_walk");
+    }
+    return 0;
+}
+
+int dpl_octav_oneread_missed(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
+                             const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+                             const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small, float* d_list0,
+                             int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_pairs <= 0 || n_pairs - n_small <= 0) return 0;
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_missed: bad tensor count / epoch");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices || !d_pair_order) return fail_msg("dpl_octav_oneread_missed: null scratch buffer");
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
+    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)(n_pairs - n_small)), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                       d_pair_order, reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors,
+                       d_pair_base, d_list0, d_slices, dynamic_sym, max_iters, g_exact_fail_every, 1);
+    DPL_LAUNCH_CHECK("k_octav_walk(only_missed)");
     return 0;
 }
 
@@ -905,19 +1363,24 @@ int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, co
                                     d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, (hipStream_t)s);
 }
 
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh, uint32_t* d_vis,
-                          uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
-                          int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
-                          dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
-                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym, int max_iters,
-                          dpl_stream_t s) {
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                          uint16_t* d_dir, uint64_t* d_lh, uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch,
+                          int64_t n_tensors, const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small,
+                          float* d_list0, float* d_list1, int sorted, int dynamic_sym, int max_iters, dpl_stream_t s) {
     if (n_slices <= 0 || n_pairs <= 0) return 0;
     if (int e = dpl_octav_oneread_prepare(d_vis, d_pred, write_epoch, reset_epoch, n_tensors, d_states, n_pairs, s)) return e;
     if (int e = dpl_octav_oneread_stream(d_slices, n_slices, d_pair_slice0, d_lh, d_pred, n_tensors, d_seg_ptrs, d_states, n_pairs,
                                          d_pair_base, d_list0, s))
         return e;
-    if (int e = dpl_octav_oneread_walk(d_slices, d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs, d_pair_base,
-                                       d_pair_order, d_list0, dynamic_sym, max_iters, s))
+    if (int e = dpl_octav_oneread_walk(d_slices, n_slices, d_pair_slice0, d_slice_chunk0, d_dir, d_lh, d_vis, d_pred, write_epoch,
+                                       n_tensors, d_states, n_pairs, d_pair_base, d_pair_order, n_small, d_list0, sorted, dynamic_sym,
+                                       max_iters, s))
+        return e;
+    if (sorted)
+        if (int e = dpl_octav_oneread_missed(d_slices, d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs,
+                                         d_pair_base, d_pair_order, n_small, d_list0, dynamic_sym, max_iters, s))
         return e;
     return dpl_octav_oneread_fallback(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
                                       d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, s);

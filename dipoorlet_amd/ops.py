@@ -141,13 +141,24 @@ class TensorSetPlan:
                 self._octav_one = False
             else:
                 arr, n, ps = built
+                chunk, small = _hip.lib().dpl_octav_sort_chunk(), _hip.lib().dpl_octav_small_pair()
+                counts = np.frombuffer(arr, dtype=np.dtype([("offset", "<u8"), ("count", "<u4"), ("seg", "<u4"), ("slot", "<u4"),
+                                                            ("reserved", "<u4")]), count=n)["count"].astype(np.int64)
+                per_slice = (counts + chunk - 1) // chunk                       # sorted runs a slice's list can have
+                chunk0 = np.zeros(n, np.int64)
+                chunk0[1:] = np.cumsum(per_slice)[:-1]
                 self._octav_one = dict(
+                    # first directory row of each slice; the directory itself: one row per run (position of each rank's first value)
+                    slice_chunk0=torch.from_numpy(chunk0.astype(np.int32)).to(self.device),
+                    dir=torch.empty(int(per_slice.sum()) * _hip.lib().dpl_octav_dir_row(), dtype=torch.int16, device=self.device),
+                    # pairs that gather their whole window (the last entries of the largest-first pair order): no sort
+                    n_small=self.batch * sum(1 for e in self.elems if e <= small),
                     slices=_upload_struct_array(arr, n, self.device), n_slices=n,
                     pair_slice0=torch.frombuffer(bytearray(bytes(ps)), dtype=torch.int32).to(self.device),
                     lh=torch.empty(n, 2048, dtype=torch.int64, device=self.device),    # one histogram row per slice
                     # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
                     vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
-                    pred=torch.zeros(self.T, 64, dtype=torch.int32, device=self.device), calls=0)
+                    pred=torch.zeros(self.T, 128, dtype=torch.int32, device=self.device), calls=0)
         return self._octav_one or None
 
     def seg_table(self, tensors):
@@ -255,7 +266,8 @@ _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 _OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
 # batches per prediction epoch of the one-read form: a batch gathers the bins the walks of the current and the previous epoch
 # stepped into (8-16 batches of history)
-_ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.10"))
+_ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.30"))
+_ONEREAD_SORT_SHARE = float(os.environ.get("DPL_ONEREAD_SORT_SHARE", "0.05"))
 _ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
 
 
@@ -292,10 +304,11 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
         k = res["calls"]
         res["calls"] = k + 1
         epoch, first = divmod(k, _ONEREAD_EPOCH)
-        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["lh"]),
+        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["slice_chunk0"]),
+                                           _ptr(res["dir"]), _ptr(res["lh"]),
                                            _ptr(res["vis"]), _ptr(res["pred"]), epoch % 2, 1 if first == 0 else 0, plan.T,
                                            *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base), _ptr(order),
-                                           _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
+                                           res["n_small"], _ptr(l0), _ptr(l1), _walk_sorted(plan), dyn, _OCTAV_MAX_ITERS, _stream()),
                    "dpl_octav_run_oneread")
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
@@ -318,6 +331,15 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
     return out
+
+
+def _walk_sorted(plan):
+    """1: the plan's next one-read batch walks sorted runs, 0: whole lists from registers (DPL_OCTAV_WALK = sorted | group
+    forces one; default: by the share of values the plan's last batches listed, see OctavPipeline._settle)."""
+    forced = os.environ.get("DPL_OCTAV_WALK", "auto")
+    if forced in ("sorted", "group"):
+        return 1 if forced == "sorted" else 0
+    return plan.__dict__.get("_octav_sorted", 0)
 
 
 class OctavPipeline:
@@ -344,7 +366,7 @@ class OctavPipeline:
         self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
         self._touched = []
         # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
-        self.batches = self.fallback_batches = self.fallback_pairs = self.switched = 0
+        self.batches = self.fallback_batches = self.fallback_pairs = self.switched = self.sorted_batches = 0
         self.list_share = 0.0    # gathered values / elements (running mean over the settled batches)
 
     @staticmethod
@@ -358,11 +380,13 @@ class OctavPipeline:
             # side-stream work, while the one of call k must survive until the host has read k's count of unfinished pairs
             plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(4)]
             plan._octav_pipe_failed = [x[off:off + 24] for x in plan._octav_pipe_states]
+            # the prediction snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
+            # taken care of (two submits later), after the snapshot of call k + 2 has been written
+            plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(3)]
             sets = []
             for j in range(2):
                 sets.append(dict(failed=torch.zeros(24, dtype=torch.uint8).pin_memory(),
                                  lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
-                                 pred=res["pred"] if j == 0 else torch.zeros_like(res["pred"]),
                                  l0=l0 if j == 0 else torch.empty_like(l0), done=None, refs=None, pending=False, k=-1))
             plan._octav_pipe_sets = sets
         return sets
@@ -370,7 +394,7 @@ class OctavPipeline:
     def _prepare(self, plan, res, st, k, stream):
         """State array + prediction snapshot (in set `st`) for the plan's call number k."""
         ep, first = divmod(k, _ONEREAD_EPOCH)
-        _hip.check(_hip.lib().dpl_octav_oneread_prepare(_ptr(res["vis"]), _ptr(st["pred"]), ep % 2, 1 if first == 0 else 0, plan.T,
+        _hip.check(_hip.lib().dpl_octav_oneread_prepare(_ptr(res["vis"]), _ptr(plan._octav_pipe_pred[k % 4]), ep % 2, 1 if first == 0 else 0, plan.T,
                                                         _ptr(plan._octav_pipe_states[k % 4]), plan.n_pairs, stream),
                    "dpl_octav_oneread_prepare")
         st["prepared"] = k
@@ -399,6 +423,14 @@ class OctavPipeline:
         # prediction, for the rest of its life.
         share = listed / max(1, plan.batch * sum(plan.elems))
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
+        # which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short, sorted
+        # runs beyond ~5 % of the elements (measured, ResNet-50 shapes: 2.8 % listed 0.59 vs 0.55 of the roofline, 9 % listed
+        # 0.38 vs 0.43, 24 % listed 0.20 vs 0.32)
+        if share > _ONEREAD_SORT_SHARE * 1.2:
+            plan._octav_sorted = 1
+        elif share < _ONEREAD_SORT_SHARE * 0.8:
+            plan._octav_sorted = 0
+        self.sorted_batches += st["sorted"]
         plan._octav_wide = plan.__dict__.get("_octav_wide", 0) + 1 if share > _ONEREAD_MAX_SHARE else 0
         if plan._octav_wide >= 2 and not plan.__dict__.get("_octav_two_read"):
             plan._octav_two_read = True
@@ -410,6 +442,13 @@ class OctavPipeline:
         tensors, tab, out = st["refs"]
         spans, base, order, _, l1 = plan.octav_scratch()
         w = plan.work("octav", per_image=True)
+        epoch = ((res["calls"] - 1) // _ONEREAD_EPOCH) % 2     # the accumulator the latest submitted batch writes to
+        if st["sorted"]:   # (the register walk takes care of its misses itself)
+            _hip.check(_hip.lib().dpl_octav_oneread_missed(_ptr(res["slices"]), _ptr(res["pair_slice0"]), _ptr(st["lh"]),
+                                                           _ptr(res["vis"]), _ptr(plan._octav_pipe_pred[st["k"] % 4]), epoch, plan.T,
+                                                           _ptr(st["states"]), plan.n_pairs, _ptr(base), _ptr(order), res["n_small"],
+                                                           _ptr(st["l0"]), self.dyn, _OCTAV_MAX_ITERS, self.side.cuda_stream),
+                       "dpl_octav_oneread_missed")
         _hip.check(_hip.lib().dpl_octav_oneread_fallback(*w.args(), _ptr(tab), _ptr(st["states"]), plan.n_pairs, _ptr(spans),
                                                          _ptr(base), _ptr(order), _ptr(st["l0"]), _ptr(l1), self.dyn,
                                                          _OCTAV_MAX_ITERS, self.side.cuda_stream), "dpl_octav_oneread_fallback")
@@ -434,6 +473,8 @@ class OctavPipeline:
         cur["refs"] = (list(tensors), tab, out)
         cur["k"] = k
         cur["states"] = plan._octav_pipe_states[k % 4]
+        cur["pred"] = plan._octav_pipe_pred[k % 4]
+        cur["sorted"] = _walk_sorted(plan)
         L = _hip.lib()
         if cur.get("prepared") != k:
             self._prepare(plan, res, cur, k, main.cuda_stream)
@@ -443,9 +484,11 @@ class OctavPipeline:
         streamed = torch.cuda.Event()
         streamed.record(main)
         self.side.wait_event(streamed)
-        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["slices"]), _ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
+        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["slice_chunk0"]),
+                                            _ptr(res["dir"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
                                             (k // _ONEREAD_EPOCH) % 2, plan.T, _ptr(cur["states"]), plan.n_pairs, _ptr(base),
-                                            _ptr(order), _ptr(cur["l0"]), self.dyn, _OCTAV_MAX_ITERS, self.side.cuda_stream),
+                                            _ptr(order), res["n_small"], _ptr(cur["l0"]), cur["sorted"], self.dyn, _OCTAV_MAX_ITERS,
+                                            self.side.cuda_stream),
                    "dpl_octav_oneread_walk")
         with torch.cuda.stream(self.side):
             cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 11
+#define DPL_ABI_VERSION 12
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -169,7 +169,19 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  *   d_lh: uint64 [n_slices, 2048] scratch: every slice writes its histogram row in full (plain coalesced stores, no
  *     read-modify-write, nothing to zero); the walk adds up the rows of a pair's slices;
  *   d_vis: uint32 [2, n_tensors, 64] epoch accumulators (slot = image * n_tensors + tensor); this batch's walks add to
- *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 64] scratch.
+ *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 128] scratch (the bins
+ *     to gather, at most 255 of them, + per bitmap word the number of gathered bins below it: a gathered bin's RANK);
+ *   dpl_octav_oneread_walk, sorted == 0: every pair is walked by one workgroup with its list in registers (k_octav_walk: the
+ *     faster way while the lists are short — up to ~5 % of the elements — and the prediction is narrow; misses are handled
+ *     inside: no dpl_octav_oneread_missed call); sorted != 0 (long lists: a scan of the whole list per iteration no longer
+ *     pays): it first SORTS every slice's list (k_octav_sort: dpl_octav_sort_chunk() values at a time, in place,
+ *     by the rank of the values' bins; d_dir: uint16 [n_chunks, dpl_octav_dir_row()] receives per chunk the position of each
+ *     rank's first value, d_slice_chunk0 [n_slices]: the first directory row of a slice = the running sum of
+ *     ceil(slice count / chunk) over the slices before it), then walks each pair with ONE WAVE over its sorted runs
+ *     (k_octav_walk_sorted: per iteration the directory entries of one rank and the values behind them); the last n_small
+ *     pairs of d_pair_order (at most dpl_octav_small_pair() elements: whole window gathered, no sort) are walked from
+ *     registers by one workgroup each (k_octav_walk), and so are — for their bracket and their compaction-route state —
+ *     the pairs the sorted walk could not finish;
  * dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot d_pred (and the
  * epoch reset); dpl_octav_oneread_stream = k_octav_oneread; dpl_octav_oneread_walk = k_octav_walk, which leaves the number
  * of pairs that need the compaction route in the control block (d_states[n_pairs].cnt_le); dpl_octav_oneread_fallback = that
@@ -178,26 +190,37 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  * latency-bound, the streaming kernel HBM-bound) when the caller orders walk(i) after stream(i) and gives concurrently
  * live batches their own d_states / d_lh / d_pred / d_list0 / d_list1; d_vis is shared (bits are only ever OR-ed in). */
 uint32_t dpl_octav_slice_cap(void);
+uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run (see below) */
+uint32_t dpl_octav_dir_row(void);    /* uint16 entries of a run's directory row */
+uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements gather their whole window */
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
 int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
                               dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
 int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
                              const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
                              int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s);
-int dpl_octav_oneread_walk(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
-                           const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
-                           const uint64_t* d_pair_base, const uint32_t* d_pair_order, const float* d_list0, int dynamic_sym,
+int dpl_octav_oneread_walk(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                           uint16_t* d_dir, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred, int write_epoch,
+                           int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs, const uint64_t* d_pair_base,
+                           const uint32_t* d_pair_order, int64_t n_small, float* d_list0, int sorted, int dynamic_sym,
                            int max_iters, dpl_stream_t s);
+/* the pairs the sorted walk marked as missed (control block count != 0), before dpl_octav_oneread_fallback: their bracket is
+ * published for the next batches (into d_vis[write_epoch]: pass the epoch current at the time of the call) and their state
+ * prepared for the compaction route; a no-op kernel when nothing was missed — a caller that can read the count skips it */
+int dpl_octav_oneread_missed(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
+                             const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+                             const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small, float* d_list0,
+                             int dynamic_sym, int max_iters, dpl_stream_t s);
 int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
                                const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
                                const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
                                float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s);
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh, uint32_t* d_vis,
-                          uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors, const dpl_work_item* d_items,
-                          int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks, const float* const* d_seg_ptrs,
-                          dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
-                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym, int max_iters,
-                          dpl_stream_t s);
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                          uint16_t* d_dir, uint64_t* d_lh, uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch,
+                          int64_t n_tensors, const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small,
+                          float* d_list0, float* d_list1, int sorted, int dynamic_sym, int max_iters, dpl_stream_t s);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 /* TEST HOOK: makes the exact walk of dpl_octav_run_bracket reject every `every`-th pair (0 = off) so that the
  * restart on the compaction route — taken in production only when an iterate leaves the bracket's bins — can be

@@ -8,6 +8,6 @@ for v in "$@"; do
   rm -rf /tmp/abl; mkdir -p /tmp/abl
   env DPL_OCTAV_PIPELINE=${PIPE:-0} $ENVS rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl/stats -o bench -- python3 bench.py --cpu-seconds 0 --steps 1 --warmup 0 --mse-steps 1 > /tmp/abl/bench.json 2> /tmp/abl/err.txt
   echo "== $v  [PIPE=${PIPE:-0} $ENVS]  $(python3 -c "import json;d=json.loads(open('/tmp/abl/bench.json').read().strip().splitlines()[-1]);print('mse img/s %.0f  frac %.4f' % (d['mse']['value'], d['mse']['roofline']['frac']))")"
-  python3 scripts/summarize_prof.py stats /tmp/abl/stats /tmp/abl/ks.md | grep "octav_walk\|octav_oneread(\|k_minmax(" | cut -c1-40,95-150
+  python3 scripts/summarize_prof.py stats /tmp/abl/stats /tmp/abl/ks.md | grep "octav_walk\|octav_oneread(\|k_minmax(\|octav_sort" | cut -c1-40,95-150
   rm -f gpurun_out/abl_$name.so
 done

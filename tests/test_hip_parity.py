@@ -389,7 +389,14 @@ def test_octav_bracket_routes(dev, form):
 
 
 @pytest.mark.parametrize("form", ["oneread", "bracket"])
-def test_octav_exact_walk_restart_path(dev, form):
+def test_octav_exact_walk_restart_path(dev, form, monkeypatch):
+    _restart_path(dev, form)
+    if form == "oneread":      # ... and with the sorted-run walk, whose misses a second kernel takes care of
+        monkeypatch.setenv("DPL_OCTAV_WALK", "sorted")
+        _restart_path(dev, form)
+
+
+def _restart_path(dev, form):
     """An iterate that leaves the bracket's bins makes the exact walk hand the pair to the compaction route.  That is
     rare by construction, so the C-ABI test hook rejects every second pair on purpose: the results must not change."""
     from dipoorlet_amd import _hip, ops
@@ -436,11 +443,14 @@ def test_channel_diff_sum(dev):
     np.testing.assert_allclose(ops.channel_diff_sum(a, b).cpu().numpy(), a.double().sum((0, 2)).cpu().numpy(), rtol=1e-12)
 
 
-def test_octav_randomised_shapes_and_distributions(dev):
-    """A seeded sweep over odd sizes (not multiples of 4, below / above the small-pair threshold, split over several
+@pytest.mark.parametrize("walk", ["group", "sorted"])
+def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
+    """(Both walks of the one-read form: whole lists scanned from registers by a workgroup per pair / one wave per pair over
+    sorted runs.)  A seeded sweep over odd sizes (not multiples of 4, below / above the small-pair threshold, split over several
     workgroups) and distributions (discrete-valued, sparse, constant, huge / tiny scale, heavy tails): the three forms
     agree with each other and with the numpy oracle, for both `dynamic_sym` settings, in batched launches."""
     from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_WALK", walk)
     rng = np.random.default_rng(20260)
     sizes = [1, 3, 17, 1023, 1025, 4099, 16383, 16385, 50001, 131071, 300003, 1200007]
 
@@ -484,11 +494,13 @@ def test_octav_randomised_shapes_and_distributions(dev):
                 assert g[1] == x.min() and g[2] == x.max()
 
 
-def test_octav_pipeline_matches_single_stream(dev, kl):
-    """OctavPipeline (walk of batch i on a side stream beside the streaming kernel of batch i + 1, double-buffered
+@pytest.mark.parametrize("walk", ["group", "sorted", "auto"])
+def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk):
+    """(walk: as above; auto = chosen by the listed share.)  OctavPipeline (walk of batch i on a side stream beside the streaming kernel of batch i + 1, double-buffered
     scratch) returns what octav_batch returns batch by batch — including the first batches, where every multi-slice pair
     takes the compaction route on the side stream — and the oracle's scales."""
     from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_WALK", walk)
     rng = np.random.default_rng(41)
     B, sizes = 4, [401408, 30000, 802816, 777, 200704]
     batches = []

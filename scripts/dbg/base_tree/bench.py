@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Benchmark of the calibration hot path on MI355X.
+
+A "step" = ONE WHOLE CALIBRATION SWEEP of BASELINE.json's headline configuration over activations already resident in
+HBM: ResNet-50 (123 tensors, 26,598,376 fp32 elements = 106.39 MB per image), `-A hist --bins 2048`, N = 1024 images per
+GPU in 32 batches of 32:
+    pass 1  running min / max of every tensor over the 32 batches      (k_minmax:   one read of the set)
+            [N > 1 GPUs: all-reduce MIN / MAX of the ranges over RCCL]
+    pass 2  |x| histograms against the global ranges                   (k_abs_hist: the second, inherent read)
+            [N > 1 GPUs: all-reduce SUM of the [123, 2048] int64 histograms over RCCL]
+    clip    percentile threshold per tensor                            (k_hist_percentile)
+so `--steps K` times K sweeps (~35 ms each) and `metric` / `config.workload` say N = 1024 whatever K is.
+
+The same JSON line carries, as `"mse"`, BASELINE configs[2]: the `-A mse` (OCTAV) sweep, N = 4096 images per GPU in 128
+batches of 32 through ops.octav_batch (one-read form) + the per-tensor clip — timed the same way over `--mse-steps` sweeps.
+
+`value` is whole-job images/s of the hist sweep; `roofline` is the hist kernel's (duration by HIP events on the launch
+stream inside the timed region); `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on a bounded
+sample of the same activations on the host cores of this box, rank 0, N = 1 only.
+
+Multi-GPU: launched by torch.distributed.run (one rank per GPU) — or, when started plainly with --gpus N > 1, this script
+starts the N ranks itself as child processes (before anything touches the GPU) and relays rank 0's line.  Images are
+sharded with no data-path collective (weak scaling: every rank sweeps its own N images); the algorithm's real exchanges
+(above) run inside the timed region.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_HIST, N_MSE, BATCH = 1024, 4096, 32   # BASELINE.json configs[1], configs[2]
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20, help="timed hist sweeps (N = 1024 images each)")
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--mse-steps", type=int, default=4, help="timed mse sweeps (N = 4096 images each); 0 skips the mse object")
+    p.add_argument("--bins", type=int, default=2048)
+    p.add_argument("--pool", type=int, default=8, help="distinct resident batches of 32 images cycled through (3.4 GB each)")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
+    p.add_argument("--dry-run", action="store_true",
+                   help="launcher / rendezvous / collective plumbing only, on CPU tensors (no kernels, no GPU): what the "
+                        "world_size-2 gloo test on the build box runs")
+    p.add_argument("--algo", choices=["hist", "mse"], default="hist",
+                   help="which sweep is the headline `value` (the other one is still reported: mse as the `mse` object)")
+    return p.parse_args()
+
+
+def self_launch(a):
+    """Started without a launcher but asked for N > 1 ranks: start them (fresh child processes, nothing here has touched
+    the GPU), rendezvous on 127.0.0.1, relay rank 0's stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(max(abs(c) for c in codes))
+
+
+def cpu_baseline(algo, bins, tensors, budget_s):
+    """Time the CPU oracle on the host cores of this box over a bounded sample of the same activations.
+    Checker code is being MEASURED here as the CPU side of the comparison, never shipped.
+
+    Main figure: the plain-C restatement (oracle/c_oracle.c, bit-compatible with the reference's numpy
+    arithmetic), OpenMP-parallel over the (image, tensor) arrays on all cores.  Also reported: the numpy
+    restatement on one thread — what the reference's own Python does per image."""
+    import warnings
+
+    from oracle import c_oracle as CO
+    from oracle import np_oracle as O
+    B = tensors[0].shape[0]
+    host = [t.cpu().numpy() for t in tensors]                       # [B, e] each
+    arrays = [h[b] for b in range(B) for h in host]                 # B * T independent arrays
+    threads = os.cpu_count() or 1
+    CO.batch(arrays[:len(host)], algo, bins, threads)               # warm up (thread pool, page faults)
+    done, t_used = 0, 0.0
+    while t_used < budget_s * 0.75:
+        t0 = time.perf_counter()
+        used = CO.batch(arrays, algo, bins, threads)[0]
+        t_used += time.perf_counter() - t0
+        done += B
+    n_np, t_np = 0, 0.0
+    while t_np < budget_s * 0.25:                                   # numpy, one thread, a few images
+        xs = [h[n_np % B] for h in host]
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mm = [O.minmax(x) for x in xs]
+            if algo == "hist":
+                for x, (lo, hi) in zip(xs, mm):
+                    O.abs_hist(x, bins, O.hist_dmax(lo, hi))
+            else:
+                for x in xs:
+                    O.octav_scale(x, 1)
+        t_np += time.perf_counter() - t0
+        n_np += 1
+    c_rate, np_rate = done / t_used, n_np / t_np
+    out = {"unit": "images/s", "kind": "port", "c_openmp_images_per_s": c_rate, "c_openmp_threads": int(used),
+           "numpy_single_thread_images_per_s": np_rate}
+    if c_rate >= np_rate:
+        out.update(value=c_rate, cores=int(used),
+                   sample=f"{done} images ({done // B} passes over {B} images' ResNet-50-shaped activations), -A {algo}, "
+                          f"C oracle with OpenMP over (image, tensor) arrays, {t_used:.1f} s; host has {os.cpu_count()} cores")
+    else:
+        out.update(value=np_rate, cores=1,
+                   sample=f"{n_np} images of the same ResNet-50-shaped activations, -A {algo}, numpy oracle on one "
+                          f"thread, {t_np:.1f} s; host has {os.cpu_count()} cores")
+    return out
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        self_launch(a)   # does not return
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run or by self_launch (also with one rank: same code path)
+    backend = os.environ.get("DPL_DIST_BACKEND", "gloo" if a.dry_run else "nccl")
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if not a.dry_run:
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+        dist.init_process_group(backend)
+    if a.dry_run:
+        # the exchanges of one hist sweep on stand-in CPU tensors: same launcher, same rendezvous, same collectives, same line
+        T, bins = 123, a.bins
+        gmin = torch.full((T,), float(-rank - 1)), torch.full((T,), float(rank + 1))
+        hist = torch.full((T, bins), rank + 1, dtype=torch.int64)
+        if use_dist:
+            dist.barrier()
+            dist.all_reduce(gmin[0], op=dist.ReduceOp.MIN)
+            dist.all_reduce(gmin[1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(hist, op=dist.ReduceOp.SUM)
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "backend": backend if use_dist else None,
+                              "range": [float(gmin[0][0]), float(gmin[1][0])], "hist_checksum": int(hist.sum().item()),
+                              "hist_checksum_expected": T * bins * world * (world + 1) // 2}), flush=True)
+        if use_dist:
+            dist.destroy_process_group()
+        return
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    from dipoorlet_amd import _hip, ops
+    from dipoorlet_amd.dist_helper import gather_rows
+    from dipoorlet_amd.synthetic import resnet50_tensors, synth_activations
+    _, devname, _, _ = _hip.device_info()
+    spec = resnet50_tensors()
+    elems = [e for _, e, _ in spec]
+    T, E = len(elems), sum(elems)
+    B = BATCH
+    # DPL_BENCH_JITTER (a tuning aid, not the headline workload): per-image contrast jitter of the synthetic activations
+    jitter = float(os.environ.get("DPL_BENCH_JITTER", "0"))
+    pool = [synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j, image_jitter=jitter) for j in range(max(1, a.pool))]
+    plan = ops.TensorSetPlan(elems, B, dev)
+
+    def fence():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if use_dist:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return dt
+
+    # ------------------------------------------------------------------ -A hist --bins 2048, N = 1024 per GPU
+    acc = ops.CalibAccumulators(T, dev, a.bins)
+    n_hist_batches = N_HIST // B
+    hist_ev = []
+
+    def hist_sweep(timed):
+        acc.reset_minmax()
+        for b in range(n_hist_batches):                                   # pass 1
+            acc.minmax_accumulate(plan, pool[b % len(pool)])
+        gmin, gmax = acc.finalize_minmax()
+        if use_dist:                                                      # the algorithm's exchange after pass 1
+            dist.all_reduce(gmin, op=dist.ReduceOp.MIN)
+            dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+            acc.set_minmax(gmin.clone(), gmax.clone())
+        acc.hist_prepare()
+        for b in range(n_hist_batches):                                   # pass 2
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            acc.abs_hist_accumulate(plan, pool[b % len(pool)])
+            if timed:
+                e1.record()
+                hist_ev.append((e0, e1))
+        if use_dist:                                                      # ... and after pass 2
+            dist.all_reduce(acc.hist, op=dist.ReduceOp.SUM)
+        return acc.hist_percentile(0.99999)
+
+    for _ in range(a.warmup):
+        hist_sweep(False)
+    fence()
+    t0 = time.perf_counter()
+    clip = None
+    for _ in range(a.steps):
+        clip = hist_sweep(True)
+    fence()
+    dt_hist = max_over_ranks(time.perf_counter() - t0)
+    hist_kern_ms = sum(s.elapsed_time(e) for s, e in hist_ev) / max(1, len(hist_ev))
+    hist_checksum = int(acc.hist.sum().item())        # = elements x images x ranks when every rank's counts arrived
+    clip_checksum = float(clip.double().abs().sum().item())
+
+    # ------------------------------------------------------------------ -A mse (OCTAV), N = 4096 per GPU
+    mse = None
+    if a.mse_steps > 0:
+        import ctypes
+        n_mse_batches = N_MSE // B
+        states = torch.empty((plan.n_pairs + 1) * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
+        rows = torch.empty(N_MSE, T, 3, dtype=torch.float32, device=dev)
+        mse_ev = []
+
+        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and os.environ.get("DPL_OCTAV_FORM", "oneread") == "oneread"
+        pipe = ops.OctavPipeline(False, dev) if pipeline else None
+
+        def mse_sweep(timed):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            if pipe is not None:       # the product's schedule (forward_net.forward_net_octav): walk(i) beside stream(i + 1)
+                outs = [pipe.submit(plan, pool[b % len(pool)]) for b in range(n_mse_batches)]
+                pipe.sync()
+                torch.cat(outs, out=rows)
+            else:
+                for b in range(n_mse_batches):
+                    rows[b * B:(b + 1) * B] = ops.octav_batch(plan, pool[b % len(pool)], False, states)
+            if timed:
+                e1.record()
+                mse_ev.append((e0, e1))
+            allr = gather_rows(rows, world) if use_dist else rows          # the algorithm's exchange: per-image rows
+            s_mean = allr[:, :, 0].mean(0)                                 # basic_algorithm.py:57-69 on the device
+            lo = torch.maximum(allr[:, :, 1].amin(0), -s_mean)
+            hi = torch.minimum(allr[:, :, 2].amax(0), s_mean)
+            return torch.stack([lo, hi], 1)
+
+        mse_sweep(False)   # (also: the plan's first batches have no prediction yet)
+        fence()
+        t0 = time.perf_counter()
+        mclip = None
+        for _ in range(a.mse_steps):
+            mclip = mse_sweep(True)
+        fence()
+        dt_mse = max_over_ranks(time.perf_counter() - t0)
+        mse_ms = sum(s.elapsed_time(e) for s, e in mse_ev) / max(1, len(mse_ev)) / n_mse_batches   # per batch, in the sweep
+        mse_bytes = 4 * E * B          # credited: ONE read of the batch, whatever the form actually reads
+        mse_ach = mse_bytes / (mse_ms * 1e-3) / 1e9 if mse_ms > 0 else 0.0
+        form = os.environ.get("DPL_OCTAV_FORM", "oneread")
+        mse = {"metric": f"calibration images/sec, ResNet-50 ONNX N={N_MSE}, -A mse", "value": N_MSE * world * a.mse_steps / dt_mse,
+               "unit": "images/s", "steps": a.mse_steps, "ms_per_step": dt_mse / a.mse_steps * 1e3,
+               "workload": f"ResNet-50 activation set, -A mse (OCTAV per image and tensor), N={N_MSE} images per GPU in "
+                           f"batches of {B}, form '{form}'",
+               "roofline": {"bound": "hbm", "kernel": f"OCTAV batch, form '{form}'" + (" (k_octav_oneread of batch i+1 beside k_octav_walk of batch i)"
+                                                                               if pipe is not None else " (k_octav_oneread + k_octav_walk)"),
+                            "achieved": mse_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mse_ach / HBM_PEAK_GBPS,
+                            "traffic": None, "bytes_per_launch": mse_bytes, "avg_batch_ms": mse_ms},
+               "clip_checksum": float(mclip.double().abs().sum().item())}
+        if pipe is not None:   # prediction misses (pairs finished on the compaction route), warm-up sweeps included
+            mse["prediction"] = {"batches": pipe.batches, "batches_with_a_miss": pipe.fallback_batches,
+                                 "pairs_missed": pipe.fallback_pairs, "pairs_per_batch": plan.n_pairs,
+                                 "listed_share_of_elements": pipe.list_share, "switched_to_two_read_form": bool(pipe.switched), "batches_walked_sorted": pipe.sorted_batches}
+
+    # ------------------------------------------------------------------ the line
+    kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once
+    achieved = kernel_bytes / (hist_kern_ms * 1e-3) / 1e9 if hist_kern_ms > 0 else 0.0
+    # HBM bytes per launch by the PMC counters (scripts/profile_gpu.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
+    # this very script).  Quoted only when the record was measured on the kernel sources this run uses (sha over csrc/), else null.
+    def measured_traffic(kernel):
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r02", "traffic.json"))
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from summarize_prof import source_sha
+            with open(tj) as f:
+                tr = json.load(f)
+            if tr.get("source_sha") == source_sha() and tr.get("batch") == B:
+                return tr["kernels"][kernel]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+        return None
+    traffic = measured_traffic("k_abs_hist")
+    if mse is not None:
+        t1, t2 = measured_traffic("k_octav_oneread"), measured_traffic("k_octav_walk")
+        mse["roofline"]["traffic"] = (t1 + t2) if (t1 is not None and t2 is not None) else None
+    images = N_HIST * world * a.steps
+    hist_rate = images / dt_hist
+    headline_mse = a.algo == "mse" and mse is not None
+    out = {
+        # BASELINE.json's metric; images/s is `value`, the achieved HBM GB/s of the dominant kernel is `roofline.achieved`
+        "metric": "calibration images/sec (whole node) + achieved HBM GB/s, ResNet-50 ONNX N=%d, -A %s"
+                  % ((N_MSE, "mse") if headline_mse else (N_HIST, "hist")),
+        "value": mse["value"] if headline_mse else hist_rate, "unit": "images/s", "n_gpus": world,
+        "steps": a.mse_steps if headline_mse else a.steps, "warmup": a.warmup,
+        "ms_per_step": mse["ms_per_step"] if headline_mse else dt_hist / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": (mse["workload"] if headline_mse else
+                                f"ResNet-50 ONNX activation set (T={T} tensors, {E} fp32 elems/img), -A hist --bins {a.bins}, "
+                                f"N={N_HIST} images per GPU in {n_hist_batches} batches of {B}: range pass + histogram pass + "
+                                f"percentile clip per step"),
+                   "batch": B, "bins": a.bins, "algo": a.algo, "images_per_step_per_gpu": N_MSE if headline_mse else N_HIST,
+                   "resident_pool_batches": len(pool), "device": devname},
+        "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9,
+        "per_gpu_images_per_s": hist_rate / world,
+        "hist_checksum": hist_checksum, "hist_checksum_expected": E * N_HIST * world, "clip_checksum": clip_checksum,
+        "roofline": (mse["roofline"] if headline_mse else
+                     {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes,
+                      "avg_kernel_ms": hist_kern_ms}),
+        "mse": mse,
+    }
+    if rank == 0:
+        if world == 1 and a.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(a.algo, a.bins, pool[0], a.cpu_seconds)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,143 @@
+"""`python -m dipoorlet_amd -M model.onnx -I calib_dir -N 1024 -A hist -D trt` — the reference's CLI
+(dipoorlet/__main__.py:23-161) over the MI355X calibration core.
+
+Same flags; same phases where they are in scope: load model -> tensor calibration (sharded over ranks)
+-> per-rank clip JSON -> rank-0 reduce -> load -> profiling (cosine similarity of the fake-quantised
+model, optional) -> weight transforms (--bc, --we, --update_bn, --adaround, --brecq [--drop], --sparse) -> platform deploy file.
+Extra flags: --calib_batch, --resident_gb, --merge {allreduce,reference}, --skip_profiling.
+"""
+import argparse
+import copy
+import os
+import sys
+import time
+
+import torch.distributed as dist
+
+from . import dist_helper
+from .deploy import to_deploy
+from .graph import ONNXGraph
+from .tensor_cali import tensor_calibration
+from .utils import load_clip_val, logger, reduce_clip_val, save_clip_val, setup_logger
+
+
+def build_parser():
+    p = argparse.ArgumentParser(prog="dipoorlet_amd")
+    p.add_argument("-M", "--model", help="onnx model")
+    p.add_argument("-I", "--input_dir", help="calibration data", required=True)
+    p.add_argument("-O", "--output_dir", help="output data path")
+    p.add_argument("-N", "--data_num", help="num of calibration pics", type=int, required=True)
+    for flag in ("--we", "--bc", "--update_bn", "--adaround", "--brecq", "--drop", "--savefp", "--stpu_wg",
+                 "--skip_prof_layer", "--slurm", "--mpirun", "--sparse", "--optim_transformer"):
+        p.add_argument(flag, default=False, action="store_true")
+    p.add_argument("-A", "--act_quant", choices=["minmax", "hist", "mse"], default="mse")
+    p.add_argument("-D", "--deploy", choices=["trt", "stpu", "magicmind", "rv", "atlas", "snpe", "ti", "imx"],
+                   required=True)
+    p.add_argument("--bins", default=2048, type=int)  # the reference omits type= and crashes on a CLI value
+    p.add_argument("--threshold", default=0.99999, type=float)
+    p.add_argument("--ada_bs", type=int, default=64)
+    p.add_argument("--ada_epoch", type=int, default=5000)
+    p.add_argument("--skip_layers", default=[], type=str, nargs="+")
+    p.add_argument("--sparse_rate", type=float, default=0.5)
+    p.add_argument("--pattern", choices=["unstruction", "nv24"], default="unstruction")
+    p.add_argument("--model_type", choices=["unet"], default=None)
+    p.add_argument("--quant_format", default="QDQ", type=str, choices=["QOP", "QDQ"])
+    # MI355X-side knobs
+    p.add_argument("--calib_batch", type=int, default=16, help="calibration images per forward")
+    p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
+    p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
+    p.add_argument("--skip_profiling", default=False, action="store_true")
+    p.add_argument("--keep_bn", default=False, action="store_true",
+                   help="do not fold BatchNormalization into the preceding Conv / Gemm (the reference always simplifies; "
+                        "note: --update_bn also keeps the BN nodes, which it re-estimates — unlike the reference, whose "
+                        "onnxsim pass has fused them before --update_bn runs)")
+    return p
+
+
+def main(argv=None):
+    """One rank of a calibration run.  A rank that fails must not leave its peers parked at the next barrier (the
+    reference's ranks hang until the launcher is killed, __main__.py:105-110): the error is logged and the process exits
+    non-zero at once, which makes torch.distributed.run / mpirun / srun take the whole group down."""
+    try:
+        return _main(argv)
+    except SystemExit:
+        raise
+    except BaseException as e:   # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        logger.error("rank %s failed: %s", os.environ.get("RANK", "0"), e)
+        sys.stdout.flush()
+        sys.stderr.flush()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            os._exit(1)   # no atexit / destructor may wait on a collective the peers will never join
+        raise
+
+
+def _main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.quant_format == "QOP":
+        raise SystemExit("--quant_format QOP (onnxruntime's QOperator export, dipoorlet/utils.py:415-435) is not built: "
+                         "use the default QDQ format")
+    if args.slurm:
+        dist_helper.init_from_slurm()
+    elif args.mpirun:
+        dist_helper.init_from_mpi()
+    else:
+        dist_helper.init_default()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if args.output_dir is None:
+        args.output_dir = os.path.join(os.path.abspath(os.path.dirname(args.model)), "results")
+    if args.model_type is not None:      # __main__.py:71-73 (the onnxruntime transformer optimiser step is not run:
+        args.optim_transformer = True    # the graph is executed as it is)
+        args.skip_prof_layer = True
+    if rank == 0:
+        os.makedirs(args.output_dir, exist_ok=True)
+        setup_logger(args)
+    dist.barrier()
+    start = time.time()
+    onnx_graph = ONNXGraph.load(args.model, args.output_dir, args.deploy, args.model_type)
+    if not args.keep_bn and not args.update_bn:     # __main__.py:101 — onnxsim's Conv + BN fusion
+        n_folded = onnx_graph.fold_batchnorm()
+        if n_folded and rank == 0:
+            logger.info("Folded {} BatchNormalization nodes into their producers.".format(n_folded))
+    args.rank, args.world_size = rank, world
+    args.local_rank = rank % max(1, __import__("torch").cuda.device_count())
+    if rank == 0:
+        logger.info("Do tensor calibration...")
+    act_clip_val, weight_clip_val = tensor_calibration(onnx_graph, args)
+    tensor_range = copy.deepcopy(act_clip_val)
+    save_clip_val(act_clip_val, weight_clip_val, args, act_fname=f"act_clip_val.json.rank{rank}",
+                  weight_fname=f"weight_clip_val.json.rank{rank}")
+    dist.barrier()
+    if rank == 0:
+        reduce_clip_val(world, args, already_merged=(args.merge != "reference"))
+    dist.barrier()
+    act_clip_val, weight_clip_val = load_clip_val(args)
+    from .weight_transform import weight_calibration
+    if rank == 0:
+        logger.info("Weight transform...")
+    graph_after_wt, graph_ori, act_clip_val, weight_clip_val = weight_calibration(onnx_graph, act_clip_val,
+                                                                                  weight_clip_val, args)
+    dist.barrier()
+    if not args.skip_profiling:
+        from .profiling import (quantize_profiling_multipass, quantize_profiling_transformer, show_model_profiling_res,
+                                show_model_ranges, weight_need_perchannel)
+        if rank == 0:
+            logger.info("Profiling...")
+        prof = quantize_profiling_transformer if args.model_type is not None else quantize_profiling_multipass   # :141-146
+        layer_cos, model_cos, qnodes = prof(graph_after_wt, graph_ori, act_clip_val, weight_clip_val, args)
+        if rank == 0:
+            show_model_profiling_res(graph_after_wt, layer_cos, model_cos, qnodes, args)
+            show_model_ranges(graph_after_wt, act_clip_val, weight_clip_val, args)
+            weight_need_perchannel(graph_after_wt, args)
+    if rank == 0:
+        logger.info("Deploy to " + args.deploy + "...")
+        to_deploy(graph_after_wt, act_clip_val, weight_clip_val, args)
+        logger.info("Total time cost: {} seconds.".format(int(time.time() - start)))
+    dist.barrier()
+    _ = tensor_range
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

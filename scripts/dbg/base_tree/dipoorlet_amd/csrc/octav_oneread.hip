@@ -1,0 +1,1389 @@
+// OCTAV ('-A mse', forward_net.py:284-342) in ONE read of the activations, one launch per batch.
+//
+// Why not two reads: measured on MI355X (scripts/mall_probe.hip, profiles/r02/mall_probe.txt) a re-read of recently
+// streamed data costs the same whether HBM or the 256 MiB Infinity Cache serves it (6.1-6.9 TB/s either way, one
+// shared fabric), so the two-read bracket form of octav_kernels.hip cannot pass ~40 % of the roofline.  And a form that
+// keeps a pair on chip until a leader has walked its bracket (tried first: k_octav_resident, round 2) spends its time
+// waiting — three cross-workgroup round trips per slice against ~16 us of residency a CU can afford at HBM rate.
+//
+// So nothing waits here.  The values the exact iteration needs are the ones in the histogram bins its iterates fall
+// into; WHICH bins is predicted from the previous batches (the bins the same tensor's iterates visited, OR-ed over the
+// images of the last two batches, cheap neighbours added) and every iterate of the exact walk is VERIFIED against the
+// set that was gathered.  A pair whose iterate leaves the gathered bins (first batch of a run, a distribution shift)
+// publishes its bracket for the next batch and finishes on the compaction route of octav_kernels.hip.  Results are the
+// reference's iterate sequence either way; only the speed depends on the prediction.
+//
+// One 256-thread workgroup per SLICE (<= kCap elements of one (image, tensor) pair):
+//   1  the slice's only HBM read, straight into registers (buffer loads: zero fill past the end, all in flight);
+//   2  per element: min / max, exact log-scale histogram of |x| in LDS (64 bins per octave: count + integer mantissa
+//      sum, as in the bracket form) and — values of predicted bins only — a branch-free append to per-lane LDS queues;
+//   3  queues -> the pair's list (one returning atomic per wave), LDS histogram -> the pair's row (agent-scope
+//      atomics), statistics -> the pair's state; ONE ticket;
+//   4  the last slice of a pair: suffix totals of the merged row, s_0, then the exact walk — totals of the bins above
+//      the iterate's bin (exact integers) + the listed values of that bin (integer mantissa sums: the result does not
+//      depend on arrival order) — verifying each iterate's bin against the gathered set, and recording the bins it
+//      visited for the next batch.
+// A pair that fits one slice never leaves its workgroup: no list, no row, no prediction — the walk runs on the
+// registers that still hold the slice.
+// Cross-workgroup traffic is agent-scope atomics and sc1 (write-through) stores read by sc1 loads: no L2 write-back
+// fences (MI355X_MICROARCH.md, inter-workgroup visibility).  No workgroup ever waits for another.
+#include <type_traits>
+#include "common.hpp"
+#include "octav_common.hpp"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// keeps the scheduler from interleaving the unrolled per-vector bodies (their temporaries would not fit beside the slice)
+#define DPL_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / kWave;
+#ifndef DPL_RES_VEC
+#define DPL_RES_VEC 20
+#endif
+#ifndef DPL_RES_OCC
+#define DPL_RES_OCC 4
+#endif
+#ifndef DPL_CHEAP_SHIFT
+#define DPL_CHEAP_SHIFT 11  // a neighbour of a visited bin is gathered too when it holds at most n >> 11 of the pair's n elements
+#endif
+#ifndef DPL_THIN_SHIFT
+#define DPL_THIN_SHIFT 9    // ... and so is every bin above which at most n >> 9 elements lie (measured: 7 / 9 -> 9 / 11: +3 %, no more misses)
+#endif
+#ifndef DPL_SORTED_OCC
+#define DPL_SORTED_OCC 4   // waves per SIMD of k_octav_walk_sorted: every pair of a batch resident at once (15 per CU at 32 x 123 pairs)
+#endif
+#ifndef DPL_WALK_OCC
+#define DPL_WALK_OCC 4
+#endif
+constexpr int kVec = DPL_RES_VEC;                               // 16-byte vectors per thread the walk keeps a list in
+constexpr uint32_t kWalkCap = (uint32_t)kThreads * kVec * 4;    // list values the walk holds in registers (20 480)
+constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this small gather their whole window (no prediction)
+#ifndef DPL_SLICE_CAP
+#define DPL_SLICE_CAP 520192
+#endif
+constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
+static_assert(kCap < (1u << 19) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed field below the flag bit");
+constexpr int kRareTiles = (int)(kCap / (kWaves * 1024u)) + 1;   // tiles of a slice one wave walks (+ the ragged one)
+#ifndef DPL_QUEUE_CAP
+#define DPL_QUEUE_CAP 832
+#endif
+constexpr int kQueueCap = DPL_QUEUE_CAP;                        // entries of a WAVE's dense survivor queue; flushed above cap - 256
+static_assert(kQueueCap > 256, "a vector of four elements per lane may add 256 survivors");
+#ifndef DPL_QUEUE_TOP
+#define DPL_QUEUE_TOP 256
+#endif
+constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a tile's drain point, above this many entries
+#ifndef DPL_APPEND_LAG
+#define DPL_APPEND_LAG 1
+#endif
+constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
+constexpr uint32_t kBigCluster = (1u << 20) / kCap + 1;         // clusters this large may overflow the packed count field
+constexpr uint32_t kMaxCluster = 64;
+// The prediction row of a tensor (d_pred): the bitmap of the bins to gather (kLogWords words, at most kMaxFlag bits set) and,
+// per word, the number of set bits in the words below it — the RANK of a gathered bin is a table index everywhere below.
+constexpr int kMaxFlag = 256;
+constexpr int kPredRow = 2 * kLogWords;
+// Sorted runs (k_octav_sort): a slice's list is sorted, kChunk values at a time, by the rank of the values' bins; the
+// directory row of a chunk holds, per rank, the position of the rank's first value in the chunk (+ the chunk's length).
+constexpr uint32_t kChunk = 8192;
+constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows are 16-byte aligned
+
+// LDS: [A: packed histogram 16 KiB, bit 63 of a word = gather flag | one dummy word per lane][B: the waves' survivor queues 13 KiB]
+constexpr int kLdsA = kLogNB * 8 + kWave * 8;                   // + the lanes' dummy words
+constexpr int kLdsB = kWaves * kQueueCap * 4;
+
+template <class T>
+__device__ __forceinline__ T ld_agent(const T* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ void st_agent(T* p, T v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T>
+__device__ __forceinline__ T add_agent(T* p, T v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#ifdef DPL_RES_PROF
+// phase cycle counters of a tuning build (scripts/res_prof.py): [workgroup][8] u64, accumulated by thread 0
+__device__ unsigned long long g_res_prof[4096 * 8];
+#define DPL_PROF_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#define DPL_PROF_ADD(slot, a, b) do { if (threadIdx.x == 0) g_res_prof[(blockIdx.x & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
+#define DPL_PROF_WAVE(idx, slot, a, b) do { if ((threadIdx.x & 63u) == 0) g_res_prof[((idx) & 4095u) * 8 + (slot)] += (b) - (a); } while (0)
+__device__ __forceinline__ void g_prof_iters_add(uint32_t b, uint32_t it) { g_res_prof[(b & 4095u) * 8 + 7] += it; }
+#define DPL_PROF_L(len) g_res_prof[(blockIdx.x & 4095u) * 8 + 6] += (len)
+#else
+#define DPL_PROF_L(len) do {} while (0)
+__device__ __forceinline__ void g_prof_iters_add(uint32_t, uint32_t) {}
+#define DPL_PROF_T(var) do {} while (0)
+#define DPL_PROF_ADD(slot, a, b) do {} while (0)
+#define DPL_PROF_WAVE(idx, slot, a, b) do {} while (0)
+#endif
+
+struct Shared {
+    double red_d[kWaves];
+    unsigned long long red_q[kWaves];
+    uint32_t red_a[kWaves], red_b[kWaves];
+    unsigned long long part_m[2][kWaves];   // walk: the waves' partial (count, mantissa sum), two alternating slots
+    uint32_t part_c[2][kWaves];
+    float red_mn[kWaves], red_mx[kWaves];
+    uint32_t rare_tiles[kWaves * kRareTiles];   // streaming kernel: tiles holding a non-zero value outside the window
+    uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
+    uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
+    uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
+    uint32_t seg_off[kMaxCluster], seg_len[kMaxCluster];   // walk: the pair's list segments (one per slice)
+    OctavStep step;
+    int jb;
+    uint32_t bad, route;
+    float s0, ud, w_s;
+    double s_above;
+    unsigned long long n_above, n_elems;
+};
+
+// Raw per-bin (count, scaled sum) in n_ge / s_ge -> suffix totals in place (N_ge[j], S_ge[j] = everything in bins >= j).
+// Thread t owns the 8 bins below 2047 - 8 t; all 256 threads; the raw values were written by their owners.
+__device__ __forceinline__ void suffix_in_place(uint32_t* n_ge, double* s_ge, Shared& sh) {
+    constexpr int kPerT = kLogNB / kThreads;
+    const int hi = kLogNB - 1 - (int)threadIdx.x * kPerT;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    uint32_t ln = 0;
+    double ls = 0.0;
+    for (int q = 0; q < kPerT; ++q) {
+        ln += n_ge[hi - q];
+        ls += s_ge[hi - q];
+    }
+    double is = ls;
+    uint32_t in = ln;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const double ts = __shfl_up(is, o, kWave);
+        const uint32_t tn = __shfl_up(in, o, kWave);
+        if (lane >= (uint32_t)o) {
+            is += ts;
+            in += tn;
+        }
+    }
+    if (lane == kWave - 1) {
+        sh.red_d[w] = is;
+        sh.red_a[w] = in;
+    }
+    __syncthreads();
+    double rs = is - ls;
+    uint32_t rn = in - ln;
+    for (int q = 0; q < w; ++q) {
+        rs += sh.red_d[q];
+        rn += sh.red_a[q];
+    }
+    for (int q = 0; q < kPerT; ++q) {
+        const int b = hi - q;
+        rn += n_ge[b];
+        rs += s_ge[b];
+        n_ge[b] = rn;
+        s_ge[b] = rs;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double bin_sum(unsigned long long mant_explicit, uint32_t count, int b) {
+    return (double)(mant_explicit + ((unsigned long long)count << 23)) * log_bin_scale(b);   // full 24-bit mantissas
+}
+
+// wave64 inclusive prefix sum by DPP (Hillis-Steele inside each row of 16, then the two row broadcasts): VALU only — the
+// ds_bpermute form is six dependent LDS round trips
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);    // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);    // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);    // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);    // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2, 3
+    return v;
+}
+
+// One slice, streamed: per element min / max, the LDS histogram, and a queue append for the values of marked bins
+// (queues -> the slice's own region of the pair's list; the region's cursor lives in LDS).  Leaves the per-wave statistics
+// in sh.red_*.
+// Its own function (not inlined): the register allocator otherwise spills the tile buffers of this hot loop to make
+// room for values that only the walk needs.  The dynamic LDS block is addressed through address-space-3 pointers taken
+// here (not handed in): ds_ instructions with constant offsets, nothing reloaded.
+typedef __attribute__((address_space(3))) unsigned long long* lptr_u64;
+typedef __attribute__((address_space(3))) uint32_t* lptr_u32;
+__device__ __attribute__((noinline)) void stream_slice(const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
+                                                       Shared& sh) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const lptr_u64 l_packed = (lptr_u64)(lds_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    float mn = INFINITY, mx = -INFINITY;
+    uint32_t nan = 0u, nz = 0u;
+    double sum = 0.0;
+    // the wave's survivor queue: dense (ballot + mbcnt positions), `tail` entries in use (wave-uniform)
+    const lptr_u32 wq = (lptr_u32)(lds_raw + kLdsA) + (uint32_t)w * kQueueCap;
+    uint32_t tail = 0u;
+    // A flush touches no global atomic: the slice owns the part of the pair's list that starts at the slice's offset in the
+    // pair (as many entries as the slice has elements), and the position inside it comes from a cursor in LDS.  Flushes
+    // need care: gfx950 has ONE in-order counter for loads and stores (vmcnt), and the waits for tile data are counts the
+    // compiler fixes statically — a store issued between a tile's loads and the wait for them makes that wait also wait
+    // for the store's acknowledgement (measured, round 2: per-lane queues flushed in mid-tile every ~7 tiles cost 56 us
+    // of 634; dropping a returning global atomic from the flush changed nothing).  So the regular flush (queue more than
+    // kQueueTop full) happens at the START of a tile's consumption, once the whole tile has arrived: the only loads
+    // outstanding then are the next tile's, and by the time those are waited for — a tile's worth of work later — the
+    // stores have long been acknowledged.  A flush in the middle of a tile remains for the case that one tile brings more
+    // than the rest of the queue holds (a small pair gathering its whole window).  The queue is dense, so the stores are
+    // full 256-byte instructions.
+    auto flush = [&]() {
+        typedef __attribute__((address_space(1))) uint32_t* gptr_u32;   // global, not flat: see for_each_tile
+        gptr_u32 gdst = (gptr_u32)dst;
+        uint32_t base = 0u;
+        if (lane == 0) base = __hip_atomic_fetch_add((lptr_u32)&sh.cursor, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < tail; i += kWave) gdst[base + i] = wq[i] & 0x7FFFFFFFu;   // |x|; the walk is a later launch
+        tail = 0u;
+    };
+    // Four elements at a time, straight-line and branch-free.  ONE LDS operation per element does both jobs: the histogram
+    // word of a bin the walk is predicted to visit carries a flag in bit 63 (set when the workgroup initialises its
+    // histogram), and the RETURNING 64-bit add {count += 1, mantissa sum += 23 explicit bits} hands the flag back — there is
+    // no separate look-up of the predicted set (measured, round 2: that look-up — address, ds_read, bit extract, ~7 of ~21
+    // VALU instructions per element — cost 95 us of a 680 us kernel that is bound by instruction issue; the atomics
+    // themselves 4 us).  A zero or a value outside the window adds to a per-LANE dummy word behind the histogram instead of
+    // being masked off (no exec juggling, no same-address pile-up: lane l's dummy lies in bank pair l); its flag is never
+    // set.  The rare non-zero value outside the window (or NaN) leaves a per-lane mark that is looked at once per tile.
+    // `issue` starts the four adds of a vector; `append` (a vector later: the returns have arrived by then) puts the flagged
+    // elements at the wave's queue tail (position = tail + the number of flagged lanes below: ballot + v_mbcnt).
+    uint32_t rare = 0u;
+    struct Ret4 {
+        uint32_t h[4];   // high words of the returned histogram entries (bit 31 = the flag)
+    };
+    constexpr uint32_t kWin = (uint32_t)(kLogNB - 1);   // window bins 1 .. kLogNB-1 (as LogHistOp, octav_kernels.hip)
+    const lptr_u64 dummy = l_packed + kLogNB + lane;
+    auto add1 = [&](uint32_t bits) {
+        const uint32_t t = ((bits >> kLogShift) & 0x3FFFu) - (kLogKey0 + 1u);   // key = 14 bits of exponent and top mantissa
+        const bool in = t < kWin;
+        const lptr_u64 slot = in ? l_packed + t + 1u : dummy;
+        rare |= in ? 0u : bits;
+        return (uint32_t)(__hip_atomic_fetch_add(slot, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_WORKGROUP) >> 32);
+    };
+    auto issue = [&](const f4& t4) {
+        Ret4 r;
+        r.h[0] = add1(__float_as_uint(t4.x));
+        r.h[1] = add1(__float_as_uint(t4.y));
+        r.h[2] = add1(__float_as_uint(t4.z));
+        r.h[3] = add1(__float_as_uint(t4.w));
+        return r;
+    };
+    auto put = [&](uint32_t bits, uint32_t hi) {
+        const bool f = (int32_t)hi < 0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, tail));
+        if (f) wq[pos] = bits;
+        tail += (uint32_t)__builtin_popcountll(m);
+    };
+    auto append = [&](const f4& t4, const Ret4& r) {
+#if defined(DPL_ABL_NOAPPEND)      // ablation builds (timing only): the returns are not looked at, nothing is queued
+#else
+        put(__float_as_uint(t4.x), r.h[0]);
+        put(__float_as_uint(t4.y), r.h[1]);
+        put(__float_as_uint(t4.z), r.h[2]);
+        put(__float_as_uint(t4.w), r.h[3]);
+        if (tail > (uint32_t)(kQueueCap - 256)) flush();   // (rare: see flush)
+#endif
+    };
+    // A tile in which some lane marked such a value is only noted (its base, per wave) and looked at again after the
+    // slice has been streamed — the hot loop carries no code for it.  A wave has at most kCap / (waves * 1024) tiles.
+    uint32_t* rare_list = sh.rare_tiles + (size_t)w * kRareTiles;
+    uint32_t rare_n = 0u;
+    for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
+        if (tail > (uint32_t)kQueueTop) {   // the regular flush: BEFORE the tile is consumed, AFTER all of it has arrived
+            asm volatile("" ::"v"(t[3].w));   // (a use of the tile's last register: the compiler waits for the whole tile here)
+#if defined(DPL_ABL_NOFLUSH)       // ablation builds (timing only): a full queue is simply dropped
+            tail = 0u;
+#else
+            flush();
+#endif
+        }
+        Ret4 r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (full) {
+                mn = fminf(mn, fminf(fminf(t[u].x, t[u].y), fminf(t[u].z, t[u].w)));
+                mx = fmaxf(mx, fmaxf(fmaxf(t[u].x, t[u].y), fmaxf(t[u].z, t[u].w)));
+            } else {   // padding is +0.0: in no histogram bin, in no marked bin; only min / max must skip it
+                const uint32_t e = base + (uint32_t)u * 256u + lane * 4u;
+                if (e + 0 < cnt) mn = fminf(mn, t[u].x), mx = fmaxf(mx, t[u].x);
+                if (e + 1 < cnt) mn = fminf(mn, t[u].y), mx = fmaxf(mx, t[u].y);
+                if (e + 2 < cnt) mn = fminf(mn, t[u].z), mx = fmaxf(mx, t[u].z);
+                if (e + 3 < cnt) mn = fminf(mn, t[u].w), mx = fmaxf(mx, t[u].w);
+            }
+            r[u] = issue(t[u]);
+            if (u >= kAppendLag) append(t[u - kAppendLag], r[u - kAppendLag]);
+        }
+#pragma unroll
+        for (int u = 4 - kAppendLag; u < 4; ++u) append(t[u], r[u]);
+        if (__any((rare & 0x7FFFFFFFu) != 0u)) {   // (a lone sign bit is -0.0: nothing to account for)
+            if (lane == 0) rare_list[rare_n] = base;
+            ++rare_n;
+        }
+        rare = 0u;
+    });
+    // the noted tiles again (cold): non-zero values outside the window, and NaNs, are accumulated directly
+    for (uint32_t r = 0; r < rare_n; ++r) {
+        const uint32_t base = __builtin_amdgcn_readfirstlane(rare_list[r]);
+        const bool aligned = (((uintptr_t)pg) & 15u) == 0;
+        f4 t[4];
+        load_tile(pg, base, cnt, aligned, t);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float xs[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t a = __float_as_uint(xs[e]) & 0x7FFFFFFFu;
+                const uint32_t tt = (a >> kLogShift) - (kLogKey0 + 1u);
+                if (!(tt < (uint32_t)(kLogNB - 1)) && a != 0u) {
+                    const float f = __uint_as_float(a);
+                    if (f > 0.0f) {
+                        sum += (double)f;
+                        ++nz;
+                    }
+                    nan |= (f != f);
+                }
+            }
+        }
+    }
+    if (tail != 0u) flush();
+    // per-wave totals of the directly accumulated statistics
+    const float wmn = wave_min(mn), wmx = wave_max(mx);
+    const uint32_t wnz = wave_sum(nz);
+    const double wsum = wave_sum(sum);
+    const uint32_t wnan = __any(nan) ? 1u : 0u;
+    if (lane == 0) {
+        sh.red_mn[w] = wmn;
+        sh.red_mx[w] = wmx;
+        sh.red_a[w] = wnz;
+        sh.red_b[w] = wnan;
+        sh.red_d[w] = wsum;
+    }
+}
+
+// K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
+// then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
+__global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
+    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
+    unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pred, uint32_t n_tensors,
+    const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
+    __shared__ Shared sh;
+
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    const uint32_t pair = it.slot, n_sl = it.reserved, cnt = it.count;
+    dpl_octav_state* me = st + pair;
+    const float* pg = segs[it.seg] + it.offset;
+    const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
+    const uint32_t tensor = pair % n_tensors;
+    // empty histogram; bit 63 of a bin's word = "gather this bin's values": what this tensor's iterates visited lately
+    // (a small pair gathers its whole window)
+    for (int b = tid; b < kLogNB; b += kThreads) {
+        const uint32_t f = small ? 1u : (pred[tensor * kPredRow + (b >> 5)] >> (b & 31)) & 1u;
+        l_packed[b] = (unsigned long long)f << 63;
+    }
+    if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
+    if (tid == 0) sh.cursor = 0u;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
+    // the slice's region of the pair's list: at the slice's element offset inside the pair
+    const uint64_t in_pair = it.offset - slices[pair_slice0[2 * pair]].offset;
+    stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh);
+    __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
+
+    // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
+    if (tid == 0) {
+        float tmn = INFINITY, tmx = -INFINITY;
+        uint32_t tnz = 0u, tnan = 0u;
+        double tsum = 0.0;
+        for (int j = 0; j < kWaves; ++j) {
+            tmn = fminf(tmn, sh.red_mn[j]);
+            tmx = fmaxf(tmx, sh.red_mx[j]);
+            tnz += sh.red_a[j];
+            tnan |= sh.red_b[j];
+            tsum += sh.red_d[j];
+        }
+        if (tnz) {
+            atomicAdd(&me->sum, tsum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)cnt);
+        if (tmn <= tmx) {
+            atomicMin(&me->min_enc, enc_f32(tmn));
+            atomicMax(&me->max_enc, enc_f32(tmx));
+        }
+        if (tnan) atomicOr(&me->nan_seen, 1u);
+    }
+    // the slice's histogram goes out as ONE row of plain, coalesced stores (16 KiB, empty bins included: nothing to zero
+    // beforehand, no read-modify-write at the memory side); the walk adds up the rows of a pair's slices
+    unsigned long long* row = lh + (uint64_t)blockIdx.x * kLogNB;
+    // (bin 0 holds no element: its word carries the length of the slice's list segment)
+    for (int b = tid; b < kLogNB; b += kThreads) row[b] = b == 0 ? (unsigned long long)sh.cursor : l_packed[b] & ~(1ull << 63);
+}
+
+// wave64 sum by DPP (row-local butterflies, then the two row broadcasts): ~6 VALU instead of six dependent ds_bpermute round
+// trips; the total arrives in lane 63 and is broadcast from there
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);   // row_mirror: every lane holds its row's sum
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {   // per-lane values below 2^56
+    const uint32_t lo = wave_sum_dpp((uint32_t)v & 0xFFFFFFu), hi = wave_sum_dpp((uint32_t)(v >> 24));
+    return (unsigned long long)lo + ((unsigned long long)hi << 24);
+}
+
+// The exact walk of one pair (one workgroup per pair, largest pairs first): suffix totals of the pair's merged row (the row is
+// handed back zeroed), s_0, then the reference's iteration — totals of the bins above the iterate's bin (exact integers)
+// + the listed values of that bin (integer mantissa sums) — verifying that every iterate lands in a gathered bin.  Records
+// the bins it stepped into (or, when it left the gathered set, the pair's bracket) for the next batches.
+__global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
+    const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
+    int only_missed) {
+    __shared__ double s_ge[kLogNB];
+    __shared__ uint32_t n_ge[kLogNB];
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
+    dpl_octav_state* me = st + pair;
+    // only_missed: the pass behind k_octav_walk_sorted — the pairs that kernel could not finish (mode 1) are walked again
+    // here up to the bin that was not gathered, for the sake of what this kernel does THEN: publish the pair's bracket for
+    // the next batches and leave the state the compaction route starts from.  No pair missed (the steady state): nothing to do.
+    if (only_missed && (ctl->cnt_le == 0ull || me->mode != 1u)) return;
+    const unsigned long long n_pair = me->n_elems;
+    if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
+    const bool small = n_pair <= (unsigned long long)kWalkCap;
+    const uint32_t tensor = pair % n_tensors;
+    DPL_PROF_T(pt0);
+    // per-bin totals = the sum of the pair's slice rows -> LDS (own bins per thread)
+    {
+        constexpr int kPerT = kLogNB / kThreads;
+        const int hi = kLogNB - 1 - (int)tid * kPerT;
+        const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
+        uint32_t cnt[kPerT];
+        unsigned long long mant[kPerT];
+#pragma unroll
+        for (int qq = 0; qq < kPerT; ++qq) {
+            cnt[qq] = 0u;
+            mant[qq] = 0ull;
+        }
+        for (uint32_t sl = sl0; sl < sl1; ++sl) {
+            const unsigned long long* row = lh + (uint64_t)sl * kLogNB;
+#pragma unroll
+            for (int qq = 0; qq < kPerT; ++qq) {
+                const unsigned long long v = row[hi - qq];
+                cnt[qq] += (uint32_t)(v >> kPackShift);
+                mant[qq] += v & kPackMask;
+            }
+        }
+#pragma unroll
+        for (int qq = 0; qq < kPerT; ++qq) {
+            const int b = hi - qq;
+            if (b == 0) cnt[qq] = 0u, mant[qq] = 0ull;   // bin 0 holds no element (its row words are the segment lengths)
+            n_ge[b] = cnt[qq];
+            s_ge[b] = bin_sum(mant[qq], cnt[qq], b);
+        }
+        // the pair's gathered values: one list segment per slice, at the slice's element offset inside the pair
+        if (tid < sl1 - sl0) {
+            sh.seg_off[tid] = (uint32_t)(slices[sl0 + tid].offset - slices[sl0].offset);
+            sh.seg_len[tid] = (uint32_t)lh[(uint64_t)(sl0 + tid) * kLogNB];
+        }
+        suffix_in_place(n_ge, s_ge, sh);
+    }
+    // the bins whose values were gathered (the walk may only step into these)
+    if (tid < (uint32_t)kLogWords) {
+        sh.bm[tid] = small ? 0xFFFFFFFFu : pred[tensor * kPredRow + tid];
+        sh.pub[tid] = 0u;
+    }
+    if (tid == 0) {
+        const double sum_out = me->sum;
+        const unsigned long long nz_out = me->cnt_gt;
+        const unsigned long long n = me->n_elems;
+        const float gmn = dec_f32(me->min_enc), gmx = dec_f32(me->max_enc);
+        const bool nanseen = me->nan_seen != 0u;
+        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+        const float ud = (dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+        // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
+        const float s0 = nanseen ? __uint_as_float(0x7FC00000u)
+            : __fdiv_rn((float)(sum_out + s_ge[1]), (float)(long long)(nz_out + n_ge[1]));
+        uint32_t route = 2u;                                         // 2: walk
+        if (s0 != s0 || max_iters <= 0) route = 0u;                  // 0: finished (NaN is a fixed point)
+        else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB))) route = 1u;   // 1: values >= 2^14 / inf: compaction route
+        sh.s0 = s0;
+        sh.ud = ud;
+        sh.n_elems = n;
+        sh.route = route;
+        me->s = s0;
+        me->unsigned_div = ud;
+        me->iters = 0u;
+        me->sum = 0.0;
+        me->cnt_gt = 0ull;
+        me->cnt_le = 0ull;
+        me->len[0] = 0u;
+        me->len[1] = 0u;
+        me->cur = 2u;
+    }
+    __syncthreads();
+    DPL_PROF_T(pt1);
+    DPL_PROF_ADD(0, pt0, pt1);
+    const uint32_t route = __builtin_amdgcn_readfirstlane(sh.route);
+    uint32_t bad = route == 1u ? 1u : 0u;
+    float s = sh.s0;
+    uint32_t iters = 0u;
+    if (route == 2u) {
+        const float ud = sh.ud;
+        const unsigned long long n_elems = sh.n_elems;
+        // the list (bit patterns of |x|) goes into registers, 1024 values per ROW (one 16-byte vector per thread); every
+        // segment starts a new row; a list of more rows than the registers hold is re-read in pieces every iteration
+        const uint32_t n_seg = __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
+        uint32_t n_rows = 0u, L = 0u;
+        for (uint32_t j = 0; j < n_seg; ++j) {
+            const uint32_t len = __builtin_amdgcn_readfirstlane(sh.seg_len[j]);
+            n_rows += (len + 1023u) >> 10;
+            L += len;
+        }
+        f4 v[kVec];
+        const uint32_t n_chunks = (n_rows + (uint32_t)kVec - 1u) / (uint32_t)kVec;
+        const float* lp = list0 + pair_base[pair];
+        auto load_chunk = [&](uint32_t row0) {
+            uint32_t j = 0u, r = row0;   // segment and row inside it of row `row0`
+            while (j < n_seg) {
+                const uint32_t rows_j = (__builtin_amdgcn_readfirstlane(sh.seg_len[j]) + 1023u) >> 10;
+                if (r < rows_j) break;
+                r -= rows_j;
+                ++j;
+            }
+            const uint32_t voff = tid << 4;
+#pragma unroll
+            for (int u = 0; u < kVec; ++u) {
+                uint32_t len = j < n_seg ? __builtin_amdgcn_readfirstlane(sh.seg_len[j]) : 0u;
+                while (j < n_seg && (r << 10) >= len) {   // past the segment's end (or an empty segment): the next one
+                    ++j;
+                    r = 0u;
+                    len = j < n_seg ? __builtin_amdgcn_readfirstlane(sh.seg_len[j]) : 0u;
+                }
+                // buffer loads: zero fill past the segment's end (one descriptor per row: the range check leaves the SGPR
+                // offset out, so the row offset goes into the base)
+                const float* p = lp;
+                int nbytes = 0;
+                if (j < n_seg) {
+                    p = lp + __builtin_amdgcn_readfirstlane(sh.seg_off[j]) + (r << 10);
+                    nbytes = (int)(min(len - (r << 10), 1024u) << 2);
+                    ++r;
+                }
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nbytes, 0x00020000);
+                v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+            }
+        };
+        if (n_chunks == 1u) load_chunk(0u);
+        auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
+        // all waves count their share of the list; ONE wave takes the step (fp64 totals, the division, the bin look-ups — some
+        // hundred instructions that would otherwise issue four times over on a CU whose issue slots are what this kernel runs
+        // out of) and hands the next iterate to the others through LDS: two barriers per iteration.  Which wave: by workgroup,
+        // so that the stepping waves of the workgroups sharing a CU do not all sit on the same SIMD
+        const int stepper = (int)(blockIdx.x & (kWaves - 1));
+        int jb = log_bin(s);
+        bad = marked(jb) ? 0u : 1u;
+        if (fail_every > 0 && pair % (uint32_t)fail_every == 0u) bad = 1u;   // test hook: the restart path
+        unsigned long long n_above = 0ull;
+        double s_above = 0.0;
+        auto enter = [&](int j) {   // exact totals of the bins above bin j; bin j goes on record
+            n_above = (j + 1 < kLogNB) ? (unsigned long long)n_ge[j + 1] : 0ull;
+            s_above = (j + 1 < kLogNB) ? s_ge[j + 1] : 0.0;
+            if (lane == 0) sh.pub[j >> 5] |= 1u << (j & 31);   // (only the stepping wave enters bins)
+        };
+        if (!bad && w == stepper) enter(jb);
+        uint32_t done = 0u;
+        DPL_PROF_T(pt2);
+        DPL_PROF_ADD(1, pt1, pt2);
+        if (tid == 0) {
+            g_prof_iters_add(blockIdx.x, 0u);
+            DPL_PROF_L(L);
+            if (!only_missed) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
+        }
+        while (!done && !bad) {
+            // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1), i.e. d = u - bits(s) - 1 below
+            // `span` (unsigned: anything at or below s wraps around).  Four VALU instructions per value — the count is a
+            // population count of the compare mask on the scalar unit — and the mantissa sum follows from the sum of d.
+            const uint32_t lo1 = __float_as_uint(s) + 1u;
+            const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
+            uint32_t c = 0u;   // (wave-uniform)
+            unsigned long long dsum = 0ull;
+            for (uint32_t ch = 0; ch < n_chunks; ++ch) {
+                if (n_chunks > 1u) load_chunk(ch * (uint32_t)kVec);
+                const uint32_t rows = min(n_rows - ch * (uint32_t)kVec, (uint32_t)kVec);
+                uint32_t ds = 0u;   // per thread: at most 80 values below 2^17
+                auto in1 = [&](float f) {
+                    const uint32_t d = __float_as_uint(f) - lo1;
+                    const bool in = d < span;
+                    c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                    ds += in ? d : 0u;
+                };
+#pragma unroll
+                for (int u = 0; u < kVec; ++u) {
+                    if ((uint32_t)u < rows) {   // uniform
+                        in1(v[u].x);
+                        in1(v[u].y);
+                        in1(v[u].z);
+                        in1(v[u].w);
+                    }
+                }
+                dsum += (unsigned long long)wave_sum_dpp(ds);   // < 64 * 80 * 2^17
+            }
+            if (lane == 0) {
+                sh.part_c[0][w] = c;
+                sh.part_m[0][w] = dsum + (unsigned long long)c * (unsigned long long)(lo1 & 0x7FFFFFu);   // sum of explicit mantissas
+            }
+            __syncthreads();
+            if (w == stepper) {
+                unsigned long long tc = 0ull, tm = 0ull;
+#pragma unroll
+                for (int j = 0; j < kWaves; ++j) {
+                    tc += sh.part_c[0][j];
+                    tm += sh.part_m[0][j];
+                }
+                const unsigned long long tg = n_above + tc;
+                const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+                const OctavStep qs = octav_step(ts, tg, n_elems - tg, ud, s, iters, max_iters);
+                s = qs.s;
+                iters = qs.iters;
+                done = qs.done;
+                if (!done) {
+                    const int jn = log_bin(s);
+                    if (!marked(jn)) {
+                        bad = 1u;   // a bin that was not gathered (or out of the binned window): the compaction route takes over
+                    } else if (jn != jb) {
+                        jb = jn;
+                        enter(jb);
+                    }
+                }
+                if (lane == 0) {
+                    sh.w_s = s;
+                    sh.jb = jb;
+                    sh.bad = done | (bad << 1);
+                }
+            }
+            __syncthreads();
+            if (w != stepper) {
+                s = sh.w_s;
+                jb = sh.jb;
+                const uint32_t fl = sh.bad;
+                done = fl & 1u;
+                bad = fl >> 1;
+            }
+        }
+        DPL_PROF_T(pt3);
+        DPL_PROF_ADD(2, pt2, pt3);
+        if (tid == 0) g_prof_iters_add(blockIdx.x, iters);
+    }
+    DPL_PROF_T(pt4);
+    // ---- what the next batches should gather for this tensor: the bins this walk stepped into — or, when it
+    // left the gathered set, the pair's bracket over the bin edges (histogram only) — plus neighbours that hold
+    // next to nothing.
+    if (!small && route == 2u) {
+        if (bad) {
+            if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
+            __syncthreads();
+            if (tid == 0) bracket_marks(n_ge, s_ge, sh.pub, sh.s0, sh.ud, sh.n_elems);
+            __syncthreads();
+        }
+        if (tid < (uint32_t)kLogWords) {
+            // neighbours: bin j-1 / j+1 of a published bin j join when they hold <= 0.2 % of the pair
+            const uint32_t cheap = (uint32_t)(sh.n_elems >> DPL_CHEAP_SHIFT);
+            const uint32_t mine = sh.pub[tid];
+            const uint32_t up = (mine << 1) | (tid > 0 ? sh.pub[tid - 1] >> 31 : 0u);                    // j + 1 candidates
+            const uint32_t dn = (mine >> 1) | (tid + 1 < (uint32_t)kLogWords ? sh.pub[tid + 1] << 31 : 0u);   // j - 1 candidates
+            uint32_t cand = (up | dn) & ~mine, add = 0u;
+            while (cand) {
+                const int bit = __ffs(cand) - 1;
+                cand &= cand - 1u;
+                const int j = (int)tid * 32 + bit;
+                if (j > 0 && j < kLogNB - 1 && n_ge[j] - n_ge[j + 1] <= cheap) add |= 1u << bit;
+            }
+            // the sparse tail, wholesale: every bin from which on no more than 1/128 of the pair lies above — that is where
+            // the late iterates land, and where they scatter most from image to image
+            const uint32_t thin = (uint32_t)(sh.n_elems >> DPL_THIN_SHIFT);
+            uint32_t tail = 0u;
+            for (int bit = 0; bit < 32; ++bit) {
+                const int j = (int)tid * 32 + bit;
+                if (j > 0 && j < kLogNB - 1 && n_ge[j] != 0u && n_ge[j] <= thin) tail |= 1u << bit;
+            }
+            const uint32_t out = mine | add | tail;
+            if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
+        }
+    }
+    DPL_PROF_T(pt5);
+    DPL_PROF_ADD(3, pt4, pt5);
+    if (tid == 0) {
+        if (route == 0u) {
+            me->done = 1u;
+            me->mode = 2u;
+        } else if (bad) {
+            // restart from s_0 (in me->s) on the compaction route: state as k_octav_update<true> leaves it
+            me->mode = 1u;
+            me->done = 0u;
+            me->len[0] = 0u;
+            if (!only_missed) atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        } else {
+            me->s = s;
+            me->iters = iters;
+            me->done = 1u;
+            me->mode = 2u;
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sorted runs.  k_octav_sort: one workgroup per slice; the slice's list (as gathered: arrival order) is sorted IN PLACE,
+// kChunk values at a time, by the rank of the values' bins — a counting sort staged in LDS: the rank's counter hands out
+// the position inside the rank (returning LDS add), an exclusive scan of the counters the rank's start, the values are
+// placed in the LDS stage and leave as full 16-byte stores; the starts go to the chunk's directory row.  Random placement
+// happens in LDS only (64 lanes to 64 global lines would cost 64 cycles per store instruction).
+// k_octav_walk_sorted then needs, per iteration, the directory entries of ONE rank and the few hundred values behind them —
+// one WAVE walks a pair, no list in registers, no barrier, and a wide prediction costs bandwidth here instead of scan time.
+__global__ __launch_bounds__(kThreads) void k_octav_sort(
+    const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ pair_slice0, const unsigned long long* __restrict__ lh,
+    const uint32_t* __restrict__ pred, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0,
+    const uint32_t* __restrict__ slice_chunk0, uint16_t* __restrict__ dir) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kChunk];
+    __shared__ uint32_t cnt[kMaxFlag], off[kMaxFlag + 1];
+    __shared__ unsigned long long bp[kLogWords];   // per word: bitmap (low half) | ranks below the word (high half)
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    if (it.reserved == 1u && it.count <= kSmallCap) return;   // a small pair (whole window gathered): walked from registers
+    const uint32_t len = (uint32_t)lh[(uint64_t)blockIdx.x * kLogNB];
+    if (len == 0u) return;
+    const uint32_t pair = it.slot, tensor = pair % n_tensors;
+    uint32_t* region = reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + (it.offset - slices[pair_slice0[2 * pair]].offset));
+    if (tid < (uint32_t)kLogWords)
+        bp[tid] = (unsigned long long)pred[tensor * kPredRow + tid] | ((unsigned long long)pred[tensor * kPredRow + kLogWords + tid] << 32);
+    constexpr int kPer = (int)(kChunk / kThreads / 4);   // 16-byte vectors per thread and chunk
+    for (uint32_t c0 = 0; c0 < len; c0 += kChunk) {
+        const uint32_t n = min(len - c0, kChunk);
+        if (tid < (uint32_t)kMaxFlag) cnt[tid] = 0u;
+        // the chunk -> registers (zero fill past its end: a zero is no entry)
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(region + c0), 0, (int)(n << 2), 0x00020000);
+        uint32_t val[kPer * 4], rp[kPer * 4];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const f4 x = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (tid + (uint32_t)k * kThreads) << 4, 0, 0));
+            val[4 * k + 0] = __float_as_uint(x.x);
+            val[4 * k + 1] = __float_as_uint(x.y);
+            val[4 * k + 2] = __float_as_uint(x.z);
+            val[4 * k + 3] = __float_as_uint(x.w);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer * 4; ++e) {   // rank of the value's bin, position inside the rank
+            const uint32_t u = val[e];
+            rp[e] = 0xFFFFFFFFu;
+            if (u != 0u) {
+                const uint32_t b = (u >> kLogShift) - kLogKey0;
+                const unsigned long long wv = bp[(b >> 5) & (uint32_t)(kLogWords - 1)];
+                const uint32_t r = (uint32_t)(wv >> 32) + (uint32_t)__popc((uint32_t)wv & ((1u << (b & 31u)) - 1u));
+                rp[e] = (min(r, (uint32_t)(kMaxFlag - 1)) << 16) | atomicAdd(&cnt[min(r, (uint32_t)(kMaxFlag - 1))], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < (uint32_t)kWave) {   // exclusive scan of the counters: four per lane
+            const uint32_t a0 = cnt[4 * tid], a1 = cnt[4 * tid + 1], a2 = cnt[4 * tid + 2], a3 = cnt[4 * tid + 3];
+            const uint32_t incl = wave_incl_scan_dpp(a0 + a1 + a2 + a3), base = incl - (a0 + a1 + a2 + a3);
+            off[4 * tid] = base;
+            off[4 * tid + 1] = base + a0;
+            off[4 * tid + 2] = base + a0 + a1;
+            off[4 * tid + 3] = base + a0 + a1 + a2;
+            if (tid == kWave - 1) off[kMaxFlag] = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < kPer * 4; ++e)
+            if (rp[e] != 0xFFFFFFFFu) stage[off[rp[e] >> 16] + (rp[e] & 0xFFFFu)] = val[e];
+        __syncthreads();
+        // the sorted chunk back over itself (every thread has long read its part), the starts into the directory
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const uint32_t i = (tid + (uint32_t)k * kThreads) * 4u;
+            if (i + 3u < n) {
+                *reinterpret_cast<uint4*>(region + c0 + i) = *reinterpret_cast<const uint4*>(stage + i);
+            } else {
+                for (uint32_t q = i; q < n; ++q) region[c0 + q] = stage[q];
+            }
+        }
+        uint16_t* drow = dir + (uint64_t)(slice_chunk0[blockIdx.x] + c0 / kChunk) * kDirRow;
+        for (uint32_t i = tid; i <= (uint32_t)kMaxFlag; i += kThreads) drow[i] = (uint16_t)off[i];
+        __syncthreads();
+    }
+}
+
+// wave64 inclusive prefix sum of doubles by DPP (the two halves moved separately; lanes a step does not reach add +0.0)
+__device__ __forceinline__ double wave_incl_scan_f64(double v) {
+#define DPL_SCAN_STEP(ctrl, rmask, bound)                                                                              \
+    {                                                                                                                  \
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);                                      \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, ctrl, rmask, 0xF, bound);       \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), ctrl, rmask, 0xF, bound); \
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                                   \
+    }
+    DPL_SCAN_STEP(0x111, 0xF, true)
+    DPL_SCAN_STEP(0x112, 0xF, true)
+    DPL_SCAN_STEP(0x114, 0xF, true)
+    DPL_SCAN_STEP(0x118, 0xF, true)
+    DPL_SCAN_STEP(0x142, 0xA, false)
+    DPL_SCAN_STEP(0x143, 0xC, false)
+#undef DPL_SCAN_STEP
+    return v;
+}
+
+constexpr int kMaxRuns = kWave;   // sorted chunks of a pair one wave handles (one per lane); more: the compaction route
+
+// The exact walk of one pair by ONE WAVE over the pair's sorted runs (all pairs but the small ones, largest first).
+//   1  the pair's slice rows -> per-bin totals -> totals ABOVE every gathered bin, by rank, in LDS (lane l owns 16 bins per
+//      half of the window, highest bins in lane 0: two passes, a DPP prefix scan over the lanes each); the bins that hold
+//      next to nothing and the sparse tail, for what is published afterwards;
+//   2  s_0, then the reference's iteration: per step the directory entries of the iterate's rank (lane = run), a flat
+//      index over the runs' segments, up to four values per lane and round in flight, count / offset sum as in k_octav_walk;
+//      every iterate is verified to lie in a gathered bin;
+//   3  the bins stepped into (+ neighbours holding next to nothing, + the sparse tail) are published for the next batches.
+// A pair that cannot finish here (a bin that was not gathered, values beyond the window, more than kMaxRuns runs) is only
+// MARKED (mode 1, counted in the control block): k_octav_walk(only_missed) publishes its bracket and prepares its state.
+__global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
+    const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ slice_chunk0, const uint16_t* __restrict__ dir,
+    int dynamic_sym, int max_iters, int fail_every) {
+    __shared__ double t_s[kMaxFlag + 1];
+    __shared__ uint32_t t_n[kMaxFlag + 1];
+    __shared__ uint32_t bm[kLogWords], pre[kLogWords], cheapw[kLogWords], thinw[kLogWords], pub[kLogWords];
+    __shared__ double s1_sum;
+    __shared__ uint32_t s1_cnt;
+    constexpr int kLdsRuns = 4;   // directory rows kept in LDS (requested before phase 1, there when the walk starts)
+    __shared__ __attribute__((aligned(16))) uint16_t dirl[kLdsRuns][kDirRow];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
+    dpl_octav_state* me = st + pair;
+    const unsigned long long n_pair = me->n_elems;
+    if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
+    const uint32_t tensor = pair % n_tensors;
+    const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
+    bm[lane] = pred[tensor * kPredRow + lane];
+    pre[lane] = pred[tensor * kPredRow + kLogWords + lane];
+    cheapw[lane] = 0u;
+    thinw[lane] = 0u;
+    pub[lane] = 0u;
+    // the pair's runs: lane r holds run r (its first value relative to the pair's list, its directory row)
+    uint32_t my_addr = 0u, my_dir = 0u, n_runs = 0u, listed = 0u;
+    for (uint32_t sl = sl0; sl < sl1; ++sl) {
+        const uint32_t len = __builtin_amdgcn_readfirstlane((uint32_t)lh[(uint64_t)sl * kLogNB]);
+        const uint32_t off = __builtin_amdgcn_readfirstlane((uint32_t)(slices[sl].offset - slices[sl0].offset));
+        const uint32_t ch0 = __builtin_amdgcn_readfirstlane(slice_chunk0[sl]);
+        listed += len;
+        for (uint32_t c = 0; c * kChunk < len; ++c) {
+            if (lane == n_runs) {
+                my_addr = off + c * kChunk;
+                my_dir = ch0 + c;
+            }
+            ++n_runs;
+        }
+    }
+    if (lane == 0) atomicAdd(&ctl->sum, (double)listed);   // the batch's gathered values: what the caller's form choice looks at
+    {   // the first runs' directory rows -> LDS (16 bytes per lane and run: kDirRow / 8 lanes)
+        uint4 dv[kLdsRuns];
+#pragma unroll
+        for (int j = 0; j < kLdsRuns; ++j) {
+            const uint32_t dj = (uint32_t)__builtin_amdgcn_readlane((int)my_dir, j);
+            dv[j] = make_uint4(0u, 0u, 0u, 0u);
+            if ((uint32_t)j < n_runs && lane < (uint32_t)(kDirRow / 8))
+                dv[j] = reinterpret_cast<const uint4*>(dir + (uint64_t)dj * kDirRow)[lane];
+        }
+#pragma unroll
+        for (int j = 0; j < kLdsRuns; ++j)
+            if (lane < (uint32_t)(kDirRow / 8)) reinterpret_cast<uint4*>(dirl[j])[lane] = dv[j];
+    }
+    __syncthreads();
+    DPL_PROF_T(qt0);
+    // ---- 1. totals above every gathered bin
+    const uint32_t cheap_n = (uint32_t)(n_pair >> DPL_CHEAP_SHIFT), thin_n = (uint32_t)(n_pair >> DPL_THIN_SHIFT);
+    uint32_t carry_n = 0u;
+    double carry_s = 0.0;
+    // All 16 bins of a lane — a quarter octave — share the exponent, so sums stay INTEGERS (explicit mantissas + count * 2^23,
+    // below 2^51 per octave) inside an octave: a conversion to fp64 happens once per octave (its total) and once per
+    // gathered bin (the integer part above it inside its octave), not once per bin (fp64 conversions run at a quarter of the
+    // rate and were most of this phase: 41 us per pair with one per bin and sweep).
+    for (int half = 1; half >= 0; --half) {
+        const int hb = half * (kLogNB / 2) + (int)(kWave - 1 - lane) * 16;   // the lane's 16 bins; lane 0: the highest
+        uint32_t cnt[16];
+        unsigned long long m[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            cnt[q] = 0u;
+            m[q] = 0ull;
+        }
+        for (uint32_t sl = sl0; sl < sl1; ++sl) {
+            const unsigned long long* row = lh + (uint64_t)sl * kLogNB + hb;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const unsigned long long v = row[q];
+                cnt[q] += (uint32_t)(v >> kPackShift);
+                m[q] += v & kPackMask;
+            }
+        }
+        if (hb == 0) {   // bin 0 holds no element (its row words are the segment lengths)
+            cnt[0] = 0u;
+            m[0] = 0ull;
+        }
+        uint32_t tot_n = 0u;
+        unsigned long long tot_m = 0ull;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            m[q] += (unsigned long long)cnt[q] << 23;   // full 24-bit mantissas
+            tot_n += cnt[q];
+            tot_m += m[q];
+        }
+        const uint32_t incl_n = wave_incl_scan_dpp(tot_n);
+        // inside the octave (four lanes): the integer total of the lanes above, and the octave's total
+        const uint32_t pos = lane & 3u;
+        const unsigned long long p1 = __shfl_up(tot_m, 1, 4), p2 = __shfl_up(tot_m, 2, 4), p3 = __shfl_up(tot_m, 3, 4);
+        const unsigned long long above_m = (pos >= 1u ? p1 : 0ull) + (pos >= 2u ? p2 : 0ull) + (pos >= 3u ? p3 : 0ull);
+        unsigned long long oct_m = tot_m + __shfl_xor(tot_m, 1, 4);
+        oct_m += __shfl_xor(oct_m, 2, 4);
+        const double scale = log_bin_scale(hb);
+        const double incl_s = wave_incl_scan_f64(pos == 3u ? (double)oct_m * scale : 0.0);   // octave totals, at the octaves' last lanes
+        const double excl_s = __shfl_up(incl_s, 1, kWave);
+        const double base_s = carry_s + (lane == 0 ? 0.0 : excl_s);   // everything in the octaves above the lane's
+        uint32_t run_n = carry_n + incl_n - tot_n;                    // everything in the bins above the lane's
+        unsigned long long run_m = above_m;
+        const uint32_t word = (uint32_t)hb >> 5, sh16 = (uint32_t)hb & 16u;
+        const uint32_t bits = (bm[word] >> sh16) & 0xFFFFu;
+        const uint32_t below = pre[word] + (uint32_t)__popc(bm[word] & ((1u << sh16) - 1u));
+        uint32_t cheap_bits = 0u, thin_bits = 0u;
+#pragma unroll
+        for (int q = 15; q >= 0; --q) {
+            if ((bits >> q) & 1u) {   // a gathered bin: totals above it, by rank
+                const uint32_t r = below + (uint32_t)__popc(bits & ((1u << q) - 1u));
+                t_n[r] = run_n;
+                t_s[r] = base_s + (double)run_m * scale;
+            }
+            run_n += cnt[q];
+            run_m += m[q];
+            cheap_bits |= (cnt[q] <= cheap_n ? 1u : 0u) << q;
+            thin_bits |= (run_n != 0u && run_n <= thin_n ? 1u : 0u) << q;
+            if (hb + q == 1) {   // forward_net.py:324 — the window's part of sum(|x|) and count(|x| > 0)
+                s1_sum = base_s + (double)run_m * scale;
+                s1_cnt = run_n;
+            }
+        }
+        atomicOr(&cheapw[word], cheap_bits << sh16);
+        atomicOr(&thinw[word], thin_bits << sh16);
+        carry_n += (uint32_t)__builtin_amdgcn_readlane((int)incl_n, kWave - 1);
+        const unsigned long long tb = (unsigned long long)__double_as_longlong(incl_s);
+        carry_s += __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tb >> 32), kWave - 1) << 32) |
+                                                    (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tb, kWave - 1)));
+    }
+    __syncthreads();
+    DPL_PROF_T(qt1);
+    DPL_PROF_ADD(0, qt0, qt1);
+    // ---- 2. s_0 and the walk (every lane carries the same state)
+    const double sum_out = me->sum;
+    const unsigned long long nz_out = me->cnt_gt;
+    const float gmn = dec_f32(me->min_enc), gmx = dec_f32(me->max_enc);
+    const bool nanseen = me->nan_seen != 0u;
+    // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+    const float ud = (dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+    const float s0 = nanseen ? __uint_as_float(0x7FC00000u) : __fdiv_rn((float)(sum_out + s1_sum), (float)(long long)(nz_out + s1_cnt));
+    uint32_t route = 2u;                                         // 2: walk
+    if (s0 != s0 || max_iters <= 0) route = 0u;                  // 0: finished (NaN is a fixed point)
+    else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB)) || n_runs > (uint32_t)kMaxRuns) route = 1u;   // 1: the compaction route
+    auto gathered = [&](int j) { return j > 0 && j < kLogNB - 1 && ((bm[j >> 5] >> (j & 31)) & 1u); };
+    uint32_t bad = route == 1u ? 1u : 0u;
+    float s = s0;
+    uint32_t iters = 0u;
+    if (route == 2u) {
+        const uint32_t* lp = reinterpret_cast<const uint32_t*>(list0 + pair_base[pair]);
+        int jb = log_bin(s);
+        bad = gathered(jb) ? 0u : 1u;
+        if (fail_every > 0 && pair % (uint32_t)fail_every == 0u) bad = 1u;   // test hook: the restart path
+        if (!bad && lane == 0) pub[jb >> 5] |= 1u << (jb & 31);
+        uint32_t done = 0u;
+        while (!done && !bad) {
+            const uint32_t r = __builtin_amdgcn_readfirstlane(pre[jb >> 5] + (uint32_t)__popc(bm[jb >> 5] & ((1u << (jb & 31)) - 1u)));
+            const unsigned long long n_above = t_n[r];
+            const double s_above = t_s[r];
+            // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1): d = u - bits(s) - 1 below `span`
+            const uint32_t lo1 = __float_as_uint(s) + 1u;
+            const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
+            uint32_t d0 = 0u, d1 = 0u;
+            if (lane < n_runs) {
+                if (lane < (uint32_t)kLdsRuns) {
+                    d0 = dirl[lane][r];
+                    d1 = dirl[lane][r + 1u];
+                } else {
+                    const uint16_t* drow = dir + (uint64_t)my_dir * kDirRow;
+                    d0 = drow[r];
+                    d1 = drow[r + 1u];
+                }
+            }
+            const uint32_t cj = d1 - d0, aj = my_addr + d0;
+            const uint32_t incl = wave_incl_scan_dpp(cj);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+            const uint32_t nr = min(n_runs, (uint32_t)kMaxRuns);
+            uint32_t c = 0u;   // (wave-uniform)
+            unsigned long long dsum = 0ull;
+            // one ROUND: flat indices f0 + 64 k + lane, k < kFl — all of a round's loads are in flight together (a dense bin
+            // of a large pair holds thousands of values: sixteen per lane and round; the bins of the late iterates: four)
+            auto round = [&](auto kfl, uint32_t f0) {
+                constexpr int kFl = decltype(kfl)::value;
+                uint32_t a[kFl];
+#pragma unroll
+                for (int k = 0; k < kFl; ++k) a[k] = 0u;
+                for (uint32_t j = 0; j < nr; ++j) {   // which run holds a flat index
+                    const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)incl, (int)j);
+                    const uint32_t nj = (uint32_t)__builtin_amdgcn_readlane((int)cj, (int)j);
+                    if (ej <= f0 || ej - nj >= f0 + (uint32_t)kFl * kWave) continue;   // (uniform) not in this round
+                    const uint32_t bj = (uint32_t)__builtin_amdgcn_readlane((int)aj, (int)j);
+#pragma unroll
+                    for (int k = 0; k < kFl; ++k) {
+                        const uint32_t rel = f0 + (uint32_t)k * kWave + lane - (ej - nj);
+                        if (rel < nj) a[k] = bj + rel;
+                    }
+                }
+                uint32_t u[kFl];
+#pragma unroll
+                for (int k = 0; k < kFl; ++k) u[k] = f0 + (uint32_t)k * kWave + lane < total ? lp[a[k]] : 0u;
+                uint32_t ds = 0u;
+#pragma unroll
+                for (int k = 0; k < kFl; ++k) {
+                    const uint32_t d = u[k] - lo1;   // (a zero wraps far beyond span)
+                    const bool in = d < span;
+                    c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                    ds += in ? d : 0u;
+                }
+                dsum += (unsigned long long)wave_sum_dpp(ds);
+            };
+            if (total <= 4u * kWave) {
+                if (total != 0u) round(std::integral_constant<int, 4>{}, 0u);
+            } else {
+                for (uint32_t f0 = 0; f0 < total; f0 += 16u * kWave) round(std::integral_constant<int, 16>{}, f0);
+            }
+            const unsigned long long tc = c, tm = dsum + (unsigned long long)c * (unsigned long long)(lo1 & 0x7FFFFFu);
+            const unsigned long long tg = n_above + tc;
+            const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+            const OctavStep qs = octav_step(ts, tg, n_pair - tg, ud, s, iters, max_iters);
+            s = qs.s;
+            iters = qs.iters;
+            done = qs.done;
+            if (!done) {
+                const int jn = log_bin(s);
+                if (!gathered(jn)) {
+                    bad = 1u;   // a bin that was not gathered (or out of the binned window): the compaction route takes over
+                } else if (jn != jb) {
+                    jb = jn;
+                    if (lane == 0) pub[jb >> 5] |= 1u << (jb & 31);
+                }
+            }
+        }
+    }
+    DPL_PROF_T(qt2);
+    DPL_PROF_ADD(2, qt1, qt2);
+    if (lane == 0) g_prof_iters_add(blockIdx.x, iters);
+    __syncthreads();
+    // ---- 3. what the next batches should gather for this tensor: the bins stepped into, neighbours that hold next to
+    // nothing, the sparse tail.  (A pair that missed is published by k_octav_walk(only_missed): its bracket.)
+    if (route == 2u && !bad) {
+        const uint32_t mine = pub[lane];
+        const uint32_t up = (mine << 1) | (lane > 0 ? pub[lane - 1] >> 31 : 0u);                                  // j + 1 candidates
+        const uint32_t dn = (mine >> 1) | (lane + 1 < (uint32_t)kLogWords ? pub[lane + 1] << 31 : 0u);           // j - 1 candidates
+        uint32_t valid = 0xFFFFFFFFu;
+        if (lane == 0) valid &= ~1u;                               // bins 1 .. kLogNB - 2
+        if (lane == (uint32_t)kLogWords - 1u) valid &= ~(1u << 31);
+        const uint32_t out = mine | (((up | dn) & ~mine & cheapw[lane]) | thinw[lane]) & valid;
+        if (out) atomicOr(vis_w + tensor * kLogWords + lane, out);
+    }
+    if (lane == 0) {
+        if (route == 0u || !bad) {
+            me->s = route == 0u ? s0 : s;
+            me->unsigned_div = ud;
+            me->iters = route == 0u ? 0u : iters;
+            me->sum = 0.0;
+            me->cnt_gt = 0ull;
+            me->cnt_le = 0ull;
+            me->len[0] = 0u;
+            me->len[1] = 0u;
+            me->cur = 2u;
+            me->done = 1u;
+            me->mode = 2u;
+        } else {
+            me->mode = 1u;   // missed: k_octav_walk(only_missed) takes it from here (the streamed statistics stay in place)
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        }
+    }
+}
+
+__global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* vis_w, const uint32_t* vis_o, uint32_t* pred,
+                                     int64_t vis_words, int zero_w) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < vis_words) {   // this batch gathers what the current and the previous epoch's walks stepped into (a snapshot: the
+                           // walks of this batch keep adding to vis_w while they run).  One wave = one tensor, lane = word.
+        const uint32_t mine = zero_w ? 0u : vis_w[i];
+        if (zero_w) vis_w[i] = 0u;
+        uint32_t x = mine | vis_o[i];
+        // at most kMaxFlag - 1 bins (lowest first): ranks are table indices; a walk that needs a dropped bin finishes on the
+        // compaction route like any other miss
+        const uint32_t lane = threadIdx.x & (kWave - 1);
+        uint32_t incl = wave_incl_scan_dpp((uint32_t)__popc(x));
+        uint32_t below = incl - (uint32_t)__popc(x);
+        if (incl > (uint32_t)(kMaxFlag - 1)) {
+            const uint32_t keep = below < (uint32_t)(kMaxFlag - 1) ? (uint32_t)(kMaxFlag - 1) - below : 0u;
+            while ((uint32_t)__popc(x) > keep) x &= ~(1u << (31 - __clz(x)));
+            below = min(below, (uint32_t)(kMaxFlag - 1));
+        }
+        const int64_t t = i / kLogWords;
+        pred[t * kPredRow + lane] = x;
+        pred[t * kPredRow + kLogWords + lane] = below;
+    }
+    if (i > n_pairs) return;  // slot n_pairs is the control block
+    dpl_octav_state z;
+    z.sum = 0.0;
+    z.cnt_gt = 0;
+    z.cnt_le = 0;
+    z.min_enc = 0xFFFFFFFFu;
+    z.max_enc = 0u;
+    z.nan_seen = 0u;
+    z.done = 0u;
+    z.s = 0.0f;
+    z.unsigned_div = 1.0f;
+    z.iters = 0u;
+    z.mode = 2u;
+    z.n_elems = 0ull;
+    z.len[0] = 0u;
+    z.len[1] = 0u;
+    z.cur = 2u;
+    z.reserved = 0u;
+    st[i] = z;
+}
+
+}  // namespace
+
+extern int g_exact_fail_every;   // octav_kernels.hip (dpl_test_hook_exact_fail_every)
+int dpl_octav_fallback_route(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                             const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                             const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                             float* d_list0, float* d_list1, int dynamic_sym, int max_iters, hipStream_t st);
+
+extern "C" {
+
+#ifdef DPL_RES_PROF
+int dpl_res_prof_read(unsigned long long* host_out, int reset) {   // tuning builds only
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_res_prof), sizeof(unsigned long long) * 4096 * 8);
+    if (e != hipSuccess) return fail("dpl_res_prof_read", e);
+    if (reset) {
+        static unsigned long long z[4096 * 8];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_res_prof), z, sizeof(z));
+        if (e != hipSuccess) return fail("dpl_res_prof_read", e);
+    }
+    return 0;
+}
+#endif
+
+uint32_t dpl_octav_slice_cap(void) { return kCap; }
+uint32_t dpl_octav_sort_chunk(void) { return kChunk; }
+uint32_t dpl_octav_dir_row(void) { return (uint32_t)kDirRow; }
+uint32_t dpl_octav_small_pair(void) { return kSmallCap; }
+
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0) {
+    if (!spans || n_spans < 0) return fail_msg("dpl_build_octav_slices: bad arguments");
+    // largest pairs first: the long ones start at once, the short ones fill the tail of the launch
+    int64_t* order = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n_spans > 0 ? n_spans : 1));
+    if (!order) return fail_msg("dpl_build_octav_slices: out of memory");
+    for (int64_t i = 0; i < n_spans; ++i) order[i] = i;
+    struct Cmp {
+        static int f(const void* a, const void* b, void* ctx) {
+            const dpl_span* sp = (const dpl_span*)ctx;
+            const int64_t ia = *(const int64_t*)a, ib = *(const int64_t*)b;
+            if (sp[ia].count != sp[ib].count) return sp[ia].count > sp[ib].count ? -1 : 1;
+            return ia < ib ? -1 : (ia > ib ? 1 : 0);
+        }
+    };
+    qsort_r(order, (size_t)n_spans, sizeof(int64_t), Cmp::f, (void*)spans);
+    int64_t n_total = 0;
+    for (int64_t oi = 0; oi < n_spans; ++oi) {
+        const dpl_span& sp = spans[order[oi]];
+        const uint64_t c = sp.count == 0 ? 0 : (sp.count + kCap - 1) / kCap;
+        if (c > kMaxCluster) {
+            free(order);
+            snprintf(g_err, sizeof(g_err), "dpl_build_octav_slices: a pair of %llu elements needs %llu slices (max %u)",
+                     (unsigned long long)sp.count, (unsigned long long)c, kMaxCluster);
+            return -3;
+        }
+        n_total += (int64_t)c;
+    }
+    if (out && n_total <= cap) {
+        int64_t p = 0;
+        // pair_slice0[2 slot], [2 slot + 1]: first and one-past-last slice of the pair in slot `slot` (slots 0 .. n_spans-1)
+        if (pair_slice0)
+            for (int64_t i = 0; i < 2 * n_spans; ++i) pair_slice0[i] = 0u;
+        for (int64_t oi = 0; oi < n_spans; ++oi) {
+            const dpl_span& sp = spans[order[oi]];
+            if (sp.count == 0) continue;
+            const uint64_t c = (sp.count + kCap - 1) / kCap;
+            const uint64_t per = (((sp.count + c - 1) / c) + 3) & ~3ull;   // equal slices, cut on multiples of 4 elements
+            if (pair_slice0 && sp.slot < (uint64_t)n_spans) {
+                pair_slice0[2 * sp.slot] = (uint32_t)p;
+                pair_slice0[2 * sp.slot + 1] = (uint32_t)(p + (int64_t)c);
+            }
+            uint64_t off = 0;
+            for (uint64_t j = 0; j < c; ++j) {
+                const uint64_t take = (j + 1 == c) ? sp.count - off : per;
+                out[p].offset = sp.offset + off;
+                out[p].count = (uint32_t)take;
+                out[p].seg = sp.seg;
+                out[p].slot = sp.slot;
+                out[p].reserved = (uint32_t)c;
+                ++p;
+                off += take;
+            }
+        }
+    }
+    free(order);
+    return n_total;
+}
+
+int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
+                              dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s) {
+    if (n_pairs <= 0) return 0;
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_prepare: bad tensor count / epoch");
+    if (!d_vis || !d_pred || !d_states) return fail_msg("dpl_octav_oneread_prepare: null buffer");
+    const int64_t vis_words = n_tensors * kLogWords;
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * vis_words;
+    const uint32_t* d_vis_o = d_vis + (int64_t)(1 - write_epoch) * vis_words;
+    const int64_t init_n = (n_pairs + 1 > vis_words ? n_pairs + 1 : vis_words);
+    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs, d_vis_w,
+                       d_vis_o, d_pred, vis_words, reset_epoch);
+    DPL_LAUNCH_CHECK("k_octav_oneread_init");
+    return 0;
+}
+
+int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
+                             const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                             int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s) {
+    if (n_slices <= 0 || n_pairs <= 0) return 0;
+    if (n_tensors < 1) return fail_msg("dpl_octav_oneread_stream: bad tensor count");
+    if (!d_lh || !d_pred || !d_pair_slice0) return fail_msg("dpl_octav_oneread_stream: null scratch buffer");
+    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
+                       d_slices, d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_pred, (uint32_t)n_tensors,
+                       d_pair_base, d_pair_slice0, d_list0);
+    DPL_LAUNCH_CHECK("k_octav_oneread");
+    return 0;
+}
+
+int dpl_octav_oneread_walk(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                           uint16_t* d_dir, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred, int write_epoch,
+                           int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs, const uint64_t* d_pair_base,
+                           const uint32_t* d_pair_order, int64_t n_small, float* d_list0, int sorted, int dynamic_sym,
+                           int max_iters, dpl_stream_t s) {
+    if (n_pairs <= 0) return 0;
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_walk: bad tensor count / epoch");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices || !d_slice_chunk0 || !d_dir || !d_pair_order)
+        return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
+    if (n_small < 0 || n_small > n_pairs || n_slices < 0) return fail_msg("dpl_octav_oneread_walk: bad counts");
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
+    const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(d_lh);
+    if (!sorted) {   // every pair walked from registers by one workgroup (misses handled inside)
+        hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                           d_pair_order, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
+                           dynamic_sym, max_iters, g_exact_fail_every, 0);
+        DPL_LAUNCH_CHECK("k_octav_walk");
+        return 0;
+    }
+    const int64_t n_big = n_pairs - n_small;   // d_pair_order: largest first, so the small pairs are its last n_small entries
+    if (n_big > 0) {
+        hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)n_slices), dim3(kThreads), 0, (hipStream_t)s, d_slices, d_pair_slice0, lh, d_pred,
+                           (uint32_t)n_tensors, d_pair_base, d_list0, d_slice_chunk0, d_dir);
+        DPL_LAUNCH_CHECK("k_octav_sort");
+        hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                           d_pair_order, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
+                           d_slice_chunk0, d_dir, dynamic_sym, max_iters, g_exact_fail_every);
+        DPL_LAUNCH_CHECK("k_octav_walk_sorted");
+    }
+    if (n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
+        hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_small), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                           d_pair_order + n_big, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
+                           dynamic_sym, max_iters, g_exact_fail_every, 0);
+        DPL_LAUNCH_CHECK("k_octav_walk");
+    }
+    return 0;
+}
+
+int dpl_octav_oneread_missed(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
+                             const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+                             const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small, float* d_list0,
+                             int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_pairs <= 0 || n_pairs - n_small <= 0) return 0;
+    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_missed: bad tensor count / epoch");
+    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices || !d_pair_order) return fail_msg("dpl_octav_oneread_missed: null scratch buffer");
+    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
+    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)(n_pairs - n_small)), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
+                       d_pair_order, reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors,
+                       d_pair_base, d_list0, d_slices, dynamic_sym, max_iters, g_exact_fail_every, 1);
+    DPL_LAUNCH_CHECK("k_octav_walk(only_missed)");
+    return 0;
+}
+
+int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                               const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                               const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                               float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_pairs <= 0 || max_iters <= 0) return 0;
+    if (int e = check_blocks("dpl_octav_oneread_fallback", n_items, d_block_begin, n_blocks)) return e;
+    return dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
+                                    d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, (hipStream_t)s);
+}
+
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                          uint16_t* d_dir, uint64_t* d_lh, uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch,
+                          int64_t n_tensors, const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small,
+                          float* d_list0, float* d_list1, int sorted, int dynamic_sym, int max_iters, dpl_stream_t s) {
+    if (n_slices <= 0 || n_pairs <= 0) return 0;
+    if (int e = dpl_octav_oneread_prepare(d_vis, d_pred, write_epoch, reset_epoch, n_tensors, d_states, n_pairs, s)) return e;
+    if (int e = dpl_octav_oneread_stream(d_slices, n_slices, d_pair_slice0, d_lh, d_pred, n_tensors, d_seg_ptrs, d_states, n_pairs,
+                                         d_pair_base, d_list0, s))
+        return e;
+    if (int e = dpl_octav_oneread_walk(d_slices, n_slices, d_pair_slice0, d_slice_chunk0, d_dir, d_lh, d_vis, d_pred, write_epoch,
+                                       n_tensors, d_states, n_pairs, d_pair_base, d_pair_order, n_small, d_list0, sorted, dynamic_sym,
+                                       max_iters, s))
+        return e;
+    if (sorted)
+        if (int e = dpl_octav_oneread_missed(d_slices, d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs,
+                                         d_pair_base, d_pair_order, n_small, d_list0, dynamic_sym, max_iters, s))
+        return e;
+    return dpl_octav_oneread_fallback(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
+                                      d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, s);
+}
+
+}  // extern "C"

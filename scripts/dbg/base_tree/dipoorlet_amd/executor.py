@@ -1,0 +1,597 @@
+"""Graph executor on PyTorch-ROCm — replaces `ort.InferenceSession(model-with-every-node-output-exposed)`
+(dipoorlet/forward_net.py:193-202, 216).
+
+The dense math (conv / GEMM / pooling) is library work through torch (MIOpen / hipBLASLt) and is not part
+of the hand-written-kernel scope; what matters for calibration is that EVERY node output of a batch of
+B images stays in HBM and is handed to the statistics kernels as-is.  FakeQuant nodes (the fused
+QuantizeLinear -> DequantizeLinear pair, quantize.QDQNode) run on k_fake_quant.
+
+Batching: the reference feeds one image per forward (model input batch dim 1).  Here B images are
+stacked on dim 0; Reshape targets and dim-0 broadcasts that were constant-folded for batch 1 are
+re-scaled to B.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .forward_net import ActivationSession
+from .utils import logger
+
+_OPS = {}
+
+
+def op(*names):
+    def deco(fn):
+        for n in names:
+            _OPS[n] = fn
+        return fn
+    return deco
+
+
+def _ints(v):
+    if isinstance(v, torch.Tensor):
+        return [int(x) for x in v.reshape(-1).tolist()]
+    return [int(x) for x in np.asarray(v).reshape(-1).tolist()]
+
+
+def _pads_nd(pads, nd):
+    """ONNX [b1..bn, e1..en] -> (symmetric tuple or None, F.pad list)."""
+    pads = list(pads) if pads else [0] * (2 * nd)
+    beg, end = pads[:nd], pads[nd:]
+    sym = tuple(beg) if beg == end else None
+    fpad = []
+    for b, e in zip(reversed(beg), reversed(end)):
+        fpad += [b, e]
+    return sym, fpad
+
+
+def _auto_pad(node, x, kernel, strides, dilations):
+    ap = node.attrs.get("auto_pad", "NOTSET")
+    nd = len(kernel)
+    if ap in ("NOTSET", ""):
+        return node.attrs.get("pads", [0] * (2 * nd))
+    if ap == "VALID":
+        return [0] * (2 * nd)
+    beg, end = [], []
+    for i in range(nd):
+        size = x.shape[2 + i]
+        out = -(-size // strides[i])
+        total = max(0, (out - 1) * strides[i] + (kernel[i] - 1) * dilations[i] + 1 - size)
+        lo = total // 2 if ap == "SAME_UPPER" else total - total // 2
+        beg.append(lo)
+        end.append(total - lo)
+    return beg + end
+
+
+@op("Conv")
+def _conv(s, node, x, w, b=None):
+    nd = w.dim() - 2
+    strides = node.attrs.get("strides", [1] * nd)
+    dil = node.attrs.get("dilations", [1] * nd)
+    pads = _auto_pad(node, x, list(w.shape[2:]), strides, dil)
+    sym, fpad = _pads_nd(pads, nd)
+    if sym is None:
+        x = F.pad(x, fpad)
+        sym = (0,) * nd
+    fn = {1: F.conv1d, 2: F.conv2d, 3: F.conv3d}[nd]
+    return fn(x, w, b, tuple(strides), sym, tuple(dil), int(node.attrs.get("group", 1)))
+
+
+@op("ConvTranspose")
+def _convt(s, node, x, w, b=None):
+    nd = w.dim() - 2
+    strides = node.attrs.get("strides", [1] * nd)
+    dil = node.attrs.get("dilations", [1] * nd)
+    sym, _ = _pads_nd(node.attrs.get("pads"), nd)
+    if sym is None:
+        raise NotImplementedError("ConvTranspose with asymmetric pads")
+    fn = {1: F.conv_transpose1d, 2: F.conv_transpose2d, 3: F.conv_transpose3d}[nd]
+    return fn(x, w, b, tuple(strides), sym, tuple(node.attrs.get("output_padding", [0] * nd)),
+              int(node.attrs.get("group", 1)), tuple(dil))
+
+
+@op("Relu")
+def _relu(s, node, x):
+    return torch.relu(x)
+
+
+@op("LeakyRelu")
+def _lrelu(s, node, x):
+    return F.leaky_relu(x, float(node.attrs.get("alpha", 0.01)))
+
+
+@op("PRelu")
+def _prelu(s, node, x, slope):
+    return torch.where(x >= 0, x, x * slope)
+
+
+@op("Sigmoid")
+def _sigmoid(s, node, x):
+    return torch.sigmoid(x)
+
+
+@op("Tanh")
+def _tanh(s, node, x):
+    return torch.tanh(x)
+
+
+@op("HardSigmoid")
+def _hsig(s, node, x):
+    return torch.clamp(x * float(node.attrs.get("alpha", 0.2)) + float(node.attrs.get("beta", 0.5)), 0, 1)
+
+
+@op("HardSwish")
+def _hswish(s, node, x):
+    return F.hardswish(x)
+
+
+@op("Clip")
+def _clip(s, node, x, lo=None, hi=None):
+    lo = node.attrs.get("min") if lo is None else float(lo)
+    hi = node.attrs.get("max") if hi is None else float(hi)
+    return torch.clamp(x, min=lo, max=hi)
+
+
+@op("Gelu")
+def _gelu(s, node, x):
+    return F.gelu(x, approximate="tanh" if node.attrs.get("approximate", "none") == "tanh" else "none")
+
+
+for _n, _f in (("Erf", torch.erf), ("Sqrt", torch.sqrt), ("Exp", torch.exp), ("Log", torch.log), ("Abs", torch.abs),
+               ("Neg", torch.neg), ("Reciprocal", torch.reciprocal), ("Floor", torch.floor), ("Ceil", torch.ceil)):
+    _OPS[_n] = (lambda f: (lambda s, node, x: f(x)))(_f)
+
+for _n, _f in (("Add", torch.add), ("Sub", torch.sub), ("Mul", torch.mul), ("Div", torch.div), ("Pow", torch.pow)):
+    _OPS[_n] = (lambda f: (lambda s, node, a, b: f(*s.match_batch(a, b))))(_f)
+_OPS["Eltwise"] = _OPS["Add"]
+
+
+@op("Softmax")
+def _softmax(s, node, x):
+    return torch.softmax(x, int(node.attrs.get("axis", -1)))
+
+
+def _pool_args(node, x):
+    k = node.attrs["kernel_shape"]
+    nd = len(k)
+    strides = node.attrs.get("strides", [1] * nd)
+    dil = node.attrs.get("dilations", [1] * nd)
+    pads = _auto_pad(node, x, k, strides, dil)
+    return k, nd, strides, dil, pads
+
+
+@op("MaxPool")
+def _maxpool(s, node, x):
+    k, nd, strides, dil, pads = _pool_args(node, x)
+    sym, fpad = _pads_nd(pads, nd)
+    if sym is None:
+        x = F.pad(x, fpad, value=float("-inf"))
+        sym = (0,) * nd
+    fn = {1: F.max_pool1d, 2: F.max_pool2d, 3: F.max_pool3d}[nd]
+    return fn(x, tuple(k), tuple(strides), sym, tuple(dil), bool(node.attrs.get("ceil_mode", 0)))
+
+
+@op("AveragePool")
+def _avgpool(s, node, x):
+    k, nd, strides, dil, pads = _pool_args(node, x)
+    sym, fpad = _pads_nd(pads, nd)
+    cip = bool(node.attrs.get("count_include_pad", 0))
+    if sym is None:
+        if not cip:
+            raise NotImplementedError("AveragePool: asymmetric pads with count_include_pad=0")
+        x = F.pad(x, fpad)
+        sym = (0,) * nd
+    fn = {1: F.avg_pool1d, 2: F.avg_pool2d, 3: F.avg_pool3d}[nd]
+    return fn(x, tuple(k), tuple(strides), sym, bool(node.attrs.get("ceil_mode", 0)), cip)
+
+
+@op("GlobalAveragePool")
+def _gap(s, node, x):
+    return x.mean(tuple(range(2, x.dim())), keepdim=True)
+
+
+@op("GlobalMaxPool")
+def _gmp(s, node, x):
+    return x.amax(tuple(range(2, x.dim())), keepdim=True)
+
+
+@op("MatMul")
+def _matmul(s, node, a, b):
+    return torch.matmul(a, b)
+
+
+@op("Gemm")
+def _gemm(s, node, a, b, c=None):
+    if node.attrs.get("transA", 0):
+        a = a.t()
+    if node.attrs.get("transB", 0):
+        b = b.t()
+    alpha, beta = float(node.attrs.get("alpha", 1.0)), float(node.attrs.get("beta", 1.0))
+    if c is not None and a.dim() == 2 and b.dim() == 2 and c.dim() <= 2:
+        return torch.addmm(c, a, b, beta=beta, alpha=alpha)      # one hipBLASLt call, bias in the epilogue
+    y = torch.matmul(a, b)
+    if alpha != 1.0:
+        y = y * alpha
+    if c is not None:
+        y = y + (c if beta == 1.0 else c * beta)
+    return y
+
+
+@op("Flatten")
+def _flatten(s, node, x):
+    ax = int(node.attrs.get("axis", 1))
+    ax = ax + x.dim() if ax < 0 else ax
+    lead = int(np.prod(x.shape[:ax])) if ax > 0 else 1
+    return x.reshape(lead, -1)
+
+
+@op("Reshape")
+def _reshape(s, node, x, shape):
+    shp = _ints(shape)
+    if not node.attrs.get("allowzero", 0):
+        shp = [x.shape[i] if d == 0 else d for i, d in enumerate(shp)]
+    # the graph was exported (and constant-folded) for batch 1: re-scale a literal leading 1 to the live batch
+    if s.batch > 1 and shp and shp[0] == 1 and x.shape[0] == s.batch:
+        want = int(np.prod([d for d in shp if d > 0]))
+        if (-1 in shp and x.numel() % (want * s.batch) == 0) or (-1 not in shp and want * s.batch == x.numel()):
+            shp[0] = s.batch
+    return x.reshape(shp)
+
+
+@op("Transpose")
+def _transpose(s, node, x):
+    perm = node.attrs.get("perm") or list(reversed(range(x.dim())))
+    return x.permute(perm)
+
+
+@op("Concat")
+def _concat(s, node, *xs):
+    ax = int(node.attrs["axis"])
+    if ax != 0 and s.batch > 1:
+        xs = [x.expand(s.batch, *x.shape[1:]) if (x.dim() > 0 and x.shape[0] == 1) else x for x in xs]
+    return torch.cat(list(xs), ax)
+
+
+@op("Split")
+def _split(s, node, x, split=None):
+    ax = int(node.attrs.get("axis", 0))
+    sizes = _ints(split) if split is not None else node.attrs.get("split")
+    if sizes is None:
+        n = len(node.output)
+        sizes = [x.shape[ax] // n] * n
+    return list(torch.split(x, sizes, ax))
+
+
+@op("Slice")
+def _slice(s, node, x, starts=None, ends=None, axes=None, steps=None):
+    starts = _ints(starts) if starts is not None else node.attrs["starts"]
+    ends = _ints(ends) if ends is not None else node.attrs["ends"]
+    axes = _ints(axes) if axes is not None else node.attrs.get("axes", list(range(len(starts))))
+    steps = _ints(steps) if steps is not None else [1] * len(starts)
+    idx = [slice(None)] * x.dim()
+    for st, en, ax, sp in zip(starts, ends, axes, steps):
+        if sp < 0:
+            raise NotImplementedError("Slice with negative step")
+        n = x.shape[ax]
+        st = max(0, min(n, st + n if st < 0 else st))
+        en = max(0, min(n, en + n if en < 0 else en))
+        idx[ax] = slice(st, en, sp)
+    return x[tuple(idx)]
+
+
+@op("Gather")
+def _gather(s, node, x, idx):
+    ax = int(node.attrs.get("axis", 0))
+    idx = idx.long()
+    if idx.dim() == 0:
+        return x.select(ax, int(idx))
+    return torch.index_select(x, ax, idx.reshape(-1)).reshape(x.shape[:ax] + tuple(idx.shape) + x.shape[ax + 1:])
+
+
+def _axes(node, extra):
+    if extra is not None:
+        return _ints(extra)
+    return node.attrs.get("axes")
+
+
+@op("Squeeze")
+def _squeeze(s, node, x, axes=None):
+    ax = _axes(node, axes)
+    if ax is None:
+        return x.squeeze()
+    for a in sorted([a + x.dim() if a < 0 else a for a in ax], reverse=True):
+        x = x.squeeze(a)
+    return x
+
+
+@op("Unsqueeze")
+def _unsqueeze(s, node, x, axes=None):
+    ax = _axes(node, axes)
+    nd = x.dim() + len(ax)
+    for a in sorted([a + nd if a < 0 else a for a in ax]):
+        x = x.unsqueeze(a)
+    return x
+
+
+def _reduce(fn):
+    def run(s, node, x, axes=None):
+        ax = _axes(node, axes)
+        keep = bool(node.attrs.get("keepdims", 1))
+        if ax is None:
+            ax = list(range(x.dim()))
+        return fn(x, tuple(ax), keep)
+    return run
+
+
+_OPS["ReduceMean"] = _reduce(lambda x, ax, k: x.mean(ax, keepdim=k))
+_OPS["ReduceSum"] = _reduce(lambda x, ax, k: x.sum(ax, keepdim=k))
+_OPS["ReduceMax"] = _reduce(lambda x, ax, k: x.amax(ax, keepdim=k))
+_OPS["ReduceMin"] = _reduce(lambda x, ax, k: x.amin(ax, keepdim=k))
+
+
+@op("BatchNormalization")
+def _bn(s, node, x, scale, bias, mean, var):
+    return F.batch_norm(x, mean, var, scale, bias, False, 0.0, float(node.attrs.get("epsilon", 1e-5)))
+
+
+@op("LayerNormalization")
+def _ln(s, node, x, scale, bias=None):
+    ax = int(node.attrs.get("axis", -1))
+    ax = ax + x.dim() if ax < 0 else ax
+    return F.layer_norm(x, tuple(x.shape[ax:]), scale, bias, float(node.attrs.get("epsilon", 1e-5)))
+
+
+@op("InstanceNormalization")
+def _in(s, node, x, scale, bias):
+    return F.instance_norm(x, weight=scale, bias=bias, eps=float(node.attrs.get("epsilon", 1e-5)))
+
+
+@op("Identity", "Dropout")
+def _identity(s, node, x, *rest):
+    return x
+
+
+_CAST = {1: torch.float32, 2: torch.uint8, 3: torch.int8, 6: torch.int32, 7: torch.int64, 9: torch.bool,
+         10: torch.float16, 11: torch.float64}
+
+
+@op("Cast")
+def _cast(s, node, x):
+    return x.to(_CAST[int(node.attrs["to"])])
+
+
+@op("Shape")
+def _shape(s, node, x):
+    return torch.tensor(list(x.shape), dtype=torch.int64, device=x.device)
+
+
+@op("ConstantOfShape")
+def _cos(s, node, shape):
+    v = node.attrs.get("value")
+    val = float(np.asarray(v).reshape(-1)[0]) if v is not None else 0.0
+    dt = torch.from_numpy(np.asarray(v)).dtype if v is not None else torch.float32
+    return torch.full(_ints(shape), val, dtype=dt, device=s.device)
+
+
+@op("Expand")
+def _expand(s, node, x, shape):
+    shp = _ints(shape)
+    return x.expand(torch.broadcast_shapes(tuple(x.shape), tuple(shp)))
+
+
+@op("Where")
+def _where(s, node, c, a, b):
+    return torch.where(c.bool(), a, b)
+
+
+@op("Equal")
+def _equal(s, node, a, b):
+    return a == b
+
+
+@op("Pad")
+def _pad(s, node, x, pads=None, value=None, axes=None):
+    pads = _ints(pads) if pads is not None else node.attrs["pads"]
+    nd = x.dim()
+    _, fpad = _pads_nd(pads, nd)
+    mode = node.attrs.get("mode", "constant")
+    v = float(value) if value is not None else float(node.attrs.get("value", 0.0))
+    return F.pad(x, fpad, mode=mode, value=v) if mode == "constant" else F.pad(x, fpad, mode=mode)
+
+
+@op("Resize", "Upsample")
+def _resize(s, node, x, roi=None, scales=None, sizes=None):
+    mode = node.attrs.get("mode", "nearest")
+    if node.op_type == "Upsample":
+        scales = roi
+    if sizes is not None and sizes.numel():
+        return F.interpolate(x, size=_ints(sizes)[2:], mode={"linear": "bilinear"}.get(mode, mode))
+    sc = [float(v) for v in scales.reshape(-1).tolist()][2:]
+    return F.interpolate(x, scale_factor=sc, mode={"linear": "bilinear"}.get(mode, mode))
+
+
+@op("FakeQuant")
+def _fake_quant(s, node, x):
+    q = s.graph._qdq[node.name]
+    if not x.is_cuda:          # shape-inference pass on the host: values are irrelevant there
+        return x
+    return q.apply(x.contiguous())
+
+
+class GraphSession(ActivationSession):
+    """All-outputs session over an ONNXGraph."""
+
+    def __init__(self, graph, device=None, expose_fake_quant=False):
+        self.graph = graph
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.device = torch.device(device)
+        self.batch = 1
+        self.consts = {}
+        for name, arr in graph.initializer.items():
+            a = np.array(arr, order="C")  # (np.ascontiguousarray would turn a 0-d scalar into shape (1,))
+            t = torch.from_numpy(a.astype(np.float32)) if a.dtype == np.float16 else torch.from_numpy(a)
+            self.consts[name] = t.to(self.device)
+        missing = sorted({n.op_type for n in graph.graph.node if n.op_type not in _OPS})
+        if missing:
+            raise NotImplementedError(f"executor: unsupported ONNX ops {missing}")
+        self.expose_fake_quant = expose_fake_quant
+        self.input_names = list(graph.network_inputs)
+        # fake-quantised WEIGHTS are constants: quantise them once here instead of on every forward
+        self._folded = set()
+        self._batched_ok = None   # decided by batched_ok() at the first batched run
+        for node in graph.graph.node:
+            if node.op_type == "FakeQuant" and node.input[0] in self.consts:
+                w = self.consts[node.input[0]]
+                self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, w) if w.is_cuda else w
+                self._folded.add(node.name)
+        self._infer()
+
+    def _infer(self):
+        """One batch-1 forward on zeros fixes every tensor's per-image shape (replaces onnx shape inference)."""
+        feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
+                                device=self.device) for n in self.input_names}
+        env = self._forward(feeds, 1)
+        names, elems = [], []
+        self.shape1 = {}
+        for n in self.input_names:
+            names.append(n)
+            elems.append(env[n].numel())
+            self.shape1[n] = tuple(env[n].shape)
+        for node in self.graph.graph.node:
+            if (node.op_type == "FakeQuant" and not self.expose_fake_quant) or node.name in self._folded:
+                continue
+            for o in node.output:
+                if o == "" or o in names:
+                    continue
+                t = env[o]
+                self.graph.set_tensor_shape(o, list(t.shape))
+                if t.is_floating_point():   # integer tensors (Shape, indices) are not calibrated
+                    names.append(o)
+                    elems.append(t.numel())
+                    self.shape1[o] = tuple(t.shape)
+        self.tensor_names, self.elems_per_image = names, elems
+
+    def match_batch(self, a, b):
+        return a, b
+
+    def set_const(self, name, tensor):
+        """Replace an initializer on the device (a weight updated by a weight transform) and refresh the folded
+        fake-quantised copy that depends on it."""
+        self.consts[name] = tensor.to(self.device)
+        for node in self.graph.graph.node:
+            if node.name in self._folded and node.input[0] == name:
+                self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, self.consts[name])
+
+    def _forward(self, feeds, batch):
+        self.batch = batch
+        env = dict(self.consts)
+        env.update(feeds)
+        for node in self.graph.graph.node:
+            if node.name in self._folded:
+                continue
+            args = [env[i] if i != "" else None for i in node.input]
+            while args and args[-1] is None:
+                args.pop()
+            out = _OPS[node.op_type](self, node, *args)
+            if isinstance(out, (list, tuple)):
+                for o, v in zip(node.output, out):
+                    env[o] = v
+            else:
+                env[node.output[0]] = out
+        return env
+
+    def _lead(self):
+        return max(1, int(self.graph.get_tensor_shape(self.input_names[0])[0]))
+
+    @torch.no_grad()
+    def _run_env(self, inputs, batch):
+        return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
+
+    def _collect(self, env, names, batch):
+        out = []
+        for n in names:
+            t = env[n]
+            if t.dtype != torch.float32:
+                t = t.float()
+            out.append(self._batch_major(n, t, batch) if n in self.shape1 else t)
+        return out
+
+    @torch.no_grad()
+    def batched_ok(self):
+        """Is running B images through a graph exported for one image the same as running them one by one?  The executor
+        batches by rewriting literal leading 1s (Reshape, Concat, ...) and by locating the batch axis of every tensor
+        (_batch_major): heuristics that a Reshape with a literal non-leading shape can defeat WITHOUT an error — the
+        calibration statistics would then silently come from scrambled data.  So, once per session: a batch-2 forward on
+        random inputs must reproduce, for every exposed tensor, two batch-1 forwards.  If not, this session runs one image
+        at a time from then on (and says so)."""
+        if self._batched_ok is None:
+            g = torch.Generator(device="cpu").manual_seed(20260)
+            lead = self._lead()
+            feeds = {n: torch.randn([2 * lead] + [max(1, int(d)) for d in self.graph.get_tensor_shape(n)[1:]], generator=g)
+                        .to(self.device) for n in self.input_names}
+            ok = True
+            try:
+                both = self._collect(self._run_env(feeds, 2), self.tensor_names, 2)
+                for k in range(2):
+                    one = self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in feeds.items()}, 1),
+                                        self.tensor_names, 1)
+                    for name, tb, t1 in zip(self.tensor_names, both, one):
+                        ref = t1.reshape(-1).double()
+                        got = tb[k].reshape(-1).double()
+                        # scrambled data is wrong by O(1); different library kernels for the two batch sizes by ~1e-4
+                        bad = got.numel() != ref.numel()
+                        if not bad:
+                            bad = float((got - ref).norm()) > 2e-2 * float(ref.norm()) + 1e-6
+                        if bad:
+                            logger.warning("executor: batched execution of this graph differs from per-image execution at "
+                                           "tensor %s: running one image at a time", name)
+                            ok = False
+                            break
+                    if not ok:
+                        break
+            except RuntimeError as e:   # e.g. no batch axis could be located
+                logger.warning("executor: batched execution of this graph failed (%s): running one image at a time", e)
+                ok = False
+            self._batched_ok = ok
+        return self._batched_ok
+
+    def _run_any(self, inputs, names):
+        first = inputs[self.input_names[0]]
+        lead = self._lead()
+        batch = first.shape[0] // lead
+        if batch > 1 and not self.batched_ok():
+            per = [self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in inputs.items()}, 1), names, 1)
+                   for k in range(batch)]
+            # [B, per-image ...] like the batched path: images stack on the leading 1 of the per-image shape, or on a new axis
+            return [torch.cat([p[i] for p in per]) if (per[0][i].dim() > 0 and per[0][i].shape[0] == 1)
+                    else torch.stack([p[i] for p in per]) for i in range(len(names))]
+        return self._collect(self._run_env(inputs, batch), names, batch)
+
+    @torch.no_grad()
+    def run(self, inputs):
+        return self._run_any(inputs, self.tensor_names)
+
+    def _batch_major(self, name, t, batch):
+        """Calibration tensors are handed on as [B, per-image...] contiguous.  A graph may carry the batch on
+        another axis (e.g. the [3, B, heads, N, d] qkv transpose of an attention block) or not at all."""
+        if batch == 1:
+            return t.contiguous()
+        s1 = self.shape1[name]
+        if tuple(t.shape) == s1:                      # batch-independent value: the same for every image
+            return t.unsqueeze(0).expand(batch, *t.shape).contiguous()
+        diff = [d for d in range(t.dim()) if t.shape[d] != s1[d]]
+        if len(s1) != t.dim() or len(diff) != 1 or t.shape[diff[0]] != s1[diff[0]] * batch:
+            raise RuntimeError(f"executor: cannot locate the batch axis of {name}: batch-1 shape {s1}, live {tuple(t.shape)}")
+        d = diff[0]
+        if d == 0:
+            return t.contiguous()
+        lead = s1[d]
+        # split axis d into (batch, lead) and bring batch to the front
+        v = t.reshape(*t.shape[:d], batch, lead, *t.shape[d + 1:])
+        return v.movedim(d, 0).reshape(batch, *s1).contiguous() if lead == 1 else v.movedim(d, 0).contiguous()
+
+    @torch.no_grad()
+    def run_named(self, inputs, names):
+        """Chosen tensors by name, laid out like run()'s ([B, per-image ...], checked batching)."""
+        return self._run_any(inputs, list(names))

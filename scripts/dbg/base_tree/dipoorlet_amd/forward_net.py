@@ -1,0 +1,356 @@
+"""Calibration statistics over the calibration set — the GPU-resident replacement of
+dipoorlet/forward_net.py:192-342 (forward_get_minmax / forward_get_hist / forward_net_octav) and its
+.bin loader (:459-464).
+
+Reference flow per image: ORT forward with every node output exposed -> copy all activations to the
+host -> numpy reductions appended to Python lists.  Here: B images per forward, activations stay in
+HBM, one batched HIP launch per statistic over the whole tensor set, persistent device accumulators.
+The functions keep the reference's names, arguments and return shapes (dict keyed by tensor name) so
+tensor_cali and tests read the same; where the reference returns one entry per image and only their
+min / max / sum is ever consumed (ranges, histograms), the list holds the already-reduced value unless
+`per_image=True` asks for the full lists.
+
+`onnx_graph` is anything offering the reference ONNXGraph's calibration-facing surface:
+    .network_inputs            list of input names
+    .get_tensor_shape(name)    model input shape (batch dim 1)
+    .make_session(args)        -> ActivationSession  (replaces ort.InferenceSession(...all outputs...))
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .dist_helper import shard_range
+from .platform_settings import platform_setting_table
+from .utils import logger
+
+DEFAULT_BATCH = 16
+
+
+class ActivationSession:
+    """What a graph executor must provide: one forward of a batch -> every calibration tensor.
+
+    tensor_names     network inputs first, then every node output in graph order (forward_net.py:220-235)
+    elems_per_image  elements of each tensor for ONE image
+    run(inputs)      inputs: {name: device tensor [B, ...]} -> list of contiguous fp32 device tensors
+                     [B, ...] aligned with tensor_names (the inputs themselves included)
+    """
+    tensor_names = ()
+    elems_per_image = ()
+
+    def run(self, inputs):
+        raise NotImplementedError
+
+
+def input_data_generator(input_dir, input_name_list, data_st_idx, data_ed_idx):
+    """forward_net.py:459-464 — one dict {input_name: flat fp32 array} per calibration image, read from
+    `{input_dir}/{input_name}/{idx}.bin` (raw little-endian fp32)."""
+    for idx in range(data_st_idx, data_ed_idx):
+        yield {n: np.fromfile(f"{input_dir}/{n}/{idx}.bin", "float32") for n in input_name_list}
+
+
+def stage_input_batch(input_dir, input_names, shapes, idx0, idx1, pinned):
+    """HOST: images [idx0, idx1) of every network input read into one (pinned) staging tensor per input.
+    Returns {name: (host tensor [b, per_image], device shape)}."""
+    out = {}
+    b = idx1 - idx0
+    for n in input_names:
+        shape = tuple(int(d) for d in shapes[n])
+        per = int(np.prod(shape))
+        stage = torch.empty((b, per), dtype=torch.float32, pin_memory=pinned)
+        sv = stage.numpy()
+        for j, idx in enumerate(range(idx0, idx1)):
+            a = np.fromfile(f"{input_dir}/{n}/{idx}.bin", "float32")
+            if a.size != per:
+                raise ValueError(f"{input_dir}/{n}/{idx}.bin holds {a.size} fp32 values, model input needs {per}")
+            sv[j] = a
+        lead = shape[0] if len(shape) > 0 else 1
+        full = (b * lead,) + shape[1:] if len(shape) > 1 else (b * per,)
+        out[n] = (stage, full)
+    return out
+
+
+def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
+    """Images [idx0, idx1) of every network input as device tensors [B, *shape[1:]]: files are read
+    into one pinned staging buffer per input and copied with a single async H2D transfer."""
+    staged = stage_input_batch(input_dir, input_names, shapes, idx0, idx1, device.type == "cuda")
+    return {n: h.to(device, non_blocking=True).reshape(full) for n, (h, full) in staged.items()}
+
+
+class CalibrationRun:
+    """One rank's sweep(s) over its shard of the calibration set."""
+
+    def __init__(self, onnx_graph, args):
+        self.graph = onnx_graph
+        self.args = args
+        self.session = onnx_graph.make_session(args)
+        self.names = list(self.session.tensor_names)
+        self.elems = [int(e) for e in self.session.elems_per_image]
+        self.T = len(self.names)
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.batch = int(getattr(args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
+        self.st, self.ed = shard_range(args.data_num, args.rank, args.world_size)
+        self._plans = {}
+        budget_gb = float(getattr(args, "resident_gb", 160.0))
+        self._budget = int(budget_gb * 2**30)
+        self._resident = []  # tensor sets kept in HBM between pass 1 and pass 2
+        self._resident_ok = True
+        self._resident_bytes = 0
+
+    def plan(self, b):
+        p = self._plans.get(b)
+        if p is None:
+            p = self._plans[b] = ops.TensorSetPlan(self.elems, b, self.device)
+        return p
+
+    def n_images(self):
+        return self.ed - self.st
+
+    def batches(self):
+        i = self.st
+        while i < self.ed:
+            j = min(i + self.batch, self.ed)
+            yield i, j
+            i = j
+
+    def _input_batches(self):
+        """(b, {input: device tensor}) per batch; the .bin files of the NEXT batch are read into pinned memory by
+        a helper thread while the GPU works on the current one (file I/O releases the GIL)."""
+        import queue
+        import threading
+        shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
+        bounds = list(self.batches())
+        if not bounds:
+            return
+        q = queue.Queue(maxsize=2)
+
+        def reader():
+            try:
+                for i, j in bounds:
+                    q.put((j - i, stage_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j,
+                                                    self.device.type == "cuda")))
+            except BaseException as e:  # surfaced in the consumer
+                q.put(e)
+
+        t = threading.Thread(target=reader, daemon=True)
+        t.start()
+        for _ in bounds:
+            item = q.get()
+            if isinstance(item, BaseException):
+                raise item
+            b, staged = item
+            yield b, {n: h.to(self.device, non_blocking=True).reshape(full) for n, (h, full) in staged.items()}
+        t.join()
+
+    def forward(self, keep=False):
+        """Yields (b, tensors) per batch.  With keep=True the tensor sets stay resident in HBM (up to
+        args.resident_gb) so a second pass re-reads them instead of re-running the network."""
+        for b, inputs in self._input_batches():
+            tensors = self.session.run(inputs)
+            if keep and self._resident_ok:
+                nbytes = sum(t.numel() * 4 for t in tensors)
+                if self._resident_bytes + nbytes <= self._budget:
+                    self._resident.append((b, tensors))
+                    self._resident_bytes += nbytes
+                else:
+                    self._resident_ok = False
+                    self._resident = []
+                    self._resident_bytes = 0
+            yield b, tensors
+
+    def second_pass(self):
+        if self._resident_ok and self._resident:
+            yield from self._resident
+        else:
+            yield from self.forward()
+
+    def release(self):
+        self._resident = []
+        self._resident_bytes = 0
+
+
+def _np32(t):
+    return t.detach().cpu().numpy().astype(np.float32, copy=False)
+
+
+def _run_of(onnx_graph, args, run):
+    return run if run is not None else CalibrationRun(onnx_graph, args)
+
+
+def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_resident=False):
+    """forward_net.py:192-237 — {name: {'max': [...], 'min': [...]}} over this rank's shard."""
+    run = _run_of(onnx_graph, args, run)
+    if per_image:
+        rows = []
+        for b, tensors in run.forward(keep=keep_resident):
+            plan = run.plan(b)
+            acc = ops.CalibAccumulators(plan.n_pairs, run.device)
+            acc.minmax_accumulate(plan, tensors, per_image=True)
+            lo, hi = acc.finalize_minmax()
+            rows.append(torch.stack([lo.reshape(b, run.T), hi.reshape(b, run.T)], -1).clone())
+        allr = _np32(torch.cat(rows)) if rows else np.zeros((0, run.T, 2), np.float32)
+        return {n: {"max": list(allr[:, t, 1]), "min": list(allr[:, t, 0])} for t, n in enumerate(run.names)}
+    acc = ops.CalibAccumulators(run.T, run.device, int(getattr(args, "bins", 2048)))
+    for b, tensors in run.forward(keep=keep_resident):
+        acc.minmax_accumulate(run.plan(b), tensors)
+    gmin, gmax = acc.finalize_minmax()
+    run.acc = acc
+    lo, hi = _np32(gmin), _np32(gmax)
+    return {n: {"max": [hi[t]], "min": [lo[t]]} for t, n in enumerate(run.names)}
+
+
+def _ranges_from_stats(stats_min_max, names, device):
+    gmin = np.array([np.min(stats_min_max[n]["min"]) for n in names], np.float32)
+    gmax = np.array([np.max(stats_min_max[n]["max"]) for n in names], np.float32)
+    return torch.from_numpy(gmin).to(device), torch.from_numpy(gmax).to(device)
+
+
+def forward_get_hist(onnx_graph, stats_min_max, args, run=None):
+    """forward_net.py:240-281 — {name: [int64[bins]]}: the |x| histogram over (0, max(max, -min)) of the
+    shard, already summed over images (the reference returns one per image and sums them later,
+    basic_algorithm.py:37-38)."""
+    run = _run_of(onnx_graph, args, run)
+    gmin, gmax = _ranges_from_stats(stats_min_max, run.names, run.device)
+    acc = hist_pass(run, gmin, gmax, int(args.bins))
+    h = acc.hist.cpu().numpy()
+    return {n: [h[t]] for t, n in enumerate(run.names)}
+
+
+def hist_pass(run, gmin, gmax, bins):
+    """Device side of forward_get_hist: install the ranges, sweep the shard, leave the uint64 histograms
+    in run.acc.hist.  Raises like np.histogram for a non-finite or degenerate range."""
+    acc = getattr(run, "acc", None)
+    if acc is None or acc.bins != bins:
+        acc = run.acc = ops.CalibAccumulators(run.T, run.device, bins)
+    acc.set_minmax(gmin, gmax)
+    acc.hist_prepare()
+    for b, tensors in run.second_pass():
+        acc.abs_hist_accumulate(run.plan(b), tensors)
+    run.release()
+    status = acc.range_status()["status"]
+    for t, n in enumerate(run.names):
+        if status[t] == 1:
+            raise ValueError(f"supplied range of [0, {gmax[t].item()}] is not finite (tensor {n})")
+        if status[t] == 2:
+            raise ValueError(f"Too many bins for data range. Cannot create {bins} finite-sized bins. (tensor {n})")
+    return acc
+
+
+def forward_net_octav(onnx_graph, args, run=None):
+    """forward_net.py:284-342 — {name: {'optimal_s': [...], 'min': [...], 'max': [...]}}, one entry per
+    image of the shard."""
+    run = _run_of(onnx_graph, args, run)
+    dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
+    rows = []
+    pipe = ops.OctavPipeline(dynamic_sym, run.device)    # the walk of batch i runs beside the forward / streaming pass of batch i + 1
+    for b, tensors in run.forward():
+        rows.append(pipe.submit(run.plan(b), tensors))
+    pipe.sync()
+    run.octav_rows = torch.cat(rows) if rows else torch.zeros(0, run.T, 3, device=run.device)
+    r = _np32(run.octav_rows)
+    return {n: {"optimal_s": list(r[:, t, 0]), "min": list(r[:, t, 1]), "max": list(r[:, t, 2])}
+            for t, n in enumerate(run.names)}
+
+
+# forward_net.py:345-456 — the reference's "*_transformer" variants compute the same statistics, only walking
+# the graph node by node through its host-side ActivationCache to bound host memory.  Here every schedule is
+# the batched, HBM-resident one, so they are the same functions.
+forward_get_minmax_transformer = forward_get_minmax
+forward_get_hist_transformer = forward_get_hist
+forward_net_octav_transformer = forward_net_octav
+
+
+class ActivationCache:
+    """Counterpart of forward_net.py:23-190 for callers that want activations by tensor name.
+
+    The reference splits the network into single-node ONNX models, runs one ORT session per node and keeps
+    every image's activation of every live tensor on the HOST, evicting by reference count.  Here one batched
+    forward of the shard keeps all calibration tensors resident in HBM (288 GB: 1024 ResNet-50 images are
+    109 GB).  `cache[name]` returns the list of per-image device tensors (views, no copies), `cache.chunks(name)`
+    the per-batch tensors [b, ...] behind them, `cache[initializer]` the initializer array.  `reset()` drops the
+    cached activations."""
+
+    def __init__(self, graph, args, st=None, ed=None):
+        self.graph, self.args = graph, args
+        self.st = 0 if st is None else st
+        self.ed = args.data_num if ed is None else ed
+        self.activation_cache = {}     # name -> [per-batch device tensors]
+        self._filled = False
+        self._selective = False        # over the HBM budget: keep only the tensors asked for (one forward each)
+        self._sess = None
+
+    def reset(self):
+        self.activation_cache.clear()
+        self._filled = False
+
+    def _session(self):
+        if self._sess is None:
+            self._sess = self.graph.make_session(self.args)
+        return self._sess
+
+    def _sweep(self, keep):
+        """One batched forward of the shard; returns {name: [per-batch tensors]} for the names in `keep`."""
+        sess = self._session()
+        dev = sess.device if hasattr(sess, "device") else torch.device("cuda", torch.cuda.current_device())
+        shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
+        batch = int(getattr(self.args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
+        per_name = {n: [] for n in sess.tensor_names if n in keep}
+        for i in range(self.st, self.ed, batch):
+            j = min(i + batch, self.ed)
+            inputs = load_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, dev)
+            for n, t in zip(sess.tensor_names, sess.run(inputs)):
+                if n in per_name:
+                    per_name[n].append(t)
+        return per_name
+
+    def _fill(self):
+        """Everything resident if it fits the budget (args.resident_gb, default 160 GB of the 288) — else SELECTIVE mode:
+        a tensor's activations are produced when first asked for by one more forward of the shard that keeps only that
+        tensor (slower, bounded memory, same values)."""
+        sess = self._session()
+        need = 4.0 * sum(sess.elems_per_image) * max(0, self.ed - self.st)
+        budget = float(getattr(self.args, "resident_gb", 160.0) or 160.0) * 1e9
+        self._selective = need > budget
+        if self._selective:
+            logger.warning("ActivationCache: %.1f GB of activations exceed the %.0f GB budget: keeping tensors on demand",
+                           need / 1e9, budget / 1e9)
+            self.activation_cache = {}
+        else:
+            self.activation_cache = self._sweep(set(sess.tensor_names))
+        self._filled = True
+
+    def chunks(self, tensor_name):
+        if not self._filled:
+            self._fill()
+        if self._selective and tensor_name not in self.activation_cache:
+            one = 4.0 * self._session().elems_per_image[self._session().tensor_names.index(tensor_name)] * (self.ed - self.st)
+            held = sum(4.0 * t.numel() for v in self.activation_cache.values() for t in v)
+            budget = float(getattr(self.args, "resident_gb", 160.0) or 160.0) * 1e9
+            if held + one > budget:
+                self.activation_cache.clear()   # make room: the evicted tensors are re-produced if asked for again
+            self.activation_cache.update(self._sweep({tensor_name}))
+        return self.activation_cache[tensor_name]
+
+    def __getitem__(self, tensor_name):
+        if tensor_name in getattr(self.graph, "initializer", {}):
+            return self.graph.get_initializer(tensor_name)
+        return [t[k] for t in self.chunks(tensor_name) for k in range(t.shape[0])]
+
+
+def forward_get_tensor(graph, net, index, args):
+    """forward_net.py:467-485 — every tensor of calibration image `index`, by name, as device tensors [1, ...]
+    (`net`, the reference's ModelProto argument, is not needed: the graph makes its own session)."""
+    from collections import OrderedDict
+    sess = graph.make_session(args)
+    dev = sess.device if hasattr(sess, "device") else torch.device("cuda", torch.cuda.current_device())
+    shapes = {n: graph.get_tensor_shape(n) for n in graph.network_inputs}
+    inputs = load_input_batch(args.input_dir, graph.network_inputs, shapes, index, index + 1, dev)
+    return OrderedDict(zip(sess.tensor_names, sess.run(inputs)))
+
+
+def log_forward_time(seconds):
+    logger.info("Forward time: {:.2f} seconds".format(seconds))
+
+
+__all__ = ["ActivationSession", "ActivationCache", "CalibrationRun", "input_data_generator", "load_input_batch", "forward_get_minmax",
+           "forward_get_hist", "forward_net_octav", "forward_get_tensor", "forward_get_minmax_transformer", "forward_get_hist_transformer",
+           "forward_net_octav_transformer", "hist_pass", "DEFAULT_BATCH"]

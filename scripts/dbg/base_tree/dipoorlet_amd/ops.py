@@ -1,0 +1,612 @@
+"""Torch-facing operators over the C ABI: device memory and streams come from PyTorch-ROCm, the
+arithmetic runs in the hand-written gfx950 kernels (csrc/calib_kernels.hip).
+
+Vocabulary: a *tensor set* is the list of activation tensors one forward of the network yields for a
+batch of B calibration images (each tensor is [B, ...] contiguous fp32).  A `TensorSetPlan` cuts the
+set into work items once; `CalibAccumulators` holds the persistent device-side statistics
+(running min/max, uint64 histograms, OCTAV states) that replace the reference's per-image Python
+lists (forward_net.py:204-235, 252-280, 297-340).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _hip
+
+_SEG_CACHE_MAX = 64
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _require_cuda(t, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _hip.DipoorletHipError(f"{name} must be a ROCm device tensor; dipoorlet_amd has no CPU path")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise _hip.DipoorletHipError(f"{name} must be contiguous float32")
+
+
+def _upload_struct_array(arr, n, device):
+    """ctypes struct array -> device uint8 tensor (one-off, synchronous)."""
+    nbytes = C.sizeof(arr._type_) * max(n, 1)
+    host = torch.frombuffer(bytearray(C.string_at(C.addressof(arr), nbytes)), dtype=torch.uint8)
+    return host.to(device)
+
+
+# Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
+# faster from HBM than many small items; the histogram wants a little more latency hiding).
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512}   # measured optima per kernel family
+
+
+def _blocks_for(kind):
+    v = os.environ.get("DPL_BLOCKS_" + kind.upper())
+    return int(v) if v else DEFAULT_BLOCKS[kind]
+
+
+class WorkSet:
+    """Device-resident work decomposition of one launch: items (+ block_begin for the balanced form)."""
+
+    def __init__(self, items, n_items, block_begin, n_blocks):
+        self.items, self.n_items, self.block_begin, self.n_blocks = items, n_items, block_begin, n_blocks
+
+    def args(self):
+        """(d_items, n_items, d_block_begin, n_blocks) as the C ABI takes them."""
+        bb = _ptr(self.block_begin) if self.block_begin is not None else C.c_void_p(0)
+        return _ptr(self.items), self.n_items, bb, self.n_blocks
+
+
+class TensorSetPlan:
+    """Static decomposition of a tensor set into work.
+
+    elems_per_image[t] = elements of tensor t for ONE image; batch = images stacked along dim 0.
+    Slots: tensor index t (per_image=False: images of a batch merge for free) or b * T + t (per image).
+    Default form: the balanced partition (dpl_build_balanced_items) with a per-kernel workgroup count.
+    chunk_elems forces the one-item-per-workgroup form (dpl_build_work_items) instead.
+    """
+
+    def __init__(self, elems_per_image, batch, device, chunk_elems=None):
+        self.elems = [int(e) for e in elems_per_image]
+        self.batch = int(batch)
+        self.T = len(self.elems)
+        self.device = torch.device(device)
+        self.total = sum(self.elems) * self.batch
+        self.chunk = int(chunk_elems) if chunk_elems else None
+        self._work = {}
+        self._seg_cache = {}
+
+    @property
+    def n_pairs(self):
+        return self.batch * self.T
+
+    def _spans(self, per_image):
+        if per_image:
+            return [(t, b * e, e, b * self.T + t) for b in range(self.batch) for t, e in enumerate(self.elems)]
+        return [(t, 0, e * self.batch, t) for t, e in enumerate(self.elems)]
+
+    def work(self, kind, per_image=False):
+        """WorkSet for kernel family `kind` in {'minmax', 'hist', 'octav', 'cos'}."""
+        nb = None if self.chunk else max(1, min(_blocks_for(kind), (self.total + 4095) // 4096))
+        key = (per_image, nb)
+        w = self._work.get(key)
+        if w is None:
+            spans = self._spans(per_image)
+            if self.chunk:
+                arr, n = _hip.build_work_items(spans, self.chunk)
+                w = WorkSet(_upload_struct_array(arr, n, self.device), n, None, n)
+            else:
+                arr, n, bb = _hip.build_balanced_items(spans, nb)
+                bbt = torch.frombuffer(bytearray(bytes(bb)), dtype=torch.int32).to(self.device)
+                w = WorkSet(_upload_struct_array(arr, n, self.device), n, bbt, nb)
+            self._work[key] = w
+        return w
+
+    def octav_scratch(self):
+        """(pair_spans, pair_base u64 [B*T], pair_order, list0, list1): where each pair's data lives, and two tail lists of
+        the batch's size with the pair regions laid out in pair order (4-element aligned: 16-byte loads)."""
+        if getattr(self, "_octav_scratch", None) is None:
+            sizes = [((e + 3) // 4) * 4 for _ in range(self.batch) for e in self.elems]
+            base = np.zeros(len(sizes), np.int64)
+            base[1:] = np.cumsum(sizes)[:-1]
+            tot = int(sum(sizes))
+            arr, ns = _hip._span_array(self._spans(True))
+            order = np.argsort(-np.array(sizes, np.int64), kind="stable").astype(np.int32)  # largest pairs first
+            self._octav_scratch = (_upload_struct_array(arr, ns, self.device), torch.from_numpy(base).to(self.device),
+                                   torch.from_numpy(order).to(self.device),
+                                   torch.empty(tot, dtype=torch.float32, device=self.device),
+                                   torch.empty(tot, dtype=torch.float32, device=self.device))
+        return self._octav_scratch
+
+    def octav_loghist_scratch(self):
+        """(count u32 [B*T, 2048], mantissa-sum u64 [B*T, 2048], bitmap u32 [B*T, 66]) for the bracket form."""
+        if getattr(self, "_octav_lh", None) is None:
+            n = self.n_pairs
+            self._octav_lh = (torch.empty(n, 2048, dtype=torch.int32, device=self.device),
+                              torch.empty(n, 2048, dtype=torch.int64, device=self.device),
+                              torch.empty(n, 66, dtype=torch.int32, device=self.device))
+        return self._octav_lh
+
+    def octav_oneread_scratch(self):
+        """Work decomposition, scratch and prediction state of the one-read OCTAV form, or None when a pair is too large
+        for it: dict(slices, n_slices, pair_slice0, lh, vis [2, T, 64], pred [T, 64], calls)."""
+        if getattr(self, "_octav_one", None) is None:
+            built = _hip.build_octav_slices(self._spans(True))
+            if built is None:
+                self._octav_one = False
+            else:
+                arr, n, ps = built
+                chunk, small = _hip.lib().dpl_octav_sort_chunk(), _hip.lib().dpl_octav_small_pair()
+                counts = np.frombuffer(arr, dtype=np.dtype([("offset", "<u8"), ("count", "<u4"), ("seg", "<u4"), ("slot", "<u4"),
+                                                            ("reserved", "<u4")]), count=n)["count"].astype(np.int64)
+                per_slice = (counts + chunk - 1) // chunk                       # sorted runs a slice's list can have
+                chunk0 = np.zeros(n, np.int64)
+                chunk0[1:] = np.cumsum(per_slice)[:-1]
+                self._octav_one = dict(
+                    # first directory row of each slice; the directory itself: one row per run (position of each rank's first value)
+                    slice_chunk0=torch.from_numpy(chunk0.astype(np.int32)).to(self.device),
+                    dir=torch.empty(int(per_slice.sum()) * _hip.lib().dpl_octav_dir_row(), dtype=torch.int16, device=self.device),
+                    # pairs that gather their whole window (the last entries of the largest-first pair order): no sort
+                    n_small=self.batch * sum(1 for e in self.elems if e <= small),
+                    slices=_upload_struct_array(arr, n, self.device), n_slices=n,
+                    pair_slice0=torch.frombuffer(bytearray(bytes(ps)), dtype=torch.int32).to(self.device),
+                    lh=torch.empty(n, 2048, dtype=torch.int64, device=self.device),    # one histogram row per slice
+                    # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
+                    vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
+                    pred=torch.zeros(self.T, 128, dtype=torch.int32, device=self.device), calls=0)
+        return self._octav_one or None
+
+    def seg_table(self, tensors):
+        """Device table of base pointers for this launch (cached per pointer tuple)."""
+        if len(tensors) != self.T:
+            raise _hip.DipoorletHipError(f"expected {self.T} tensors, got {len(tensors)}")
+        for t, (x, e) in enumerate(zip(tensors, self.elems)):
+            _require_cuda(x, f"tensor {t}")
+            if x.numel() != e * self.batch:
+                raise _hip.DipoorletHipError(f"tensor {t}: {x.numel()} elements, plan expects {e * self.batch}")
+        key = tuple(x.data_ptr() for x in tensors)
+        tab = self._seg_cache.get(key)
+        if tab is None:
+            if len(self._seg_cache) >= _SEG_CACHE_MAX:
+                self._seg_cache.clear()
+            host = torch.tensor(key, dtype=torch.int64).pin_memory()
+            tab = host.to(self.device, non_blocking=True)
+            self._seg_cache[key] = (tab, host)  # keep the pinned source alive until the copy has run
+            return tab
+        return tab[0]
+
+
+class CalibAccumulators:
+    """Persistent per-tensor statistics on the device."""
+
+    def __init__(self, n_slots, device, bins=2048):
+        self.n = int(n_slots)
+        self.device = torch.device(device)
+        self.bins = int(bins)
+        if not (1 <= self.bins <= _hip.MAX_BINS):
+            raise _hip.DipoorletHipError(f"bins must be in [1, {_hip.MAX_BINS}]")
+        self.min_enc = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.max_enc = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.nan = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        self.gmin = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        self.gmax = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        self.hist = None
+        self.ranges = None
+        self.reset_minmax()
+
+    def reset_minmax(self):
+        _hip.check(_hip.lib().dpl_minmax_init(_ptr(self.min_enc), _ptr(self.max_enc), _ptr(self.nan), self.n,
+                                              _stream()), "dpl_minmax_init")
+
+    # ---- pass 1
+    def minmax_accumulate(self, plan, tensors, per_image=False):
+        """per_image=False: slot = tensor (n_slots = T).  per_image=True: slot = image * T + tensor
+        (n_slots = B * T), the reference's one-entry-per-image lists."""
+        tab = plan.seg_table(tensors)
+        w = plan.work("minmax", per_image)
+        if self.n < (plan.n_pairs if per_image else plan.T):
+            raise _hip.DipoorletHipError("accumulator has fewer slots than the plan addresses")
+        _hip.check(_hip.lib().dpl_minmax_accumulate(*w.args(), _ptr(tab), _ptr(self.min_enc), _ptr(self.max_enc),
+                                                    _ptr(self.nan), _stream()), "dpl_minmax_accumulate")
+
+    def finalize_minmax(self):
+        """-> (gmin, gmax) fp32 device tensors [n_slots]."""
+        _hip.check(_hip.lib().dpl_minmax_finalize(_ptr(self.min_enc), _ptr(self.max_enc), _ptr(self.nan), self.n,
+                                                  _ptr(self.gmin), _ptr(self.gmax), _stream()),
+                   "dpl_minmax_finalize")
+        return self.gmin, self.gmax
+
+    def set_minmax(self, gmin, gmax):
+        """Install merged ranges (e.g. after an all-reduce across ranks)."""
+        self.gmin.copy_(gmin)
+        self.gmax.copy_(gmax)
+        _hip.check(_hip.lib().dpl_minmax_encode(_ptr(self.gmin), _ptr(self.gmax), self.n, _ptr(self.min_enc),
+                                                _ptr(self.max_enc), _ptr(self.nan), _stream()), "dpl_minmax_encode")
+
+    # ---- pass 2
+    def hist_prepare(self):
+        """Derive per-tensor histogram ranges from gmin/gmax (call after finalize_minmax / set_minmax)."""
+        if self.hist is None:
+            self.hist = torch.zeros(self.n, self.bins, dtype=torch.int64, device=self.device)
+            self.ranges = torch.empty(self.n * C.sizeof(_hip.HistRange), dtype=torch.uint8, device=self.device)
+        else:
+            self.hist.zero_()
+        _hip.check(_hip.lib().dpl_hist_prepare(_ptr(self.gmin), _ptr(self.gmax), self.n, self.bins,
+                                               _ptr(self.ranges), _stream()), "dpl_hist_prepare")
+
+    def abs_hist_accumulate(self, plan, tensors):
+        tab = plan.seg_table(tensors)
+        w = plan.work("hist")
+        _hip.check(_hip.lib().dpl_abs_hist_accumulate(*w.args(), _ptr(tab), _ptr(self.ranges), self.bins,
+                                                      _ptr(self.hist), _stream()), "dpl_abs_hist_accumulate")
+
+    def range_status(self):
+        """HOST (synchronises): per-slot status from dpl_hist_prepare: 0 ok, 1 not finite, 2 too many bins."""
+        raw = self.ranges.cpu().numpy().view(np.dtype([("first", "<f4"), ("last", "<f4"), ("step", "<f4"),
+                                                       ("inv", "<f4"), ("zero_bin", "<u4"), ("status", "<u4"),
+                                                       ("dmax", "<f4"), ("exact_div", "<u4")]))
+        return raw
+
+    def hist_percentile(self, threshold):
+        clip = torch.empty(self.n, 2, dtype=torch.float32, device=self.device)
+        _hip.check(_hip.lib().dpl_hist_percentile(_ptr(self.hist), _ptr(self.gmin), _ptr(self.gmax), self.n,
+                                                  self.bins, float(threshold), _ptr(clip), _stream()),
+                   "dpl_hist_percentile")
+        return clip
+
+
+_OCTAV_MAX_ITERS = 20  # forward_net.py:325
+
+
+_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
+# batches per prediction epoch of the one-read form: a batch gathers the bins the walks of the current and the previous epoch
+# stepped into (8-16 batches of history)
+_ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.30"))
+_ONEREAD_SORT_SHARE = float(os.environ.get("DPL_ONEREAD_SORT_SHARE", "0.05"))
+_ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
+
+
+def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):
+    """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max).
+
+    Four forms computing the SAME iterate sequence (forward_net.py:323-330):
+      'oneread' (default)  ONE read, one launch: statistics, exact log-scale histogram and the values of the bins the
+                           iterates are predicted to visit (from the same tensor in the previous batches of this plan)
+                           in a single pass; the exact iteration verifies every iterate against what was gathered and
+                           mispredicted pairs (all of them in a plan's first batch) finish on the compaction route
+                           (csrc/octav_oneread.hip).  A tensor set with a pair too large for it uses 'bracket'
+      'bracket'            two reads: statistics + exact log-scale histogram, bracket walk, gather of the marked
+                           bins, exact per-pair iteration; pairs it cannot serve finish on the compaction route
+      'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists
+      'full'               every evaluation re-reads the full data (21 passes)
+    `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default."""
+    if form is None:
+        form = ("compact" if compact else "full") if compact is not None else os.environ.get("DPL_OCTAV_FORM", "oneread")
+    mode = _OCTAV_MODE[form]
+    res = plan.octav_oneread_scratch() if mode == 3 else None
+    if mode == 3 and res is None:
+        mode = 2
+    w = plan.work("octav", per_image=True)
+    n_pairs = plan.n_pairs
+    nbytes = (n_pairs + 1) * C.sizeof(_hip.OctavState)  # + control block
+    if states is None or states.numel() < nbytes:
+        states = torch.empty(nbytes, dtype=torch.uint8, device=plan.device)
+    tab = plan.seg_table(tensors)
+    L = _hip.lib()
+    dyn = 1 if dynamic_sym else 0
+    if mode == 3:
+        spans, base, order, l0, l1 = plan.octav_scratch()
+        k = res["calls"]
+        res["calls"] = k + 1
+        epoch, first = divmod(k, _ONEREAD_EPOCH)
+        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["slice_chunk0"]),
+                                           _ptr(res["dir"]), _ptr(res["lh"]),
+                                           _ptr(res["vis"]), _ptr(res["pred"]), epoch % 2, 1 if first == 0 else 0, plan.T,
+                                           *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base), _ptr(order),
+                                           res["n_small"], _ptr(l0), _ptr(l1), _walk_sorted(plan), dyn, _OCTAV_MAX_ITERS, _stream()),
+                   "dpl_octav_run_oneread")
+        out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+        _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
+        return out
+    _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, mode, _stream()), "dpl_octav_init")
+    if mode == 0:
+        _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, dyn, _OCTAV_MAX_ITERS, _stream()),
+                   "dpl_octav_run")
+    else:
+        spans, base, order, l0, l1 = plan.octav_scratch()
+        if mode == 1:
+            _hip.check(L.dpl_octav_run_compact(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
+                                               _ptr(order), _ptr(l0), _ptr(l1), dyn, _OCTAV_MAX_ITERS, _stream()),
+                       "dpl_octav_run_compact")
+        else:
+            cnt, msum, bitmap = plan.octav_loghist_scratch()
+            _hip.check(L.dpl_octav_run_bracket(*w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base),
+                                               _ptr(order), _ptr(l0), _ptr(l1), _ptr(cnt), _ptr(msum), _ptr(bitmap),
+                                               dyn, _OCTAV_MAX_ITERS, _stream()), "dpl_octav_run_bracket")
+    out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+    _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
+    return out
+
+
+def _walk_sorted(plan):
+    """1: the plan's next one-read batch walks sorted runs, 0: whole lists from registers (DPL_OCTAV_WALK = sorted | group
+    forces one; default: by the share of values the plan's last batches listed, see OctavPipeline._settle)."""
+    forced = os.environ.get("DPL_OCTAV_WALK", "auto")
+    if forced in ("sorted", "group"):
+        return 1 if forced == "sorted" else 0
+    return plan.__dict__.get("_octav_sorted", 0)
+
+
+class OctavPipeline:
+    """OCTAV over a RUN of batches in the one-read form with the two halves of a batch on two HIP streams: the streaming
+    kernel of batch i + 1 (HBM-bound, the caller's stream) runs beside the per-pair walk of batch i (latency-bound: ~20
+    dependent iterations per pair, a side stream).  Same kernels, same results as octav_batch(form='oneread').
+
+        pipe = OctavPipeline(dynamic_sym)
+        rows = [pipe.submit(plan, tensors) for ...]     # [B, T, 3] each, NOT valid yet
+        pipe.sync()                                     # rows are valid for work on the caller's stream
+
+    Each plan keeps two sets of per-batch scratch (states, histogram rows, prediction snapshot, gather list) so that
+    batch i + 1 can stream while batch i walks.  The walk leaves the number of pairs it could not finish (a bin outside the
+    prediction: every multi-slice pair of a plan's first batch, rare afterwards) in the set's control block; that count is
+    copied to pinned memory and read when the set comes up for reuse two submits later (or in sync()), and only then, if it
+    is non-zero, is the compaction route launched for that batch — in steady state no no-op launches queue up behind the
+    streaming kernel.  The activations of a batch, its pointer table and its result stay referenced from the set until
+    then.  The host therefore runs at most two batches ahead of the device.
+    A tensor set the one-read form cannot take (a pair above 64 slices) runs octav_batch on the caller's stream instead."""
+
+    def __init__(self, dynamic_sym, device=None):
+        self.dyn = 1 if dynamic_sym else 0
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
+        self._touched = []
+        # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
+        self.batches = self.fallback_batches = self.fallback_pairs = self.switched = self.sorted_batches = 0
+        self.list_share = 0.0    # gathered values / elements (running mean over the settled batches)
+
+    @staticmethod
+    def _sets(plan, res):
+        sets = getattr(plan, "_octav_pipe_sets", None)
+        if sets is None:
+            _, _, _, l0, _ = plan.octav_scratch()
+            nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
+            off = plan.n_pairs * C.sizeof(_hip.OctavState) + _hip.OctavState.sum.offset    # control block: sum, cnt_gt, cnt_le
+            # four state arrays in rotation (call k uses k % 4): the array for call k + 2 is initialised at the end of call k's
+            # side-stream work, while the one of call k must survive until the host has read k's count of unfinished pairs
+            plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(4)]
+            plan._octav_pipe_failed = [x[off:off + 24] for x in plan._octav_pipe_states]
+            # the prediction snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
+            # taken care of (two submits later), after the snapshot of call k + 2 has been written
+            plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(3)]
+            sets = []
+            for j in range(2):
+                sets.append(dict(failed=torch.zeros(24, dtype=torch.uint8).pin_memory(),
+                                 lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
+                                 l0=l0 if j == 0 else torch.empty_like(l0), done=None, refs=None, pending=False, k=-1))
+            plan._octav_pipe_sets = sets
+        return sets
+
+    def _prepare(self, plan, res, st, k, stream):
+        """State array + prediction snapshot (in set `st`) for the plan's call number k."""
+        ep, first = divmod(k, _ONEREAD_EPOCH)
+        _hip.check(_hip.lib().dpl_octav_oneread_prepare(_ptr(res["vis"]), _ptr(plan._octav_pipe_pred[k % 4]), ep % 2, 1 if first == 0 else 0, plan.T,
+                                                        _ptr(plan._octav_pipe_states[k % 4]), plan.n_pairs, stream),
+                   "dpl_octav_oneread_prepare")
+        st["prepared"] = k
+
+    def _finish(self, plan, res, st):
+        """Side stream: results of the set's batch -> its output rows, the set made ready for its next use, completion event."""
+        side = self.side.cuda_stream
+        _hip.check(_hip.lib().dpl_octav_finalize(_ptr(st["states"]), plan.n_pairs, _ptr(st["refs"][2]), side), "dpl_octav_finalize")
+        self._prepare(plan, res, st, st["k"] + 2, side)    # off the caller's stream: the set's next use is two calls away
+        st["done"] = torch.cuda.Event()
+        st["done"].record(self.side)
+
+    def _settle(self, plan, res, st):
+        """HOST wait for the set's walk; the compaction route for its batch if some pair needs it."""
+        if not st["pending"]:
+            return
+        st["pending"] = False
+        st["done"].synchronize()
+        ctl = st["failed"].numpy()
+        listed, failed = float(ctl[0:8].view(np.float64)[0]), int(ctl[16:24].view(np.int64)[0])
+        self.batches += 1
+        # The one-read form is only as good as its prediction: images that differ (contrast, content) widen the set of bins
+        # a tensor's walks visit, the gathered lists grow with it and both kernels slow down (measured on ResNet-50 shapes:
+        # 4 % of the elements listed at 0.59 of the roofline; 10 % image-to-image contrast jitter: 0.20).  Beyond
+        # _ONEREAD_MAX_SHARE on two batches in a row the plan switches to the two-read bracket form, which needs no
+        # prediction, for the rest of its life.
+        share = listed / max(1, plan.batch * sum(plan.elems))
+        self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
+        # which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short, sorted
+        # runs beyond ~5 % of the elements (measured, ResNet-50 shapes: 2.8 % listed 0.59 vs 0.55 of the roofline, 9 % listed
+        # 0.38 vs 0.43, 24 % listed 0.20 vs 0.32)
+        if share > _ONEREAD_SORT_SHARE * 1.2:
+            plan._octav_sorted = 1
+        elif share < _ONEREAD_SORT_SHARE * 0.8:
+            plan._octav_sorted = 0
+        self.sorted_batches += st["sorted"]
+        plan._octav_wide = plan.__dict__.get("_octav_wide", 0) + 1 if share > _ONEREAD_MAX_SHARE else 0
+        if plan._octav_wide >= 2 and not plan.__dict__.get("_octav_two_read"):
+            plan._octav_two_read = True
+            self.switched += 1
+        if failed == 0:
+            return
+        self.fallback_pairs += failed
+        self.fallback_batches += 1
+        tensors, tab, out = st["refs"]
+        spans, base, order, _, l1 = plan.octav_scratch()
+        w = plan.work("octav", per_image=True)
+        epoch = ((res["calls"] - 1) // _ONEREAD_EPOCH) % 2     # the accumulator the latest submitted batch writes to
+        if st["sorted"]:   # (the register walk takes care of its misses itself)
+            _hip.check(_hip.lib().dpl_octav_oneread_missed(_ptr(res["slices"]), _ptr(res["pair_slice0"]), _ptr(st["lh"]),
+                                                           _ptr(res["vis"]), _ptr(plan._octav_pipe_pred[st["k"] % 4]), epoch, plan.T,
+                                                           _ptr(st["states"]), plan.n_pairs, _ptr(base), _ptr(order), res["n_small"],
+                                                           _ptr(st["l0"]), self.dyn, _OCTAV_MAX_ITERS, self.side.cuda_stream),
+                       "dpl_octav_oneread_missed")
+        _hip.check(_hip.lib().dpl_octav_oneread_fallback(*w.args(), _ptr(tab), _ptr(st["states"]), plan.n_pairs, _ptr(spans),
+                                                         _ptr(base), _ptr(order), _ptr(st["l0"]), _ptr(l1), self.dyn,
+                                                         _OCTAV_MAX_ITERS, self.side.cuda_stream), "dpl_octav_oneread_fallback")
+        self._finish(plan, res, st)
+
+    def submit(self, plan, tensors):
+        form = os.environ.get("DPL_OCTAV_FORM", "oneread")
+        res = plan.octav_oneread_scratch() if form == "oneread" and not plan.__dict__.get("_octav_two_read") else None
+        if res is None:
+            return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form == "oneread" else form)
+        main = torch.cuda.current_stream(plan.device)
+        sets = self._sets(plan, res)
+        k = res["calls"]
+        res["calls"] = k + 1
+        cur = sets[k % 2]
+        self._settle(plan, res, cur)
+        if cur["done"] is not None:
+            main.wait_event(cur["done"])        # everything that last used this set has finished
+        _, base, order, _, _ = plan.octav_scratch()
+        tab = plan.seg_table(tensors)
+        out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+        cur["refs"] = (list(tensors), tab, out)
+        cur["k"] = k
+        cur["states"] = plan._octav_pipe_states[k % 4]
+        cur["pred"] = plan._octav_pipe_pred[k % 4]
+        cur["sorted"] = _walk_sorted(plan)
+        L = _hip.lib()
+        if cur.get("prepared") != k:
+            self._prepare(plan, res, cur, k, main.cuda_stream)
+        _hip.check(L.dpl_octav_oneread_stream(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(cur["pred"]), plan.T,
+                                              _ptr(tab), _ptr(cur["states"]), plan.n_pairs, _ptr(base), _ptr(cur["l0"]),
+                                              main.cuda_stream), "dpl_octav_oneread_stream")
+        streamed = torch.cuda.Event()
+        streamed.record(main)
+        self.side.wait_event(streamed)
+        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["slice_chunk0"]),
+                                            _ptr(res["dir"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
+                                            (k // _ONEREAD_EPOCH) % 2, plan.T, _ptr(cur["states"]), plan.n_pairs, _ptr(base),
+                                            _ptr(order), res["n_small"], _ptr(cur["l0"]), cur["sorted"], self.dyn, _OCTAV_MAX_ITERS,
+                                            self.side.cuda_stream),
+                   "dpl_octav_oneread_walk")
+        with torch.cuda.stream(self.side):
+            cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)
+        self._finish(plan, res, cur)
+        cur["pending"] = True
+        if all(p is not plan for p, _ in self._touched):
+            self._touched.append((plan, res))
+        return out
+
+    def sync(self):
+        """Settle every outstanding batch (host waits for the walks), order the caller's stream after the side stream and
+        let go of the batches' tensors."""
+        for plan, res in self._touched:
+            for st in sorted(plan._octav_pipe_sets, key=lambda q: q["k"]):
+                self._settle(plan, res, st)
+        torch.cuda.current_stream(self.device).wait_stream(self.side)
+        for plan, _ in self._touched:
+            for st in plan._octav_pipe_sets:
+                st["refs"] = None
+        self._touched = []
+
+
+# ------------------------------------------------------------------------------- single-tensor conveniences
+def minmax(x):
+    """(min, max) of one device tensor as a fp32 device tensor [2] (NaN if x holds a NaN)."""
+    _require_cuda(x)
+    plan = TensorSetPlan([x.numel()], 1, x.device)
+    acc = CalibAccumulators(1, x.device)
+    acc.minmax_accumulate(plan, [x])
+    lo, hi = acc.finalize_minmax()
+    return torch.stack([lo[0], hi[0]])
+
+
+def abs_hist(x, bins, gmin, gmax):
+    """np.histogram(|x|, bins, (0, max(gmax, -gmin)))[0] as an int64 device tensor [bins]."""
+    _require_cuda(x)
+    plan = TensorSetPlan([x.numel()], 1, x.device)
+    acc = CalibAccumulators(1, x.device, bins)
+    acc.set_minmax(torch.tensor([gmin], dtype=torch.float32, device=x.device),
+                   torch.tensor([gmax], dtype=torch.float32, device=x.device))
+    acc.hist_prepare()
+    acc.abs_hist_accumulate(plan, [x])
+    return acc.hist[0], acc
+
+
+def rowwise_minmax(w2d):
+    """Per-row (min, max) of a [rows, cols] fp32 device matrix (basic_algorithm.py:88-90)."""
+    _require_cuda(w2d, "w2d")
+    rows, cols = w2d.shape
+    lo = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    hi = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    _hip.check(_hip.lib().dpl_rowwise_minmax(_ptr(w2d), rows, cols, _ptr(lo), _ptr(hi), _stream()),
+               "dpl_rowwise_minmax")
+    return lo, hi
+
+
+def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None):
+    """Fused QuantizeLinear -> DequantizeLinear (quantize.py:197-239) on the device.
+
+    scale: fp32 device tensor [1] or [C]; zero_point: int32 device tensor of the same length;
+    axis: channel axis when len(scale) > 1.  y = (clamp(rint(x/scale)+zp, qlo, qhi) - zp) * scale.
+    """
+    _require_cuda(x, "x")
+    scale = scale.to(device=x.device, dtype=torch.float32).contiguous().reshape(-1)
+    zero_point = zero_point.to(device=x.device, dtype=torch.int32).contiguous().reshape(-1)
+    nch = scale.numel()
+    if zero_point.numel() != nch:
+        raise _hip.DipoorletHipError("scale and zero_point lengths differ")
+    inner = 1
+    if nch > 1:
+        if axis is None:
+            raise _hip.DipoorletHipError("per-channel fake_quant needs an axis")
+        if x.shape[axis] != nch:
+            raise _hip.DipoorletHipError(f"axis {axis} has {x.shape[axis]} channels, scale has {nch}")
+        for d in x.shape[axis + 1:]:
+            inner *= int(d)
+    y = torch.empty_like(x) if out is None else out
+    _hip.check(_hip.lib().dpl_fake_quant(_ptr(x), _ptr(y), x.numel(), _ptr(scale), _ptr(zero_point), nch, inner,
+                                         int(qlo), int(qhi), _stream()), "dpl_fake_quant")
+    return y
+
+
+def cos_accumulate(a, b, acc, slot=0):
+    """acc[slot] += (sum a*b, sum a*a, sum b*b) in fp64 (utils.py:273-278 partial sums)."""
+    _require_cuda(a, "a")
+    _require_cuda(b, "b")
+    if a.numel() != b.numel():
+        raise _hip.DipoorletHipError("cos_accumulate: size mismatch")
+    _hip.check(_hip.lib().dpl_cos_accumulate(_ptr(a), _ptr(b), a.numel(), _ptr(acc), slot, _stream()),
+               "dpl_cos_accumulate")
+    return acc
+
+
+def channel_diff_sum(a, b, acc=None):
+    """acc[c] += sum over every axis but the channel one of (a - b), fp64 (bias_correction.py:9-13).
+    a, b: [n, C, spatial...] (channel axis 1) or [n, C]; returns the fp64 device tensor [C]."""
+    _require_cuda(a, "a")
+    _require_cuda(b, "b")
+    if a.shape != b.shape or a.dim() < 2:
+        raise _hip.DipoorletHipError("channel_diff_sum: shapes must match and carry a channel axis")
+    n_ch = int(a.shape[1])
+    inner = 1
+    for d in a.shape[2:]:
+        inner *= int(d)
+    if acc is None:
+        acc = torch.zeros(n_ch, dtype=torch.float64, device=a.device)
+    _hip.check(_hip.lib().dpl_channel_diff_sum(_ptr(a), _ptr(b), int(a.shape[0]), n_ch, inner, _ptr(acc), _stream()),
+               "dpl_channel_diff_sum")
+    return acc
+
+
+def cos_per_image(plan, tensors_a, tensors_b):
+    """Cosine partial sums for every (image, tensor) pair of two tensor sets with the same geometry ->
+    fp64 device tensor [B, T, 3] = (sum a*b, sum a*a, sum b*b)."""
+    w = plan.work("cos", per_image=True)
+    ta = plan.seg_table(tensors_a)
+    tb = plan.seg_table(tensors_b)
+    acc = torch.zeros(plan.batch, plan.T, 3, dtype=torch.float64, device=plan.device)
+    _hip.check(_hip.lib().dpl_cos_items_accumulate(*w.args(), _ptr(ta), _ptr(tb), _ptr(acc), _stream()),
+               "dpl_cos_items_accumulate")
+    return acc

@@ -1,0 +1,125 @@
+"""Activation clip-range search: the three registry algorithms of the reference
+(dipoorlet/tensor_cali/basic_algorithm.py:8-69) plus the per-channel weight ranges (:72-91), computed
+on the MI355X.
+
+Registry keys, call form and return type are the reference's: `tensor_cali_dispatcher(key, graph, args)`
+-> {tensor_name: [lo, hi]} with numpy scalars (they must support .tolist(), utils.py:314-316); an
+unknown key logs "Calibration Algorithm Not Found!" and returns None.
+
+Multi-rank: with args.world_size > 1 and args.merge != 'reference' (default) the per-rank statistics
+are merged with RCCL collectives (dist_helper.merge_*), so every rank returns the clip ranges of the
+WHOLE calibration set — equal to the reference run with world_size = 1.  args.merge == 'reference'
+keeps the reference's behaviour: per-rank ranges / histograms / means, to be averaged afterwards by
+utils.reduce_clip_val exactly as __main__.py:121-128 does.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..dist_helper import gather_rows, merge_hist, merge_ranges
+from ..forward_net import (CalibrationRun, forward_get_minmax, forward_net_octav, hist_pass)
+from ..platform_settings import LAYER_HAS_WEIGHT
+from ..utils import dispatch_functool, logger
+
+
+@dispatch_functool
+def tensor_cali_dispatcher(*args, **kwargs):
+    logger.info("Calibration Algorithm Not Found!")
+
+
+def _merged(args):
+    return getattr(args, "world_size", 1) > 1 and getattr(args, "merge", "allreduce") != "reference"
+
+
+def _as_clip_dict(names, lo, hi):
+    lo = lo.detach().cpu().numpy().astype(np.float32, copy=False)
+    hi = hi.detach().cpu().numpy().astype(np.float32, copy=False)
+    return {n: [lo[t], hi[t]] for t, n in enumerate(names)}
+
+
+@tensor_cali_dispatcher.register("minmax")
+def find_clip_val_minmax(onnx_graph, args, **kwargs):
+    """basic_algorithm.py:13-22 — [min over images, max over images] per tensor."""
+    run = CalibrationRun(onnx_graph, args)
+    forward_get_minmax(onnx_graph, args, run=run)
+    gmin, gmax = run.acc.gmin, run.acc.gmax
+    if _merged(args):
+        merge_ranges(gmin, gmax, args.world_size)
+    return _as_clip_dict(run.names, gmin, gmax)
+
+
+@tensor_cali_dispatcher.register("hist")
+def find_clip_val_hist(onnx_graph, args, store_stats=None, **kwargs):
+    """basic_algorithm.py:25-54 — percentile (cumulative mass >= args.threshold) of the |x| histogram.
+
+    store_stats = {'minmax': {name: {'min': [...], 'max': [...]}}, 'hist': {name: int64[bins]}} skips the
+    sweeps (the reference's unused hook, :26-29) and only runs the percentile search on the device."""
+    bins = int(args.bins)  # the reference leaves a CLI --bins as str and crashes at :47; int() is the fix
+    if store_stats:
+        names = list(store_stats["hist"].keys())
+        dev = torch.device("cuda", torch.cuda.current_device())
+        acc = ops.CalibAccumulators(len(names), dev, bins)
+        mm = store_stats["minmax"]
+        acc.set_minmax(torch.tensor([float(np.min(mm[n]["min"])) for n in names], dtype=torch.float32, device=dev),
+                       torch.tensor([float(np.max(mm[n]["max"])) for n in names], dtype=torch.float32, device=dev))
+        acc.hist_prepare()
+        acc.hist.copy_(torch.from_numpy(np.stack([np.asarray(store_stats["hist"][n], np.int64) for n in names])))
+    else:
+        run = CalibrationRun(onnx_graph, args)
+        forward_get_minmax(onnx_graph, args, run=run, keep_resident=True)   # pass 1
+        gmin, gmax = run.acc.gmin.clone(), run.acc.gmax.clone()
+        if _merged(args):
+            merge_ranges(gmin, gmax, args.world_size)
+        acc = hist_pass(run, gmin, gmax, bins)                                # pass 2
+        if _merged(args):
+            merge_hist(acc.hist, args.world_size)
+        names = run.names
+    clip = acc.hist_percentile(float(args.threshold))
+    return _as_clip_dict(names, clip[:, 0], clip[:, 1])
+
+
+@tensor_cali_dispatcher.register("mse")
+def find_clip_val_octav(onnx_graph, args, **kwargs):
+    """basic_algorithm.py:57-69 — OCTAV scale per image, then [max(min_all, -mean s), min(max_all, mean s)].
+    The mean is taken with numpy in fp32 over the per-image list exactly as the reference does, so it is
+    reproduced bit for bit given the per-image scales (python max/min: a NaN mean falls back to the range)."""
+    run = CalibrationRun(onnx_graph, args)
+    forward_net_octav(onnx_graph, args, run=run)
+    rows = run.octav_rows
+    if _merged(args):
+        rows = gather_rows(rows, args.world_size)
+    r = rows.detach().cpu().numpy().astype(np.float32, copy=False)
+    clip_val = {}
+    for t, name in enumerate(run.names):
+        with np.errstate(all="ignore"):
+            mean_s = np.array(list(r[:, t, 0])).mean()
+        data_max = np.array(list(r[:, t, 2])).max()
+        data_min = np.array(list(r[:, t, 1])).min()
+        clip_val[name] = [max(data_min, -mean_s), min(data_max, mean_s)]
+    return clip_val
+
+
+def find_clip_val_minmax_weight(onnx_graph, args):
+    """basic_algorithm.py:72-91 — per output channel [min, max] of every initializer input (node.input[1:])
+    of Conv / Gemm / ConvTranspose / PRelu / BatchNormalization; ConvTranspose weights are viewed
+    [1,0,2,3]-transposed; 0-d initializers are skipped.  Row reductions run in k_rowwise_minmax."""
+    weight_tensor, need_transpose = {}, []
+    for node in onnx_graph.graph.node:
+        if node.op_type in LAYER_HAS_WEIGHT:
+            for in_tensor in list(node.input)[1:]:
+                weight_tensor[in_tensor] = onnx_graph.get_initializer(in_tensor)
+            if node.op_type == "ConvTranspose":
+                need_transpose.append(node.input[1])
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = {}
+    for name, tensor in weight_tensor.items():
+        tensor = np.asarray(tensor)
+        if tensor.ndim < 1:
+            continue
+        if name in need_transpose:
+            tensor = tensor.transpose([1, 0, 2, 3])
+        c = tensor.shape[0]
+        w2 = torch.from_numpy(np.ascontiguousarray(tensor.reshape(c, -1), dtype=np.float32)).to(dev)
+        lo, hi = ops.rowwise_minmax(w2)
+        out[name] = [lo.cpu().numpy(), hi.cpu().numpy()]
+    return out

@@ -1,0 +1,192 @@
+"""`--bc` bias correction on the GPU — counterpart of dipoorlet/weight_transform/bias_correction.py:9-55
+(and its call site weight_trans_base.py:21-29).
+
+Reference: for every Conv / Gemm node in topological order it re-builds the fake-quantised graph,
+creates one ONNXRuntime session per node through the host-side ActivationCache (forward_net.py:23-190),
+pulls the node's fp and quantised outputs for ALL N images to the host and adds mean(fp - q) over
+(N, H, W) to the bias, so that later nodes see the corrected upstream biases.
+
+Here the whole calibration set's frontier stays resident in HBM and the two networks (fp and
+fake-quantised) are walked ONCE, node-major: each node is executed for all images before the next one
+starts (activations are kept as lists of per-chunk device tensors and freed by reference count), so the
+sequential dependence "correct bias k, then everything downstream sees it" costs O(nodes) node
+executions instead of O(nodes^2).  The bias enters a Conv / Gemm output linearly, so after the update the
+already computed quantised output is fixed up in place (q_out += diff) instead of being recomputed.
+The fake-quant structure does not depend on bias values, so the quantised graph is built once.
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from ..executor import _OPS, GraphSession
+from ..forward_net import load_input_batch
+from ..graph import ONNXGraph
+from ..quantize import quant_graph
+from ..utils import logger
+
+BIAS_CORRECTION_NODE_TYPE = ["Conv", "Gemm"]
+
+
+def _channel_mean_diff(fp_chunks, q_chunks, is_conv):
+    """bias_correction.py:10-13 — mean(fp - q) over every axis but the channel one (axis 1 of a Conv output
+    [n, C, spatial...]; the last axis of a Gemm output [n, C]): one fused kernel per chunk pair, fp64 sums."""
+    acc, cnt = None, 0
+    for a, b in zip(fp_chunks, q_chunks):
+        if not is_conv:
+            a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
+        acc = ops.channel_diff_sum(a.contiguous(), b.contiguous(), acc)
+        cnt += a.numel() // a.shape[1]
+    return (acc / cnt).float()
+
+
+def update_conv_node_bias(graph_bc, node, fp_activations, q_activations):
+    """bias_correction.py:9-31 on device tensors: bias += mean(fp - q) over every axis but the channel one (Conv output
+    chunks [n, C, H, W], Gemm output chunks [n, C]); a node without a bias input gets `<node>_bias`.  Returns the
+    per-channel difference (fp32 device tensor) that was added.  `*_activations`: lists of per-chunk device tensors."""
+    diff = _channel_mean_diff(fp_activations, q_activations, node.op_type == "Conv")
+    bc_node = next(n for n in graph_bc.graph.node if n.name == node.name)
+    if len(bc_node.input) > 2:
+        bname = bc_node.input[2]
+        new_bias = graph_bc.get_initializer(bname).astype(np.float32) + diff.cpu().numpy()
+    else:
+        bname = node.name + "_bias"
+        new_bias = diff.cpu().numpy()
+        bc_node.input.append(bname)
+        graph_bc.input.append(bname)
+    graph_bc.set_initializer(bname, new_bias.astype(np.float32))
+    return diff
+
+
+def _frontier_peak_elems(graph, session):
+    """Largest number of live activation elements per image during a node-major walk (reference-count simulation over
+    the per-image tensor sizes the session inferred)."""
+    size = dict(zip(session.tensor_names, session.elems_per_image))
+    ref = {}
+    for node in graph.graph.node:
+        if node.name in session._folded:
+            continue
+        for i in node.input:
+            if i != "" and i not in session.consts:
+                ref[i] = ref.get(i, 0) + 1
+    for o in graph.network_outputs:
+        ref[o] = ref.get(o, 0) + 1
+    live = {n: size.get(n, 0) for n in graph.network_inputs}
+    peak = sum(live.values())
+    for node in graph.graph.node:
+        if node.name in session._folded:
+            continue
+        for o in node.output:
+            if o != "":
+                live[o] = size.get(o, size.get(node.input[0], 0) if node.input else 0)
+        peak = max(peak, sum(live.values()))
+        for i in node.input:
+            if i in ref:
+                ref[i] -= 1
+                if ref[i] == 0:
+                    live.pop(i, None)
+        for o in node.output:
+            if o not in ref:
+                live.pop(o, None)
+    return peak
+
+
+class _Frontier:
+    """Activations of every live tensor for the whole calibration set, as lists of per-chunk tensors."""
+
+    def __init__(self, session, graph):
+        self.sess, self.graph = session, graph
+        self.env = {}
+        self.ref = {}
+        for node in graph.graph.node:
+            if node.name in session._folded:
+                continue
+            for i in node.input:
+                if i != "" and i not in session.consts:
+                    self.ref[i] = self.ref.get(i, 0) + 1
+        for o in graph.network_outputs:
+            self.ref[o] = self.ref.get(o, 0) + 1
+
+    def run(self, node, n_chunks, chunk_sizes):
+        outs = [[] for _ in node.output]
+        for c in range(n_chunks):
+            self.sess.batch = chunk_sizes[c]
+            args = [None if i == "" else (self.sess.consts[i] if i in self.sess.consts else self.env[i][c])
+                    for i in node.input]
+            while args and args[-1] is None:
+                args.pop()
+            r = _OPS[node.op_type](self.sess, node, *args)
+            r = list(r) if isinstance(r, (list, tuple)) else [r]
+            for k, v in enumerate(r[:len(outs)]):
+                outs[k].append(v)
+        for o, v in zip(node.output, outs):
+            if o != "":
+                self.env[o] = v
+        for i in node.input:
+            if i in self.ref:
+                self.ref[i] -= 1
+                if self.ref[i] == 0:
+                    self.env.pop(i, None)
+        for o in node.output:  # outputs nobody consumes
+            if o not in self.ref:
+                self.env.pop(o, None)
+
+
+@torch.no_grad()
+def bias_correction(graph, act_clip_val, weight_clip_val, args):
+    """bias_correction.py:34-55 -> the bias-corrected graph (also saved as update_bias_model.onnx)."""
+    clip_val = act_clip_val.copy()
+    clip_val.update(weight_clip_val)
+    clip_val = {k: [np.copy(v[0]), np.copy(v[1])] for k, v in clip_val.items()}
+    graph_bc = ONNXGraph()
+    graph_bc.copy_from(graph)
+    graph_q, _ = quant_graph(graph_bc, clip_val, args)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    s_fp = GraphSession(graph, device=dev)
+    s_q = GraphSession(graph_q, device=dev)
+    chunk = int(getattr(args, "calib_batch", 16) or 16)
+    N = args.data_num  # rank 0 walks ALL images, like the reference (forward_net.py:50-52)
+    bounds = [(i, min(i + chunk, N)) for i in range(0, N, chunk)]
+    sizes = [j - i for i, j in bounds]
+    shapes = {n: graph.get_tensor_shape(n) for n in graph.network_inputs}
+    # HBM budget: the two frontiers hold the WHOLE set's live activations.  Refuse up front with a plain message rather than
+    # die in the allocator halfway through (the other ranks would be left at the next barrier).
+    need = 4.0 * N * (_frontier_peak_elems(graph, s_fp) + _frontier_peak_elems(graph_q, s_q))
+    budget = float(getattr(args, "resident_gb", 160.0) or 160.0) * 1e9
+    if need > budget:
+        raise MemoryError(f"--bc keeps the live activations of all {N} images of both networks in HBM: about {need / 1e9:.0f} GB "
+                          f"at the widest point of this graph, over the {budget / 1e9:.0f} GB budget (--resident_gb); "
+                          f"lower -N for --bc or raise --resident_gb")
+    fp, qf = _Frontier(s_fp, graph), _Frontier(s_q, graph_q)
+    for n in graph.network_inputs:
+        chunks = [load_input_batch(args.input_dir, [n], shapes, i, j, dev)[n] for i, j in bounds]
+        fp.env[n] = chunks
+        qf.env[n] = chunks
+    fp_nodes = {n.name: n for n in graph.graph.node}
+    for node in graph_q.graph.node:
+        if node.name in s_q._folded:
+            continue
+        if node.name not in fp_nodes:
+            qf.run(node, len(bounds), sizes)
+            continue  # a FakeQuant node
+        fp_node = fp_nodes[node.name]
+        keep_fp = fp.env  # outputs needed below are still referenced until their consumers ran
+        fp.ref[fp_node.output[0]] = fp.ref.get(fp_node.output[0], 0) + 1  # hold both outputs for the diff BEFORE the nodes
+        qf.ref[node.output[0]] = qf.ref.get(node.output[0], 0) + 1        # run: an output nobody consumes is dropped at once
+        qf.run(node, len(bounds), sizes)
+        fp.run(fp_node, len(bounds), sizes)
+        out = node.output[0]
+        if node.op_type in BIAS_CORRECTION_NODE_TYPE:
+            logger.info("Update bias for node: {}".format(node.name))
+            diff = update_conv_node_bias(graph_bc, node, keep_fp[out], qf.env[out])
+            shape = [1, -1] + [1] * (qf.env[out][0].dim() - 2)
+            for t in qf.env[out]:  # the bias is additive in the output: fix the computed q output in place
+                t.add_(diff.reshape(shape))
+        for env_ref, o in ((fp, fp_node.output[0]), (qf, out)):   # drop the extra hold
+            env_ref.ref[o] -= 1
+            if env_ref.ref[o] == 0:
+                env_ref.env.pop(o, None)
+    graph_bc.update_model()
+    if getattr(args, "output_dir", None):
+        graph_bc.output_dir = args.output_dir
+        graph_bc.save_onnx_model("update_bias_model")
+    return graph_bc

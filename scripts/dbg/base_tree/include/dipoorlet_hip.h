@@ -1,0 +1,330 @@
+/*
+ * dipoorlet_hip.h — C ABI of the MI355X (gfx950) activation-calibration core.
+ *
+ * Drop-in boundary for Dipoorlet's calibration hot path.  The reference has no native layer: the
+ * arithmetic below is what its Python does with numpy on host copies of every activation
+ * (citations are into the reference tree, dipoorlet/...).  Each entry point names the reference
+ * code it replaces.  All device work is enqueued on the caller's HIP stream, never synchronises,
+ * never allocates; every buffer is caller-owned device memory unless marked HOST.
+ *
+ * Conventions
+ *   - return value: 0 = ok, negative = error; dpl_last_error() gives a thread-local message.
+ *   - "slot"  : index of an accumulator (one per calibrated tensor, or per (image,tensor) pair).
+ *   - "seg"   : index into a device table of base pointers (one per live activation tensor).
+ *   - "span"  : `count` consecutive fp32 elements at `offset` inside a segment, feeding one slot.
+ *   - spans are cut into work items (one workgroup each) by dpl_build_work_items().
+ *   - fp32 min/max accumulators are kept order-encoded in uint32 so integer atomics apply:
+ *         enc(f) = bits(f) ^ (bits(f) >> 31 ? 0xFFFFFFFF : 0x80000000)
+ */
+#ifndef DIPOORLET_HIP_H
+#define DIPOORLET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPL_ABI_VERSION 12
+#define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
+
+typedef void* dpl_stream_t; /* hipStream_t */
+
+typedef struct dpl_span {
+    uint64_t offset; /* elements from the segment base */
+    uint64_t count;  /* elements */
+    uint32_t seg;
+    uint32_t slot;
+} dpl_span;
+
+typedef struct dpl_work_item {
+    uint64_t offset;
+    uint32_t count;
+    uint32_t seg;
+    uint32_t slot;
+    uint32_t reserved;
+} dpl_work_item;
+
+/* Per-slot histogram range, derived on device from the running min/max (np.histogram semantics,
+ * forward_net.py:266-268): first/last outer edges, fp32 step, reciprocal for the index estimate. */
+typedef struct dpl_hist_range {
+    float first, last, step, inv;
+    uint32_t zero_bin; /* bin that |x| == 0 falls in */
+    uint32_t status;   /* 0 ok, 1 range not finite (numpy raises ValueError), 2 too many bins for range */
+    float dmax;        /* max(gmax, -gmin) before the degenerate +-0.5 expansion */
+    uint32_t exact_div; /* 1: use the correctly rounded divide for the index estimate */
+} dpl_hist_range;
+
+/* Per-(image,tensor) OCTAV state (forward_net.py:315-340). */
+typedef struct dpl_octav_state {
+    double sum;       /* sum |x| (first pass) / sum_{|x|>s} |x| */
+    uint64_t cnt_gt;  /* count(|x|>0) (first pass) / count(|x|>s) */
+    uint64_t cnt_le;  /* count(|x|<=s) */
+    uint32_t min_enc, max_enc;
+    uint32_t nan_seen;
+    uint32_t done;
+    float s;
+    float unsigned_div; /* 1 or 4 */
+    uint32_t iters;
+    uint32_t mode;      /* 0: every evaluation re-reads the full data; 1: tail lists (dpl_octav_run_compact);
+                           2: log-histogram bracket (dpl_octav_run_bracket) */
+    uint64_t n_elems;   /* elements of the pair (counted by the first pass) */
+    uint32_t len[2];    /* lengths of the two tail lists */
+    uint32_t cur;       /* list holding the values above the previous iterate: 0, 1, or 2 = none yet */
+    uint32_t reserved;  /* compaction route: float bits of the iterate the current tail list was built at */
+} dpl_octav_state;
+
+int dpl_abi_version(void);
+const char* dpl_last_error(void);
+/* 0 when the current HIP device is a gfx950 part; fills name (HOST buffer) when non-null. */
+int dpl_device_info(char* name, int name_cap, int* compute_units, uint64_t* hbm_bytes);
+
+/* HOST-only: cut spans into work items of at most `chunk_elems` (multiple of 1024) elements.
+ * Returns the number of items (may exceed cap: call again with a larger buffer), <0 on error. */
+int64_t dpl_build_work_items(const dpl_span* spans, int64_t n_spans, uint64_t chunk_elems,
+                             dpl_work_item* out, int64_t cap);
+/* HOST-only: split the concatenated element stream of `spans` into n_blocks contiguous, equal shares
+ * (cuts 4 KiB-aligned inside a span).  Writes the items in stream order and block_begin[0..n_blocks]
+ * (workgroup b owns items [block_begin[b], block_begin[b+1])).  Returns the item count (call with
+ * out = NULL to size the buffer).  Few large, equal shares stream faster from HBM than many small items. */
+int64_t dpl_build_balanced_items(const dpl_span* spans, int64_t n_spans, int64_t n_blocks, dpl_work_item* out,
+                                 int64_t cap, uint32_t* block_begin);
+
+/* ---- running min / max: replaces ort_outs[i].max()/.min() per tensor per image
+ *      (forward_net.py:220-235) and np.min/np.max over the per-image lists (basic_algorithm.py:21). */
+int dpl_minmax_init(uint32_t* d_min_enc, uint32_t* d_max_enc, uint32_t* d_nan, int64_t n_slots, dpl_stream_t s);
+/* d_block_begin: device copy of block_begin (n_blocks + 1 entries), or NULL with n_blocks == n_items. */
+int dpl_minmax_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, uint32_t* d_min_enc,
+                          uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s);
+/* decode to fp32; a slot that saw a NaN yields NaN for both (numpy max/min propagate NaN). */
+int dpl_minmax_finalize(const uint32_t* d_min_enc, const uint32_t* d_max_enc, const uint32_t* d_nan,
+                        int64_t n_slots, float* d_min, float* d_max, dpl_stream_t s);
+/* inverse of finalize for merged (e.g. all-reduced) fp32 ranges. */
+int dpl_minmax_encode(const float* d_min, const float* d_max, int64_t n_slots, uint32_t* d_min_enc,
+                      uint32_t* d_max_enc, uint32_t* d_nan, dpl_stream_t s);
+
+/* ---- |x| histogram: replaces np.histogram(np.abs(x), int(bins), (0, data_max)) per tensor per image
+ *      and the np.stack(hist).sum(0) (forward_net.py:265-280, basic_algorithm.py:37-38).
+ *      Counts are bit-exact with numpy; d_hist is uint64 [n_slots, bins], accumulated in place. */
+int dpl_hist_prepare(const float* d_min, const float* d_max, int64_t n_slots, int bins,
+                     dpl_hist_range* d_ranges, dpl_stream_t s);
+int dpl_abs_hist_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                            int64_t n_blocks, const float* const* d_seg_ptrs, const dpl_hist_range* d_ranges,
+                            int bins, uint64_t* d_hist, dpl_stream_t s);
+/* ---- percentile clip: replaces the python loop of basic_algorithm.py:40-53. d_clip: fp32 [n_slots,2]. */
+int dpl_hist_percentile(const uint64_t* d_hist, const float* d_min, const float* d_max, int64_t n_slots,
+                        int bins, double threshold, float* d_clip, dpl_stream_t s);
+
+/* ---- OCTAV ("mse"): replaces forward_net.py:315-330 per (image,tensor) pair (slot = pair).
+ *      dpl_octav_run enqueues the first pass plus 20 (pass, update) rounds; converged pairs exit early. */
+/* d_states holds n_pairs + 1 entries: the last one is a control block (count of pairs in full-pass mode). */
+int dpl_octav_init(dpl_octav_state* d_states, int64_t n_pairs, int list_mode, dpl_stream_t s);
+int dpl_octav_run(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                  const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs, int dynamic_sym,
+                  int max_iters, dpl_stream_t s);
+/* Same iterate sequence with tail compaction (init with list_mode = 1): the first evaluation reads the data
+ * once and writes the values above s_0 to d_list0; then ONE launch walks all remaining iterations with a
+ * persistent workgroup per pair over the shrinking tail lists (~2.5x smaller per step).
+ * d_pair_spans[pair] = where the pair's data lives (seg, offset, count); d_pair_base[pair] = element offset of
+ * the pair's region in both lists (a region holds the pair's element count); d_pair_order = pair indices,
+ * largest first (launch order of the per-pair workgroups), may be NULL.  Pairs whose iterate decreases
+ * (degenerate data) finish on the full data. */
+int dpl_octav_run_compact(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, int dynamic_sym,
+                          int max_iters, dpl_stream_t s);
+/* Same iterate sequence in TWO reads of the data and no tail lists (init with list_mode = 2): pass 1 takes the
+ * statistics and an exact log-scale histogram of |x| (64 bins per octave over 2^-18..2^14: per bin a count
+ * and an integer sum of mantissas); a per-pair bracket walk over the bin edges marks the few dozen bins the
+ * iterates can visit; pass 2 gathers only those elements (about 2 %) into d_list0; a per-pair kernel then runs the
+ * exact iteration from (exact totals of the bins above) + (gathered elements of the current bin), verifying
+ * that every iterate lands in a marked bin.  Pairs it cannot serve (bracket explodes on flat / degenerate
+ * distributions, values >= 2^14, failed verification) are finished by the compaction route above.
+ * d_lh_cnt: uint32 [n_pairs, 2048]; d_lh_sum: uint64 [n_pairs, 2048] (scratch: after the bracket walk they hold the
+ * suffix totals N_ge[j] / S_ge[j] (fp64 bits) the exact walk reads); d_bitmap: uint32 [n_pairs, 66]
+ * (64 words of marks + the gathered value range as two float bit patterns). */
+int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                          int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
+                          const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
+                          uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
+/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip), two kernels per batch:
+ *   k_octav_oneread — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one pair): the slice's only HBM
+ *     read yields the pair's statistics, the slice's exact log-scale histogram row and the values of the bins the exact
+ *     iteration is PREDICTED to visit (appended to the pair's list);
+ *   k_octav_walk — one workgroup per pair: per-bin totals = the sum of the pair's slice rows, suffix totals, s_0, then the
+ *     reference's iteration on (exact totals of the bins above) + (listed values of the iterate's bin), every iterate
+ *     VERIFIED to lie in a gathered bin.
+ * The prediction is what the same tensor's walks stepped into in earlier batches (two alternating epoch accumulators in
+ * d_vis; d_pred receives the snapshot this batch uses).  A walk that meets a bin that was not gathered publishes the pair's
+ * bracket for the following batches and hands the pair to the compaction route (d_items .. d_list1 as for
+ * dpl_octav_run_bracket; always the case for a tensor's first batch: start with d_vis zeroed); pairs of at most 20480
+ * elements gather their whole window and never need a prediction.
+ *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
+ *     of 4 elements); item.reserved = the pair's slice count; pair_slice0[2 slot], [2 slot + 1] = first / one-past-last
+ *     slice of the pair in slot `slot` (spans carry slots 0 .. n_spans-1).  Returns the slice count (call with out = NULL
+ *     to size), -3 when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
+ *   d_lh: uint64 [n_slices, 2048] scratch: every slice writes its histogram row in full (plain coalesced stores, no
+ *     read-modify-write, nothing to zero); the walk adds up the rows of a pair's slices;
+ *   d_vis: uint32 [2, n_tensors, 64] epoch accumulators (slot = image * n_tensors + tensor); this batch's walks add to
+ *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 128] scratch (the bins
+ *     to gather, at most 255 of them, + per bitmap word the number of gathered bins below it: a gathered bin's RANK);
+ *   dpl_octav_oneread_walk, sorted == 0: every pair is walked by one workgroup with its list in registers (k_octav_walk: the
+ *     faster way while the lists are short — up to ~5 % of the elements — and the prediction is narrow; misses are handled
+ *     inside: no dpl_octav_oneread_missed call); sorted != 0 (long lists: a scan of the whole list per iteration no longer
+ *     pays): it first SORTS every slice's list (k_octav_sort: dpl_octav_sort_chunk() values at a time, in place,
+ *     by the rank of the values' bins; d_dir: uint16 [n_chunks, dpl_octav_dir_row()] receives per chunk the position of each
+ *     rank's first value, d_slice_chunk0 [n_slices]: the first directory row of a slice = the running sum of
+ *     ceil(slice count / chunk) over the slices before it), then walks each pair with ONE WAVE over its sorted runs
+ *     (k_octav_walk_sorted: per iteration the directory entries of one rank and the values behind them); the last n_small
+ *     pairs of d_pair_order (at most dpl_octav_small_pair() elements: whole window gathered, no sort) are walked from
+ *     registers by one workgroup each (k_octav_walk), and so are — for their bracket and their compaction-route state —
+ *     the pairs the sorted walk could not finish;
+ * dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot d_pred (and the
+ * epoch reset); dpl_octav_oneread_stream = k_octav_oneread; dpl_octav_oneread_walk = k_octav_walk, which leaves the number
+ * of pairs that need the compaction route in the control block (d_states[n_pairs].cnt_le); dpl_octav_oneread_fallback = that
+ * route (every kernel of it is a no-op when the count is 0, but a launch still has to be scheduled: a caller that can read
+ * the count skips the call); dpl_octav_run_oneread = all four on one stream.  stream and walk may run on different streams (the walk of batch i beside the streaming kernel of batch i + 1: the walk is
+ * latency-bound, the streaming kernel HBM-bound) when the caller orders walk(i) after stream(i) and gives concurrently
+ * live batches their own d_states / d_lh / d_pred / d_list0 / d_list1; d_vis is shared (bits are only ever OR-ed in). */
+uint32_t dpl_octav_slice_cap(void);
+uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run (see below) */
+uint32_t dpl_octav_dir_row(void);    /* uint16 entries of a run's directory row */
+uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements gather their whole window */
+int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
+int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
+                              dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
+int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
+                             const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
+                             int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s);
+int dpl_octav_oneread_walk(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                           uint16_t* d_dir, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred, int write_epoch,
+                           int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs, const uint64_t* d_pair_base,
+                           const uint32_t* d_pair_order, int64_t n_small, float* d_list0, int sorted, int dynamic_sym,
+                           int max_iters, dpl_stream_t s);
+/* the pairs the sorted walk marked as missed (control block count != 0), before dpl_octav_oneread_fallback: their bracket is
+ * published for the next batches (into d_vis[write_epoch]: pass the epoch current at the time of the call) and their state
+ * prepared for the compaction route; a no-op kernel when nothing was missed — a caller that can read the count skips it */
+int dpl_octav_oneread_missed(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
+                             const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
+                             const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small, float* d_list0,
+                             int dynamic_sym, int max_iters, dpl_stream_t s);
+int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                               const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                               const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
+                               float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s);
+int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
+                          uint16_t* d_dir, uint64_t* d_lh, uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch,
+                          int64_t n_tensors, const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
+                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small,
+                          float* d_list0, float* d_list1, int sorted, int dynamic_sym, int max_iters, dpl_stream_t s);
+/* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
+/* TEST HOOK: makes the exact walk of dpl_octav_run_bracket reject every `every`-th pair (0 = off) so that the
+ * restart on the compaction route — taken in production only when an iterate leaves the bracket's bins — can be
+ * exercised; returns the previous setting. */
+int dpl_test_hook_exact_fail_every(int every);
+int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
+
+/* ---- per-output-channel weight ranges: replaces np.min/np.max(tensor.reshape(C,-1), -1)
+ *      (basic_algorithm.py:88-90).  d_w row-major [rows, cols]. */
+int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_min, float* d_max, dpl_stream_t s);
+
+/* ---- fused QuantizeLinear->DequantizeLinear (quantize.py:197-239; ONNX opset-13 semantics) and the
+ *      reference-owned torch restatement quant_acti (weight_transform/ada_quant_layer.py:28-36):
+ *      y = (clamp(rint(x / scale[c]) + zp[c], qlo, qhi) - zp[c]) * scale[c]
+ *      n_channels == 1: per tensor.  Otherwise channel c = (i / inner) % n_channels. */
+int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
+                   int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s);
+
+/* ---- cosine-similarity partial sums (utils.py:273-278): d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a),
+ *      sum(b*b) in fp64. */
+int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_acc, int64_t slot, dpl_stream_t s);
+
+/* Bias correction (bias_correction.py:9-13: bias += mean(fp_out - q_out) over every axis but the channel one):
+ * a, b viewed as [outer, n_channels, inner] (Conv output [n, C, H, W]; Gemm output [n, C] with inner = 1);
+ * d_acc[c] += sum over outer and inner of (a - b), accumulated in fp64. */
+int dpl_channel_diff_sum(const float* d_a, const float* d_b, int64_t outer, int64_t n_channels, int64_t inner,
+                         double* d_acc, dpl_stream_t s);
+
+/* Same sums per work-item slot (slot = (image, tensor) pair in the profiling flow, profiling.py:57-64):
+ * d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a), sum(b*b); a from d_seg_a, b from d_seg_b (same geometry). */
+int dpl_cos_items_accumulate(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
+                             int64_t n_blocks, const float* const* d_seg_a, const float* const* d_seg_b,
+                             double* d_acc, dpl_stream_t s);
+
+/* ------------------------------------------------------------------ AdaRound / BRECQ / QDrop inner loop (N4)
+ * Replaces the eager torch arithmetic of weight_transform/ada_quant_layer.py:28-50 (quant_acti, quant_weight),
+ * :96-112 (adaround_reg), :115-116 (L2_norm), :147 (round-mask initialisation) and the torch.optim.Adam update of
+ * adaround.py:119-133 / brecq.py:158-186.  Weights are viewed as [n_channels, inner] (output channel first; a
+ * ConvTranspose weight is transposed by the caller as adaround.py:58-59 does); scale / q_min / q_max hold
+ * n_channels entries (1 for per-tensor).  `clamp` follows the reference: only its per-channel branch clamps
+ * (the per-tensor branch discards the clamp result, ada_quant_layer.py:44-45). */
+typedef struct dpl_round_step_params {
+    double lr, adam_beta1, adam_beta2, adam_eps; /* torch.optim.Adam defaults: 1e-3, 0.9, 0.999, 1e-8 */
+    int32_t step;      /* Adam step t >= 1 of this update */
+    int32_t adam;      /* 0: gradients only (mask, moments and weight are left untouched) */
+    int32_t clamp;
+    int32_t reserved;
+    float grad_scale;  /* multiplies dL/d(qw): 1 / world_size after a SUM all-reduce (DDP's mean), else 1 */
+    float reg_beta;    /* regulariser temperature of this iteration (TempDecay, ada_quant_layer.py:119-134); 0: off */
+    float reg_lambda;  /* regulariser weight (adaround_reg.alpha = 0.01) */
+    float reserved2;
+} dpl_round_step_params;
+
+/* Device-resident schedule of a learner, so that a whole iteration can be captured in a hipGraph and replayed:
+ * dpl_round_sched_advance (one thread) sets this iteration's regulariser temperature (TempDecay over t_max
+ * iterations) and Adam bias corrections, then counts the iteration; dpl_round_step reads them when d_sched != NULL
+ * (p->step, p->reg_beta are then ignored).  Zero-initialise before the first iteration. */
+typedef struct dpl_round_sched {
+    int32_t iter;       /* iterations completed */
+    int32_t adam_step;  /* Adam steps completed */
+    float reg_beta, step_size, bc2_sqrt, reserved;
+} dpl_round_sched;
+int dpl_round_sched_advance(dpl_round_sched* d_sched, int32_t t_max, double lr, double adam_beta1, double adam_beta2,
+                            dpl_stream_t s);
+
+/* wfloor = floor(w / scale);  alpha = -log((zeta - gamma) / (w / scale - wfloor - gamma) - 1) */
+int dpl_round_init(const float* d_w, const float* d_scale, int64_t n, int64_t n_channels, int64_t inner,
+                   float* d_wfloor, float* d_alpha, dpl_stream_t s);
+/* qw = clamp?(wfloor + h(alpha)) * scale;  h = rectified sigmoid (soft) or (alpha >= 0) (hard) */
+int dpl_round_quant(const float* d_wfloor, const float* d_alpha, const float* d_scale, const float* d_qmin,
+                    const float* d_qmax, int64_t n, int64_t n_channels, int64_t inner, int clamp, int soft,
+                    float* d_qw, dpl_stream_t s);
+/* One learning step in one pass: g = dL/d(alpha) from d_grad_qw (may be null) through the soft quantiser, plus
+ * the regulariser's gradient; *d_reg_loss += lambda * sum(1 - |2h - 1|^beta) (may be null); Adam update of
+ * alpha / m / v in place; d_qw_next (may be null) = the soft-quantised weight at the updated alpha;
+ * d_grad_alpha (may be null) receives g. */
+int dpl_round_step(const float* d_grad_qw, const float* d_wfloor, float* d_alpha, float* d_m, float* d_v,
+                   const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
+                   int64_t inner, const dpl_round_step_params* p, const dpl_round_sched* d_sched, float* d_qw_next,
+                   float* d_grad_alpha, double* d_reg_loss, dpl_stream_t s);
+/* Sparse + quantised weight with a straight-through round (sparse_quant_layer.py:9-29, 61-66):
+ * qw = clamp?(rint(w * mask / scale)) * scale; d_mask (0 / 1 per weight) may be null. */
+int dpl_sparse_quant(const float* d_w, const float* d_mask, const float* d_scale, const float* d_qmin,
+                     const float* d_qmax, int64_t n, int64_t n_channels, int64_t inner, int clamp, float* d_qw,
+                     dpl_stream_t s);
+/* Its gradient fused with torch.optim.SGD's update (sparse_quant.py:107-109: momentum, weight decay):
+ * g = ((dL/dqw * grad_scale * scale) * clamp_pass) / scale * mask; d_grad_w (may be null) receives g; when `update`:
+ * g += weight_decay * w; buf = first ? g : momentum * buf + g; w -= lr * buf. */
+int dpl_sparse_step(const float* d_grad_qw, float* d_w, const float* d_mask, float* d_momentum_buf,
+                    const float* d_scale, const float* d_qmin, const float* d_qmax, int64_t n, int64_t n_channels,
+                    int64_t inner, int clamp, float grad_scale, float lr, float momentum, float weight_decay, int first,
+                    int update, float* d_grad_w, dpl_stream_t s);
+/* *d_loss += sum((y - target)^2) * inv_m with y = relu ? max(z, 0) : z  (L2_norm: inv_m = 1 / (elements / dim 1));
+ * d_grad (may be null) = grad_coef * (y - target), zero where the ReLU is closed. */
+int dpl_l2_loss(const float* d_z, const float* d_target, int64_t n, int relu, float grad_coef, double inv_m,
+                float* d_grad, double* d_loss, dpl_stream_t s);
+/* quant_acti with QDrop: y = rand < prob ? fake_quant(x) : x  (d_rand null: always quantised);
+ * gradient as torch autograd defines it for the reference code: 0 through round(), 1 through the kept values. */
+int dpl_acti_drop_fwd(const float* d_x, const float* d_rand, int64_t n, float scale, float qmin, float qmax,
+                      float prob, float* d_y, dpl_stream_t s);
+int dpl_acti_drop_bwd(const float* d_rand, const float* d_grad_y, int64_t n, float prob, float* d_grad_x,
+                      dpl_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

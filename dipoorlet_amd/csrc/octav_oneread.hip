@@ -41,7 +41,7 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / kWave;
 #ifndef DPL_RES_VEC
-#define DPL_RES_VEC 20
+#define DPL_RES_VEC 16
 #endif
 #ifndef DPL_RES_OCC
 #define DPL_RES_OCC 4
@@ -59,8 +59,8 @@ constexpr int kWaves = kThreads / kWave;
 #define DPL_WALK_OCC 4
 #endif
 constexpr int kVec = DPL_RES_VEC;                               // 16-byte vectors per thread the walk keeps a list in
-constexpr uint32_t kWalkCap = (uint32_t)kThreads * kVec * 4;    // list values the walk holds in registers (20 480)
-constexpr uint32_t kSmallCap = kWalkCap;                        // pairs this small gather their whole window (no prediction)
+constexpr int kOver = 4;                                         // rows of a list beyond the resident ones streamed per step of an iteration
+constexpr uint32_t kSmallCap = 20480;                           // pairs this small gather their whole window (no prediction)
 #ifndef DPL_SLICE_CAP
 #define DPL_SLICE_CAP 520192
 #endif
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     if (only_missed && (ctl->cnt_le == 0ull || me->mode != 1u)) return;
     const unsigned long long n_pair = me->n_elems;
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
-    const bool small = n_pair <= (unsigned long long)kWalkCap;
+    const bool small = n_pair <= (unsigned long long)kSmallCap;
     const uint32_t tensor = pair % n_tensors;
     DPL_PROF_T(pt0);
     // per-bin totals = the sum of the pair's slice rows -> LDS (own bins per thread)
@@ -565,10 +565,12 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             n_rows += (len + 1023u) >> 10;
             L += len;
         }
-        f4 v[kVec];
-        const uint32_t n_chunks = (n_rows + (uint32_t)kVec - 1u) / (uint32_t)kVec;
+        // the first kVec rows stay in registers for the whole walk; the rows beyond (the 3 % lists of the largest pairs) are
+        // streamed kOver at a time in every iteration — requested before the resident rows are scanned, consumed after
+        f4 v[kVec], ov[kOver];
         const float* lp = list0 + pair_base[pair];
-        auto load_chunk = [&](uint32_t row0) {
+        auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
+            constexpr int kN = decltype(count)::value;
             uint32_t j = 0u, r = row0;   // segment and row inside it of row `row0`
             while (j < n_seg) {
                 const uint32_t rows_j = (__builtin_amdgcn_readfirstlane(sh.seg_len[j]) + 1023u) >> 10;
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             }
             const uint32_t voff = tid << 4;
 #pragma unroll
-            for (int u = 0; u < kVec; ++u) {
+            for (int u = 0; u < kN; ++u) {
                 uint32_t len = j < n_seg ? __builtin_amdgcn_readfirstlane(sh.seg_len[j]) : 0u;
                 while (j < n_seg && (r << 10) >= len) {   // past the segment's end (or an empty segment): the next one
                     ++j;
@@ -595,10 +597,10 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
                     ++r;
                 }
                 const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, nbytes, 0x00020000);
-                v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                dst[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
             }
         };
-        if (n_chunks == 1u) load_chunk(0u);
+        load_rows(v, std::integral_constant<int, kVec>{}, 0u);
         auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
         // all waves count their share of the list; ONE wave takes the step (fp64 totals, the division, the bin look-ups — some
         // hundred instructions that would otherwise issue four times over on a CU whose issue slots are what this kernel runs
@@ -632,16 +634,16 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
             uint32_t c = 0u;   // (wave-uniform)
             unsigned long long dsum = 0ull;
-            for (uint32_t ch = 0; ch < n_chunks; ++ch) {
-                if (n_chunks > 1u) load_chunk(ch * (uint32_t)kVec);
-                const uint32_t rows = min(n_rows - ch * (uint32_t)kVec, (uint32_t)kVec);
-                uint32_t ds = 0u;   // per thread: at most 80 values below 2^17
-                auto in1 = [&](float f) {
-                    const uint32_t d = __float_as_uint(f) - lo1;
-                    const bool in = d < span;
-                    c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
-                    ds += in ? d : 0u;
-                };
+            uint32_t ds = 0u;   // per thread: at most 80 values below 2^17 between two wave sums
+            auto in1 = [&](float f) {
+                const uint32_t d = __float_as_uint(f) - lo1;
+                const bool in = d < span;
+                c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                ds += in ? d : 0u;
+            };
+            if (n_rows > (uint32_t)kVec) load_rows(ov, std::integral_constant<int, kOver>{}, (uint32_t)kVec);
+            {
+                const uint32_t rows = min(n_rows, (uint32_t)kVec);
 #pragma unroll
                 for (int u = 0; u < kVec; ++u) {
                     if ((uint32_t)u < rows) {   // uniform
@@ -652,6 +654,19 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
                     }
                 }
                 dsum += (unsigned long long)wave_sum_dpp(ds);   // < 64 * 80 * 2^17
+                ds = 0u;
+            }
+            for (uint32_t r0 = (uint32_t)kVec; r0 < n_rows; r0 += (uint32_t)kOver) {
+#pragma unroll
+                for (int u = 0; u < kOver; ++u) {   // (rows past the list's end were loaded as zeros)
+                    in1(ov[u].x);
+                    in1(ov[u].y);
+                    in1(ov[u].z);
+                    in1(ov[u].w);
+                }
+                if (r0 + (uint32_t)kOver < n_rows) load_rows(ov, std::integral_constant<int, kOver>{}, r0 + (uint32_t)kOver);
+                dsum += (unsigned long long)wave_sum_dpp(ds);
+                ds = 0u;
             }
             if (lane == 0) {
                 sh.part_c[0][w] = c;

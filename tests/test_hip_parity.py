@@ -118,14 +118,25 @@ def test_hist_prepare_flags_bad_ranges(dev):
     assert acc.range_status()["status"][0] == 2
 
 
+def _same_steps(a, b):
+    """Two forms walked the same iterate sequence: min / max identical, scales equal up to the ORDER in which atomically
+    merged fp64 partial sums were added (the compaction and full-pass routes merge per-workgroup sums with atomics: one
+    fp32 ulp at most, seen once in some hundred runs; a different iterate sequence differs by 1e-6 and more)."""
+    return np.array_equal(a[..., 1:], b[..., 1:], equal_nan=True) and \
+        np.allclose(a[..., 0], b[..., 0], rtol=2.4e-7, atol=0, equal_nan=True)
+
+
 def _octav(ops, plan, tensors, dyn, form, states=None):
     """octav_batch; the one-read form is run three times on the same plan — the first call has no prediction (every
-    multi-slice pair finishes on the compaction route), the later ones gather the predicted bins — and must agree."""
+    multi-slice pair finishes on the compaction route), the later ones gather the predicted bins and walk exact integer
+    sums: bit-identical among themselves (returned: the last), same steps as the first."""
     got = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
     if form == "oneread":
-        for _ in range(2):
-            again = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
-            assert np.array_equal(got, again, equal_nan=True)
+        first = got
+        got = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
+        again = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
+        assert np.array_equal(got, again, equal_nan=True)
+        assert _same_steps(first, got)
     return got
 
 
@@ -415,7 +426,7 @@ def _restart_path(dev, form):
     finally:
         _hip.lib().dpl_test_hook_exact_fail_every(old)
     assert int(ctl[2]) == plan.n_pairs // 2                 # control block: pairs that took the compaction route
-    assert np.array_equal(got, want)
+    assert _same_steps(got, want)
     for t in range(len(sizes)):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -480,9 +491,9 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
     plan = ops.TensorSetPlan(elems, B, dev)
     for dyn in (False, True):
         got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("oneread", "bracket", "compact", "full")}
-        assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)
-        assert np.array_equal(got["bracket"], got["compact"], equal_nan=True)
-        assert np.array_equal(got["bracket"], got["full"], equal_nan=True)
+        assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)   # (both: exact integer sums)
+        assert _same_steps(got["bracket"], got["compact"])
+        assert _same_steps(got["bracket"], got["full"])
         for t, n in enumerate(sizes):
             for b in range(B):
                 x = raw[t][b]

@@ -84,6 +84,41 @@ def test_build_balanced_items_host(lib):
             assert (o - base) % 1024 == 0
 
 
+def test_build_octav_slices_host(lib):
+    """HOST side of the one-read OCTAV form: every pair cut into ceil(count / cap) equal slices on multiples of 4 elements,
+    largest pairs first, pair_slice0 = the pair's contiguous slice range; a pair beyond 64 slices refuses the form."""
+    import random
+    rnd = random.Random(9)
+    cap = _hip.lib().dpl_octav_slice_cap()
+    assert cap % 4096 == 0 and _hip.lib().dpl_octav_sort_chunk() == 8192 and _hip.lib().dpl_octav_dir_row() % 8 == 0
+    assert _hip.lib().dpl_octav_small_pair() == 20480
+    for trial in range(20):
+        n = rnd.randint(1, 40)
+        spans = [(i % 5, 1000 * i, rnd.choice([0, 1, 3, 777, 20480, 20481, 401408, cap, cap + 1, 802816, 3 * cap + 5]), i)
+                 for i in range(n)]
+        arr, ns, ps = _hip.build_octav_slices(spans)
+        items = [(arr[i].seg, arr[i].offset, arr[i].count, arr[i].slot, arr[i].reserved) for i in range(ns)]
+        sizes_seen = []
+        for seg, off, cnt, slot in spans:
+            lo, hi = ps[2 * slot], ps[2 * slot + 1]
+            want = 0 if cnt == 0 else -(-cnt // cap)
+            assert hi - lo == want
+            pos = off
+            for k in range(lo, hi):
+                s_, o, c, sl, res = items[k]
+                assert (s_, o, sl, res) == (seg, pos, slot, want) and 0 < c <= cap
+                assert (o - off) % 4 == 0
+                if k + 1 < hi:
+                    assert c % 4 == 0 and c == items[lo][2]          # equal slices; only the last one takes the remainder
+                pos += c
+            assert pos == off + cnt
+            if want:
+                sizes_seen.append((lo, cnt))
+        order = [c for _, c in sorted(sizes_seen)]
+        assert order == sorted(order, reverse=True)                   # largest pairs first
+    assert _hip.build_octav_slices([(0, 0, 65 * cap, 0)]) is None
+
+
 def test_ops_refuse_cpu_tensors(lib):
     import torch
     from dipoorlet_amd import ops

@@ -1,32 +1,33 @@
-// OCTAV ('-A mse', forward_net.py:284-342) in ONE read of the activations, one launch per batch.
+// OCTAV ('-A mse', forward_net.py:284-342) in ONE read of the activations.
 //
 // Why not two reads: measured on MI355X (scripts/mall_probe.hip, profiles/r02/mall_probe.txt) a re-read of recently
 // streamed data costs the same whether HBM or the 256 MiB Infinity Cache serves it (6.1-6.9 TB/s either way, one
 // shared fabric), so the two-read bracket form of octav_kernels.hip cannot pass ~40 % of the roofline.  And a form that
-// keeps a pair on chip until a leader has walked its bracket (tried first: k_octav_resident, round 2) spends its time
-// waiting — three cross-workgroup round trips per slice against ~16 us of residency a CU can afford at HBM rate.
+// keeps a pair on chip until a leader has walked its bracket (tried first, round 2) spends its time waiting — three
+// cross-workgroup round trips per slice against ~16 us of residency a CU can afford at HBM rate.
 //
 // So nothing waits here.  The values the exact iteration needs are the ones in the histogram bins its iterates fall
 // into; WHICH bins is predicted from the previous batches (the bins the same tensor's iterates visited, OR-ed over the
-// images of the last two batches, cheap neighbours added) and every iterate of the exact walk is VERIFIED against the
-// set that was gathered.  A pair whose iterate leaves the gathered bins (first batch of a run, a distribution shift)
-// publishes its bracket for the next batch and finishes on the compaction route of octav_kernels.hip.  Results are the
-// reference's iterate sequence either way; only the speed depends on the prediction.
+// images of two alternating epochs of batches, neighbours that hold next to nothing and the sparse tail added) and every
+// iterate of the exact walk is VERIFIED against the set that was gathered.  A pair whose iterate leaves the gathered bins
+// (first batch of a run, a distribution shift) publishes its bracket for the next batches and finishes on the compaction
+// route of octav_kernels.hip.  Results are the reference's iterate sequence either way; only the speed depends on the
+// prediction.
 //
-// One 256-thread workgroup per SLICE (<= kCap elements of one (image, tensor) pair):
-//   1  the slice's only HBM read, straight into registers (buffer loads: zero fill past the end, all in flight);
-//   2  per element: min / max, exact log-scale histogram of |x| in LDS (64 bins per octave: count + integer mantissa
-//      sum, as in the bracket form) and — values of predicted bins only — a branch-free append to per-lane LDS queues;
-//   3  queues -> the pair's list (one returning atomic per wave), LDS histogram -> the pair's row (agent-scope
-//      atomics), statistics -> the pair's state; ONE ticket;
-//   4  the last slice of a pair: suffix totals of the merged row, s_0, then the exact walk — totals of the bins above
-//      the iterate's bin (exact integers) + the listed values of that bin (integer mantissa sums: the result does not
-//      depend on arrival order) — verifying each iterate's bin against the gathered set, and recording the bins it
-//      visited for the next batch.
-// A pair that fits one slice never leaves its workgroup: no list, no row, no prediction — the walk runs on the
-// registers that still hold the slice.
-// Cross-workgroup traffic is agent-scope atomics and sc1 (write-through) stores read by sc1 loads: no L2 write-back
-// fences (MI355X_MICROARCH.md, inter-workgroup visibility).  No workgroup ever waits for another.
+// Kernels:
+//   k_octav_oneread      one 256-thread workgroup per SLICE (<= kCap elements of one (image, tensor) pair): the slice's
+//                        only HBM read; per element min / max and ONE returning 64-bit LDS add on the bin's word of an
+//                        exact log-scale histogram (64 bins per octave: count + integer mantissa sum) whose bit 63 says
+//                        "gather"; gathered values -> dense per-wave LDS queues -> the slice's own region of the pair's
+//                        list (LDS cursor, no global atomic); the histogram leaves as one row per slice.
+//   k_octav_walk         one workgroup per pair: rows -> suffix totals in LDS -> s_0 -> the exact iteration with the list
+//                        in registers (totals of the bins above the iterate's bin: exact integers; listed values of that
+//                        bin: integer mantissa sums), every iterate verified, visited bins recorded for the next batches.
+//   k_octav_sort + k_octav_walk_sorted   the walk for LONG lists (images that differ widen the prediction): a slice's
+//                        list sorted by bin rank in 8192-value runs, then one WAVE per pair looking up one rank per
+//                        iteration.
+//   k_octav_oneread_init state + prediction snapshot (bitmap of at most 255 bins + per-word rank prefix) of a batch.
+// No workgroup ever waits for another; what crosses kernels crosses launches.
 #include <type_traits>
 #include "common.hpp"
 #include "octav_common.hpp"

@@ -44,7 +44,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--mse-steps", type=int, default=4, help="timed mse sweeps (N = 4096 images each); 0 skips the mse object")
     p.add_argument("--bins", type=int, default=2048)
-    p.add_argument("--pool", type=int, default=8, help="distinct resident batches of 32 images cycled through (3.4 GB each)")
+    p.add_argument("--pool", type=int, default=17, help="distinct resident batches of 32 images cycled through (3.4 GB each); "
+                   "17 = more than the one-read OCTAV prediction remembers (2 x 8 batches)")
+    p.add_argument("--mse-jitter", default="0.03,0.1", help="extra one-sweep mse objects with per-image contrast jitter (comma list; '' = none)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher / rendezvous / collective plumbing only, on CPU tensors (no kernels, no GPU): what the "
@@ -231,62 +233,106 @@ def main():
     clip_checksum = float(clip.double().abs().sum().item())
 
     # ------------------------------------------------------------------ -A mse (OCTAV), N = 4096 per GPU
-    mse = None
+    # A timed sweep is ONE COLD calibration run (forward_net.py:297-340: one independent pass over the shard): the plan forgets
+    # what earlier sweeps learned (octav_reset) inside the timed region, so the first batches run without a prediction as they
+    # do in a fresh process.  The pool holds more distinct batches than the prediction remembers (2 epochs of
+    # DPL_ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
+    mse, mse_jitter = None, {}
     if a.mse_steps > 0:
         import ctypes
         n_mse_batches = N_MSE // B
         states = torch.empty((plan.n_pairs + 1) * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
         rows = torch.empty(N_MSE, T, 3, dtype=torch.float32, device=dev)
-        mse_ev = []
-
-        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and os.environ.get("DPL_OCTAV_FORM", "oneread") == "oneread"
-        pipe = ops.OctavPipeline(False, dev) if pipeline else None
-
-        def mse_sweep(timed):
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            if pipe is not None:       # the product's schedule (forward_net.forward_net_octav): walk(i) beside stream(i + 1)
-                outs = [pipe.submit(plan, pool[b % len(pool)]) for b in range(n_mse_batches)]
-                pipe.sync()
-                torch.cat(outs, out=rows)
-            else:
-                for b in range(n_mse_batches):
-                    rows[b * B:(b + 1) * B] = ops.octav_batch(plan, pool[b % len(pool)], False, states)
-            if timed:
-                e1.record()
-                mse_ev.append((e0, e1))
-            allr = gather_rows(rows, world) if use_dist else rows          # the algorithm's exchange: per-image rows
-            s_mean = allr[:, :, 0].mean(0)                                 # basic_algorithm.py:57-69 on the device
-            lo = torch.maximum(allr[:, :, 1].amin(0), -s_mean)
-            hi = torch.minimum(allr[:, :, 2].amax(0), s_mean)
-            return torch.stack([lo, hi], 1)
-
-        mse_sweep(False)   # (also: the plan's first batches have no prediction yet)
-        fence()
-        t0 = time.perf_counter()
-        mclip = None
-        for _ in range(a.mse_steps):
-            mclip = mse_sweep(True)
-        fence()
-        dt_mse = max_over_ranks(time.perf_counter() - t0)
-        mse_ms = sum(s.elapsed_time(e) for s, e in mse_ev) / max(1, len(mse_ev)) / n_mse_batches   # per batch, in the sweep
-        mse_bytes = 4 * E * B          # credited: ONE read of the batch, whatever the form actually reads
-        mse_ach = mse_bytes / (mse_ms * 1e-3) / 1e9 if mse_ms > 0 else 0.0
         form = os.environ.get("DPL_OCTAV_FORM", "oneread")
-        mse = {"metric": f"calibration images/sec, ResNet-50 ONNX N={N_MSE}, -A mse", "value": N_MSE * world * a.mse_steps / dt_mse,
-               "unit": "images/s", "steps": a.mse_steps, "ms_per_step": dt_mse / a.mse_steps * 1e3,
-               "workload": f"ResNet-50 activation set, -A mse (OCTAV per image and tensor), N={N_MSE} images per GPU in "
-                           f"batches of {B}, form '{form}'",
-               "roofline": {"bound": "hbm", "kernel": f"OCTAV batch, form '{form}'" + (" (k_octav_oneread of batch i+1 beside k_octav_walk of batch i)"
-                                                                               if pipe is not None else " (k_octav_oneread + k_octav_walk)"),
-                            "achieved": mse_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mse_ach / HBM_PEAK_GBPS,
-                            "traffic": None, "bytes_per_launch": mse_bytes, "avg_batch_ms": mse_ms},
-               "clip_checksum": float(mclip.double().abs().sum().item())}
-        if pipe is not None:   # prediction misses (pairs finished on the compaction route), warm-up sweeps included
-            mse["prediction"] = {"batches": pipe.batches, "batches_with_a_miss": pipe.fallback_batches,
-                                 "pairs_missed": pipe.fallback_pairs, "pairs_per_batch": plan.n_pairs,
-                                 "listed_share_of_elements": pipe.list_share, "switched_to_two_read_form": bool(pipe.switched), "batches_walked_sorted": pipe.sorted_batches}
+        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form == "oneread"
+        pipe = ops.OctavPipeline(False, dev) if pipeline else None
+        min_pool = 2 * ops._ONEREAD_EPOCH + 1
+        # DPL_BENCH_FAIL_EVERY=n (a tuning aid, not the headline workload): the C ABI's test hook makes every n-th pair's walk
+        # report a missed prediction, to price the device-side rescue of such pairs
+        inject = int(os.environ.get("DPL_BENCH_FAIL_EVERY", "0"))
+        if inject > 0:
+            _hip.lib().dpl_test_hook_exact_fail_every(inject)
+
+        def run_mse(mpool, steps, jit):
+            mse_ev = []
+
+            def mse_sweep(timed):
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                plan.octav_reset()         # a cold run: nothing learned from the previous sweep
+                if pipe is not None:       # the product's schedule (forward_net.forward_net_octav): walk(i) beside stream(i + 1)
+                    outs = [pipe.submit(plan, mpool[b % len(mpool)]) for b in range(n_mse_batches)]
+                    pipe.sync()
+                    torch.cat(outs, out=rows)
+                else:
+                    for b in range(n_mse_batches):
+                        rows[b * B:(b + 1) * B] = ops.octav_batch(plan, mpool[b % len(mpool)], False, states, form=form)
+                if timed:
+                    e1.record()
+                    mse_ev.append((e0, e1))
+                allr = gather_rows(rows, world) if use_dist else rows          # the algorithm's exchange: per-image rows
+                s_mean = allr[:, :, 0].mean(0)                                 # basic_algorithm.py:57-69 on the device
+                lo = torch.maximum(allr[:, :, 1].amin(0), -s_mean)
+                hi = torch.minimum(allr[:, :, 2].amax(0), s_mean)
+                return torch.stack([lo, hi], 1)
+
+            mse_sweep(False)   # warm-up of the allocator / code objects only: every timed sweep starts cold
+            if pipe is not None:
+                pipe.reset_stats()
+            fence()
+            t0 = time.perf_counter()
+            mclip = None
+            for _ in range(steps):
+                mclip = mse_sweep(True)
+            fence()
+            dt_mse = max_over_ranks(time.perf_counter() - t0)
+            mse_ms = sum(s.elapsed_time(e) for s, e in mse_ev) / max(1, len(mse_ev)) / n_mse_batches   # per batch, in the sweep
+            mse_bytes = 4 * E * B          # credited: ONE read of the batch, whatever the form actually reads
+            mse_ach = mse_bytes / (mse_ms * 1e-3) / 1e9 if mse_ms > 0 else 0.0
+            # parity spot check against the CPU oracle (checker, after the timed region): 8 (image, tensor) pairs of the last batch
+            last = mpool[(n_mse_batches - 1) % len(mpool)]
+            ok, worst = True, 0.0
+            if rank == 0:
+                from oracle import np_oracle as O
+                import numpy as np
+                rs = np.random.RandomState(7)
+                for t in [0, 1, 2] + list(rs.choice(T, 5, replace=False)):
+                    img = int(rs.randint(B))
+                    want = float(O.octav_scale(last[t][img].cpu().numpy(), 1))
+                    got = float(rows[(n_mse_batches - 1) * B + img, t, 0].item())
+                    err = abs(got - want) / max(abs(want), 1.0)
+                    worst = max(worst, err)
+                    ok = ok and err <= 1e-5
+            obj = {"metric": f"calibration images/sec, ResNet-50 ONNX N={N_MSE}, -A mse", "value": N_MSE * world * steps / dt_mse,
+                   "unit": "images/s", "steps": steps, "ms_per_step": dt_mse / steps * 1e3,
+                   "workload": f"ResNet-50 activation set, -A mse (OCTAV per image and tensor), N={N_MSE} images per GPU in "
+                               f"batches of {B}, form '{form}', every sweep a cold run, {len(mpool)} distinct resident batches"
+                               + (f", per-image contrast jitter +-{jit:g}" if jit else ""),
+                   "roofline": {"bound": "hbm", "kernel": f"OCTAV batch, form '{form}'" + (" (k_octav_oneread of batch i+1 beside k_octav_walk of batch i)"
+                                                                                   if pipe is not None else ""),
+                                "achieved": mse_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mse_ach / HBM_PEAK_GBPS,
+                                "traffic": None, "bytes_per_launch": mse_bytes, "avg_batch_ms": mse_ms},
+                   "clip_checksum": float(mclip.double().abs().sum().item()),
+                   "sample_ok": bool(ok), "sample_worst_rel_err": worst}
+            if inject > 0:
+                obj["injected_miss_every"] = inject
+            if pipe is not None:   # prediction misses (pairs finished by a re-read of the pair), timed sweeps only
+                obj["prediction"] = {"batches": pipe.batches, "batches_with_a_miss": pipe.fallback_batches,
+                                     "pairs_missed": pipe.fallback_pairs, "pairs_per_batch": plan.n_pairs,
+                                     "listed_share_of_elements": pipe.list_share, "listed_share_max": pipe.max_share,
+                                     "batches_walked_sorted": pipe.sorted_batches}
+            return obj
+
+        if len(pool) < min_pool and rank == 0:
+            print(f"bench.py: --pool {len(pool)} < {min_pool}: batches repeat inside the prediction's memory", file=sys.stderr)
+        mse = run_mse(pool, a.mse_steps, jitter)
+        # the same sweep over images that differ in contrast (one sweep each): what a prediction from other images costs
+        for jit in ([float(x) for x in a.mse_jitter.split(",") if x] if jitter == 0.0 else []):
+            jp = [synth_activations(spec, B, dev, seed=99 + 1000 * rank + j, image_jitter=jit) for j in range(len(pool))]
+            mse_jitter[f"{jit:g}"] = run_mse(jp, 1, jit)
+            del jp
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ the line
     kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once
@@ -294,7 +340,7 @@ def main():
     # HBM bytes per launch by the PMC counters (scripts/profile_gpu.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     # this very script).  Quoted only when the record was measured on the kernel sources this run uses (sha over csrc/), else null.
     def measured_traffic(kernel):
-        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r02", "traffic.json"))
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r03", "traffic.json"))
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             from summarize_prof import source_sha
@@ -333,7 +379,7 @@ def main():
                      {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes,
                       "avg_kernel_ms": hist_kern_ms}),
-        "mse": mse,
+        "mse": mse, "mse_jitter": mse_jitter or None,
     }
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:

@@ -45,6 +45,7 @@ constexpr int kLogWords = kLogNB / 32;
 constexpr int kBitmapRow = kLogWords + 2;                   // + the gather range [lo, hi) as float bits
 constexpr int kLogMaxMarked = 256;
 constexpr uint32_t kSmallPair = 16384;                      // pairs this small are gathered whole
+constexpr uint32_t kRescueUnit = 16384;                     // elements of a pair one workgroup of k_octav_rescue_gather re-reads
 
 __device__ __forceinline__ int log_bin(float a) {
     const int b = (int)(__float_as_uint(a) >> kLogShift) - (int)kLogKey0;

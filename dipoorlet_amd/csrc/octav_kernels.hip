@@ -757,6 +757,57 @@ constexpr int kKeyWords = (1 << (31 - kLogShift)) / 32;   // 512
 constexpr int kKeyWord0 = (int)(kLogKey0 >> 5);           // word of the window's first bin (kLogKey0 is a multiple of 32)
 static_assert((kLogKey0 & 31u) == 0u, "the window must start on a bitmap word");
 
+// One span of one pair: the values of the marked bins (bm: the bitmap over the whole key space, in LDS) -> per-lane queues
+// -> the pair's list (cursor: me->len[0], a returning global atomic per wave flush).
+__device__ __forceinline__ void gather_span(const float* __restrict__ p, uint32_t count, const uint32_t* bm, uint32_t* q,
+                                            dpl_octav_state* me, uint32_t* __restrict__ dst) {
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    uint32_t cnt = 0;
+    auto flush = [&]() {
+        uint32_t inc = cnt;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o, kWave);
+            if (lane >= (uint32_t)o) inc += t;
+        }
+        const uint32_t total = __shfl(inc, kWave - 1, kWave);
+        uint32_t base = 0;
+        if (lane == kWave - 1) base = atomicAdd(&me->len[0], total);
+        base = __shfl(base, kWave - 1, kWave) + inc - cnt;
+        for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j * kWave];
+        cnt = 0;
+    };
+    for_each_tile<kBlock>(p, count, [&](const f4 (&v)[4], uint32_t, bool) {
+        // phase 1: all 16 bitmap words are fetched back to back (one LDS wait for the tile)
+        uint32_t u[16], word[16];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            u[4 * c + 0] = __float_as_uint(v[c].x) & 0x7FFFFFFFu;
+            u[4 * c + 1] = __float_as_uint(v[c].y) & 0x7FFFFFFFu;
+            u[4 * c + 2] = __float_as_uint(v[c].z) & 0x7FFFFFFFu;
+            u[4 * c + 3] = __float_as_uint(v[c].w) & 0x7FFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) word[j] = bm[u[j] >> (kLogShift + 5)];
+        uint32_t hit[16], any = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            hit[j] = (word[j] >> ((u[j] >> kLogShift) & 31u)) & 1u;
+            any |= hit[j];
+        }
+        // phase 2: branch-free append (a tile without any survivor in the wave skips it)
+        if (__any(any != 0u)) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                q[cnt * kWave] = u[j];
+                cnt += hit[j];
+            }
+        }
+        if (__any(cnt > (uint32_t)(kQueueCap - 16))) flush();
+    });
+    if (__any(cnt != 0u)) flush();
+}
+
 __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __restrict__ items,
                                                           const uint32_t* __restrict__ bb,
                                                           const float* const* __restrict__ segs,
@@ -782,52 +833,57 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
             bm[i] = (j >= 0 && j < kLogWords) ? bitmap[(uint64_t)it.slot * kBitmapRow + j] : 0u;
         }
         __syncthreads();
-        const float* p = segs[it.seg] + it.offset;
-        uint32_t* dst = reinterpret_cast<uint32_t*>(list0 + pair_base[it.slot]);
-        uint32_t cnt = 0;
-        auto flush = [&]() {
-            uint32_t inc = cnt;
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t t = __shfl_up(inc, o, kWave);
-                if (lane >= (uint32_t)o) inc += t;
+        gather_span(segs[it.seg] + it.offset, it.count, bm, q, me,
+                    reinterpret_cast<uint32_t*>(list0 + pair_base[it.slot]));
+    }
+}
+
+// The RESCUE of the one-read form (octav_oneread.hip): the pairs whose walk stepped outside the gathered bins are listed in
+// `missed` (pair, first unit, units: a unit = kRescueUnit elements of the pair) with their exact bracket in `bm_rows`; this
+// kernel re-reads those pairs ALONE and gathers the bracket's bins into list 1 — many workgroups per pair (a single
+// workgroup pulls ~20 GB/s: the compaction route, whose workgroups own a fixed share of the batch, took 470 us for 70
+// such pairs).  A persistent grid over the units; nothing to do (the usual case): every workgroup returns at once.
+__global__ __launch_bounds__(kBlock) void k_octav_rescue_gather(const uint32_t* __restrict__ missed,
+                                                                 const dpl_octav_state* __restrict__ ctl,
+                                                                 dpl_octav_state* __restrict__ st,
+                                                                 const dpl_span* __restrict__ pair_spans,
+                                                                 const float* const* __restrict__ segs,
+                                                                 const uint32_t* __restrict__ bm_rows,
+                                                                 const uint64_t* __restrict__ pair_base,
+                                                                 float* __restrict__ list1) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t queues[];
+    __shared__ uint32_t bm[kKeyWords];
+    __shared__ uint32_t found[3];
+    const uint32_t n_missed = ctl->len[0], n_units = ctl->len[1];
+    if (n_missed == 0u) return;
+    const int w = threadIdx.x / kWave;
+    const uint32_t lane = threadIdx.x & (kWave - 1);
+    uint32_t* q = queues + (size_t)w * kWave * kQueueStride + lane;
+    uint32_t held = 0xFFFFFFFFu;   // the pair whose bitmap sits in bm
+    for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < n_missed; e += kBlock) {   // which entry holds unit u (entries are in arrival order)
+            const uint32_t u0 = missed[3 * e + 1], nu = missed[3 * e + 2];
+            if (u - u0 < nu) {
+                found[0] = missed[3 * e];
+                found[1] = u - u0;
             }
-            const uint32_t total = __shfl(inc, kWave - 1, kWave);
-            uint32_t base = 0;
-            if (lane == kWave - 1) base = atomicAdd(&me->len[0], total);
-            base = __shfl(base, kWave - 1, kWave) + inc - cnt;
-            for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j * kWave];
-            cnt = 0;
-        };
-        for_each_tile<kBlock>(p, it.count, [&](const f4 (&v)[4], uint32_t, bool) {
-            // phase 1: all 16 bitmap words are fetched back to back (one LDS wait for the tile)
-            uint32_t u[16], word[16];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                u[4 * c + 0] = __float_as_uint(v[c].x) & 0x7FFFFFFFu;
-                u[4 * c + 1] = __float_as_uint(v[c].y) & 0x7FFFFFFFu;
-                u[4 * c + 2] = __float_as_uint(v[c].z) & 0x7FFFFFFFu;
-                u[4 * c + 3] = __float_as_uint(v[c].w) & 0x7FFFFFFFu;
+        }
+        __syncthreads();
+        const uint32_t pair = found[0], c = found[1];
+        dpl_octav_state* me = st + pair;
+        if (pair != held) {
+            for (int i = threadIdx.x; i < kKeyWords; i += kBlock) {
+                const int j = i - kKeyWord0;
+                bm[i] = (j >= 0 && j < kLogWords) ? bm_rows[(uint64_t)pair * kLogWords + j] : 0u;
             }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) word[j] = bm[u[j] >> (kLogShift + 5)];
-            uint32_t hit[16], any = 0u;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                hit[j] = (word[j] >> ((u[j] >> kLogShift) & 31u)) & 1u;
-                any |= hit[j];
-            }
-            // phase 2: branch-free append (a tile without any survivor in the wave skips it)
-            if (__any(any != 0u)) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    q[cnt * kWave] = u[j];
-                    cnt += hit[j];
-                }
-            }
-            if (__any(cnt > (uint32_t)(kQueueCap - 16))) flush();
-        });
-        if (__any(cnt != 0u)) flush();
+            held = pair;
+            __syncthreads();
+        }
+        const dpl_span sp = pair_spans[pair];
+        const uint64_t off = (uint64_t)c * kRescueUnit;
+        const uint32_t cnt = (uint32_t)min((uint64_t)kRescueUnit, sp.count - off);
+        gather_span(segs[sp.seg] + sp.offset + off, cnt, bm, q, me, reinterpret_cast<uint32_t*>(list1 + pair_base[pair]));
     }
 }
 
@@ -1057,6 +1113,17 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
 }  // namespace
 
 int g_exact_fail_every = 0;   // dpl_test_hook_exact_fail_every
+int g_rescue_fail_every = 0;  // dpl_test_hook_rescue_fail_every
+
+// (octav_oneread.hip) gather pass of the rescue: see k_octav_rescue_gather
+int dpl_octav_rescue_gather_launch(const uint32_t* d_missed, dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans,
+                                   const float* const* d_seg_ptrs, const uint32_t* d_bm_rows, const uint64_t* d_pair_base,
+                                   float* d_list1, hipStream_t st) {
+    hipLaunchKernelGGL(k_octav_rescue_gather, dim3(2048), dim3(kBlock), (size_t)kBlock * kQueueStride * sizeof(uint32_t), st,
+                       d_missed, d_states + n_pairs, d_states, d_pair_spans, d_seg_ptrs, d_bm_rows, d_pair_base, d_list1);
+    DPL_LAUNCH_CHECK("k_octav_rescue_gather");
+    return 0;
+}
 
 // The compaction route on its own, for the pairs a histogram form marked mode 1 (shared with octav_resident.hip).
 int dpl_octav_fallback_route(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
@@ -1082,6 +1149,12 @@ extern "C" {
 int dpl_test_hook_exact_fail_every(int every) {
     const int old = g_exact_fail_every;
     g_exact_fail_every = every;
+    return old;
+}
+
+int dpl_test_hook_rescue_fail_every(int every) {
+    const int old = g_rescue_fail_every;
+    g_rescue_fail_every = every;
     return old;
 }
 

@@ -461,7 +461,11 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
-    int only_missed) {
+    int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const float* __restrict__ list_rescue) {
+    // phase 0: the walk of every pair.  phase 1 (only_missed): the pass behind k_octav_walk_sorted, see below.  phase 2: the
+    // RESCUE walk — the pairs phase 0 / 1 could not finish (mode 3), over the values k_octav_rescue_gather collected for them
+    // from a second read of those pairs alone: the bins of the pair's exact bracket (rescue_bm), one list (list_rescue).
+    const bool only_missed = phase == 1, rescue = phase == 2;
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
@@ -473,7 +477,8 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     // only_missed: the pass behind k_octav_walk_sorted — the pairs that kernel could not finish (mode 1) are walked again
     // here up to the bin that was not gathered, for the sake of what this kernel does THEN: publish the pair's bracket for
     // the next batches and leave the state the compaction route starts from.  No pair missed (the steady state): nothing to do.
-    if (only_missed && (ctl->cnt_le == 0ull || me->mode != 1u)) return;
+    if (only_missed && (ctl->iters == 0u || me->mode != 1u)) return;
+    if (rescue && (ctl->len[0] == 0u || me->mode != 3u || me->done)) return;
     const unsigned long long n_pair = me->n_elems;
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const bool small = n_pair <= (unsigned long long)kSmallCap;
@@ -508,7 +513,12 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             s_ge[b] = bin_sum(mant[qq], cnt[qq], b);
         }
         // the pair's gathered values: one list segment per slice, at the slice's element offset inside the pair
-        if (tid < sl1 - sl0) {
+        if (rescue) {   // one list: what the rescue's gather pass wrote
+            if (tid == 0) {
+                sh.seg_off[0] = 0u;
+                sh.seg_len[0] = me->len[0];
+            }
+        } else if (tid < sl1 - sl0) {
             sh.seg_off[tid] = (uint32_t)(slices[sl0 + tid].offset - slices[sl0].offset);
             sh.seg_len[tid] = (uint32_t)lh[(uint64_t)(sl0 + tid) * kLogNB];
         }
@@ -516,10 +526,15 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
-        sh.bm[tid] = small ? 0xFFFFFFFFu : pred[tensor * kPredRow + tid];
+        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : small ? 0xFFFFFFFFu : pred[tensor * kPredRow + tid];
         sh.pub[tid] = 0u;
     }
-    if (tid == 0) {
+    if (tid == 0 && rescue) {   // s_0 and the divisor are in the state since the first walk
+        sh.s0 = me->s;
+        sh.ud = me->unsigned_div;
+        sh.n_elems = me->n_elems;
+        sh.route = 2u;
+    } else if (tid == 0) {
         const double sum_out = me->sum;
         const unsigned long long nz_out = me->cnt_gt;
         const unsigned long long n = me->n_elems;
@@ -559,7 +574,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         const unsigned long long n_elems = sh.n_elems;
         // the list (bit patterns of |x|) goes into registers, 1024 values per ROW (one 16-byte vector per thread); every
         // segment starts a new row; a list of more rows than the registers hold is re-read in pieces every iteration
-        const uint32_t n_seg = __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
+        const uint32_t n_seg = rescue ? 1u : __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
         uint32_t n_rows = 0u, L = 0u;
         for (uint32_t j = 0; j < n_seg; ++j) {
             const uint32_t len = __builtin_amdgcn_readfirstlane(sh.seg_len[j]);
@@ -569,7 +584,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         // the first kVec rows stay in registers for the whole walk; the rows beyond (the 3 % lists of the largest pairs) are
         // streamed kOver at a time in every iteration — requested before the resident rows are scanned, consumed after
         f4 v[kVec], ov[kOver];
-        const float* lp = list0 + pair_base[pair];
+        const float* lp = (rescue ? list_rescue : list0) + pair_base[pair];
         auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
             constexpr int kN = decltype(count)::value;
             uint32_t j = 0u, r = row0;   // segment and row inside it of row `row0`
@@ -625,7 +640,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         if (tid == 0) {
             g_prof_iters_add(blockIdx.x, 0u);
             DPL_PROF_L(L);
-            if (!only_missed) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
+            if (phase == 0) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
         }
         while (!done && !bad) {
             // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1), i.e. d = u - bits(s) - 1 below
@@ -719,12 +734,17 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     // ---- what the next batches should gather for this tensor: the bins this walk stepped into — or, when it
     // left the gathered set, the pair's bracket over the bin edges (histogram only) — plus neighbours that hold
     // next to nothing.
-    if (!small && route == 2u) {
+    // A pair that left the gathered set is RESCUED: its exact bracket (+ the same cheap extras) goes to its rescue row and the
+    // pair on the list of k_octav_rescue_gather, which re-reads this pair alone; only a bracket that cannot be formed (a flat
+    // distribution, values beyond the window) or a rescue walk that fails sends the pair to the compaction route.
+    bool rescued = false;
+    if (!small && route == 2u && !rescue) {
         if (bad) {
             if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
             __syncthreads();
-            if (tid == 0) bracket_marks(n_ge, s_ge, sh.pub, sh.s0, sh.ud, sh.n_elems);
+            if (tid == 0) sh.route = bracket_marks(n_ge, s_ge, sh.pub, sh.s0, sh.ud, sh.n_elems).route;
             __syncthreads();
+            rescued = sh.route == 2u;
         }
         if (tid < (uint32_t)kLogWords) {
             // neighbours: bin j-1 / j+1 of a published bin j join when they hold <= 0.2 % of the pair
@@ -749,6 +769,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             }
             const uint32_t out = mine | add | tail;
             if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
+            if (rescued) rescue_bm[(uint64_t)pair * kLogWords + tid] = out;
         }
     }
     DPL_PROF_T(pt5);
@@ -757,12 +778,22 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
         if (route == 0u) {
             me->done = 1u;
             me->mode = 2u;
+        } else if (bad && rescued) {
+            // restart from s_0 (in me->s) on the pair's exact bracket: its units go on the rescue's work list
+            me->mode = 3u;
+            me->done = 0u;
+            me->len[0] = 0u;
+            const uint32_t nu = (uint32_t)((sh.n_elems + kRescueUnit - 1) / kRescueUnit);
+            const uint32_t e = atomicAdd(&ctl->len[0], 1u), u0 = atomicAdd(&ctl->len[1], nu);
+            missed[3 * e] = pair;
+            missed[3 * e + 1] = u0;
+            missed[3 * e + 2] = nu;
         } else if (bad) {
             // restart from s_0 (in me->s) on the compaction route: state as k_octav_update<true> leaves it
             me->mode = 1u;
             me->done = 0u;
             me->len[0] = 0u;
-            if (!only_missed) atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
         } else {
             me->s = s;
             me->iters = iters;
@@ -1154,7 +1185,7 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
             me->mode = 2u;
         } else {
             me->mode = 1u;   // missed: k_octav_walk(only_missed) takes it from here (the streamed statistics stay in place)
-            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+            atomicAdd(&ctl->iters, 1u);
         }
     }
 }
@@ -1204,7 +1235,10 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
 
 }  // namespace
 
-extern int g_exact_fail_every;   // octav_kernels.hip (dpl_test_hook_exact_fail_every)
+extern int g_exact_fail_every, g_rescue_fail_every;   // octav_kernels.hip (dpl_test_hook_exact_fail_every / _rescue_fail_every)
+int dpl_octav_rescue_gather_launch(const uint32_t* d_missed, dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans,
+                                   const float* const* d_seg_ptrs, const uint32_t* d_bm_rows, const uint64_t* d_pair_base,
+                                   float* d_list1, hipStream_t st);
 int dpl_octav_fallback_route(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
                              const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
                              const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
@@ -1288,118 +1322,104 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_
     return n_total;
 }
 
-int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
-                              dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s) {
-    if (n_pairs <= 0) return 0;
-    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_prepare: bad tensor count / epoch");
-    if (!d_vis || !d_pred || !d_states) return fail_msg("dpl_octav_oneread_prepare: null buffer");
-    const int64_t vis_words = n_tensors * kLogWords;
-    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * vis_words;
-    const uint32_t* d_vis_o = d_vis + (int64_t)(1 - write_epoch) * vis_words;
-    const int64_t init_n = (n_pairs + 1 > vis_words ? n_pairs + 1 : vis_words);
-    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, d_states, n_pairs, d_vis_w,
-                       d_vis_o, d_pred, vis_words, reset_epoch);
+static int check_job(const char* who, const dpl_octav_oneread_job* j) {
+    if (!j) return fail_msg("dpl_octav_oneread: null job");
+    if (j->n_pairs <= 0 || j->n_slices <= 0) return 1;   // nothing to do
+    if (j->n_tensors < 1 || (j->write_epoch != 0 && j->write_epoch != 1)) {
+        snprintf(g_err, sizeof(g_err), "%s: bad tensor count / epoch", who);
+        return -1;
+    }
+    if (!j->d_slices || !j->d_pair_slice0 || !j->d_slice_chunk0 || !j->d_pair_spans || !j->d_pair_base || !j->d_pair_order ||
+        !j->d_seg_ptrs || !j->d_states || !j->d_lh || !j->d_pred || !j->d_list0 || !j->d_list1 || !j->d_dir || !j->d_rescue_bm ||
+        !j->d_missed || !j->d_vis) {
+        snprintf(g_err, sizeof(g_err), "%s: null buffer in the job", who);
+        return -1;
+    }
+    if (j->n_small < 0 || j->n_small > j->n_pairs) {
+        snprintf(g_err, sizeof(g_err), "%s: bad small-pair count", who);
+        return -1;
+    }
+    return 0;
+}
+#define DPL_JOB_CHECK(who)                       \
+    if (int e_ = check_job(who, j)) return e_ > 0 ? 0 : e_
+
+int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* j, dpl_stream_t s) {
+    DPL_JOB_CHECK("dpl_octav_oneread_prepare");
+    const int64_t vis_words = j->n_tensors * kLogWords;
+    uint32_t* d_vis_w = j->d_vis + (int64_t)j->write_epoch * vis_words;
+    const uint32_t* d_vis_o = j->d_vis + (int64_t)(1 - j->write_epoch) * vis_words;
+    const int64_t init_n = (j->n_pairs + 1 > vis_words ? j->n_pairs + 1 : vis_words);
+    hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, j->d_states, j->n_pairs, d_vis_w,
+                       d_vis_o, j->d_pred, vis_words, j->reset_epoch);
     DPL_LAUNCH_CHECK("k_octav_oneread_init");
     return 0;
 }
 
-int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
-                             const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
-                             int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s) {
-    if (n_slices <= 0 || n_pairs <= 0) return 0;
-    if (n_tensors < 1) return fail_msg("dpl_octav_oneread_stream: bad tensor count");
-    if (!d_lh || !d_pred || !d_pair_slice0) return fail_msg("dpl_octav_oneread_stream: null scratch buffer");
-    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
-                       d_slices, d_seg_ptrs, d_states, reinterpret_cast<unsigned long long*>(d_lh), d_pred, (uint32_t)n_tensors,
-                       d_pair_base, d_pair_slice0, d_list0);
+int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
+    DPL_JOB_CHECK("dpl_octav_oneread_stream");
+    hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
+                       j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), j->d_pred,
+                       (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
 }
 
-int dpl_octav_oneread_walk(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
-                           uint16_t* d_dir, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred, int write_epoch,
-                           int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs, const uint64_t* d_pair_base,
-                           const uint32_t* d_pair_order, int64_t n_small, float* d_list0, int sorted, int dynamic_sym,
-                           int max_iters, dpl_stream_t s) {
-    if (n_pairs <= 0) return 0;
-    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_walk: bad tensor count / epoch");
-    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices || !d_slice_chunk0 || !d_dir || !d_pair_order)
-        return fail_msg("dpl_octav_oneread_walk: null scratch buffer");
-    if (n_small < 0 || n_small > n_pairs || n_slices < 0) return fail_msg("dpl_octav_oneread_walk: bad counts");
-    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
-    const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(d_lh);
-    if (!sorted) {   // every pair walked from registers by one workgroup (misses handled inside)
-        hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_pairs), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
-                           d_pair_order, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
-                           dynamic_sym, max_iters, g_exact_fail_every, 0);
+// Everything behind the streaming kernel, in stream order, nothing decided on the host:
+//   the walk (k_octav_walk, or k_octav_sort + k_octav_walk_sorted + k_octav_walk for the small pairs and, phase 1, for the pairs
+//   the sorted walk could not finish)  ->  the rescue of the pairs whose walk left the gathered bins (k_octav_rescue_gather:
+//   those pairs re-read alone for their exact bracket's bins; k_octav_walk phase 2)  ->  the compaction route for what even
+//   that could not finish.  Every kernel behind the walk returns at once when the control block says there is nothing for it.
+int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
+    DPL_JOB_CHECK("dpl_octav_oneread_finish");
+    hipStream_t st = (hipStream_t)s;
+    uint32_t* d_vis_w = j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords;
+    const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(j->d_lh);
+    dpl_octav_state* ctl = j->d_states + j->n_pairs;
+    auto walk = [&](unsigned grid, const uint32_t* order, int phase) {
+        hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, j->d_pred,
+                           d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
+                           phase == 2 ? g_rescue_fail_every : g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_list1);
+    };
+    const int64_t n_big = j->n_pairs - j->n_small;   // d_pair_order: largest first, so the small pairs are its last n_small entries
+    if (!j->sorted) {   // every pair walked from registers by one workgroup
+        walk((unsigned)j->n_pairs, j->d_pair_order, 0);
         DPL_LAUNCH_CHECK("k_octav_walk");
-        return 0;
+    } else {
+        if (n_big > 0) {
+            hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)j->n_slices), dim3(kThreads), 0, st, j->d_slices, j->d_pair_slice0, lh, j->d_pred,
+                               (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slice_chunk0, j->d_dir);
+            DPL_LAUNCH_CHECK("k_octav_sort");
+            hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, st, j->d_states, ctl, j->d_pair_order, lh,
+                               j->d_pair_slice0, j->d_pred, d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices,
+                               j->d_slice_chunk0, j->d_dir, j->dynamic_sym, j->max_iters, g_exact_fail_every);
+            DPL_LAUNCH_CHECK("k_octav_walk_sorted");
+        }
+        if (j->n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
+            walk((unsigned)j->n_small, j->d_pair_order + n_big, 0);
+            DPL_LAUNCH_CHECK("k_octav_walk");
+        }
+        if (n_big > 0) {        // the pairs the sorted walk marked: their bracket, their place on the rescue list
+            walk((unsigned)n_big, j->d_pair_order, 1);
+            DPL_LAUNCH_CHECK("k_octav_walk(only_missed)");
+        }
     }
-    const int64_t n_big = n_pairs - n_small;   // d_pair_order: largest first, so the small pairs are its last n_small entries
-    if (n_big > 0) {
-        hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)n_slices), dim3(kThreads), 0, (hipStream_t)s, d_slices, d_pair_slice0, lh, d_pred,
-                           (uint32_t)n_tensors, d_pair_base, d_list0, d_slice_chunk0, d_dir);
-        DPL_LAUNCH_CHECK("k_octav_sort");
-        hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, (hipStream_t)s, d_states, d_states + n_pairs,
-                           d_pair_order, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
-                           d_slice_chunk0, d_dir, dynamic_sym, max_iters, g_exact_fail_every);
-        DPL_LAUNCH_CHECK("k_octav_walk_sorted");
-    }
-    if (n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
-        hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)n_small), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
-                           d_pair_order + n_big, lh, d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors, d_pair_base, d_list0, d_slices,
-                           dynamic_sym, max_iters, g_exact_fail_every, 0);
-        DPL_LAUNCH_CHECK("k_octav_walk");
-    }
-    return 0;
+    if (j->max_iters <= 0) return 0;
+    if (int e = dpl_octav_rescue_gather_launch(j->d_missed, j->d_states, j->n_pairs, j->d_pair_spans, j->d_seg_ptrs, j->d_rescue_bm,
+                                               j->d_pair_base, j->d_list1, st))
+        return e;
+    walk((unsigned)j->n_pairs, j->d_pair_order, 2);
+    DPL_LAUNCH_CHECK("k_octav_walk(rescue)");
+    if (int e = check_blocks("dpl_octav_oneread_finish", j->n_items, j->d_block_begin, j->n_blocks)) return e;
+    return dpl_octav_fallback_route(j->d_items, j->n_items, j->d_block_begin, j->n_blocks, j->d_seg_ptrs, j->d_states, j->n_pairs,
+                                    j->d_pair_spans, j->d_pair_base, j->d_pair_order, j->d_list0, j->d_list1, j->dynamic_sym,
+                                    j->max_iters, st);
 }
 
-int dpl_octav_oneread_missed(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
-                             const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
-                             const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small, float* d_list0,
-                             int dynamic_sym, int max_iters, dpl_stream_t s) {
-    if (n_pairs <= 0 || n_pairs - n_small <= 0) return 0;
-    if (n_tensors < 1 || (write_epoch != 0 && write_epoch != 1)) return fail_msg("dpl_octav_oneread_missed: bad tensor count / epoch");
-    if (!d_lh || !d_pair_slice0 || !d_vis || !d_pred || !d_slices || !d_pair_order) return fail_msg("dpl_octav_oneread_missed: null scratch buffer");
-    uint32_t* d_vis_w = d_vis + (int64_t)write_epoch * n_tensors * kLogWords;
-    hipLaunchKernelGGL(k_octav_walk, dim3((unsigned)(n_pairs - n_small)), dim3(kThreads), 0, (hipStream_t)s, d_states, d_states + n_pairs,
-                       d_pair_order, reinterpret_cast<const unsigned long long*>(d_lh), d_pair_slice0, d_pred, d_vis_w, (uint32_t)n_tensors,
-                       d_pair_base, d_list0, d_slices, dynamic_sym, max_iters, g_exact_fail_every, 1);
-    DPL_LAUNCH_CHECK("k_octav_walk(only_missed)");
-    return 0;
-}
-
-int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
-                               const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                               const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
-                               float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s) {
-    if (n_pairs <= 0 || max_iters <= 0) return 0;
-    if (int e = check_blocks("dpl_octav_oneread_fallback", n_items, d_block_begin, n_blocks)) return e;
-    return dpl_octav_fallback_route(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
-                                    d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, (hipStream_t)s);
-}
-
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
-                          uint16_t* d_dir, uint64_t* d_lh, uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch,
-                          int64_t n_tensors, const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
-                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small,
-                          float* d_list0, float* d_list1, int sorted, int dynamic_sym, int max_iters, dpl_stream_t s) {
-    if (n_slices <= 0 || n_pairs <= 0) return 0;
-    if (int e = dpl_octav_oneread_prepare(d_vis, d_pred, write_epoch, reset_epoch, n_tensors, d_states, n_pairs, s)) return e;
-    if (int e = dpl_octav_oneread_stream(d_slices, n_slices, d_pair_slice0, d_lh, d_pred, n_tensors, d_seg_ptrs, d_states, n_pairs,
-                                         d_pair_base, d_list0, s))
-        return e;
-    if (int e = dpl_octav_oneread_walk(d_slices, n_slices, d_pair_slice0, d_slice_chunk0, d_dir, d_lh, d_vis, d_pred, write_epoch,
-                                       n_tensors, d_states, n_pairs, d_pair_base, d_pair_order, n_small, d_list0, sorted, dynamic_sym,
-                                       max_iters, s))
-        return e;
-    if (sorted)
-        if (int e = dpl_octav_oneread_missed(d_slices, d_pair_slice0, d_lh, d_vis, d_pred, write_epoch, n_tensors, d_states, n_pairs,
-                                         d_pair_base, d_pair_order, n_small, d_list0, dynamic_sym, max_iters, s))
-        return e;
-    return dpl_octav_oneread_fallback(d_items, n_items, d_block_begin, n_blocks, d_seg_ptrs, d_states, n_pairs, d_pair_spans,
-                                      d_pair_base, d_pair_order, d_list0, d_list1, dynamic_sym, max_iters, s);
+int dpl_octav_run_oneread(const dpl_octav_oneread_job* j, dpl_stream_t s) {
+    if (int e = dpl_octav_oneread_prepare(j, s)) return e;
+    if (int e = dpl_octav_oneread_stream(j, s)) return e;
+    return dpl_octav_oneread_finish(j, s);
 }
 
 }  // extern "C"

@@ -158,8 +158,27 @@ class TensorSetPlan:
                     lh=torch.empty(n, 2048, dtype=torch.int64, device=self.device),    # one histogram row per slice
                     # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
                     vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
-                    pred=torch.zeros(self.T, 128, dtype=torch.int32, device=self.device), calls=0)
+                    pred=torch.zeros(self.T, 128, dtype=torch.int32, device=self.device), calls=0,
+                    # rescue of the pairs a walk could not finish: their exact bracket, the work list of the re-read
+                    rescue_bm=torch.empty(self.n_pairs, 64, dtype=torch.int32, device=self.device),
+                    missed=torch.empty(self.n_pairs, 3, dtype=torch.int32, device=self.device))
         return self._octav_one or None
+
+    def octav_reset(self):
+        """Cold start of the one-read OCTAV form: what the plan learned from earlier batches (bins visited, choice of walk) is
+        forgotten — the state of a plan that has never run.  Call between independent calibration runs that share a plan
+        (after OctavPipeline.sync())."""
+        one = getattr(self, "_octav_one", None)
+        if one:
+            one["vis"].zero_()
+            one["pred"].zero_()
+            one["calls"] = 0
+        for st in getattr(self, "_octav_pipe_sets", None) or []:
+            if st["pending"]:
+                raise _hip.DipoorletHipError("octav_reset with batches in flight: call OctavPipeline.sync() first")
+            st["prepared"] = None
+            st["k"] = -1
+        self.__dict__.pop("_octav_sorted", None)
 
     def seg_table(self, tensors):
         """Device table of base pointers for this launch (cached per pointer tuple)."""
@@ -304,12 +323,9 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
         k = res["calls"]
         res["calls"] = k + 1
         epoch, first = divmod(k, _ONEREAD_EPOCH)
-        _hip.check(L.dpl_octav_run_oneread(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["slice_chunk0"]),
-                                           _ptr(res["dir"]), _ptr(res["lh"]),
-                                           _ptr(res["vis"]), _ptr(res["pred"]), epoch % 2, 1 if first == 0 else 0, plan.T,
-                                           *w.args(), _ptr(tab), _ptr(states), n_pairs, _ptr(spans), _ptr(base), _ptr(order),
-                                           res["n_small"], _ptr(l0), _ptr(l1), _walk_sorted(plan), dyn, _OCTAV_MAX_ITERS, _stream()),
-                   "dpl_octav_run_oneread")
+        job = _oneread_job(plan, res, tab, states, res["lh"], res["pred"], l0, epoch % 2, 1 if first == 0 else 0,
+                           _walk_sorted(plan), dyn)
+        _hip.check(L.dpl_octav_run_oneread(C.byref(job), _stream()), "dpl_octav_run_oneread")
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
         return out
@@ -331,6 +347,24 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
     return out
+
+
+def _oneread_job(plan, res, tab, states, lh, pred, l0, write_epoch, reset_epoch, sorted_walk, dyn):
+    """The C ABI's dpl_octav_oneread_job for one batch of `plan` (all device pointers; the tensors stay alive in the caller)."""
+    spans, base, order, _, l1 = plan.octav_scratch()
+    w = plan.work("octav", per_image=True)
+    d_items, n_items, d_bb, n_blocks = w.args()
+    j = _hip.OctavOnereadJob()
+    j.d_slices, j.n_slices = res["slices"].data_ptr(), res["n_slices"]
+    j.d_pair_slice0, j.d_slice_chunk0 = res["pair_slice0"].data_ptr(), res["slice_chunk0"].data_ptr()
+    j.d_pair_spans, j.d_pair_base, j.d_pair_order = spans.data_ptr(), base.data_ptr(), order.data_ptr()
+    j.n_pairs, j.n_tensors, j.n_small = plan.n_pairs, plan.T, res["n_small"]
+    j.d_items, j.n_items, j.d_block_begin, j.n_blocks = d_items.value, n_items, d_bb.value, n_blocks
+    j.d_seg_ptrs, j.d_states, j.d_lh, j.d_pred = tab.data_ptr(), states.data_ptr(), lh.data_ptr(), pred.data_ptr()
+    j.d_list0, j.d_list1, j.d_dir = l0.data_ptr(), l1.data_ptr(), res["dir"].data_ptr()
+    j.d_rescue_bm, j.d_missed, j.d_vis = res["rescue_bm"].data_ptr(), res["missed"].data_ptr(), res["vis"].data_ptr()
+    j.write_epoch, j.reset_epoch, j.sorted, j.dynamic_sym, j.max_iters = write_epoch, reset_epoch, sorted_walk, dyn, _OCTAV_MAX_ITERS
+    return j
 
 
 def _walk_sorted(plan):
@@ -366,8 +400,11 @@ class OctavPipeline:
         self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
         self._touched = []
         # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
-        self.batches = self.fallback_batches = self.fallback_pairs = self.switched = self.sorted_batches = 0
-        self.list_share = 0.0    # gathered values / elements (running mean over the settled batches)
+        self.reset_stats()
+
+    def reset_stats(self):
+        self.batches = self.fallback_batches = self.fallback_pairs = self.sorted_batches = self.compaction_pairs = 0
+        self.list_share = self.max_share = 0.0    # gathered values / elements (running mean / maximum over the settled batches)
 
     @staticmethod
     def _sets(plan, res):
@@ -375,17 +412,17 @@ class OctavPipeline:
         if sets is None:
             _, _, _, l0, _ = plan.octav_scratch()
             nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
-            off = plan.n_pairs * C.sizeof(_hip.OctavState) + _hip.OctavState.sum.offset    # control block: sum, cnt_gt, cnt_le
+            off, csz = plan.n_pairs * C.sizeof(_hip.OctavState), C.sizeof(_hip.OctavState)    # the control block
             # four state arrays in rotation (call k uses k % 4): the array for call k + 2 is initialised at the end of call k's
             # side-stream work, while the one of call k must survive until the host has read k's count of unfinished pairs
             plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(4)]
-            plan._octav_pipe_failed = [x[off:off + 24] for x in plan._octav_pipe_states]
+            plan._octav_pipe_failed = [x[off:off + csz] for x in plan._octav_pipe_states]
             # the prediction snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
             # taken care of (two submits later), after the snapshot of call k + 2 has been written
             plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(3)]
             sets = []
             for j in range(2):
-                sets.append(dict(failed=torch.zeros(24, dtype=torch.uint8).pin_memory(),
+                sets.append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(),
                                  lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
                                  l0=l0 if j == 0 else torch.empty_like(l0), done=None, refs=None, pending=False, k=-1))
             plan._octav_pipe_sets = sets
@@ -394,9 +431,9 @@ class OctavPipeline:
     def _prepare(self, plan, res, st, k, stream):
         """State array + prediction snapshot (in set `st`) for the plan's call number k."""
         ep, first = divmod(k, _ONEREAD_EPOCH)
-        _hip.check(_hip.lib().dpl_octav_oneread_prepare(_ptr(res["vis"]), _ptr(plan._octav_pipe_pred[k % 4]), ep % 2, 1 if first == 0 else 0, plan.T,
-                                                        _ptr(plan._octav_pipe_states[k % 4]), plan.n_pairs, stream),
-                   "dpl_octav_oneread_prepare")
+        job = _oneread_job(plan, res, plan._octav_pipe_pred[k % 4], plan._octav_pipe_states[k % 4], st["lh"], plan._octav_pipe_pred[k % 4],
+                           st["l0"], ep % 2, 1 if first == 0 else 0, 0, self.dyn)    # (prepare reads neither tensors nor the walk choice)
+        _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
         st["prepared"] = k
 
     def _finish(self, plan, res, st):
@@ -408,21 +445,21 @@ class OctavPipeline:
         st["done"].record(self.side)
 
     def _settle(self, plan, res, st):
-        """HOST wait for the set's walk; the compaction route for its batch if some pair needs it."""
+        """HOST: read the statistics the set's last batch left in pinned memory (the walk finished long ago: the set comes up
+        for reuse two submits later) and choose the walk of the plan's next batches.  Nothing is launched here: the pairs a
+        walk could not finish are taken care of on the device, behind the walk, without the host (submit)."""
         if not st["pending"]:
             return
         st["pending"] = False
         st["done"].synchronize()
-        ctl = st["failed"].numpy()
-        listed, failed = float(ctl[0:8].view(np.float64)[0]), int(ctl[16:24].view(np.int64)[0])
+        ctl = _hip.OctavState.from_buffer_copy(st["failed"].numpy().tobytes())
+        # gathered values; pairs rescued by a re-read of the pair + pairs that ended on the compaction route
+        listed, failed = float(ctl.sum), int(ctl.len0) + int(ctl.cnt_le)
+        self.compaction_pairs += int(ctl.cnt_le)
         self.batches += 1
-        # The one-read form is only as good as its prediction: images that differ (contrast, content) widen the set of bins
-        # a tensor's walks visit, the gathered lists grow with it and both kernels slow down (measured on ResNet-50 shapes:
-        # 4 % of the elements listed at 0.59 of the roofline; 10 % image-to-image contrast jitter: 0.20).  Beyond
-        # _ONEREAD_MAX_SHARE on two batches in a row the plan switches to the two-read bracket form, which needs no
-        # prediction, for the rest of its life.
         share = listed / max(1, plan.batch * sum(plan.elems))
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
+        self.max_share = max(self.max_share, share)
         # which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short, sorted
         # runs beyond ~5 % of the elements (measured, ResNet-50 shapes: 2.8 % listed 0.59 vs 0.55 of the roofline, 9 % listed
         # 0.38 vs 0.43, 24 % listed 0.20 vs 0.32)
@@ -431,32 +468,13 @@ class OctavPipeline:
         elif share < _ONEREAD_SORT_SHARE * 0.8:
             plan._octav_sorted = 0
         self.sorted_batches += st["sorted"]
-        plan._octav_wide = plan.__dict__.get("_octav_wide", 0) + 1 if share > _ONEREAD_MAX_SHARE else 0
-        if plan._octav_wide >= 2 and not plan.__dict__.get("_octav_two_read"):
-            plan._octav_two_read = True
-            self.switched += 1
-        if failed == 0:
-            return
-        self.fallback_pairs += failed
-        self.fallback_batches += 1
-        tensors, tab, out = st["refs"]
-        spans, base, order, _, l1 = plan.octav_scratch()
-        w = plan.work("octav", per_image=True)
-        epoch = ((res["calls"] - 1) // _ONEREAD_EPOCH) % 2     # the accumulator the latest submitted batch writes to
-        if st["sorted"]:   # (the register walk takes care of its misses itself)
-            _hip.check(_hip.lib().dpl_octav_oneread_missed(_ptr(res["slices"]), _ptr(res["pair_slice0"]), _ptr(st["lh"]),
-                                                           _ptr(res["vis"]), _ptr(plan._octav_pipe_pred[st["k"] % 4]), epoch, plan.T,
-                                                           _ptr(st["states"]), plan.n_pairs, _ptr(base), _ptr(order), res["n_small"],
-                                                           _ptr(st["l0"]), self.dyn, _OCTAV_MAX_ITERS, self.side.cuda_stream),
-                       "dpl_octav_oneread_missed")
-        _hip.check(_hip.lib().dpl_octav_oneread_fallback(*w.args(), _ptr(tab), _ptr(st["states"]), plan.n_pairs, _ptr(spans),
-                                                         _ptr(base), _ptr(order), _ptr(st["l0"]), _ptr(l1), self.dyn,
-                                                         _OCTAV_MAX_ITERS, self.side.cuda_stream), "dpl_octav_oneread_fallback")
-        self._finish(plan, res, st)
+        if failed:
+            self.fallback_pairs += failed
+            self.fallback_batches += 1
 
     def submit(self, plan, tensors):
         form = os.environ.get("DPL_OCTAV_FORM", "oneread")
-        res = plan.octav_oneread_scratch() if form == "oneread" and not plan.__dict__.get("_octav_two_read") else None
+        res = plan.octav_oneread_scratch() if form == "oneread" else None
         if res is None:
             return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form == "oneread" else form)
         main = torch.cuda.current_stream(plan.device)
@@ -478,20 +496,16 @@ class OctavPipeline:
         L = _hip.lib()
         if cur.get("prepared") != k:
             self._prepare(plan, res, cur, k, main.cuda_stream)
-        _hip.check(L.dpl_octav_oneread_stream(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(cur["lh"]), _ptr(cur["pred"]), plan.T,
-                                              _ptr(tab), _ptr(cur["states"]), plan.n_pairs, _ptr(base), _ptr(cur["l0"]),
-                                              main.cuda_stream), "dpl_octav_oneread_stream")
+        job = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0,
+                           cur["sorted"], self.dyn)
+        _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
         streamed = torch.cuda.Event()
         streamed.record(main)
         self.side.wait_event(streamed)
-        _hip.check(L.dpl_octav_oneread_walk(_ptr(res["slices"]), res["n_slices"], _ptr(res["pair_slice0"]), _ptr(res["slice_chunk0"]),
-                                            _ptr(res["dir"]), _ptr(cur["lh"]), _ptr(res["vis"]), _ptr(cur["pred"]),
-                                            (k // _ONEREAD_EPOCH) % 2, plan.T, _ptr(cur["states"]), plan.n_pairs, _ptr(base),
-                                            _ptr(order), res["n_small"], _ptr(cur["l0"]), cur["sorted"], self.dyn, _OCTAV_MAX_ITERS,
-                                            self.side.cuda_stream),
-                   "dpl_octav_oneread_walk")
+        # the walk and, behind it on the device, the rescue of the pairs it could not finish: no host round trip decides anything
+        _hip.check(L.dpl_octav_oneread_finish(C.byref(job), C.c_void_p(self.side.cuda_stream)), "dpl_octav_oneread_finish")
         with torch.cuda.stream(self.side):
-            cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)
+            cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)    # (statistics only: _settle)
         self._finish(plan, res, cur)
         cur["pending"] = True
         if all(p is not plan for p, _ in self._touched):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 12
+#define DPL_ABI_VERSION 13
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -67,7 +67,7 @@ typedef struct dpl_octav_state {
     float unsigned_div; /* 1 or 4 */
     uint32_t iters;
     uint32_t mode;      /* 0: every evaluation re-reads the full data; 1: tail lists (dpl_octav_run_compact);
-                           2: log-histogram bracket (dpl_octav_run_bracket) */
+                           2: log-histogram bracket (dpl_octav_run_bracket) / one-read walk; 3: one-read rescue */
     uint64_t n_elems;   /* elements of the pair (counted by the first pass) */
     uint32_t len[2];    /* lengths of the two tail lists */
     uint32_t cur;       /* list holding the values above the previous iterate: 0, 1, or 2 = none yet */
@@ -150,77 +150,79 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
                           uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
-/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip), two kernels per batch:
+/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip; replaces forward_net.py:323-330's 21 numpy passes):
  *   k_octav_oneread — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one pair): the slice's only HBM
  *     read yields the pair's statistics, the slice's exact log-scale histogram row and the values of the bins the exact
  *     iteration is PREDICTED to visit (appended to the pair's list);
  *   k_octav_walk — one workgroup per pair: per-bin totals = the sum of the pair's slice rows, suffix totals, s_0, then the
  *     reference's iteration on (exact totals of the bins above) + (listed values of the iterate's bin), every iterate
- *     VERIFIED to lie in a gathered bin.
- * The prediction is what the same tensor's walks stepped into in earlier batches (two alternating epoch accumulators in
- * d_vis; d_pred receives the snapshot this batch uses).  A walk that meets a bin that was not gathered publishes the pair's
- * bracket for the following batches and hands the pair to the compaction route (d_items .. d_list1 as for
- * dpl_octav_run_bracket; always the case for a tensor's first batch: start with d_vis zeroed); pairs of at most 20480
- * elements gather their whole window and never need a prediction.
+ *     VERIFIED to lie in a gathered bin (for long lists: k_octav_sort + k_octav_walk_sorted, one wave per pair over runs
+ *     sorted by bin rank; job.sorted != 0);
+ *   the RESCUE of a pair whose iterate left the gathered bins, on the device and without the host: the walk forms the pair's
+ *     exact bracket from its histogram and puts the pair on a work list (d_missed); k_octav_rescue_gather re-reads THOSE PAIRS
+ *     ALONE (many workgroups per pair) for the bracket's bins and k_octav_walk (phase 2) walks them; what even that cannot
+ *     finish (a bracket that cannot be formed: flat distributions, values >= 2^14) ends on the compaction route.  All of
+ *     these are launched behind every walk and return at once when the control block (d_states[n_pairs]) lists nothing.
+ * The prediction (job.d_pred rows: the bins to gather, at most 255 of them, + per bitmap word the number of gathered bins
+ * below it: a gathered bin's RANK) is what the same tensor's walks stepped into in earlier batches (two alternating epoch
+ * accumulators in d_vis, snapshot taken by dpl_octav_oneread_prepare; a plan's first batch has none: start with d_vis
+ * zeroed, every large pair is then rescued); pairs of at most dpl_octav_small_pair() elements gather their whole window.
  *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
  *     of 4 elements); item.reserved = the pair's slice count; pair_slice0[2 slot], [2 slot + 1] = first / one-past-last
  *     slice of the pair in slot `slot` (spans carry slots 0 .. n_spans-1).  Returns the slice count (call with out = NULL
  *     to size), -3 when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
- *   d_lh: uint64 [n_slices, 2048] scratch: every slice writes its histogram row in full (plain coalesced stores, no
- *     read-modify-write, nothing to zero); the walk adds up the rows of a pair's slices;
- *   d_vis: uint32 [2, n_tensors, 64] epoch accumulators (slot = image * n_tensors + tensor); this batch's walks add to
- *     d_vis[write_epoch], which is cleared first when reset_epoch != 0; d_pred: uint32 [n_tensors, 128] scratch (the bins
- *     to gather, at most 255 of them, + per bitmap word the number of gathered bins below it: a gathered bin's RANK);
- *   dpl_octav_oneread_walk, sorted == 0: every pair is walked by one workgroup with its list in registers (k_octav_walk: the
- *     faster way while the lists are short — up to ~5 % of the elements — and the prediction is narrow; misses are handled
- *     inside: no dpl_octav_oneread_missed call); sorted != 0 (long lists: a scan of the whole list per iteration no longer
- *     pays): it first SORTS every slice's list (k_octav_sort: dpl_octav_sort_chunk() values at a time, in place,
- *     by the rank of the values' bins; d_dir: uint16 [n_chunks, dpl_octav_dir_row()] receives per chunk the position of each
- *     rank's first value, d_slice_chunk0 [n_slices]: the first directory row of a slice = the running sum of
- *     ceil(slice count / chunk) over the slices before it), then walks each pair with ONE WAVE over its sorted runs
- *     (k_octav_walk_sorted: per iteration the directory entries of one rank and the values behind them); the last n_small
- *     pairs of d_pair_order (at most dpl_octav_small_pair() elements: whole window gathered, no sort) are walked from
- *     registers by one workgroup each (k_octav_walk), and so are — for their bracket and their compaction-route state —
- *     the pairs the sorted walk could not finish;
- * dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot d_pred (and the
- * epoch reset); dpl_octav_oneread_stream = k_octav_oneread; dpl_octav_oneread_walk = k_octav_walk, which leaves the number
- * of pairs that need the compaction route in the control block (d_states[n_pairs].cnt_le); dpl_octav_oneread_fallback = that
- * route (every kernel of it is a no-op when the count is 0, but a launch still has to be scheduled: a caller that can read
- * the count skips the call); dpl_octav_run_oneread = all four on one stream.  stream and walk may run on different streams (the walk of batch i beside the streaming kernel of batch i + 1: the walk is
- * latency-bound, the streaming kernel HBM-bound) when the caller orders walk(i) after stream(i) and gives concurrently
- * live batches their own d_states / d_lh / d_pred / d_list0 / d_list1; d_vis is shared (bits are only ever OR-ed in). */
+ * One HOST struct carries a batch's buffers (all pointers are device pointers):
+ *   dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot;
+ *   dpl_octav_oneread_stream  = k_octav_oneread;
+ *   dpl_octav_oneread_finish  = the walk and everything behind it;       dpl_octav_run_oneread = all three on one stream.
+ * stream and finish may run on different streams (the walk of batch i beside the streaming kernel of batch i + 1) when the
+ * caller orders finish(i) after stream(i) and gives concurrently live batches their own d_states / d_lh / d_pred / d_list0 /
+ * d_rescue_bm / d_missed; d_vis is shared (bits are only ever OR-ed in), d_list1 may be shared by batches whose finish calls
+ * are on one stream. */
+typedef struct dpl_octav_oneread_job {
+    /* the tensor set's decomposition (static per plan) */
+    const dpl_work_item* d_slices;   /* dpl_build_octav_slices */
+    int64_t n_slices;
+    const uint32_t* d_pair_slice0;   /* [n_pairs, 2] */
+    const uint32_t* d_slice_chunk0;  /* [n_slices]: first directory row of a slice = running sum of ceil(slice count / dpl_octav_sort_chunk()) */
+    const dpl_span* d_pair_spans;    /* [n_pairs]: where each pair's data lives */
+    const uint64_t* d_pair_base;     /* [n_pairs]: element offset of the pair's region in the lists (a region holds the pair's element count) */
+    const uint32_t* d_pair_order;    /* [n_pairs]: pair indices, largest first; its last n_small entries gather their whole window */
+    int64_t n_pairs, n_tensors, n_small;
+    const dpl_work_item* d_items;    /* the balanced partition of the same pairs (compaction route), as for dpl_octav_run_compact */
+    int64_t n_items;
+    const uint32_t* d_block_begin;
+    int64_t n_blocks;
+    /* this batch */
+    const float* const* d_seg_ptrs;
+    dpl_octav_state* d_states;       /* [n_pairs + 1]; the last one is the control block */
+    uint64_t* d_lh;                  /* [n_slices, 2048]: one histogram row per slice (plain stores, nothing to zero) */
+    uint32_t* d_pred;                /* [n_tensors, 128] */
+    float* d_list0;                  /* gathered values, region per pair */
+    float* d_list1;                  /* rescue / compaction lists, same layout */
+    uint16_t* d_dir;                 /* [n_chunks, dpl_octav_dir_row()]: per sorted run the position of each rank's first value */
+    uint32_t* d_rescue_bm;           /* [n_pairs, 64]: exact bracket of a rescued pair */
+    uint32_t* d_missed;              /* [n_pairs, 3]: (pair, first unit, units) of the rescued pairs */
+    /* carried across batches */
+    uint32_t* d_vis;                 /* [2, n_tensors, 64] epoch accumulators; walks add to d_vis[write_epoch], cleared first when reset_epoch != 0 */
+    int32_t write_epoch, reset_epoch;
+    int32_t sorted;                  /* 0: lists scanned whole from registers (short lists), 1: sorted runs */
+    int32_t dynamic_sym, max_iters, reserved;
+} dpl_octav_oneread_job;
 uint32_t dpl_octav_slice_cap(void);
-uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run (see below) */
+uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run */
 uint32_t dpl_octav_dir_row(void);    /* uint16 entries of a run's directory row */
 uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements gather their whole window */
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
-int dpl_octav_oneread_prepare(uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch, int64_t n_tensors,
-                              dpl_octav_state* d_states, int64_t n_pairs, dpl_stream_t s);
-int dpl_octav_oneread_stream(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, uint64_t* d_lh,
-                             const uint32_t* d_pred, int64_t n_tensors, const float* const* d_seg_ptrs, dpl_octav_state* d_states,
-                             int64_t n_pairs, const uint64_t* d_pair_base, float* d_list0, dpl_stream_t s);
-int dpl_octav_oneread_walk(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
-                           uint16_t* d_dir, const uint64_t* d_lh, uint32_t* d_vis, const uint32_t* d_pred, int write_epoch,
-                           int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs, const uint64_t* d_pair_base,
-                           const uint32_t* d_pair_order, int64_t n_small, float* d_list0, int sorted, int dynamic_sym,
-                           int max_iters, dpl_stream_t s);
-/* the pairs the sorted walk marked as missed (control block count != 0), before dpl_octav_oneread_fallback: their bracket is
- * published for the next batches (into d_vis[write_epoch]: pass the epoch current at the time of the call) and their state
- * prepared for the compaction route; a no-op kernel when nothing was missed — a caller that can read the count skips it */
-int dpl_octav_oneread_missed(const dpl_work_item* d_slices, const uint32_t* d_pair_slice0, const uint64_t* d_lh, uint32_t* d_vis,
-                             const uint32_t* d_pred, int write_epoch, int64_t n_tensors, dpl_octav_state* d_states, int64_t n_pairs,
-                             const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small, float* d_list0,
-                             int dynamic_sym, int max_iters, dpl_stream_t s);
-int dpl_octav_oneread_fallback(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
-                               const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                               const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order,
-                               float* d_list0, float* d_list1, int dynamic_sym, int max_iters, dpl_stream_t s);
-int dpl_octav_run_oneread(const dpl_work_item* d_slices, int64_t n_slices, const uint32_t* d_pair_slice0, const uint32_t* d_slice_chunk0,
-                          uint16_t* d_dir, uint64_t* d_lh, uint32_t* d_vis, uint32_t* d_pred, int write_epoch, int reset_epoch,
-                          int64_t n_tensors, const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin,
-                          int64_t n_blocks, const float* const* d_seg_ptrs, dpl_octav_state* d_states, int64_t n_pairs,
-                          const dpl_span* d_pair_spans, const uint64_t* d_pair_base, const uint32_t* d_pair_order, int64_t n_small,
-                          float* d_list0, float* d_list1, int sorted, int dynamic_sym, int max_iters, dpl_stream_t s);
+int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* job, dpl_stream_t s);
+int dpl_octav_oneread_stream(const dpl_octav_oneread_job* job, dpl_stream_t s);
+int dpl_octav_oneread_finish(const dpl_octav_oneread_job* job, dpl_stream_t s);
+int dpl_octav_run_oneread(const dpl_octav_oneread_job* job, dpl_stream_t s);
+/* TEST HOOKS (0 = off; return the previous setting): _exact_ makes the exact walk of dpl_octav_run_bracket and the first walk
+ * of the one-read form reject every `every`-th pair, so that the restart paths — taken in production only when an iterate
+ * leaves the gathered bins — can be exercised; _rescue_ does the same to the one-read form's rescue walk (-> compaction route). */
+int dpl_test_hook_exact_fail_every(int every);
+int dpl_test_hook_rescue_fail_every(int every);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
 /* TEST HOOK: makes the exact walk of dpl_octav_run_bracket reject every `every`-th pair (0 = off) so that the
  * restart on the compaction route — taken in production only when an iterate leaves the bracket's bins — can be

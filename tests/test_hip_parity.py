@@ -418,14 +418,30 @@ def _restart_path(dev, form):
                                           for _ in range(B)])).to(dev) for t, n in enumerate(sizes)]
     plan = ops.TensorSetPlan(sizes, B, dev)
     want = _octav(ops, plan, tensors, False, form)     # (one-read: also warms the prediction up, so that only the hook fails pairs)
-    old = _hip.lib().dpl_test_hook_exact_fail_every(2)
-    try:
-        states = torch.empty((plan.n_pairs + 1) * 80, dtype=torch.uint8, device=dev)
-        got = ops.octav_batch(plan, tensors, False, states, form=form).cpu().numpy()
-        ctl = states.cpu().numpy()[-80:].view(np.uint64)
-    finally:
-        _hip.lib().dpl_test_hook_exact_fail_every(old)
-    assert int(ctl[2]) == plan.n_pairs // 2                 # control block: pairs that took the compaction route
+    states = torch.empty((plan.n_pairs + 1) * 80, dtype=torch.uint8, device=dev)
+
+    def hooked(rescue_fail):
+        old = _hip.lib().dpl_test_hook_exact_fail_every(2)
+        old_r = _hip.lib().dpl_test_hook_rescue_fail_every(rescue_fail)
+        try:
+            got = ops.octav_batch(plan, tensors, False, states, form=form).cpu().numpy()
+            ctl = _hip.OctavState.from_buffer_copy(states.cpu().numpy()[-80:].tobytes())
+        finally:
+            _hip.lib().dpl_test_hook_exact_fail_every(old)
+            _hip.lib().dpl_test_hook_rescue_fail_every(old_r)
+        return got, ctl
+
+    got, ctl = hooked(0)
+    if form == "oneread":
+        # the one-read form RESCUES a rejected pair (its exact bracket, a re-read of that pair alone, a second walk); only
+        # the pairs that gather their whole window anyway (here: the 1000-element tensor) go straight to the compaction route
+        assert int(ctl.len0) + int(ctl.cnt_le) == plan.n_pairs // 2 and int(ctl.len0) >= plan.n_pairs // 4
+        assert int(ctl.len1) >= int(ctl.len0)                # units of the re-read
+        got2, ctl2 = hooked(2)                               # ... and when the rescue walk rejects them too: compaction route
+        assert int(ctl2.cnt_le) == plan.n_pairs // 2
+        assert _same_steps(got2, want)
+    else:
+        assert int(ctl.cnt_le) == plan.n_pairs // 2          # control block: pairs that took the compaction route
     assert _same_steps(got, want)
     for t in range(len(sizes)):
         with warnings.catch_warnings():

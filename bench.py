@@ -319,9 +319,12 @@ def main():
                 obj["injected_miss_every"] = inject
             if pipe is not None:   # prediction misses (pairs finished by a re-read of the pair), timed sweeps only
                 obj["prediction"] = {"batches": pipe.batches, "batches_with_a_miss": pipe.fallback_batches,
-                                     "pairs_missed": pipe.fallback_pairs, "pairs_per_batch": plan.n_pairs,
+                                     "pairs_missed": pipe.fallback_pairs, "pairs_compaction": pipe.compaction_pairs,
+                                     "pairs_per_batch": plan.n_pairs,
                                      "listed_share_of_elements": pipe.list_share, "listed_share_max": pipe.max_share,
-                                     "batches_walked_sorted": pipe.sorted_batches}
+                                     "batches_walked_sorted": pipe.sorted_batches,
+                                     "source": os.environ.get("DPL_OCTAV_PREDICT", "auto"),
+                                     "tensors_predicted_from_own_sample": pipe.probe_tensors / max(1, pipe.batches * T)}
             return obj
 
         if len(pool) < min_pool and rank == 0:

@@ -54,12 +54,14 @@ class OctavOnereadJob(C.Structure):
                 ("n_pairs", C.c_int64), ("n_tensors", C.c_int64), ("n_small", C.c_int64),
                 ("d_items", C.c_void_p), ("n_items", C.c_int64), ("d_block_begin", C.c_void_p), ("n_blocks", C.c_int64),
                 ("d_seg_ptrs", C.c_void_p), ("d_states", C.c_void_p), ("d_lh", C.c_void_p), ("d_pred", C.c_void_p),
+                ("d_pred_pair", C.c_void_p), ("d_use_probe", C.c_void_p),
                 ("d_list0", C.c_void_p), ("d_list1", C.c_void_p), ("d_dir", C.c_void_p), ("d_rescue_bm", C.c_void_p),
-                ("d_missed", C.c_void_p), ("d_vis", C.c_void_p), ("write_epoch", C.c_int32), ("reset_epoch", C.c_int32),
-                ("sorted", C.c_int32), ("dynamic_sym", C.c_int32), ("max_iters", C.c_int32), ("reserved", C.c_int32)]
+                ("d_missed", C.c_void_p), ("d_vis", C.c_void_p), ("d_tstat", C.c_void_p), ("write_epoch", C.c_int32),
+                ("reset_epoch", C.c_int32), ("sorted", C.c_int32), ("dynamic_sym", C.c_int32), ("max_iters", C.c_int32),
+                ("predict", C.c_int32), ("probe_z", C.c_float), ("compaction_inline", C.c_int32)]
 
 
-assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 216
+assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 248
 assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 80
 
 _P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
@@ -89,8 +91,10 @@ SIGNATURES = {
     "dpl_octav_small_pair": (C.c_uint32, []),
     "dpl_build_octav_slices": (_I64, [_P, _I64, _P, _I64, _P]),
     "dpl_octav_oneread_prepare": (C.c_int, [_P, _P]),
+    "dpl_octav_oneread_probe": (C.c_int, [_P, _P]),
     "dpl_octav_oneread_stream": (C.c_int, [_P, _P]),
     "dpl_octav_oneread_finish": (C.c_int, [_P, _P]),
+    "dpl_octav_oneread_compaction": (C.c_int, [_P, _P]),
     "dpl_octav_run_oneread": (C.c_int, [_P, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_test_hook_rescue_fail_every": (C.c_int, [C.c_int]),

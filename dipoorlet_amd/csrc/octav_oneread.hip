@@ -83,6 +83,7 @@ constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a
 constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
 constexpr uint32_t kBigCluster = (1u << 20) / kCap + 1;         // clusters this large may overflow the packed count field
 constexpr uint32_t kMaxCluster = 64;
+constexpr unsigned kRescueGrid = 512;   // workgroups of the rescue's persistent kernels
 // The prediction row of a tensor (d_pred): the bitmap of the bins to gather (kLogWords words, at most kMaxFlag bits set) and,
 // per word, the number of set bits in the words below it — the RANK of a gathered bin is a table index everywhere below.
 constexpr int kMaxFlag = 256;
@@ -91,6 +92,14 @@ constexpr int kPredRow = 2 * kLogWords;
 // directory row of a chunk holds, per rank, the position of the rank's first value in the chunk (+ the chunk's length).
 constexpr uint32_t kChunk = 8192;
 constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows are 16-byte aligned
+// Per tensor, what its prediction from earlier batches would have cost lately (floats, halved every batch):
+// [0] values it would have listed, [1] elements walked, [2] walks it would not have covered, [3] walks, [4] current choice
+constexpr int kTstatRow = 8;
+#ifndef DPL_PROBE_RATE
+#define DPL_PROBE_RATE 16
+#endif
+constexpr uint32_t kProbeRate = DPL_PROBE_RATE;   // k_octav_probe reads one 64-byte chunk of every kProbeRate
+constexpr uint32_t kProbeThin = 64;               // sampled values above a bracket's lower end below which the whole tail is gathered
 
 // LDS: [A: packed histogram 16 KiB, bit 63 of a word = gather flag | one dummy word per lane][B: the waves' survivor queues 13 KiB]
 constexpr int kLdsA = kLogNB * 8 + kWave * 8;                   // + the lanes' dummy words
@@ -393,7 +402,7 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     // empty histogram; bit 63 of a bin's word = "gather this bin's values": what this tensor's iterates visited lately
     // (a small pair gathers its whole window)
     for (int b = tid; b < kLogNB; b += kThreads) {
-        const uint32_t f = small ? 1u : (pred[tensor * kPredRow + (b >> 5)] >> (b & 31)) & 1u;
+        const uint32_t f = small ? 1u : (pred[(uint64_t)pair * kPredRow + (b >> 5)] >> (b & 31)) & 1u;
         l_packed[b] = (unsigned long long)f << 63;
     }
     if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
@@ -456,29 +465,27 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 // handed back zeroed), s_0, then the reference's iteration — totals of the bins above the iterate's bin (exact integers)
 // + the listed values of that bin (integer mantissa sums) — verifying that every iterate lands in a gathered bin.  Records
 // the bins it stepped into (or, when it left the gathered set, the pair's bracket) for the next batches.
-__global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
-    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
+__device__ __forceinline__ void walk_pair(
+    const uint32_t pair, double* s_ge, uint32_t* n_ge, Shared& sh,
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl,
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
-    int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const float* __restrict__ list_rescue) {
+    int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const float* __restrict__ list_rescue,
+    const uint32_t* __restrict__ pred_t, float* __restrict__ tstat) {
     // phase 0: the walk of every pair.  phase 1 (only_missed): the pass behind k_octav_walk_sorted, see below.  phase 2: the
     // RESCUE walk — the pairs phase 0 / 1 could not finish (mode 3), over the values k_octav_rescue_gather collected for them
     // from a second read of those pairs alone: the bins of the pair's exact bracket (rescue_bm), one list (list_rescue).
     const bool only_missed = phase == 1, rescue = phase == 2;
-    __shared__ double s_ge[kLogNB];
-    __shared__ uint32_t n_ge[kLogNB];
-    __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const int w = tid / kWave;
-    const uint32_t pair = pair_order ? pair_order[blockIdx.x] : blockIdx.x;
     dpl_octav_state* me = st + pair;
     // only_missed: the pass behind k_octav_walk_sorted — the pairs that kernel could not finish (mode 1) are walked again
     // here up to the bin that was not gathered, for the sake of what this kernel does THEN: publish the pair's bracket for
     // the next batches and leave the state the compaction route starts from.  No pair missed (the steady state): nothing to do.
     if (only_missed && (ctl->iters == 0u || me->mode != 1u)) return;
-    if (rescue && (ctl->len[0] == 0u || me->mode != 3u || me->done)) return;
+    if (rescue && (me->mode != 3u || me->done)) return;
     const unsigned long long n_pair = me->n_elems;
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const bool small = n_pair <= (unsigned long long)kSmallCap;
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
-        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : small ? 0xFFFFFFFFu : pred[tensor * kPredRow + tid];
+        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : small ? 0xFFFFFFFFu : pred[(uint64_t)pair * kPredRow + tid];
         sh.pub[tid] = 0u;
     }
     if (tid == 0 && rescue) {   // s_0 and the divisor are in the state since the first walk
@@ -770,6 +777,26 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
             const uint32_t out = mine | add | tail;
             if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
             if (rescued) rescue_bm[(uint64_t)pair * kLogWords + tid] = out;
+            // (these 64 threads are wave 0)  What the tensor's prediction FROM EARLIER BATCHES would have listed for this pair and
+            // whether it would have covered the bins this walk needed: k_octav_oneread_init chooses per tensor between that
+            // prediction and the one from a sample of the pair itself (k_octav_probe)
+            const uint32_t lw = pred_t[tensor * kPredRow + tid];
+            uint32_t c = 0u, bits = lw;
+            while (bits) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1u;
+                const int j = (int)tid * 32 + bit;
+                if (j > 0 && j < kLogNB - 1) c += n_ge[j] - n_ge[j + 1];
+            }
+            const uint32_t would_list = wave_sum_dpp(c);
+            const bool would_miss = __builtin_amdgcn_ballot_w64((mine & ~lw) != 0u) != 0ull;
+            if (tid == 0) {
+                float* ts = tstat + (size_t)tensor * kTstatRow;
+                atomicAdd(ts + 0, (float)would_list);
+                atomicAdd(ts + 1, (float)sh.n_elems);
+                atomicAdd(ts + 2, would_miss ? 1.0f : 0.0f);
+                atomicAdd(ts + 3, 1.0f);
+            }
         }
     }
     DPL_PROF_T(pt5);
@@ -803,6 +830,38 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     }
 }
 
+__global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
+    const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
+    int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const uint32_t* __restrict__ pred_t,
+    float* __restrict__ tstat) {
+    __shared__ double s_ge[kLogNB];
+    __shared__ uint32_t n_ge[kLogNB];
+    __shared__ Shared sh;
+    walk_pair(pair_order ? pair_order[blockIdx.x] : blockIdx.x, s_ge, n_ge, sh, st, ctl, lh, pair_slice0, pred, vis_w, n_tensors,
+              pair_base, list0, slices, dynamic_sym, max_iters, fail_every, phase, rescue_bm, missed, nullptr, pred_t, tstat);
+}
+
+// The rescue walk (phase 2): a small persistent grid over the list of rescued pairs — usually empty, and a launch that has
+// nothing to do should not have thousands of workgroups to schedule between those of the next batch's streaming kernel.
+__global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
+    dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const unsigned long long* __restrict__ lh,
+    const uint32_t* __restrict__ pair_slice0, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
+    const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every, uint32_t* __restrict__ rescue_bm,
+    uint32_t* __restrict__ missed, const float* __restrict__ list_rescue) {
+    __shared__ double s_ge[kLogNB];
+    __shared__ uint32_t n_ge[kLogNB];
+    __shared__ Shared sh;
+    const uint32_t n_missed = ctl->len[0];
+    for (uint32_t e = blockIdx.x; e < n_missed; e += gridDim.x) {
+        walk_pair(missed[3 * e], s_ge, n_ge, sh, st, ctl, lh, pair_slice0, nullptr, nullptr, n_tensors, pair_base, nullptr, slices,
+                  dynamic_sym, max_iters, fail_every, 2, rescue_bm, missed, list_rescue, nullptr, nullptr);
+        __syncthreads();
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Sorted runs.  k_octav_sort: one workgroup per slice; the slice's list (as gathered: arrival order) is sorted IN PLACE,
@@ -827,7 +886,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_sort(
     const uint32_t pair = it.slot, tensor = pair % n_tensors;
     uint32_t* region = reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + (it.offset - slices[pair_slice0[2 * pair]].offset));
     if (tid < (uint32_t)kLogWords)
-        bp[tid] = (unsigned long long)pred[tensor * kPredRow + tid] | ((unsigned long long)pred[tensor * kPredRow + kLogWords + tid] << 32);
+        bp[tid] = (unsigned long long)pred[(uint64_t)pair * kPredRow + tid] | ((unsigned long long)pred[(uint64_t)pair * kPredRow + kLogWords + tid] << 32);
     constexpr int kPer = (int)(kChunk / kThreads / 4);   // 16-byte vectors per thread and chunk
     for (uint32_t c0 = 0; c0 < len; c0 += kChunk) {
         const uint32_t n = min(len - c0, kChunk);
@@ -922,7 +981,7 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
     const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ slice_chunk0, const uint16_t* __restrict__ dir,
-    int dynamic_sym, int max_iters, int fail_every) {
+    int dynamic_sym, int max_iters, int fail_every, const uint32_t* __restrict__ pred_t, float* __restrict__ tstat) {
     __shared__ double t_s[kMaxFlag + 1];
     __shared__ uint32_t t_n[kMaxFlag + 1];
     __shared__ uint32_t bm[kLogWords], pre[kLogWords], cheapw[kLogWords], thinw[kLogWords], pub[kLogWords];
@@ -937,8 +996,8 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const uint32_t tensor = pair % n_tensors;
     const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
-    bm[lane] = pred[tensor * kPredRow + lane];
-    pre[lane] = pred[tensor * kPredRow + kLogWords + lane];
+    bm[lane] = pred[(uint64_t)pair * kPredRow + lane];
+    pre[lane] = pred[(uint64_t)pair * kPredRow + kLogWords + lane];
     cheapw[lane] = 0u;
     thinw[lane] = 0u;
     pub[lane] = 0u;
@@ -975,7 +1034,7 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
     DPL_PROF_T(qt0);
     // ---- 1. totals above every gathered bin
     const uint32_t cheap_n = (uint32_t)(n_pair >> DPL_CHEAP_SHIFT), thin_n = (uint32_t)(n_pair >> DPL_THIN_SHIFT);
-    uint32_t carry_n = 0u;
+    uint32_t carry_n = 0u, would_list = 0u;
     double carry_s = 0.0;
     // All 16 bins of a lane — a quarter octave — share the exponent, so sums stay INTEGERS (explicit mantissas + count * 2^23,
     // below 2^51 per octave) inside an octave: a conversion to fp64 happens once per octave (its total) and once per
@@ -1028,8 +1087,10 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
         const uint32_t bits = (bm[word] >> sh16) & 0xFFFFu;
         const uint32_t below = pre[word] + (uint32_t)__popc(bm[word] & ((1u << sh16) - 1u));
         uint32_t cheap_bits = 0u, thin_bits = 0u;
+        const uint32_t lbits = (pred_t[tensor * kPredRow + word] >> sh16) & 0xFFFFu;   // the tensor's prediction from earlier batches
 #pragma unroll
         for (int q = 15; q >= 0; --q) {
+            would_list += ((lbits >> q) & 1u) ? cnt[q] : 0u;
             if ((bits >> q) & 1u) {   // a gathered bin: totals above it, by rank
                 const uint32_t r = below + (uint32_t)__popc(bits & ((1u << q) - 1u));
                 t_n[r] = run_n;
@@ -1167,8 +1228,18 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
         uint32_t valid = 0xFFFFFFFFu;
         if (lane == 0) valid &= ~1u;                               // bins 1 .. kLogNB - 2
         if (lane == (uint32_t)kLogWords - 1u) valid &= ~(1u << 31);
-        const uint32_t out = mine | (((up | dn) & ~mine & cheapw[lane]) | thinw[lane]) & valid;
+        const uint32_t out = mine | ((((up | dn) & ~mine & cheapw[lane]) | thinw[lane]) & valid);
         if (out) atomicOr(vis_w + tensor * kLogWords + lane, out);
+        // selection statistics, as in k_octav_walk (a pair that missed is counted by its second walk there)
+        const uint32_t wl = wave_sum_dpp(would_list);
+        const bool would_miss = __builtin_amdgcn_ballot_w64((mine & ~pred_t[tensor * kPredRow + lane]) != 0u) != 0ull;
+        if (lane == 0) {
+            float* ts = tstat + (size_t)tensor * kTstatRow;
+            atomicAdd(ts + 0, (float)wl);
+            atomicAdd(ts + 1, (float)n_pair);
+            atomicAdd(ts + 2, would_miss ? 1.0f : 0.0f);
+            atomicAdd(ts + 3, 1.0f);
+        }
     }
     if (lane == 0) {
         if (route == 0u || !bad) {
@@ -1191,7 +1262,7 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
 }
 
 __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* vis_w, const uint32_t* vis_o, uint32_t* pred,
-                                     int64_t vis_words, int zero_w) {
+                                     int64_t vis_words, int zero_w, float* tstat, uint32_t* use_probe, int predict) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < vis_words) {   // this batch gathers what the current and the previous epoch's walks stepped into (a snapshot: the
                            // walks of this batch keep adding to vis_w while they run).  One wave = one tensor, lane = word.
@@ -1211,6 +1282,30 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
         const int64_t t = i / kLogWords;
         pred[t * kPredRow + lane] = x;
         pred[t * kPredRow + kLogWords + lane] = below;
+        if (lane == 0) {
+            // Which prediction this tensor's pairs get in this batch: the one above (what earlier images' walks visited: the
+            // narrowest there is when the images are alike) or the one from a sample of the pair itself (k_octav_probe: wider,
+            // costs a read of 1 / kProbeRate of the pair, but does not care how the images differ).  Judged by what the
+            // first would have cost in the last batches' walks; with hysteresis; no history: the sample.
+            float* ts = tstat + t * kTstatRow;
+            const float listed = ts[0], elems = ts[1], misses = ts[2], walks = ts[3];
+            uint32_t probe = ts[4] != 0.0f ? 1u : 0u;
+            if (walks < 0.5f) {
+                probe = 1u;
+            } else if (probe) {   // (measured, ResNet-50 shapes: the sample costs what a prediction listing ~8 % costs)
+                if (listed < 0.055f * elems && misses < 0.04f * walks) probe = 0u;
+            } else {
+                if (listed > 0.080f * elems || misses > 0.08f * walks) probe = 1u;
+            }
+            if (predict == 0) probe = 0u;   // forced: earlier batches only
+            if (predict == 1) probe = 1u;   // forced: the pair's own sample
+            ts[0] = 0.5f * listed;
+            ts[1] = 0.5f * elems;
+            ts[2] = 0.5f * misses;
+            ts[3] = 0.5f * walks;
+            ts[4] = probe ? 1.0f : 0.0f;
+            use_probe[t] = probe;
+        }
     }
     if (i > n_pairs) return;  // slot n_pairs is the control block
     dpl_octav_state z;
@@ -1231,6 +1326,190 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
     z.cur = 2u;
     z.reserved = 0u;
     st[i] = z;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_octav_probe: the prediction of a pair FROM THE PAIR ITSELF — one 64-byte chunk of every kProbeRate (a strided sample:
+// every channel and every region of the feature map contributes), binned like the full pass (count, sum per bin) plus a
+// sum of squares; then the iteration is walked on the SAMPLE's histogram (linear inside a bin) carrying the sampling
+// variance of every iterate along: Var(s_{k+1}) ~ Var(tail mean above s_k) / (sampled tail count) + F'(s_k)^2 Var(s_k).
+// Gathered: the bins within kProbeZ standard deviations of every sampled iterate, and — from the first iterate on whose
+// lower end fewer than kProbeThin sampled values lie — everything above (the late iterates' tail holds next to nothing).
+// Nothing here needs to be exact: the walk verifies every iterate against what was gathered and a pair whose iterate
+// falls outside is rescued (re-read alone).  One workgroup per pair; a tensor whose pairs use the prediction from earlier
+// batches (use_probe == 0) only copies that row.
+constexpr float kProbeZ = 3.0f;
+__global__ __launch_bounds__(kThreads) void k_octav_probe(
+    const dpl_span* __restrict__ pair_spans, const float* const* __restrict__ segs, const uint32_t* __restrict__ pred_t,
+    const uint32_t* __restrict__ use_probe, uint32_t* __restrict__ pred_p, uint32_t n_tensors, int dynamic_sym, int max_iters,
+    float z, const uint32_t* __restrict__ pair_order) {
+    __shared__ double s_ge[kLogNB];      // packed sample histogram, then the suffix sums
+    __shared__ uint32_t n_ge[kLogNB];
+    __shared__ float q_ge[kLogNB];       // suffix sums of squares
+    __shared__ Shared sh;
+    __shared__ float red_q[kWaves];
+    __shared__ int red_top[kWaves];
+    const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    const uint32_t pair = pair_order[blockIdx.x], tensor = pair % n_tensors;   // largest pairs first
+    const dpl_span sp = pair_spans[pair];
+    if (sp.count <= (uint64_t)kSmallCap) return;   // gathers its whole window: no prediction row is read
+    uint32_t* row = pred_p + (uint64_t)pair * kPredRow;
+    if (!use_probe[tensor]) {
+        if (tid < (uint32_t)kPredRow) row[tid] = pred_t[tensor * kPredRow + tid];
+        return;
+    }
+    unsigned long long* packed = reinterpret_cast<unsigned long long*>(s_ge);
+    for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
+    __syncthreads();
+    // ---- the sample: chunk g (16 floats) starts at element g * 16 * kProbeRate behind the first 16-byte boundary
+    const float* p0 = segs[sp.seg] + sp.offset;
+    const uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)p0 & 15u)) & 15u) >> 2);
+    const uint32_t n = (uint32_t)sp.count - head;
+    gptr_f4 pv = (gptr_f4)(p0 + head);
+    const uint32_t n_chunks = n / (16u * kProbeRate);            // whole strides only (the last partial one is skipped)
+    float mn = INFINITY;
+    uint32_t m = 0u;
+    auto eat = [&](float x) {
+        mn = fminf(mn, x);
+        const uint32_t bits = __float_as_uint(x);
+        const uint32_t t = ((bits >> kLogShift) & 0x3FFFu) - (kLogKey0 + 1u);
+        if (t < (uint32_t)(kLogNB - 1)) atomicAdd(packed + t + 1u, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu));
+    };
+    constexpr int kIn = 4;   // loads in flight per lane
+    for (uint32_t g0 = tid >> 2; g0 < n_chunks; g0 += (kThreads >> 2) * kIn) {
+        f4 v[kIn];
+#pragma unroll
+        for (int u = 0; u < kIn; ++u) {
+            const uint32_t g = g0 + (uint32_t)u * (kThreads >> 2);
+            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + (size_t)g * 4u * kProbeRate + (tid & 3u)) : f4{0.f, 0.f, 0.f, 0.f};
+            m += g < n_chunks ? 4u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kIn; ++u) {
+            eat(v[u].x);
+            eat(v[u].y);
+            eat(v[u].z);
+            eat(v[u].w);
+        }
+    }
+    m = wave_sum(m);
+    mn = wave_min(mn);
+    if (lane == 0) {
+        sh.red_a[w] = m;
+        sh.red_mn[w] = mn;
+    }
+    __syncthreads();
+    const uint32_t m_all = sh.red_a[0] + sh.red_a[1] + sh.red_a[2] + sh.red_a[3];   // (read before the scans reuse the scratch)
+    const float smn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
+    // ---- per-bin (count, sum, sum of squares) -> suffix sums (thread t owns the 8 bins below 2047 - 8 t)
+    {
+        constexpr int kPerT = kLogNB / kThreads;
+        const int hi = kLogNB - 1 - (int)tid * kPerT;
+        uint32_t c[kPerT];
+        double sm[kPerT];
+        float sq[kPerT], lq = 0.0f;
+        int my_top = 0;   // the highest sampled bin
+#pragma unroll
+        for (int q = 0; q < kPerT; ++q) {
+            const int b = hi - q;
+            const unsigned long long v = b == 0 ? 0ull : packed[b];
+            c[q] = (uint32_t)(v >> kPackShift);
+            my_top = max(my_top, c[q] ? b : 0);
+            sm[q] = bin_sum(v & kPackMask, c[q], b);
+            // values of a bin: mean^2 + (bin width)^2 / 12 each
+            const float mean = c[q] ? (float)(sm[q] / (double)c[q]) : 0.0f, wd = log_edge(b + 1) - log_edge(b);
+            sq[q] = (float)c[q] * (mean * mean + wd * wd * (1.0f / 12.0f));
+            lq += sq[q];
+        }
+        __syncthreads();   // every thread has read its packed words: the arrays may be overwritten
+#pragma unroll
+        for (int q = 0; q < kPerT; ++q) {
+            n_ge[hi - q] = c[q];
+            s_ge[hi - q] = sm[q];
+        }
+        float iq = lq;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const float t = __shfl_up(iq, o, kWave);
+            if (lane >= (uint32_t)o) iq += t;
+        }
+        if (lane == kWave - 1) red_q[w] = iq;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) my_top = max(my_top, __shfl_xor(my_top, o, kWave));
+        if (lane == 0) red_top[w] = my_top;
+        suffix_in_place(n_ge, s_ge, sh);   // (syncs)
+        float rq = iq - lq;
+        for (int q = 0; q < w; ++q) rq += red_q[q];
+#pragma unroll
+        for (int q = 0; q < kPerT; ++q) {
+            rq += sq[q];
+            q_ge[hi - q] = rq;
+        }
+    }
+    if (tid < (uint32_t)kLogWords) sh.bm[tid] = 0u;
+    __syncthreads();
+    // ---- the iteration on the sample, with its uncertainty (one thread: ~20 steps of a few dozen operations)
+    if (tid == 0) {
+        const float ud = (dynamic_sym && fabsf(smn) < 1e-6f) ? 4.0f : 1.0f;
+        const float c = (float)(1.0 / 65536.0 / 3.0) / ud;
+        const float fpc = 1.0f - 1.0f / (float)kProbeRate;     // finite population: the sample is a fixed share of the pair
+        auto mark = [&](int a, int b) {   // bins a .. b
+            a = max(a, 1);
+            b = min(b, kLogNB - 2);
+            for (int w0 = a >> 5; w0 <= b >> 5; ++w0) {
+                const int lo_b = max(a, w0 << 5) & 31, hi_b = min(b, (w0 << 5) + 31) & 31;
+                sh.bm[w0] |= (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
+            }
+        };
+        const float nz = (float)n_ge[1];
+        if (nz > 0.0f && m_all > 0u) {
+            // highest sampled bin + an octave: the pair's maximum lies above the sample's
+            const int top = min(max(max(red_top[0], red_top[1]), max(red_top[2], red_top[3])) + 64, kLogNB - 2);
+            float s = (float)s_ge[1] / nz;
+            float V = fmaxf(q_ge[1] / nz - s * s, 0.0f) / nz * fpc;
+            for (int k = 0; k <= max_iters; ++k) {
+                const float sd = sqrtf(V), lo = fmaxf(s - z * sd, 1e-30f), hi = s + z * sd;
+                const int jl = max(log_bin(lo), 1), jh = log_bin(hi);
+                if (n_ge[jl] < kProbeThin) {   // the sparse tail, wholesale
+                    mark(jl, top);
+                    break;
+                }
+                mark(jl, jh);
+                const int j = min(max(log_bin(s), 1), kLogNB - 2);
+                const float e0 = log_edge(j), e1 = log_edge(j + 1), fr = fminf(fmaxf((e1 - s) / (e1 - e0), 0.0f), 1.0f);
+                const float cj = (float)(n_ge[j] - n_ge[j + 1]);
+                const float ngt = (float)n_ge[j + 1] + fr * cj;
+                const float sgt = (float)s_ge[j + 1] + fr * (float)(s_ge[j] - s_ge[j + 1]);
+                const float qgt = q_ge[j + 1] + fr * (q_ge[j] - q_ge[j + 1]);
+                if (!(ngt > 0.0f)) {
+                    mark(jl, top);
+                    break;
+                }
+                const float s1 = sgt / (c * ((float)m_all - ngt) + ngt);
+                const float mean_t = sgt / ngt, var_t = fmaxf(qgt / ngt - mean_t * mean_t, 0.0f);
+                const float fp = fminf(fmaxf(cj / (e1 - e0) * (s1 - s) / ngt, 0.0f), 1.0f);   // F'(s) = density (F - s) / N_gt
+                V = var_t / ngt * fpc + fp * fp * V;
+                if (fabsf(s1 - s) < 1e-6f || !(s1 == s1)) break;
+                s = s1;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the row: at most kMaxFlag - 1 bins (lowest first) + per word the number of gathered bins below it (wave 0)
+    if (tid < (uint32_t)kLogWords) {
+        uint32_t x = sh.bm[tid];
+        const uint32_t incl = wave_incl_scan_dpp((uint32_t)__popc(x));
+        uint32_t below = incl - (uint32_t)__popc(x);
+        if (incl > (uint32_t)(kMaxFlag - 1)) {
+            const uint32_t keep = below < (uint32_t)(kMaxFlag - 1) ? (uint32_t)(kMaxFlag - 1) - below : 0u;
+            while ((uint32_t)__popc(x) > keep) x &= ~(1u << (31 - __clz(x)));
+            below = min(below, (uint32_t)(kMaxFlag - 1));
+        }
+        row[tid] = x;
+        row[kLogWords + tid] = below;
+    }
 }
 
 }  // namespace
@@ -1331,7 +1610,7 @@ static int check_job(const char* who, const dpl_octav_oneread_job* j) {
     }
     if (!j->d_slices || !j->d_pair_slice0 || !j->d_slice_chunk0 || !j->d_pair_spans || !j->d_pair_base || !j->d_pair_order ||
         !j->d_seg_ptrs || !j->d_states || !j->d_lh || !j->d_pred || !j->d_list0 || !j->d_list1 || !j->d_dir || !j->d_rescue_bm ||
-        !j->d_missed || !j->d_vis) {
+        !j->d_missed || !j->d_vis || !j->d_pred_pair || !j->d_use_probe || !j->d_tstat) {
         snprintf(g_err, sizeof(g_err), "%s: null buffer in the job", who);
         return -1;
     }
@@ -1350,16 +1629,26 @@ int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     uint32_t* d_vis_w = j->d_vis + (int64_t)j->write_epoch * vis_words;
     const uint32_t* d_vis_o = j->d_vis + (int64_t)(1 - j->write_epoch) * vis_words;
     const int64_t init_n = (j->n_pairs + 1 > vis_words ? j->n_pairs + 1 : vis_words);
+    if (j->predict < 0 || j->predict > 2) return fail_msg("dpl_octav_oneread_prepare: predict must be 0, 1 or 2");
     hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, j->d_states, j->n_pairs, d_vis_w,
-                       d_vis_o, j->d_pred, vis_words, j->reset_epoch);
+                       d_vis_o, j->d_pred, vis_words, j->reset_epoch, j->d_tstat, j->d_use_probe, j->predict);
     DPL_LAUNCH_CHECK("k_octav_oneread_init");
+    return 0;
+}
+
+int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
+    DPL_JOB_CHECK("dpl_octav_oneread_probe");
+    hipLaunchKernelGGL(k_octav_probe, dim3((unsigned)j->n_pairs), dim3(kThreads), 0, (hipStream_t)s, j->d_pair_spans, j->d_seg_ptrs,
+                       j->d_pred, j->d_use_probe, j->d_pred_pair, (uint32_t)j->n_tensors, j->dynamic_sym, j->max_iters,
+                       j->probe_z > 0.0f ? j->probe_z : kProbeZ, j->d_pair_order);
+    DPL_LAUNCH_CHECK("k_octav_probe");
     return 0;
 }
 
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
-                       j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), j->d_pred,
+                       j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), j->d_pred_pair,
                        (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
@@ -1377,9 +1666,9 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(j->d_lh);
     dpl_octav_state* ctl = j->d_states + j->n_pairs;
     auto walk = [&](unsigned grid, const uint32_t* order, int phase) {
-        hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, j->d_pred,
+        hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, j->d_pred_pair,
                            d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
-                           phase == 2 ? g_rescue_fail_every : g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_list1);
+                           g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_pred, j->d_tstat);
     };
     const int64_t n_big = j->n_pairs - j->n_small;   // d_pair_order: largest first, so the small pairs are its last n_small entries
     if (!j->sorted) {   // every pair walked from registers by one workgroup
@@ -1387,12 +1676,12 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
         DPL_LAUNCH_CHECK("k_octav_walk");
     } else {
         if (n_big > 0) {
-            hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)j->n_slices), dim3(kThreads), 0, st, j->d_slices, j->d_pair_slice0, lh, j->d_pred,
+            hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)j->n_slices), dim3(kThreads), 0, st, j->d_slices, j->d_pair_slice0, lh, j->d_pred_pair,
                                (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slice_chunk0, j->d_dir);
             DPL_LAUNCH_CHECK("k_octav_sort");
             hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, st, j->d_states, ctl, j->d_pair_order, lh,
-                               j->d_pair_slice0, j->d_pred, d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices,
-                               j->d_slice_chunk0, j->d_dir, j->dynamic_sym, j->max_iters, g_exact_fail_every);
+                               j->d_pair_slice0, j->d_pred_pair, d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices,
+                               j->d_slice_chunk0, j->d_dir, j->dynamic_sym, j->max_iters, g_exact_fail_every, j->d_pred, j->d_tstat);
             DPL_LAUNCH_CHECK("k_octav_walk_sorted");
         }
         if (j->n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
@@ -1408,9 +1697,22 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     if (int e = dpl_octav_rescue_gather_launch(j->d_missed, j->d_states, j->n_pairs, j->d_pair_spans, j->d_seg_ptrs, j->d_rescue_bm,
                                                j->d_pair_base, j->d_list1, st))
         return e;
-    walk((unsigned)j->n_pairs, j->d_pair_order, 2);
-    DPL_LAUNCH_CHECK("k_octav_walk(rescue)");
-    if (int e = check_blocks("dpl_octav_oneread_finish", j->n_items, j->d_block_begin, j->n_blocks)) return e;
+    hipLaunchKernelGGL(k_octav_walk_rescue, dim3(kRescueGrid), dim3(kThreads), 0, st, j->d_states, ctl, lh, j->d_pair_slice0,
+                       (uint32_t)j->n_tensors, j->d_pair_base, j->d_slices, j->dynamic_sym, j->max_iters, g_rescue_fail_every,
+                       j->d_rescue_bm, j->d_missed, j->d_list1);
+    DPL_LAUNCH_CHECK("k_octav_walk_rescue");
+    return j->compaction_inline ? dpl_octav_oneread_compaction(j, s) : 0;
+}
+
+// The compaction route for the pairs the control block counts in cnt_le (after dpl_octav_oneread_finish): what neither the walk
+// nor the rescue could finish.  Its kernels return at once when there is none, but a caller that can read the count later (the
+// pipeline: two batches on) skips the call — four launches with large footprints would otherwise wait for slots beside the
+// next batch's streaming kernel.
+int dpl_octav_oneread_compaction(const dpl_octav_oneread_job* j, dpl_stream_t s) {
+    DPL_JOB_CHECK("dpl_octav_oneread_compaction");
+    if (j->max_iters <= 0) return 0;
+    if (int e = check_blocks("dpl_octav_oneread_compaction", j->n_items, j->d_block_begin, j->n_blocks)) return e;
+    hipStream_t st = (hipStream_t)s;
     return dpl_octav_fallback_route(j->d_items, j->n_items, j->d_block_begin, j->n_blocks, j->d_seg_ptrs, j->d_states, j->n_pairs,
                                     j->d_pair_spans, j->d_pair_base, j->d_pair_order, j->d_list0, j->d_list1, j->dynamic_sym,
                                     j->max_iters, st);
@@ -1418,8 +1720,10 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
 
 int dpl_octav_run_oneread(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     if (int e = dpl_octav_oneread_prepare(j, s)) return e;
+    if (int e = dpl_octav_oneread_probe(j, s)) return e;
     if (int e = dpl_octav_oneread_stream(j, s)) return e;
-    return dpl_octav_oneread_finish(j, s);
+    if (int e = dpl_octav_oneread_finish(j, s)) return e;
+    return j && !j->compaction_inline ? dpl_octav_oneread_compaction(j, s) : 0;
 }
 
 }  // extern "C"

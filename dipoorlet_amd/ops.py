@@ -159,6 +159,11 @@ class TensorSetPlan:
                     # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
                     vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
                     pred=torch.zeros(self.T, 128, dtype=torch.int32, device=self.device), calls=0,
+                    # the row each pair gathers by (the tensor's row above, or the one from a sample of the pair itself), this
+                    # batch's choice per tensor, and what the choice is made from
+                    pred_pair=torch.zeros(self.n_pairs, 128, dtype=torch.int32, device=self.device),
+                    use_probe=torch.zeros(self.T, dtype=torch.int32, device=self.device),
+                    tstat=torch.zeros(self.T, 8, dtype=torch.float32, device=self.device),
                     # rescue of the pairs a walk could not finish: their exact bracket, the work list of the re-read
                     rescue_bm=torch.empty(self.n_pairs, 64, dtype=torch.int32, device=self.device),
                     missed=torch.empty(self.n_pairs, 3, dtype=torch.int32, device=self.device))
@@ -172,6 +177,7 @@ class TensorSetPlan:
         if one:
             one["vis"].zero_()
             one["pred"].zero_()
+            one["tstat"].zero_()
             one["calls"] = 0
         for st in getattr(self, "_octav_pipe_sets", None) or []:
             if st["pending"]:
@@ -323,8 +329,8 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
         k = res["calls"]
         res["calls"] = k + 1
         epoch, first = divmod(k, _ONEREAD_EPOCH)
-        job = _oneread_job(plan, res, tab, states, res["lh"], res["pred"], l0, epoch % 2, 1 if first == 0 else 0,
-                           _walk_sorted(plan), dyn)
+        job = _oneread_job(plan, res, tab, states, res["lh"], res["pred"], res["pred_pair"], res["use_probe"], l0, epoch % 2,
+                           1 if first == 0 else 0, _walk_sorted(plan), dyn)
         _hip.check(L.dpl_octav_run_oneread(C.byref(job), _stream()), "dpl_octav_run_oneread")
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
@@ -349,7 +355,11 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     return out
 
 
-def _oneread_job(plan, res, tab, states, lh, pred, l0, write_epoch, reset_epoch, sorted_walk, dyn):
+_PREDICT = {"learned": 0, "probe": 1, "auto": 2}
+
+
+def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, write_epoch, reset_epoch, sorted_walk, dyn,
+                 compaction_inline=1):
     """The C ABI's dpl_octav_oneread_job for one batch of `plan` (all device pointers; the tensors stay alive in the caller)."""
     spans, base, order, _, l1 = plan.octav_scratch()
     w = plan.work("octav", per_image=True)
@@ -361,9 +371,14 @@ def _oneread_job(plan, res, tab, states, lh, pred, l0, write_epoch, reset_epoch,
     j.n_pairs, j.n_tensors, j.n_small = plan.n_pairs, plan.T, res["n_small"]
     j.d_items, j.n_items, j.d_block_begin, j.n_blocks = d_items.value, n_items, d_bb.value, n_blocks
     j.d_seg_ptrs, j.d_states, j.d_lh, j.d_pred = tab.data_ptr(), states.data_ptr(), lh.data_ptr(), pred.data_ptr()
+    j.d_pred_pair, j.d_use_probe, j.d_tstat = pred_pair.data_ptr(), use_probe.data_ptr(), res["tstat"].data_ptr()
+    # DPL_OCTAV_PREDICT = learned | probe | auto: where a pair's prediction comes from (auto: chosen per tensor on the device)
+    j.predict = _PREDICT[os.environ.get("DPL_OCTAV_PREDICT", "auto")]
+    j.probe_z = float(os.environ.get("DPL_PROBE_Z", "0"))
     j.d_list0, j.d_list1, j.d_dir = l0.data_ptr(), l1.data_ptr(), res["dir"].data_ptr()
     j.d_rescue_bm, j.d_missed, j.d_vis = res["rescue_bm"].data_ptr(), res["missed"].data_ptr(), res["vis"].data_ptr()
     j.write_epoch, j.reset_epoch, j.sorted, j.dynamic_sym, j.max_iters = write_epoch, reset_epoch, sorted_walk, dyn, _OCTAV_MAX_ITERS
+    j.compaction_inline = compaction_inline
     return j
 
 
@@ -404,6 +419,7 @@ class OctavPipeline:
 
     def reset_stats(self):
         self.batches = self.fallback_batches = self.fallback_pairs = self.sorted_batches = self.compaction_pairs = 0
+        self.probe_tensors = 0
         self.list_share = self.max_share = 0.0    # gathered values / elements (running mean / maximum over the settled batches)
 
     @staticmethod
@@ -420,11 +436,15 @@ class OctavPipeline:
             # the prediction snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
             # taken care of (two submits later), after the snapshot of call k + 2 has been written
             plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(3)]
+            plan._octav_pipe_use = [res["use_probe"]] + [torch.zeros_like(res["use_probe"]) for _ in range(3)]
             sets = []
             for j in range(2):
                 sets.append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(),
+                                 use_host=torch.zeros(plan.T, dtype=torch.int32).pin_memory(),
                                  lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
-                                 l0=l0 if j == 0 else torch.empty_like(l0), done=None, refs=None, pending=False, k=-1))
+                                 l0=l0 if j == 0 else torch.empty_like(l0),
+                                 pred_pair=res["pred_pair"] if j == 0 else torch.zeros_like(res["pred_pair"]),
+                                 done=None, refs=None, pending=False, k=-1))
             plan._octav_pipe_sets = sets
         return sets
 
@@ -432,7 +452,8 @@ class OctavPipeline:
         """State array + prediction snapshot (in set `st`) for the plan's call number k."""
         ep, first = divmod(k, _ONEREAD_EPOCH)
         job = _oneread_job(plan, res, plan._octav_pipe_pred[k % 4], plan._octav_pipe_states[k % 4], st["lh"], plan._octav_pipe_pred[k % 4],
-                           st["l0"], ep % 2, 1 if first == 0 else 0, 0, self.dyn)    # (prepare reads neither tensors nor the walk choice)
+                           st["pred_pair"], plan._octav_pipe_use[k % 4], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
+                           self.dyn)    # (prepare reads neither tensors nor the walk choice)
         _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
         st["prepared"] = k
 
@@ -456,6 +477,7 @@ class OctavPipeline:
         # gathered values; pairs rescued by a re-read of the pair + pairs that ended on the compaction route
         listed, failed = float(ctl.sum), int(ctl.len0) + int(ctl.cnt_le)
         self.compaction_pairs += int(ctl.cnt_le)
+        self.probe_tensors += int(st["use_host"].sum().item())     # tensors whose pairs predicted from a sample of themselves
         self.batches += 1
         share = listed / max(1, plan.batch * sum(plan.elems))
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
@@ -471,6 +493,13 @@ class OctavPipeline:
         if failed:
             self.fallback_pairs += failed
             self.fallback_batches += 1
+        if ctl.cnt_le:
+            # what neither the walk nor the rescue could finish (a bracket that cannot be formed: flat distributions, values
+            # beyond 2^14): the compaction route, launched only now that the count is known — the set's batch is two submits
+            # old, its tensors are still referenced — and its results written over the batch's output rows
+            _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(st["job"]), C.c_void_p(self.side.cuda_stream)),
+                       "dpl_octav_oneread_compaction")
+            self._finish(plan, res, st)
 
     def submit(self, plan, tensors):
         form = os.environ.get("DPL_OCTAV_FORM", "oneread")
@@ -496,8 +525,10 @@ class OctavPipeline:
         L = _hip.lib()
         if cur.get("prepared") != k:
             self._prepare(plan, res, cur, k, main.cuda_stream)
-        job = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0,
-                           cur["sorted"], self.dyn)
+        job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
+                                        plan._octav_pipe_use[k % 4], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
+                                        compaction_inline=0)
+        _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
         _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
         streamed = torch.cuda.Event()
         streamed.record(main)
@@ -506,6 +537,7 @@ class OctavPipeline:
         _hip.check(L.dpl_octav_oneread_finish(C.byref(job), C.c_void_p(self.side.cuda_stream)), "dpl_octav_oneread_finish")
         with torch.cuda.stream(self.side):
             cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)    # (statistics only: _settle)
+            cur["use_host"].copy_(plan._octav_pipe_use[k % 4], non_blocking=True)
         self._finish(plan, res, cur)
         cur["pending"] = True
         if all(p is not plan for p, _ in self._touched):

@@ -161,20 +161,28 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  *   the RESCUE of a pair whose iterate left the gathered bins, on the device and without the host: the walk forms the pair's
  *     exact bracket from its histogram and puts the pair on a work list (d_missed); k_octav_rescue_gather re-reads THOSE PAIRS
  *     ALONE (many workgroups per pair) for the bracket's bins and k_octav_walk (phase 2) walks them; what even that cannot
- *     finish (a bracket that cannot be formed: flat distributions, values >= 2^14) ends on the compaction route.  All of
- *     these are launched behind every walk and return at once when the control block (d_states[n_pairs]) lists nothing.
- * The prediction (job.d_pred rows: the bins to gather, at most 255 of them, + per bitmap word the number of gathered bins
- * below it: a gathered bin's RANK) is what the same tensor's walks stepped into in earlier batches (two alternating epoch
- * accumulators in d_vis, snapshot taken by dpl_octav_oneread_prepare; a plan's first batch has none: start with d_vis
- * zeroed, every large pair is then rescued); pairs of at most dpl_octav_small_pair() elements gather their whole window.
+ *     finish (a bracket that cannot be formed: flat distributions, values >= 2^14) ends on the compaction route
+ *     (dpl_octav_oneread_compaction).  The rescue kernels are launched behind every walk and return at once when the
+ *     control block (d_states[n_pairs]) lists nothing.
+ * The prediction (a row per pair: the bins to gather, at most 255 of them, + per bitmap word the number of gathered bins
+ * below it: a gathered bin's RANK) comes from one of two sources, chosen per tensor and batch on the device (job.predict):
+ *   - what the same tensor's walks stepped into in earlier batches (two alternating epoch accumulators in d_vis, snapshot
+ *     d_pred taken by dpl_octav_oneread_prepare): the narrowest there is while the images are alike, useless when they differ;
+ *   - a strided SAMPLE of the pair itself (dpl_octav_oneread_probe, k_octav_probe: 64 bytes of every 1 KiB binned like the
+ *     full pass, the iteration walked on the sample's histogram with the sampling variance of every iterate carried along;
+ *     gathered: the bins within 3 standard deviations of each sampled iterate + the sparse tail): costs a read of 1/16 of
+ *     the pair and about twice the gathered values, but does not depend on any other image.
+ * Pairs of at most dpl_octav_small_pair() elements gather their whole window.
  *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
  *     of 4 elements); item.reserved = the pair's slice count; pair_slice0[2 slot], [2 slot + 1] = first / one-past-last
  *     slice of the pair in slot `slot` (spans carry slots 0 .. n_spans-1).  Returns the slice count (call with out = NULL
  *     to size), -3 when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
  * One HOST struct carries a batch's buffers (all pointers are device pointers):
- *   dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot;
+ *   dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot and the choice per tensor;
+ *   dpl_octav_oneread_probe   = the pairs' prediction rows (needs the batch's tensors: d_seg_ptrs);
  *   dpl_octav_oneread_stream  = k_octav_oneread;
- *   dpl_octav_oneread_finish  = the walk and everything behind it;       dpl_octav_run_oneread = all three on one stream.
+ *   dpl_octav_oneread_finish  = the walk and the rescue behind it (+ dpl_octav_oneread_compaction when job.compaction_inline);
+ *   dpl_octav_run_oneread = all of them on one stream.
  * stream and finish may run on different streams (the walk of batch i beside the streaming kernel of batch i + 1) when the
  * caller orders finish(i) after stream(i) and gives concurrently live batches their own d_states / d_lh / d_pred / d_list0 /
  * d_rescue_bm / d_missed; d_vis is shared (bits are only ever OR-ed in), d_list1 may be shared by batches whose finish calls
@@ -197,7 +205,9 @@ typedef struct dpl_octav_oneread_job {
     const float* const* d_seg_ptrs;
     dpl_octav_state* d_states;       /* [n_pairs + 1]; the last one is the control block */
     uint64_t* d_lh;                  /* [n_slices, 2048]: one histogram row per slice (plain stores, nothing to zero) */
-    uint32_t* d_pred;                /* [n_tensors, 128] */
+    uint32_t* d_pred;                /* [n_tensors, 128]: the prediction from earlier batches (snapshot of d_vis) */
+    uint32_t* d_pred_pair;           /* [n_pairs, 128]: the row each pair's slices gather by (dpl_octav_oneread_probe writes it) */
+    uint32_t* d_use_probe;           /* [n_tensors]: this batch's choice per tensor (dpl_octav_oneread_prepare writes it) */
     float* d_list0;                  /* gathered values, region per pair */
     float* d_list1;                  /* rescue / compaction lists, same layout */
     uint16_t* d_dir;                 /* [n_chunks, dpl_octav_dir_row()]: per sorted run the position of each rank's first value */
@@ -205,9 +215,15 @@ typedef struct dpl_octav_oneread_job {
     uint32_t* d_missed;              /* [n_pairs, 3]: (pair, first unit, units) of the rescued pairs */
     /* carried across batches */
     uint32_t* d_vis;                 /* [2, n_tensors, 64] epoch accumulators; walks add to d_vis[write_epoch], cleared first when reset_epoch != 0 */
+    float* d_tstat;                  /* [n_tensors, 8]: what each tensor's prediction from earlier batches would have cost lately (zeroed by the caller once) */
     int32_t write_epoch, reset_epoch;
     int32_t sorted;                  /* 0: lists scanned whole from registers (short lists), 1: sorted runs */
-    int32_t dynamic_sym, max_iters, reserved;
+    int32_t dynamic_sym, max_iters;
+    int32_t predict;                 /* 0: every tensor predicts from earlier batches, 1: every pair from a sample of itself, 2: chosen per
+                                        tensor and batch on the device (by what the first would have listed / missed in the last batches) */
+    float probe_z;                   /* width of the sample's brackets in standard deviations; 0: the default (3) */
+    int32_t compaction_inline;       /* 1: dpl_octav_oneread_finish ends with dpl_octav_oneread_compaction; 0: the caller reads d_states[n_pairs].cnt_le
+                                        when the batch is done and calls it only when that is non-zero */
 } dpl_octav_oneread_job;
 uint32_t dpl_octav_slice_cap(void);
 uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run */
@@ -215,8 +231,10 @@ uint32_t dpl_octav_dir_row(void);    /* uint16 entries of a run's directory row 
 uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements gather their whole window */
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
 int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* job, dpl_stream_t s);
+int dpl_octav_oneread_probe(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_finish(const dpl_octav_oneread_job* job, dpl_stream_t s);
+int dpl_octav_oneread_compaction(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_run_oneread(const dpl_octav_oneread_job* job, dpl_stream_t s);
 /* TEST HOOKS (0 = off; return the previous setting): _exact_ makes the exact walk of dpl_octav_run_bracket and the first walk
  * of the one-read form reject every `every`-th pair, so that the restart paths — taken in production only when an iterate

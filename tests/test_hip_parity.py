@@ -435,10 +435,10 @@ def _restart_path(dev, form):
     if form == "oneread":
         # the one-read form RESCUES a rejected pair (its exact bracket, a re-read of that pair alone, a second walk); only
         # the pairs that gather their whole window anyway (here: the 1000-element tensor) go straight to the compaction route
-        assert int(ctl.len0) + int(ctl.cnt_le) == plan.n_pairs // 2 and int(ctl.len0) >= plan.n_pairs // 4
+        assert int(ctl.len0) + int(ctl.cnt_le) >= plan.n_pairs // 2 and int(ctl.len0) >= plan.n_pairs // 4
         assert int(ctl.len1) >= int(ctl.len0)                # units of the re-read
         got2, ctl2 = hooked(2)                               # ... and when the rescue walk rejects them too: compaction route
-        assert int(ctl2.cnt_le) == plan.n_pairs // 2
+        assert int(ctl2.cnt_le) >= plan.n_pairs // 2
         assert _same_steps(got2, want)
     else:
         assert int(ctl.cnt_le) == plan.n_pairs // 2          # control block: pairs that took the compaction route

@@ -48,6 +48,7 @@ def parse():
                    "17 = more than the one-read OCTAV prediction remembers (2 x 8 batches)")
     p.add_argument("--mse-jitter", default="0.03,0.1", help="extra one-sweep mse objects with per-image contrast jitter (comma list; '' = none)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
+    p.add_argument("--fq-reps", type=int, default=3, help="timed passes of the fake-quant object (0 skips it)")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher / rendezvous / collective plumbing only, on CPU tensors (no kernels, no GPU): what the "
                         "world_size-2 gloo test on the build box runs")
@@ -156,8 +157,16 @@ def main():
             dist.all_reduce(gmin[1], op=dist.ReduceOp.MAX)
             dist.all_reduce(hist, op=dist.ReduceOp.SUM)
             dist.barrier()
+        ok = torch.tensor([1.0 if int(hist[0, 0]) == world * (world + 1) // 2 else 0.0])
+        per_rank_ok = [torch.zeros(1) for _ in range(world)]
+        if use_dist:
+            dist.all_gather(per_rank_ok, ok)
+        else:
+            per_rank_ok = [ok]
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "backend": backend if use_dist else None,
+                              "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
+                              "per_rank_ok": [bool(x.item()) for x in per_rank_ok],
                               "range": [float(gmin[0][0]), float(gmin[1][0])], "hist_checksum": int(hist.sum().item()),
                               "hist_checksum_expected": T * bins * world * (world + 1) // 2}), flush=True)
         if use_dist:
@@ -227,7 +236,14 @@ def main():
     for _ in range(a.steps):
         clip = hist_sweep(True)
     fence()
-    dt_hist = max_over_ranks(time.perf_counter() - t0)
+    dt_local = time.perf_counter() - t0
+    dt_hist = max_over_ranks(dt_local)
+    if use_dist:   # every rank's own rate (images/s over its own clock), gathered for the line
+        rates = [torch.zeros(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu") for _ in range(world)]
+        dist.all_gather(rates, torch.tensor([N_HIST * a.steps / dt_local], dtype=torch.float64, device=rates[0].device))
+        per_rank_rates = [float(r.item()) for r in rates]
+    else:
+        per_rank_rates = [N_HIST * a.steps / dt_local]
     hist_kern_ms = sum(s.elapsed_time(e) for s, e in hist_ev) / max(1, len(hist_ev))
     hist_checksum = int(acc.hist.sum().item())        # = elements x images x ranks when every rank's counts arrived
     clip_checksum = float(clip.double().abs().sum().item())
@@ -337,6 +353,47 @@ def main():
             del jp
             torch.cuda.empty_cache()
 
+    # ------------------------------------------------------------------ the fake-quant forward (quantize.py:197-239)
+    # One batch of the ResNet-50 activation set through k_fake_quant_*: per tensor (what the reference's activation Q/DQ nodes
+    # do) and per channel (axis 1, the weights' granularity, on the same data): 4 B read + 4 B written per element; the time
+    # is the sum of the kernels' HIP-event durations on the launch stream.
+    fake_quant = None
+    if a.fq_reps > 0:
+        from dipoorlet_amd.synthetic import resnet50_tensor_shapes
+        shapes = resnet50_tensor_shapes()
+        xs = pool[0]
+        ybuf = torch.empty(B * max(elems), dtype=torch.float32, device=dev)
+        qp = []
+        for x, (c, h, w) in zip(xs, shapes):
+            amax = x.abs().amax().clamp_min(1e-6)
+            cmax = x.view(B, c, h * w).abs().amax((0, 2)).clamp_min(1e-6)
+            qp.append(((amax / 127.0).reshape(1), torch.zeros(1, dtype=torch.int32, device=dev),
+                       (cmax / 127.0).contiguous(), torch.zeros(c, dtype=torch.int32, device=dev)))
+        fq = {}
+        for mode in ("per_tensor", "per_channel"):
+            tot = []
+            for rep in range(a.fq_reps + 1):
+                evs = []
+                for x, (c, h, w), (s1, z1, sc, zc) in zip(xs, shapes, qp):
+                    y = ybuf[:x.numel()].view(B, c, h * w)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    if mode == "per_tensor":
+                        ops.fake_quant(x.view(B, c, h * w), s1, z1, -128, 127, out=y)
+                    else:
+                        ops.fake_quant(x.view(B, c, h * w), sc, zc, -128, 127, axis=1, out=y)
+                    e1.record()
+                    evs.append((e0, e1))
+                torch.cuda.synchronize()
+                if rep > 0:   # (the first pass warms up)
+                    tot.append(sum(p.elapsed_time(q) for p, q in evs))
+            ms = sum(tot) / len(tot)
+            gbps = 8 * E * B / (ms * 1e-3) / 1e9
+            fq[mode] = {"kernel_ms_per_batch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": T}
+        fake_quant = {"workload": f"ResNet-50 activation set, one batch of {B} images, fused QuantizeLinear -> DequantizeLinear, int8 grid",
+                      "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "bytes_per_batch": 8 * E * B, **fq}
+        del ybuf
+
     # ------------------------------------------------------------------ the line
     kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once
     achieved = kernel_bytes / (hist_kern_ms * 1e-3) / 1e9 if hist_kern_ms > 0 else 0.0
@@ -376,13 +433,15 @@ def main():
                    "batch": B, "bins": a.bins, "algo": a.algo, "images_per_step_per_gpu": N_MSE if headline_mse else N_HIST,
                    "resident_pool_batches": len(pool), "device": devname},
         "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9,
-        "per_gpu_images_per_s": hist_rate / world,
+        "per_gpu_images_per_s": hist_rate / world, "per_rank_images_per_s": per_rank_rates,
+        "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
+        "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if use_dist else None,
         "hist_checksum": hist_checksum, "hist_checksum_expected": E * N_HIST * world, "clip_checksum": clip_checksum,
         "roofline": (mse["roofline"] if headline_mse else
                      {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes,
                       "avg_kernel_ms": hist_kern_ms}),
-        "mse": mse, "mse_jitter": mse_jitter or None,
+        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant,
     }
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:

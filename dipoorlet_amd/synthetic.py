@@ -68,6 +68,23 @@ def resnet50_tensor_elems():
     return [e for _, e, _ in resnet50_tensors()]
 
 
+def resnet50_tensor_shapes():
+    """(C, H, W) per image of every tensor of resnet50_tensors(), same order (the fully connected ones as (C, 1, 1))."""
+    out = [(3, 224, 224), (64, 112, 112), (64, 112, 112), (64, 56, 56)]
+    sp = 56
+    for li, (nb, w) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
+        for bi in range(nb):
+            osp = sp // 2 if (bi == 0 and li > 0) else sp
+            out += [(w, sp, sp), (w, sp, sp), (w, osp, osp), (w, osp, osp), (4 * w, osp, osp)]
+            if bi == 0:
+                out.append((4 * w, osp, osp))
+            out += [(4 * w, osp, osp), (4 * w, osp, osp)]
+            sp = osp
+    out += [(2048, 1, 1), (2048, 1, 1), (1000, 1, 1)]
+    assert [c * h * w for c, h, w in out] == resnet50_tensor_elems()
+    return out
+
+
 def synth_activations(spec, batch, device, seed=1234, image_jitter=0.0):
     """One batched tensor set on the device.  `spec`: list of (name, elems, kind) or of bare elems.
     image_jitter > 0 scales every image of every tensor by its own factor in [1 - jitter, 1 + jitter] (images of real

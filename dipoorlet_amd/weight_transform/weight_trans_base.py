@@ -29,8 +29,8 @@ def _recalibrate(graph, args):
     save_clip_val(act, weight, args, act_fname=f"act_clip_val.json.rank{rank}",
                   weight_fname=f"weight_clip_val.json.rank{rank}")
     dist.barrier()
-    if rank == 0:
-        reduce_clip_val(world, args)
+    if rank == 0:   # (as __main__: with the statistics merged over RCCL every rank already holds the whole set's clips)
+        reduce_clip_val(world, args, already_merged=(getattr(args, "merge", "allreduce") != "reference"))
     dist.barrier()
     return load_clip_val(args)
 

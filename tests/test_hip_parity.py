@@ -267,6 +267,48 @@ def test_fake_quant_per_channel_and_zero_point_vs_oracle(dev):
     assert np.array_equal(y.cpu().numpy(), O.fake_quant_qdq(x, np.float32(0.037), -5, signed=True))
 
 
+@pytest.mark.parametrize("shape,axis", [((64, 64, 3, 3), 0), ((512, 2048, 1, 1), 0), ((8, 256, 56, 56), 1)])
+def test_fake_quant_per_channel_vectorised_kernel_vs_oracle(dev, shape, axis):
+    """a12 (quantize.py:197-239, ada_quant_layer.py:28-36): the per-channel kernel every real Conv weight / activation takes
+    — k_fake_quant_channel<true>: inner extent a multiple of 4 and 16-byte aligned buffers, one division per 16-byte vector —
+    against the oracle, bit for bit; then the same data through an UNALIGNED view, which the dispatcher sends to
+    k_fake_quant_channel<false>.  Zero points 0 / 3 / 191 / 255 (uint8) and their int8 storage forms, saturation at both
+    ends, exact .5 ties (power-of-two scales: x / scale is exact), -0.0, values far outside the grid."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(sum(shape) + axis)
+    C_ = shape[axis]
+    inner = int(np.prod(shape[axis + 1:]))
+    assert inner % 4 == 0                                   # -> the vectorised variant (calib_kernels.hip dpl_fake_quant)
+    scale = rng.uniform(0.01, 0.1, C_).astype(np.float32)
+    scale[::3] = np.float32(2.0) ** rng.integers(-6, -2, scale[::3].size)          # power-of-two scales: exact ties
+    x = rng.standard_normal(shape).astype(np.float32) * 4
+    flat = x.reshape(-1)
+    k = rng.integers(-300, 300, flat.size // 8).astype(np.float32)
+    sc_full = np.broadcast_to(scale.reshape([-1 if i == axis else 1 for i in range(len(shape))]), shape).reshape(-1)
+    idx = rng.choice(flat.size, k.size, replace=False)
+    flat[idx] = (k + np.float32(0.5)) * sc_full[idx]                                # ties (exact where the scale is 2^-n)
+    flat[rng.choice(flat.size, 64, replace=False)] = np.float32(1e6)                # saturates high
+    flat[rng.choice(flat.size, 64, replace=False)] = np.float32(-1e6)               # saturates low
+    flat[rng.choice(flat.size, 64, replace=False)] = np.float32(-0.0)
+    xt = torch.from_numpy(x).to(dev)
+    buf = torch.empty(x.size + 1, dtype=torch.float32, device=dev)
+    x_un = buf[1:].view(shape)                              # 4-byte aligned only: forces k_fake_quant_channel<false>
+    x_un.copy_(xt)
+    assert xt.data_ptr() % 16 == 0 and x_un.data_ptr() % 16 != 0
+    zps = np.array([0, 3, 191, 255], np.int32)
+    for signed in (False, True):
+        zp_u = zps[rng.integers(0, 4, C_)]
+        zp = np.where(zp_u > 127, zp_u - 256, zp_u).astype(np.int32) if signed else zp_u
+        qlo, qhi = (-128, 127) if signed else (0, 255)
+        ref = O.fake_quant_qdq(x, scale, zp, axis=axis, signed=signed)
+        assert (np.abs(ref).max() > 0) and np.isfinite(ref).all()
+        for name, src in (("vectorised", xt), ("unaligned view", x_un)):
+            y = ops.fake_quant(src, torch.from_numpy(scale), torch.from_numpy(zp), qlo, qhi, axis=axis)
+            got = y.cpu().numpy()
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (name, signed, shape,
+                                                                               int((got.view(np.uint32) != ref.view(np.uint32)).sum()))
+
+
 def test_cos_accumulate(dev):
     from dipoorlet_amd import ops
     a = make_tensor("normal", 123457, 1)

@@ -48,6 +48,8 @@ def parse():
                    "17 = more than the one-read OCTAV prediction remembers (2 x 8 batches)")
     p.add_argument("--mse-jitter", default="0.03,0.1", help="extra one-sweep mse objects with per-image contrast jitter (comma list; '' = none)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
+    p.add_argument("--e2e-images", type=int, default=1024, help="N of the end-to-end CLI object (real .onnx + .bin files, fresh process; 0 skips it)")
+    p.add_argument("--vit-images", type=int, default=256, help="N of the ViT-B/16 mse object (0 skips it)")
     p.add_argument("--fq-reps", type=int, default=3, help="timed passes of the fake-quant object (0 skips it)")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher / rendezvous / collective plumbing only, on CPU tensors (no kernels, no GPU): what the "
@@ -187,6 +189,7 @@ def main():
     jitter = float(os.environ.get("DPL_BENCH_JITTER", "0"))
     pool = [synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j, image_jitter=jitter) for j in range(max(1, a.pool))]
     plan = ops.TensorSetPlan(elems, B, dev)
+    n_pool = len(pool)
 
     def fence():
         torch.cuda.synchronize()
@@ -253,12 +256,9 @@ def main():
     # what earlier sweeps learned (octav_reset) inside the timed region, so the first batches run without a prediction as they
     # do in a fresh process.  The pool holds more distinct batches than the prediction remembers (2 epochs of
     # DPL_ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
-    mse, mse_jitter = None, {}
+    mse, mse_jitter, vit_mse = None, {}, None
     if a.mse_steps > 0:
         import ctypes
-        n_mse_batches = N_MSE // B
-        states = torch.empty((plan.n_pairs + 1) * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
-        rows = torch.empty(N_MSE, T, 3, dtype=torch.float32, device=dev)
         form = os.environ.get("DPL_OCTAV_FORM", "oneread")
         pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form == "oneread"
         pipe = ops.OctavPipeline(False, dev) if pipeline else None
@@ -269,8 +269,12 @@ def main():
         if inject > 0:
             _hip.lib().dpl_test_hook_exact_fail_every(inject)
 
-        def run_mse(mpool, steps, jit):
+        def run_mse(mpool, steps, jit, plan=plan, n_images=N_MSE, net="ResNet-50"):
             mse_ev = []
+            B, T, E = plan.batch, plan.T, sum(plan.elems)        # (the ViT object runs its own plan through the same code)
+            n_mse_batches = n_images // B
+            rows = torch.empty(n_images, T, 3, dtype=torch.float32, device=dev)
+            states = torch.empty((plan.n_pairs + 1) * ctypes.sizeof(_hip.OctavState), dtype=torch.uint8, device=dev)
 
             def mse_sweep(timed):
                 if timed:
@@ -320,9 +324,9 @@ def main():
                     err = abs(got - want) / max(abs(want), 1.0)
                     worst = max(worst, err)
                     ok = ok and err <= 1e-5
-            obj = {"metric": f"calibration images/sec, ResNet-50 ONNX N={N_MSE}, -A mse", "value": N_MSE * world * steps / dt_mse,
+            obj = {"metric": f"calibration images/sec, {net} ONNX N={n_images}, -A mse", "value": n_images * world * steps / dt_mse,
                    "unit": "images/s", "steps": steps, "ms_per_step": dt_mse / steps * 1e3,
-                   "workload": f"ResNet-50 activation set, -A mse (OCTAV per image and tensor), N={N_MSE} images per GPU in "
+                   "workload": f"{net} activation set (T={T} tensors, {E} fp32 elems/img), -A mse (OCTAV per image and tensor), N={n_images} images per GPU in "
                                f"batches of {B}, form '{form}', every sweep a cold run, {len(mpool)} distinct resident batches"
                                + (f", per-image contrast jitter +-{jit:g}" if jit else ""),
                    "roofline": {"bound": "hbm", "kernel": f"OCTAV batch, form '{form}'" + (" (k_octav_oneread of batch i+1 beside k_octav_walk of batch i)"
@@ -340,7 +344,9 @@ def main():
                                      "listed_share_of_elements": pipe.list_share, "listed_share_max": pipe.max_share,
                                      "batches_walked_sorted": pipe.sorted_batches,
                                      "source": os.environ.get("DPL_OCTAV_PREDICT", "auto"),
-                                     "tensors_predicted_from_own_sample": pipe.probe_tensors / max(1, pipe.batches * T)}
+                                     "tensors_predicted_from_own_sample": pipe.probe_tensors / max(1, pipe.batches * T),
+                                     # 1024-element tiles holding a non-zero value outside the 2^-18 .. 2^14 window (read twice)
+                                     "tiles_read_twice_share": pipe.tiles_reread / max(1, pipe.batches * B * sum((e + 1023) // 1024 for e in plan.elems))}
             return obj
 
         if len(pool) < min_pool and rank == 0:
@@ -351,6 +357,21 @@ def main():
             jp = [synth_activations(spec, B, dev, seed=99 + 1000 * rank + j, image_jitter=jit) for j in range(len(pool))]
             mse_jitter[f"{jit:g}"] = run_mse(jp, 1, jit)
             del jp
+            torch.cuda.empty_cache()
+        # BASELINE configs[4]'s workload on one GPU: ViT-B/16 activations produced by the repo's own graph executor (every node
+        # output exposed: 557 tensors, LayerNorm / erf-GELU / attention-probability tensors among them; the attention logits are
+        # scaled up so that most probabilities lie below the OCTAV window, as in a trained network), N = 256 in batches of 8
+        if a.vit_images > 0:
+            from dipoorlet_amd import models
+            vsess = models.vit_b16(seed=5, attn_gain=10.0).make_session()
+            VB = 8
+            vplan = ops.TensorSetPlan([int(e) for e in vsess.elems_per_image], VB, dev)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(4242 + rank)
+            vpool = [[t.reshape(VB, -1) for t in vsess.run({"input": torch.randn(VB, 3, 224, 224, generator=gen, device=dev)})]
+                     for _ in range(min_pool)]
+            vit_mse = run_mse(vpool, 1, 0.0, plan=vplan, n_images=a.vit_images, net="ViT-B/16")
+            del vpool, vsess
             torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ the fake-quant forward (quantize.py:197-239)
@@ -392,7 +413,55 @@ def main():
             fq[mode] = {"kernel_ms_per_batch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": T}
         fake_quant = {"workload": f"ResNet-50 activation set, one batch of {B} images, fused QuantizeLinear -> DequantizeLinear, int8 grid",
                       "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "bytes_per_batch": 8 * E * B, **fq}
-        del ybuf
+        del ybuf, xs, qp
+
+    # ------------------------------------------------------------------ end to end: real .onnx + .bin files through the CLI
+    # (forward_net.py:192-281 is what this replaces.)  ResNet-50 written as an .onnx by the repo's graph layer, N = 1024 raw fp32
+    # .bin images under a temporary directory, `python -m dipoorlet_amd ... -A hist -D trt --calib_batch 32` in a FRESH child
+    # process (HIP context, MIOpen algorithm search, cold file cache all inside its wall time); the split is the child's own
+    # (--timing_json: host .bin ingest seconds, GPU seconds of the network forward — library work — and of the statistics)
+    e2e = None
+    cpu_sample = [t.cpu() for t in pool[0]] if (rank == 0 and world == 1 and a.cpu_seconds > 0) else None
+    if a.e2e_images > 0 and rank == 0 and world == 1:
+        pool = None            # the child keeps its own 109 GB of activations resident between its two passes
+        torch.cuda.empty_cache()
+        import shutil
+        import tempfile
+        import numpy as np
+        from dipoorlet_amd import models
+        d = tempfile.mkdtemp(prefix="dpl_e2e_")
+        try:
+            g = models.resnet50()
+            g.output_dir = d
+            g.save_onnx_model("r50")
+            os.makedirs(os.path.join(d, "calib", "input"))
+            rs = np.random.default_rng(0)
+            base = rs.standard_normal((64, 3 * 224 * 224)).astype(np.float32)
+            for i in range(a.e2e_images):      # distinct images from 64 base draws (scaled): file I/O is what matters here
+                (base[i % 64] * np.float32(1.0 + 0.01 * (i // 64))).tofile(os.path.join(d, "calib", "input", f"{i}.bin"))
+            del g, base
+            tj = os.path.join(d, "timing.json")
+            cmd = [sys.executable, "-m", "dipoorlet_amd", "-M", os.path.join(d, "r50.onnx"), "-I", os.path.join(d, "calib"),
+                   "-N", str(a.e2e_images), "-A", "hist", "-D", "trt", "-O", os.path.join(d, "out"), "--calib_batch", "32",
+                   "--skip_profiling", "--timing_json", tj]
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+            env["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+            torch.cuda.empty_cache()
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+            wall = time.perf_counter() - t0
+            if r.returncode == 0 and os.path.exists(tj):
+                with open(tj) as f:
+                    tm = json.load(f)
+                with open(os.path.join(d, "out", "act_clip_val.json")) as f:
+                    n_clips = len(json.load(f))
+                e2e = {"command": "python -m dipoorlet_amd -M r50.onnx -I calib -N %d -A hist -D trt --calib_batch 32 --skip_profiling" % a.e2e_images,
+                       "process_wall_s": wall, "images_per_s_process": a.e2e_images / wall,
+                       "images_per_s_calibration": a.e2e_images / tm["tensor_calibration_wall_s"], "tensors": n_clips, "split": tm}
+            else:
+                e2e = {"error": (r.stderr or r.stdout)[-600:], "returncode": r.returncode}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
 
     # ------------------------------------------------------------------ the line
     kernel_bytes = 4 * E * B                                   # k_abs_hist reads the batch once
@@ -431,7 +500,7 @@ def main():
                                 f"N={N_HIST} images per GPU in {n_hist_batches} batches of {B}: range pass + histogram pass + "
                                 f"percentile clip per step"),
                    "batch": B, "bins": a.bins, "algo": a.algo, "images_per_step_per_gpu": N_MSE if headline_mse else N_HIST,
-                   "resident_pool_batches": len(pool), "device": devname},
+                   "resident_pool_batches": n_pool, "device": devname},
         "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9,
         "per_gpu_images_per_s": hist_rate / world, "per_rank_images_per_s": per_rank_rates,
         "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
@@ -441,11 +510,11 @@ def main():
                      {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes,
                       "avg_kernel_ms": hist_kern_ms}),
-        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant,
+        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "e2e": e2e,
     }
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(a.algo, a.bins, pool[0], a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(a.algo, a.bins, cpu_sample, a.cpu_seconds)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

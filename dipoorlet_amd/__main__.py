@@ -4,7 +4,7 @@
 Same flags; same phases where they are in scope: load model -> tensor calibration (sharded over ranks)
 -> per-rank clip JSON -> rank-0 reduce -> load -> profiling (cosine similarity of the fake-quantised
 model, optional) -> weight transforms (--bc, --we, --update_bn, --adaround, --brecq [--drop], --sparse) -> platform deploy file.
-Extra flags: --calib_batch, --resident_gb, --merge {allreduce,reference}, --skip_profiling.
+Extra flags: --calib_batch, --resident_gb, --merge {allreduce,reference}, --skip_profiling, --timing_json.
 """
 import argparse
 import copy
@@ -47,6 +47,8 @@ def build_parser():
     p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
     p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
     p.add_argument("--skip_profiling", default=False, action="store_true")
+    p.add_argument("--timing_json", default=None, help="rank 0 writes where the calibration time went (host .bin ingest, GPU "
+                                                        "forward, GPU statistics, wall) to this file")
     p.add_argument("--keep_bn", default=False, action="store_true",
                    help="do not fold BatchNormalization into the preceding Conv / Gemm (the reference always simplifies; "
                         "note: --update_bn also keeps the BN nodes, which it re-estimates — unlike the reference, whose "
@@ -104,7 +106,16 @@ def _main(argv=None):
     args.local_rank = rank % max(1, __import__("torch").cuda.device_count())
     if rank == 0:
         logger.info("Do tensor calibration...")
+    t_cal = time.time()
     act_clip_val, weight_clip_val = tensor_calibration(onnx_graph, args)
+    if args.timing_json and rank == 0:
+        import json
+        from .forward_net import CalibrationRun
+        tm = CalibrationRun.last.timing() if CalibrationRun.last is not None else {}
+        tm.update(tensor_calibration_wall_s=time.time() - t_cal, load_model_wall_s=t_cal - start, act_quant=args.act_quant,
+                  calib_batch=args.calib_batch, world_size=world)
+        with open(args.timing_json, "w") as f:
+            json.dump(tm, f)
     tensor_range = copy.deepcopy(act_clip_val)
     save_clip_val(act_clip_val, weight_clip_val, args, act_fname=f"act_clip_val.json.rank{rank}",
                   weight_fname=f"weight_clip_val.json.rank{rank}")

@@ -121,11 +121,17 @@ __device__ __forceinline__ BracketResult bracket_marks(const uint32_t* n_ge, con
         }
         double nlo = INFINITY, nhi = -INFINITY;
         for (int j = jl; j <= jh + 1; ++j) {  // F with everything in bins >= j counted as "above"
+            // An edge above every value of the pair is no bound: no iterate reaches it (F is a mean of the pair's values), and F
+            // there — 0 — would drag the bracket down to the bottom of the window.  Seen on erf outputs, whose values pile up
+            // just below 1: the iteration ends inside that top bin.  (An iterate that does fall below the marked bins — few
+            // values above it — is caught by the exact walk like any other.)
+            if (n_ge[j] == 0u) continue;
             const double ng = (double)n_ge[j];
             const double f = s_ge[j] / (c * ((double)(long long)n - ng) + ng);
             nlo = fmin(nlo, f);
             nhi = fmax(nhi, f);
         }
+        if (!(nlo <= nhi)) break;           // nothing above the bracket's bins at all
         if (nlo == lo && nhi == hi) break;  // the bracket stopped moving
         lo = nlo;
         hi = nhi;

@@ -225,7 +225,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 typedef __attribute__((address_space(3))) unsigned long long* lptr_u64;
 typedef __attribute__((address_space(3))) uint32_t* lptr_u32;
 __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
-                                                       Shared& sh) {
+                                                       Shared& sh, dpl_octav_state* __restrict__ ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const lptr_u64 l_packed = (lptr_u64)(lds_raw);
     const uint32_t tid = threadIdx.x;
@@ -368,6 +368,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
         }
     }
     if (tail != 0u) flush();
+    if (rare_n != 0u && lane == 0) atomicAdd(&ctl->reserved, rare_n);   // (statistics: tiles read a second time)
     // per-wave totals of the directly accumulated statistics
     const float wmn = wave_min(mn), wmx = wave_max(mx);
     const uint32_t wnz = wave_sum(nz);
@@ -387,7 +388,8 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
 __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
     unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pred, uint32_t n_tensors,
-    const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0) {
+    const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0,
+    dpl_octav_state* __restrict__ ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
     __shared__ Shared sh;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
     // the slice's region of the pair's list: at the slice's element offset inside the pair
     const uint64_t in_pair = it.offset - slices[pair_slice0[2 * pair]].offset;
-    stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh);
+    stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh, ctl);
     __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
 
     // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
@@ -1350,6 +1352,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
     __shared__ Shared sh;
     __shared__ float red_q[kWaves];
     __shared__ int red_top[kWaves];
+    __shared__ double red_de[kWaves][6];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const int w = tid / kWave;
     const uint32_t pair = pair_order[blockIdx.x], tensor = pair % n_tensors;   // largest pairs first
@@ -1363,7 +1366,10 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
     unsigned long long* packed = reinterpret_cast<unsigned long long*>(s_ge);
     for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
     __syncthreads();
-    // ---- the sample: chunk g (16 floats) starts at element g * 16 * kProbeRate behind the first 16-byte boundary
+    // ---- the sample: chunk g (16 floats = 64 bytes) lies in the g-th window of 16 * kProbeRate elements behind the first
+    // 16-byte boundary, at a slot of the window drawn from a hash of g: a regular stride would alias with the rows of the
+    // tensor (a [197, 768] activation has rows of exactly three 1 KiB windows: a fixed slot sees the same 48 of its 768
+    // channels in every token, and such a sample's iterates miss the pair's by whole bins)
     const float* p0 = segs[sp.seg] + sp.offset;
     const uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)p0 & 15u)) & 15u) >> 2);
     const uint32_t n = (uint32_t)sp.count - head;
@@ -1371,11 +1377,25 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
     const uint32_t n_chunks = n / (16u * kProbeRate);            // whole strides only (the last partial one is skipped)
     float mn = INFINITY;
     uint32_t m = 0u;
+    // the 16 values of a chunk are neighbours (one token, one row of a feature map): not independent draws.  The variance of
+    // the sample mean is therefore taken BETWEEN chunks and compared with what independent draws would give (the design
+    // effect of cluster sampling); every iterate's variance is scaled by that ratio.
+    float c_sum = 0.0f, c_sq = 0.0f, e_sum = 0.0f, e_sq = 0.0f;   // per lane: chunk sums (lanes 0 mod 4) / element sums of |x|
+    uint32_t o_cnt = 0u;      // non-zero values outside the binned window (a softmax output: most of them) ...
+    float o_sum = 0.0f;       // ... and their sum
     auto eat = [&](float x) {
         mn = fminf(mn, x);
         const uint32_t bits = __float_as_uint(x);
         const uint32_t t = ((bits >> kLogShift) & 0x3FFFu) - (kLogKey0 + 1u);
-        if (t < (uint32_t)(kLogNB - 1)) atomicAdd(packed + t + 1u, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu));
+        if (t < (uint32_t)(kLogNB - 1)) {
+            atomicAdd(packed + t + 1u, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu));
+        } else {   // outside the binned window: still part of s_0 = sum |x| / count(|x| > 0) (forward_net.py:324)
+            const float ax = fabsf(x);
+            if (ax > 0.0f && ax < INFINITY) {
+                o_cnt += 1u;
+                o_sum += ax;
+            }
+        }
     };
     constexpr int kIn = 4;   // loads in flight per lane
     for (uint32_t g0 = tid >> 2; g0 < n_chunks; g0 += (kThreads >> 2) * kIn) {
@@ -1383,7 +1403,8 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
 #pragma unroll
         for (int u = 0; u < kIn; ++u) {
             const uint32_t g = g0 + (uint32_t)u * (kThreads >> 2);
-            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + (size_t)g * 4u * kProbeRate + (tid & 3u)) : f4{0.f, 0.f, 0.f, 0.f};
+            const uint32_t slot = ((g * 0x9E3779B1u) >> 16) % kProbeRate;   // where in its window chunk g lies
+            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + ((size_t)g * kProbeRate + slot) * 4u + (tid & 3u)) : f4{0.f, 0.f, 0.f, 0.f};
             m += g < n_chunks ? 4u : 0u;
         }
 #pragma unroll
@@ -1392,17 +1413,50 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
             eat(v[u].y);
             eat(v[u].z);
             eat(v[u].w);
+            const float a0 = fabsf(v[u].x), a1 = fabsf(v[u].y), a2 = fabsf(v[u].z), a3 = fabsf(v[u].w);
+            float cs = (a0 + a1) + (a2 + a3);
+            e_sum += cs;
+            e_sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+            cs += __shfl_xor(cs, 1, kWave);
+            cs += __shfl_xor(cs, 2, kWave);
+            if ((tid & 3u) == 0u) {
+                c_sum += cs;
+                c_sq += cs * cs;
+            }
         }
     }
     m = wave_sum(m);
     mn = wave_min(mn);
+    const double w_cs = wave_sum((double)c_sum), w_cq = wave_sum((double)c_sq), w_es = wave_sum((double)e_sum), w_eq = wave_sum((double)e_sq);
+    const double w_os = wave_sum((double)o_sum);
+    o_cnt = wave_sum(o_cnt);
     if (lane == 0) {
+        red_de[w][4] = w_os;
+        red_de[w][5] = (double)o_cnt;
         sh.red_a[w] = m;
         sh.red_mn[w] = mn;
+        red_de[w][0] = w_cs;
+        red_de[w][1] = w_cq;
+        red_de[w][2] = w_es;
+        red_de[w][3] = w_eq;
     }
     __syncthreads();
     const uint32_t m_all = sh.red_a[0] + sh.red_a[1] + sh.red_a[2] + sh.red_a[3];   // (read before the scans reuse the scratch)
     const float smn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
+    float deff = 1.0f, out_sum = 0.0f, out_cnt = 0.0f;
+    {
+        double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int q = 0; q < kWaves; ++q)
+            for (int i = 0; i < 6; ++i) t[i] += red_de[q][i];
+        out_sum = (float)t[4];
+        out_cnt = (float)t[5];
+        const double nc = (double)(m_all / 16u), ne = (double)m_all;
+        if (nc > 1.0) {
+            const double var_c = t[1] / nc - (t[0] / nc) * (t[0] / nc);     // variance of the chunk sums
+            const double var_e = t[3] / ne - (t[2] / ne) * (t[2] / ne);     // variance of the elements
+            if (var_e > 0.0) deff = (float)fmin(fmax(var_c / (16.0 * var_e), 1.0), 64.0);
+        }
+    }
     // ---- per-bin (count, sum, sum of squares) -> suffix sums (thread t owns the 8 bins below 2047 - 8 t)
     {
         constexpr int kPerT = kLogNB / kThreads;
@@ -1463,12 +1517,12 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
                 sh.bm[w0] |= (0xFFFFFFFFu >> (31 - hi_b)) & (0xFFFFFFFFu << lo_b);
             }
         };
-        const float nz = (float)n_ge[1];
-        if (nz > 0.0f && m_all > 0u) {
+        const float nz = (float)n_ge[1] + out_cnt;
+        if (n_ge[1] > 0u && m_all > 0u) {
             // highest sampled bin + an octave: the pair's maximum lies above the sample's
             const int top = min(max(max(red_top[0], red_top[1]), max(red_top[2], red_top[3])) + 64, kLogNB - 2);
-            float s = (float)s_ge[1] / nz;
-            float V = fmaxf(q_ge[1] / nz - s * s, 0.0f) / nz * fpc;
+            float s = ((float)s_ge[1] + out_sum) / nz;
+            float V = fmaxf(q_ge[1] / nz - s * s, 0.0f) / nz * fpc * deff;
             for (int k = 0; k <= max_iters; ++k) {
                 const float sd = sqrtf(V), lo = fmaxf(s - z * sd, 1e-30f), hi = s + z * sd;
                 const int jl = max(log_bin(lo), 1), jh = log_bin(hi);
@@ -1490,7 +1544,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
                 const float s1 = sgt / (c * ((float)m_all - ngt) + ngt);
                 const float mean_t = sgt / ngt, var_t = fmaxf(qgt / ngt - mean_t * mean_t, 0.0f);
                 const float fp = fminf(fmaxf(cj / (e1 - e0) * (s1 - s) / ngt, 0.0f), 1.0f);   // F'(s) = density (F - s) / N_gt
-                V = var_t / ngt * fpc + fp * fp * V;
+                V = var_t / ngt * fpc * deff + fp * fp * V;
                 if (fabsf(s1 - s) < 1e-6f || !(s1 == s1)) break;
                 s = s1;
             }
@@ -1649,7 +1703,7 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
                        j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), j->d_pred_pair,
-                       (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0);
+                       (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0, j->d_states + j->n_pairs);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
 }

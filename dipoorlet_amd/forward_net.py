@@ -78,8 +78,10 @@ def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
 
 class CalibrationRun:
     """One rank's sweep(s) over its shard of the calibration set."""
+    last = None    # the most recent run of this process (its timing() is what --timing_json reports)
 
     def __init__(self, onnx_graph, args):
+        CalibrationRun.last = self
         self.graph = onnx_graph
         self.args = args
         self.session = onnx_graph.make_session(args)
@@ -95,6 +97,33 @@ class CalibrationRun:
         self._resident = []  # tensor sets kept in HBM between pass 1 and pass 2
         self._resident_ok = True
         self._resident_bytes = 0
+        # where a run's time goes (--timing_json): host seconds reading .bin files, GPU milliseconds (HIP events on the launch
+        # stream) of the network forward and of the statistics kernels
+        self.ingest_s = 0.0
+        self._events = {"forward": [], "statistics": []}
+
+    def timed(self, phase):
+        """Context manager: HIP events around the GPU work launched inside, summed by timing()."""
+        run = self
+
+        class _T:
+            def __enter__(self):
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+
+            def __exit__(self, *exc):
+                self.e1.record()
+                run._events[phase].append((self.e0, self.e1))
+        return _T()
+
+    def timing(self):
+        """HOST (synchronises): {'ingest_s', 'forward_gpu_s', 'statistics_gpu_s', 'images'} of this rank so far."""
+        torch.cuda.synchronize()
+        out = {"images": self.n_images(), "ingest_host_s": self.ingest_s}
+        for k, evs in self._events.items():
+            out[k + "_gpu_s"] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
+        return out
 
     def plan(self, b):
         p = self._plans.get(b)
@@ -125,9 +154,13 @@ class CalibrationRun:
 
         def reader():
             try:
+                import time
                 for i, j in bounds:
-                    q.put((j - i, stage_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j,
-                                                    self.device.type == "cuda")))
+                    t0 = time.perf_counter()
+                    staged = stage_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j,
+                                               self.device.type == "cuda")
+                    self.ingest_s += time.perf_counter() - t0
+                    q.put((j - i, staged))
             except BaseException as e:  # surfaced in the consumer
                 q.put(e)
 
@@ -145,7 +178,8 @@ class CalibrationRun:
         """Yields (b, tensors) per batch.  With keep=True the tensor sets stay resident in HBM (up to
         args.resident_gb) so a second pass re-reads them instead of re-running the network."""
         for b, inputs in self._input_batches():
-            tensors = self.session.run(inputs)
+            with self.timed("forward"):
+                tensors = self.session.run(inputs)
             if keep and self._resident_ok:
                 nbytes = sum(t.numel() * 4 for t in tensors)
                 if self._resident_bytes + nbytes <= self._budget:
@@ -191,7 +225,8 @@ def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_residen
         return {n: {"max": list(allr[:, t, 1]), "min": list(allr[:, t, 0])} for t, n in enumerate(run.names)}
     acc = ops.CalibAccumulators(run.T, run.device, int(getattr(args, "bins", 2048)))
     for b, tensors in run.forward(keep=keep_resident):
-        acc.minmax_accumulate(run.plan(b), tensors)
+        with run.timed("statistics"):
+            acc.minmax_accumulate(run.plan(b), tensors)
     gmin, gmax = acc.finalize_minmax()
     run.acc = acc
     lo, hi = _np32(gmin), _np32(gmax)
@@ -224,7 +259,8 @@ def hist_pass(run, gmin, gmax, bins):
     acc.set_minmax(gmin, gmax)
     acc.hist_prepare()
     for b, tensors in run.second_pass():
-        acc.abs_hist_accumulate(run.plan(b), tensors)
+        with run.timed("statistics"):
+            acc.abs_hist_accumulate(run.plan(b), tensors)
     run.release()
     status = acc.range_status()["status"]
     for t, n in enumerate(run.names):

@@ -96,8 +96,10 @@ def resnet50(seed=0, **kw):
     return _resnet("bottleneck", (3, 4, 6, 3), seed, **kw)
 
 
-def vit(seed=0, image=224, patch=16, dim=768, depth=12, heads=12, mlp=3072, num_classes=1000):
-    """ViT-B/16 with decomposed LayerNorm / attention / erf-GELU, as the TorchScript exporter emits them."""
+def vit(seed=0, image=224, patch=16, dim=768, depth=12, heads=12, mlp=3072, num_classes=1000, attn_gain=1.0):
+    """ViT-B/16 with decomposed LayerNorm / attention / erf-GELU, as the TorchScript exporter emits them.
+    attn_gain scales the attention logits: random weights give near-uniform attention rows, a trained network peaked ones
+    (most probabilities far below 2^-18); a gain of 8 .. 12 makes the random network's softmax outputs look like the latter."""
     g = _B(seed)
     n_tok = (image // patch) ** 2
     hd = dim // heads
@@ -132,7 +134,7 @@ def vit(seed=0, image=224, patch=16, dim=768, depth=12, heads=12, mlp=3072, num_
         k = g.node("Gather", [qkv, g.const(p + ".i1", np.array(1, np.int64))], axis=0)
         v = g.node("Gather", [qkv, g.const(p + ".i2", np.array(2, np.int64))], axis=0)
         att = g.node("MatMul", [q, g.node("Transpose", [k], perm=[0, 1, 3, 2])])
-        att = g.node("Mul", [att, g.const(p + ".scale", np.float32(hd ** -0.5))])
+        att = g.node("Mul", [att, g.const(p + ".scale", np.float32(hd ** -0.5 * attn_gain))])
         att = g.node("Softmax", [att], axis=-1)
         y = g.node("MatMul", [att, v])
         y = g.node("Transpose", [y], perm=[0, 2, 1, 3])

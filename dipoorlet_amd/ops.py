@@ -419,7 +419,7 @@ class OctavPipeline:
 
     def reset_stats(self):
         self.batches = self.fallback_batches = self.fallback_pairs = self.sorted_batches = self.compaction_pairs = 0
-        self.probe_tensors = 0
+        self.probe_tensors = self.tiles_reread = 0
         self.list_share = self.max_share = 0.0    # gathered values / elements (running mean / maximum over the settled batches)
 
     @staticmethod
@@ -478,6 +478,7 @@ class OctavPipeline:
         listed, failed = float(ctl.sum), int(ctl.len0) + int(ctl.cnt_le)
         self.compaction_pairs += int(ctl.cnt_le)
         self.probe_tensors += int(st["use_host"].sum().item())     # tensors whose pairs predicted from a sample of themselves
+        self.tiles_reread += int(ctl.reserved)                     # 1024-element tiles holding a non-zero value outside the window
         self.batches += 1
         share = listed / max(1, plan.batch * sum(plan.elems))
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share

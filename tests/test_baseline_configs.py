@@ -154,3 +154,67 @@ def test_config2_resnet50_mse_n256_plus_ragged(r50_pool):
                 warnings.simplefilter("ignore")
                 s = O.octav_scale(x, 1)
             assert _close(allr[256 + k, t, 0], s), (t, k)
+
+
+def test_config4_vit_b16_real_shapes_hist_and_mse():
+    """BASELINE configs[4]'s workload on one GPU at its real shapes: ViT-B/16 (dim 768, depth 12, 197 tokens) run by the
+    repo's own graph executor with every node output exposed — 557 calibration tensors per image, among them LayerNorm
+    outputs, erf-GELU outputs and the twelve attention-probability tensors (softmax rows summing to 1; the attention logits
+    are scaled up so that, as in a trained network, most probabilities lie far below the OCTAV histogram's 2^-18 window).
+    Ranges against torch, |x| histogram mass, and -A mse (forward_net.py:404-456, forward_net_octav_transformer) through the
+    product's pipeline against the oracle on sampled pairs including EVERY attention-probability tensor."""
+    from dipoorlet_amd import models, ops
+    dev = torch.device("cuda:0")
+    g = models.vit_b16(seed=5, attn_gain=10.0)
+    sess = g.make_session()
+    names = list(sess.tensor_names)
+    elems = [int(e) for e in sess.elems_per_image]
+    T = len(names)
+    assert T == 557 and sum(elems) > 130_000_000
+    softmax = [names.index(n.output[0]) for n in g.graph.node if n.op_type == "Softmax"]
+    gelu = [names.index(n.output[0]) for n in g.graph.node if n.op_type == "Erf"]
+    assert len(softmax) == 12 and all(elems[t] == 12 * 197 * 197 for t in softmax)
+    B = 4
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(77)
+    batches = []
+    for _ in range(3):
+        x = torch.randn(B, 3, 224, 224, generator=gen, device=dev)
+        batches.append([t.reshape(B, -1) for t in sess.run({"input": x})])
+    t0 = batches[0][softmax[3]]
+    assert torch.allclose(t0.view(B, 12, 197, 197).sum(-1), torch.ones(B, 12, 197, device=dev), atol=1e-4)
+    assert (t0 < 2.0 ** -18).float().mean().item() > 0.5            # most of the mass lies below the log histogram's window
+    plan = ops.TensorSetPlan(elems, B, dev)
+    # ranges + |x| histograms (-A hist): exact ranges, every element counted once
+    acc = ops.CalibAccumulators(T, dev, 2048)
+    for tensors in batches:
+        acc.minmax_accumulate(plan, tensors)
+    gmin, gmax = acc.finalize_minmax()
+    for t in range(T):
+        assert gmin[t].item() == min(b[t].min().item() for b in batches) and gmax[t].item() == max(b[t].max().item() for b in batches), t
+    acc.hist_prepare()
+    for tensors in batches:
+        acc.abs_hist_accumulate(plan, tensors)
+    assert acc.hist.sum(1).cpu().tolist() == [3 * B * e for e in elems]
+    # -A mse through the pipeline (three batches: the choice of prediction settles over them)
+    pipe = ops.OctavPipeline(False, dev)
+    rows = [pipe.submit(plan, tensors) for tensors in batches]
+    pipe.sync()
+    torch.cuda.synchronize()
+    single = ops.octav_batch(ops.TensorSetPlan(elems, B, dev), batches[2], False).cpu().numpy()   # a fresh plan, one stream
+    got = [r.cpu().numpy() for r in rows]
+    assert np.isfinite(got[2]).all()
+    np.testing.assert_allclose(got[2][:, :, 0], single[:, :, 0], rtol=2.4e-7)
+    assert np.array_equal(got[2][:, :, 1:], single[:, :, 1:])
+    rng = np.random.default_rng(11)
+    picks = [(int(rng.integers(0, 3)), t, int(rng.integers(0, B))) for t in softmax]
+    picks += [(2, t, 1) for t in gelu[:3]] + [(1, 0, 0), (0, T - 1, 2)]
+    picks += [(int(rng.integers(0, 3)), int(rng.integers(0, T)), int(rng.integers(0, B))) for _ in range(10)]
+    assert len(picks) >= 20
+    for b, t, k in picks:
+        xk = batches[b][t][k].cpu().numpy()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            s = O.octav_scale(xk, 1)
+        assert _close(got[b][k, t, 0], s), (names[t], b, k, got[b][k, t], s)
+        assert got[b][k, t, 1] == xk.min() and got[b][k, t, 2] == xk.max()

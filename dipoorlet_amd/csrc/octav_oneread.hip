@@ -135,6 +135,17 @@ __device__ __forceinline__ void g_prof_iters_add(uint32_t, uint32_t) {}
 #define DPL_PROF_WAVE(idx, slot, a, b) do {} while (0)
 #endif
 
+// Where a pair's prediction row lives: the tensor's row from earlier batches, or the pair's own row from k_octav_probe —
+// by this batch's choice for the tensor.
+struct PredRows {
+    const uint32_t* t;     // [n_tensors, kPredRow]
+    const uint32_t* p;     // [n_pairs, kPredRow]
+    const uint32_t* use;   // [n_tensors]
+    __device__ __forceinline__ const uint32_t* row(uint32_t pair, uint32_t tensor) const {
+        return use[tensor] ? p + (uint64_t)pair * kPredRow : t + (uint64_t)tensor * kPredRow;
+    }
+};
+
 struct Shared {
     double red_d[kWaves];
     unsigned long long red_q[kWaves];
@@ -387,7 +398,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
 // then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
 __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
-    unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pred, uint32_t n_tensors,
+    unsigned long long* __restrict__ lh, const PredRows pred, uint32_t n_tensors,
     const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0,
     dpl_octav_state* __restrict__ ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -401,10 +412,11 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const float* pg = segs[it.seg] + it.offset;
     const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
     const uint32_t tensor = pair % n_tensors;
-    // empty histogram; bit 63 of a bin's word = "gather this bin's values": what this tensor's iterates visited lately
+    // empty histogram; bit 63 of a bin's word = "gather this bin's values": the pair's prediction row
     // (a small pair gathers its whole window)
+    const uint32_t* prow = pred.row(pair, tensor);
     for (int b = tid; b < kLogNB; b += kThreads) {
-        const uint32_t f = small ? 1u : (pred[(uint64_t)pair * kPredRow + (b >> 5)] >> (b & 31)) & 1u;
+        const uint32_t f = small ? 1u : (prow[b >> 5] >> (b & 31)) & 1u;
         l_packed[b] = (unsigned long long)f << 63;
     }
     if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
@@ -470,7 +482,7 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 __device__ __forceinline__ void walk_pair(
     const uint32_t pair, double* s_ge, uint32_t* n_ge, Shared& sh,
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl,
-    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const PredRows pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
     int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const float* __restrict__ list_rescue,
@@ -535,7 +547,7 @@ __device__ __forceinline__ void walk_pair(
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
-        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : small ? 0xFFFFFFFFu : pred[(uint64_t)pair * kPredRow + tid];
+        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : small ? 0xFFFFFFFFu : pred.row(pair, tensor)[tid];
         sh.pub[tid] = 0u;
     }
     if (tid == 0 && rescue) {   // s_0 and the divisor are in the state since the first walk
@@ -834,7 +846,7 @@ __device__ __forceinline__ void walk_pair(
 
 __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
-    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const PredRows pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
     int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const uint32_t* __restrict__ pred_t,
@@ -858,7 +870,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
     __shared__ Shared sh;
     const uint32_t n_missed = ctl->len[0];
     for (uint32_t e = blockIdx.x; e < n_missed; e += gridDim.x) {
-        walk_pair(missed[3 * e], s_ge, n_ge, sh, st, ctl, lh, pair_slice0, nullptr, nullptr, n_tensors, pair_base, nullptr, slices,
+        walk_pair(missed[3 * e], s_ge, n_ge, sh, st, ctl, lh, pair_slice0, PredRows{nullptr, nullptr, nullptr}, nullptr, n_tensors, pair_base, nullptr, slices,
                   dynamic_sym, max_iters, fail_every, 2, rescue_bm, missed, list_rescue, nullptr, nullptr);
         __syncthreads();
     }
@@ -875,7 +887,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
 // one WAVE walks a pair, no list in registers, no barrier, and a wide prediction costs bandwidth here instead of scan time.
 __global__ __launch_bounds__(kThreads) void k_octav_sort(
     const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ pair_slice0, const unsigned long long* __restrict__ lh,
-    const uint32_t* __restrict__ pred, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0,
+    const PredRows pred, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0,
     const uint32_t* __restrict__ slice_chunk0, uint16_t* __restrict__ dir) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[kChunk];
     __shared__ uint32_t cnt[kMaxFlag], off[kMaxFlag + 1];
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_sort(
     const uint32_t pair = it.slot, tensor = pair % n_tensors;
     uint32_t* region = reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + (it.offset - slices[pair_slice0[2 * pair]].offset));
     if (tid < (uint32_t)kLogWords)
-        bp[tid] = (unsigned long long)pred[(uint64_t)pair * kPredRow + tid] | ((unsigned long long)pred[(uint64_t)pair * kPredRow + kLogWords + tid] << 32);
+        bp[tid] = (unsigned long long)pred.row(pair, tensor)[tid] | ((unsigned long long)pred.row(pair, tensor)[kLogWords + tid] << 32);
     constexpr int kPer = (int)(kChunk / kThreads / 4);   // 16-byte vectors per thread and chunk
     for (uint32_t c0 = 0; c0 < len; c0 += kChunk) {
         const uint32_t n = min(len - c0, kChunk);
@@ -980,7 +992,7 @@ constexpr int kMaxRuns = kWave;   // sorted chunks of a pair one wave handles (o
 // MARKED (mode 1, counted in the control block): k_octav_walk(only_missed) publishes its bracket and prepares its state.
 __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
-    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const uint32_t* __restrict__ pred,
+    const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const PredRows pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
     const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ slice_chunk0, const uint16_t* __restrict__ dir,
     int dynamic_sym, int max_iters, int fail_every, const uint32_t* __restrict__ pred_t, float* __restrict__ tstat) {
@@ -998,8 +1010,8 @@ __global__ __launch_bounds__(kWave, DPL_SORTED_OCC) void k_octav_walk_sorted(
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const uint32_t tensor = pair % n_tensors;
     const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
-    bm[lane] = pred[(uint64_t)pair * kPredRow + lane];
-    pre[lane] = pred[(uint64_t)pair * kPredRow + kLogWords + lane];
+    bm[lane] = pred.row(pair, tensor)[lane];
+    pre[lane] = pred.row(pair, tensor)[kLogWords + lane];
     cheapw[lane] = 0u;
     thinw[lane] = 0u;
     pub[lane] = 0u;
@@ -1358,11 +1370,8 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
     const uint32_t pair = pair_order[blockIdx.x], tensor = pair % n_tensors;   // largest pairs first
     const dpl_span sp = pair_spans[pair];
     if (sp.count <= (uint64_t)kSmallCap) return;   // gathers its whole window: no prediction row is read
+    if (!use_probe[tensor]) return;                // this batch, the tensor's pairs gather by its row from earlier batches
     uint32_t* row = pred_p + (uint64_t)pair * kPredRow;
-    if (!use_probe[tensor]) {
-        if (tid < (uint32_t)kPredRow) row[tid] = pred_t[tensor * kPredRow + tid];
-        return;
-    }
     unsigned long long* packed = reinterpret_cast<unsigned long long*>(s_ge);
     for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
     __syncthreads();
@@ -1702,7 +1711,7 @@ int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
-                       j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), j->d_pred_pair,
+                       j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                        (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0, j->d_states + j->n_pairs);
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
@@ -1720,7 +1729,7 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(j->d_lh);
     dpl_octav_state* ctl = j->d_states + j->n_pairs;
     auto walk = [&](unsigned grid, const uint32_t* order, int phase) {
-        hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, j->d_pred_pair,
+        hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                            d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
                            g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_pred, j->d_tstat);
     };
@@ -1730,11 +1739,11 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
         DPL_LAUNCH_CHECK("k_octav_walk");
     } else {
         if (n_big > 0) {
-            hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)j->n_slices), dim3(kThreads), 0, st, j->d_slices, j->d_pair_slice0, lh, j->d_pred_pair,
+            hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)j->n_slices), dim3(kThreads), 0, st, j->d_slices, j->d_pair_slice0, lh, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                                (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slice_chunk0, j->d_dir);
             DPL_LAUNCH_CHECK("k_octav_sort");
             hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, st, j->d_states, ctl, j->d_pair_order, lh,
-                               j->d_pair_slice0, j->d_pred_pair, d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices,
+                               j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe}, d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices,
                                j->d_slice_chunk0, j->d_dir, j->dynamic_sym, j->max_iters, g_exact_fail_every, j->d_pred, j->d_tstat);
             DPL_LAUNCH_CHECK("k_octav_walk_sorted");
         }

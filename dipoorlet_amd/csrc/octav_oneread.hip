@@ -81,7 +81,6 @@ constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a
 #define DPL_APPEND_LAG 1
 #endif
 constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
-constexpr uint32_t kBigCluster = (1u << 20) / kCap + 1;         // clusters this large may overflow the packed count field
 constexpr uint32_t kMaxCluster = 64;
 constexpr unsigned kRescueGrid = 512;   // workgroups of the rescue's persistent kernels
 // The prediction row of a tensor (d_pred): the bitmap of the bins to gather (kLogWords words, at most kMaxFlag bits set) and,
@@ -1354,17 +1353,26 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
 // falls outside is rescued (re-read alone).  One workgroup per pair; a tensor whose pairs use the prediction from earlier
 // batches (use_probe == 0) only copies that row.
 constexpr float kProbeZ = 3.0f;
-__global__ __launch_bounds__(kThreads) void k_octav_probe(
+__global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     const dpl_span* __restrict__ pair_spans, const float* const* __restrict__ segs, const uint32_t* __restrict__ pred_t,
     const uint32_t* __restrict__ use_probe, uint32_t* __restrict__ pred_p, uint32_t n_tensors, int dynamic_sym, int max_iters,
     float z, const uint32_t* __restrict__ pair_order) {
-    __shared__ double s_ge[kLogNB];      // packed sample histogram, then the suffix sums
+    // 24 KiB of LDS per workgroup (six per CU): the packed sample histogram, overlaid after the conversion by the suffix sums
+    // of the values and of their squares (fp32: nothing here has to be exact), and the suffix counts
+    __shared__ __attribute__((aligned(16))) unsigned long long packed[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
-    __shared__ float q_ge[kLogNB];       // suffix sums of squares
-    __shared__ Shared sh;
-    __shared__ float red_q[kWaves];
+    float* s_ge = reinterpret_cast<float*>(packed);
+    float* q_ge = s_ge + kLogNB;
+    struct ProbeShared {
+        uint32_t bm[kLogWords];
+        uint32_t red_a[kWaves];
+        float red_mn[kWaves];
+    };
+    __shared__ ProbeShared sh;
+    __shared__ float red_q[kWaves], red_s[kWaves];
+    __shared__ uint32_t red_n[kWaves];
     __shared__ int red_top[kWaves];
-    __shared__ double red_de[kWaves][6];
+    __shared__ double red_de[kWaves][7];
     const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
     const int w = tid / kWave;
     const uint32_t pair = pair_order[blockIdx.x], tensor = pair % n_tensors;   // largest pairs first
@@ -1372,24 +1380,28 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
     if (sp.count <= (uint64_t)kSmallCap) return;   // gathers its whole window: no prediction row is read
     if (!use_probe[tensor]) return;                // this batch, the tensor's pairs gather by its row from earlier batches
     uint32_t* row = pred_p + (uint64_t)pair * kPredRow;
-    unsigned long long* packed = reinterpret_cast<unsigned long long*>(s_ge);
     for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
     __syncthreads();
-    // ---- the sample: chunk g (16 floats = 64 bytes) lies in the g-th window of 16 * kProbeRate elements behind the first
+    // ---- the sample: chunk g (32 floats = 128 bytes, one L2 line: 64-byte chunks fetched whole lines for half the use —
+    // 75 us instead of 40 for the 213 MB of a ResNet-50 batch) lies in the g-th window of 32 * kProbeRate elements behind the first
     // 16-byte boundary, at a slot of the window drawn from a hash of g: a regular stride would alias with the rows of the
-    // tensor (a [197, 768] activation has rows of exactly three 1 KiB windows: a fixed slot sees the same 48 of its 768
+    // tensor (a [197, 768] activation's rows are a multiple of a 1 KiB window: a fixed slot sees the same few dozen of its 768
     // channels in every token, and such a sample's iterates miss the pair's by whole bins)
     const float* p0 = segs[sp.seg] + sp.offset;
     const uint32_t head = (uint32_t)(((16u - (uint32_t)((uintptr_t)p0 & 15u)) & 15u) >> 2);
     const uint32_t n = (uint32_t)sp.count - head;
     gptr_f4 pv = (gptr_f4)(p0 + head);
-    const uint32_t n_chunks = n / (16u * kProbeRate);            // whole strides only (the last partial one is skipped)
+    constexpr uint32_t kChunkLanes = 8u;                         // lanes (16 bytes each) per chunk: 128 bytes = one L2 line
+    constexpr uint32_t kChunkElems = kChunkLanes * 4u;
+    const uint32_t n_chunks = n / (kChunkElems * kProbeRate);    // whole windows only (the last partial one is skipped)
     float mn = INFINITY;
     uint32_t m = 0u;
     // the 16 values of a chunk are neighbours (one token, one row of a feature map): not independent draws.  The variance of
-    // the sample mean is therefore taken BETWEEN chunks and compared with what independent draws would give (the design
-    // effect of cluster sampling); every iterate's variance is scaled by that ratio.
-    float c_sum = 0.0f, c_sq = 0.0f, e_sum = 0.0f, e_sq = 0.0f;   // per lane: chunk sums (lanes 0 mod 4) / element sums of |x|
+    // the sample mean is therefore taken BETWEEN groups of neighbours (each lane's four) and compared with what independent
+    // draws would give — the design effect of cluster sampling, extrapolated to the chunk's 16; every iterate's variance is
+    // scaled by it.
+    float c_sum = 0.0f, c_sq = 0.0f, e_sum = 0.0f, e_sq = 0.0f;   // per lane: sums over its groups of 4 / over elements of |x|
+    uint32_t c_n = 0u;        // groups of 4 counted
     uint32_t o_cnt = 0u;      // non-zero values outside the binned window (a softmax output: most of them) ...
     float o_sum = 0.0f;       // ... and their sum
     auto eat = [&](float x) {
@@ -1406,14 +1418,19 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
             }
         }
     };
-    constexpr int kIn = 4;   // loads in flight per lane
-    for (uint32_t g0 = tid >> 2; g0 < n_chunks; g0 += (kThreads >> 2) * kIn) {
+    constexpr int kIn = 8;    // loads in flight per lane: the sample of the largest pairs (3 136 chunks) in seven round trips
+    for (uint32_t g0 = tid / kChunkLanes; g0 < n_chunks; g0 += (kThreads / kChunkLanes) * kIn) {
         f4 v[kIn];
 #pragma unroll
         for (int u = 0; u < kIn; ++u) {
-            const uint32_t g = g0 + (uint32_t)u * (kThreads >> 2);
+            const uint32_t g = g0 + (uint32_t)u * (kThreads / kChunkLanes);
+#ifdef DPL_PROBE_FIXSLOT
+            const uint32_t slot = 0u;
+#else
             const uint32_t slot = ((g * 0x9E3779B1u) >> 16) % kProbeRate;   // where in its window chunk g lies
-            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + ((size_t)g * kProbeRate + slot) * 4u + (tid & 3u)) : f4{0.f, 0.f, 0.f, 0.f};
+#endif
+            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + ((size_t)g * kProbeRate + slot) * kChunkLanes + (tid & (kChunkLanes - 1u)))
+                                : f4{0.f, 0.f, 0.f, 0.f};
             m += g < n_chunks ? 4u : 0u;
         }
 #pragma unroll
@@ -1422,16 +1439,16 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
             eat(v[u].y);
             eat(v[u].z);
             eat(v[u].w);
+#ifndef DPL_PROBE_NODEFF
+            if (u & 1) continue;                         // (every other load: an estimate of a ratio of variances)
             const float a0 = fabsf(v[u].x), a1 = fabsf(v[u].y), a2 = fabsf(v[u].z), a3 = fabsf(v[u].w);
-            float cs = (a0 + a1) + (a2 + a3);
+            const float cs = (a0 + a1) + (a2 + a3);     // the lane's four neighbours: a cluster of the sample
             e_sum += cs;
             e_sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            cs += __shfl_xor(cs, 1, kWave);
-            cs += __shfl_xor(cs, 2, kWave);
-            if ((tid & 3u) == 0u) {
-                c_sum += cs;
-                c_sq += cs * cs;
-            }
+            c_sum += cs;
+            c_sq += cs * cs;
+            c_n += g0 + (uint32_t)u * (kThreads / kChunkLanes) < n_chunks ? 1u : 0u;
+#endif
         }
     }
     m = wave_sum(m);
@@ -1439,40 +1456,42 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
     const double w_cs = wave_sum((double)c_sum), w_cq = wave_sum((double)c_sq), w_es = wave_sum((double)e_sum), w_eq = wave_sum((double)e_sq);
     const double w_os = wave_sum((double)o_sum);
     o_cnt = wave_sum(o_cnt);
+    c_n = wave_sum(c_n);
     if (lane == 0) {
-        red_de[w][4] = w_os;
-        red_de[w][5] = (double)o_cnt;
-        sh.red_a[w] = m;
-        sh.red_mn[w] = mn;
+        red_de[w][6] = (double)c_n;
         red_de[w][0] = w_cs;
         red_de[w][1] = w_cq;
         red_de[w][2] = w_es;
         red_de[w][3] = w_eq;
+        red_de[w][4] = w_os;
+        red_de[w][5] = (double)o_cnt;
+        sh.red_a[w] = m;
+        sh.red_mn[w] = mn;
     }
     __syncthreads();
-    const uint32_t m_all = sh.red_a[0] + sh.red_a[1] + sh.red_a[2] + sh.red_a[3];   // (read before the scans reuse the scratch)
+    const uint32_t m_all = sh.red_a[0] + sh.red_a[1] + sh.red_a[2] + sh.red_a[3];
     const float smn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
     float deff = 1.0f, out_sum = 0.0f, out_cnt = 0.0f;
     {
-        double t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double t[7] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int q = 0; q < kWaves; ++q)
-            for (int i = 0; i < 6; ++i) t[i] += red_de[q][i];
+            for (int i = 0; i < 7; ++i) t[i] += red_de[q][i];
         out_sum = (float)t[4];
         out_cnt = (float)t[5];
-        const double nc = (double)(m_all / 16u), ne = (double)m_all;
+        const double nc = t[6], ne = 4.0 * t[6];
         if (nc > 1.0) {
-            const double var_c = t[1] / nc - (t[0] / nc) * (t[0] / nc);     // variance of the chunk sums
+            const double var_c = t[1] / nc - (t[0] / nc) * (t[0] / nc);     // variance of the sums of 4 neighbours
             const double var_e = t[3] / ne - (t[2] / ne) * (t[2] / ne);     // variance of the elements
-            if (var_e > 0.0) deff = (float)fmin(fmax(var_c / (16.0 * var_e), 1.0), 64.0);
+            // clusters of 4: deff_4 = 1 + 3 rho; the sample's clusters hold 32: deff_32 = 1 + 31 rho
+            if (var_e > 0.0) deff = (float)fmin(fmax(1.0 + (31.0 / 3.0) * (var_c / (4.0 * var_e) - 1.0), 1.0), 64.0);
         }
     }
-    // ---- per-bin (count, sum, sum of squares) -> suffix sums (thread t owns the 8 bins below 2047 - 8 t)
+    // ---- per-bin (count, sum, sum of squares) -> suffix sums (thread t owns the 8 bins below 2047 - 8 t; everything in bins >= j)
     {
         constexpr int kPerT = kLogNB / kThreads;
         const int hi = kLogNB - 1 - (int)tid * kPerT;
-        uint32_t c[kPerT];
-        double sm[kPerT];
-        float sq[kPerT], lq = 0.0f;
+        uint32_t c[kPerT], ln = 0u;
+        float sm[kPerT], sq[kPerT], ls = 0.0f, lq = 0.0f;
         int my_top = 0;   // the highest sampled bin
 #pragma unroll
         for (int q = 0; q < kPerT; ++q) {
@@ -1480,40 +1499,58 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
             const unsigned long long v = b == 0 ? 0ull : packed[b];
             c[q] = (uint32_t)(v >> kPackShift);
             my_top = max(my_top, c[q] ? b : 0);
-            sm[q] = bin_sum(v & kPackMask, c[q], b);
+            sm[q] = (float)bin_sum(v & kPackMask, c[q], b);
             // values of a bin: mean^2 + (bin width)^2 / 12 each
-            const float mean = c[q] ? (float)(sm[q] / (double)c[q]) : 0.0f, wd = log_edge(b + 1) - log_edge(b);
+            const float mean = c[q] ? sm[q] / (float)c[q] : 0.0f, wd = log_edge(b + 1) - log_edge(b);
             sq[q] = (float)c[q] * (mean * mean + wd * wd * (1.0f / 12.0f));
+            ln += c[q];
+            ls += sm[q];
             lq += sq[q];
         }
-        __syncthreads();   // every thread has read its packed words: the arrays may be overwritten
-#pragma unroll
-        for (int q = 0; q < kPerT; ++q) {
-            n_ge[hi - q] = c[q];
-            s_ge[hi - q] = sm[q];
-        }
-        float iq = lq;
+        uint32_t in = ln;
+        float is = ls, iq = lq;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
-            const float t = __shfl_up(iq, o, kWave);
-            if (lane >= (uint32_t)o) iq += t;
+            const uint32_t tn = __shfl_up(in, o, kWave);
+            const float ts = __shfl_up(is, o, kWave), tq = __shfl_up(iq, o, kWave);
+            if (lane >= (uint32_t)o) {
+                in += tn;
+                is += ts;
+                iq += tq;
+            }
         }
-        if (lane == kWave - 1) red_q[w] = iq;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) my_top = max(my_top, __shfl_xor(my_top, o, kWave));
+        if (lane == kWave - 1) {
+            red_n[w] = in;
+            red_s[w] = is;
+            red_q[w] = iq;
+        }
         if (lane == 0) red_top[w] = my_top;
-        suffix_in_place(n_ge, s_ge, sh);   // (syncs)
-        float rq = iq - lq;
-        for (int q = 0; q < w; ++q) rq += red_q[q];
+        __syncthreads();   // every thread has read its packed words: the area may be overwritten
+        uint32_t rn = in - ln;
+        float rs = is - ls, rq = iq - lq;
+        for (int q = 0; q < w; ++q) {
+            rn += red_n[q];
+            rs += red_s[q];
+            rq += red_q[q];
+        }
 #pragma unroll
         for (int q = 0; q < kPerT; ++q) {
+            rn += c[q];
+            rs += sm[q];
             rq += sq[q];
+            n_ge[hi - q] = rn;
+            s_ge[hi - q] = rs;
             q_ge[hi - q] = rq;
         }
     }
     if (tid < (uint32_t)kLogWords) sh.bm[tid] = 0u;
     __syncthreads();
     // ---- the iteration on the sample, with its uncertainty (one thread: ~20 steps of a few dozen operations)
+#ifdef DPL_PROBE_NOWALK
+    if (tid == 0) sh.bm[20] = 0xFFu;
+#else
     if (tid == 0) {
         const float ud = (dynamic_sym && fabsf(smn) < 1e-6f) ? 4.0f : 1.0f;
         const float c = (float)(1.0 / 65536.0 / 3.0) / ud;
@@ -1530,7 +1567,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
         if (n_ge[1] > 0u && m_all > 0u) {
             // highest sampled bin + an octave: the pair's maximum lies above the sample's
             const int top = min(max(max(red_top[0], red_top[1]), max(red_top[2], red_top[3])) + 64, kLogNB - 2);
-            float s = ((float)s_ge[1] + out_sum) / nz;
+            float s = (s_ge[1] + out_sum) / nz;
             float V = fmaxf(q_ge[1] / nz - s * s, 0.0f) / nz * fpc * deff;
             for (int k = 0; k <= max_iters; ++k) {
                 const float sd = sqrtf(V), lo = fmaxf(s - z * sd, 1e-30f), hi = s + z * sd;
@@ -1544,7 +1581,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
                 const float e0 = log_edge(j), e1 = log_edge(j + 1), fr = fminf(fmaxf((e1 - s) / (e1 - e0), 0.0f), 1.0f);
                 const float cj = (float)(n_ge[j] - n_ge[j + 1]);
                 const float ngt = (float)n_ge[j + 1] + fr * cj;
-                const float sgt = (float)s_ge[j + 1] + fr * (float)(s_ge[j] - s_ge[j + 1]);
+                const float sgt = s_ge[j + 1] + fr * (s_ge[j] - s_ge[j + 1]);
                 const float qgt = q_ge[j + 1] + fr * (q_ge[j] - q_ge[j + 1]);
                 if (!(ngt > 0.0f)) {
                     mark(jl, top);
@@ -1559,6 +1596,7 @@ __global__ __launch_bounds__(kThreads) void k_octav_probe(
             }
         }
     }
+#endif
     __syncthreads();
     // ---- the row: at most kMaxFlag - 1 bins (lowest first) + per word the number of gathered bins below it (wave 0)
     if (tid < (uint32_t)kLogWords) {

@@ -28,12 +28,18 @@ for rep in range(2):
     pipe.reset_stats()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    outs = [pipe.submit(plan, pool[b % npool]) for b in range(nb)]
-    pipe.sync()
+    if os.environ.get("DPL_SINGLE"):     # one stream, kernels back to back: their durations ALONE
+        outs = [ops.octav_batch(plan, pool[b % npool], False) for b in range(nb)]
+    else:
+        outs = [pipe.submit(plan, pool[b % npool]) for b in range(nb)]
+        pipe.sync()
     e1.record()
     torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / nb
 gb = 4 * sum(elems) * B / 1e9
+if os.environ.get("DPL_SINGLE"):
+    print(f"{which} (single stream): {ms:.3f} ms/batch")
+    sys.exit(0)
 print(f"{which}: {ms:.3f} ms/batch, {gb / ms * 1e3:.0f} GB/s credited = {gb / ms / 8:.3f} of 8 TB/s; misses/batch {pipe.fallback_pairs / pipe.batches:.1f} "
       f"compaction {pipe.compaction_pairs} listed {pipe.list_share:.4f} sorted {pipe.sorted_batches}/{pipe.batches} "
       f"own-sample {pipe.probe_tensors / (pipe.batches * len(elems)):.2f} tiles twice/batch {pipe.tiles_reread / pipe.batches:.0f}")

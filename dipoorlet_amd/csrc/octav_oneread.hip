@@ -94,6 +94,7 @@ constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows
 // Per tensor, what its prediction from earlier batches would have cost lately (floats, halved every batch):
 // [0] values it would have listed, [1] elements walked, [2] walks it would not have covered, [3] walks, [4] current choice
 constexpr int kTstatRow = 8;
+constexpr int kRescRow = kLogNB + kLogNB / 2;   // u64 words of a rescued pair's row: 2048 suffix sums (fp64) + 2048 suffix counts (u32)
 #ifndef DPL_PROBE_RATE
 #define DPL_PROBE_RATE 16
 #endif
@@ -103,6 +104,7 @@ constexpr uint32_t kProbeThin = 64;               // sampled values above a brac
 // LDS: [A: packed histogram 16 KiB, bit 63 of a word = gather flag | one dummy word per lane][B: the waves' survivor queues 13 KiB]
 constexpr int kLdsA = kLogNB * 8 + kWave * 8;                   // + the lanes' dummy words
 constexpr int kLdsB = kWaves * kQueueCap * 4;
+static_assert(kLdsB >= kLogNB * 4, "the fused walk keeps its suffix counts in the queues' space");
 
 template <class T>
 __device__ __forceinline__ T ld_agent(const T* p) {
@@ -156,6 +158,9 @@ struct Shared {
     uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
     uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
     uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
+    double f_sum;                 // streaming kernel -> its own walk (a single-slice pair): the statistics it just published
+    uint32_t f_nz, f_nan;
+    float f_mn, f_mx;
     uint32_t seg_off[kMaxCluster], seg_len[kMaxCluster];   // walk: the pair's list segments (one per slice)
     OctavStep step;
     int jb;
@@ -393,71 +398,6 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
     }
 }
 
-// K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
-// then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
-__global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
-    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
-    unsigned long long* __restrict__ lh, const PredRows pred, uint32_t n_tensors,
-    const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0,
-    dpl_octav_state* __restrict__ ctl) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
-    __shared__ Shared sh;
-
-    const uint32_t tid = threadIdx.x;
-    const dpl_work_item it = slices[blockIdx.x];
-    const uint32_t pair = it.slot, n_sl = it.reserved, cnt = it.count;
-    dpl_octav_state* me = st + pair;
-    const float* pg = segs[it.seg] + it.offset;
-    const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
-    const uint32_t tensor = pair % n_tensors;
-    // empty histogram; bit 63 of a bin's word = "gather this bin's values": the pair's prediction row
-    // (a small pair gathers its whole window)
-    const uint32_t* prow = pred.row(pair, tensor);
-    for (int b = tid; b < kLogNB; b += kThreads) {
-        const uint32_t f = small ? 1u : (prow[b >> 5] >> (b & 31)) & 1u;
-        l_packed[b] = (unsigned long long)f << 63;
-    }
-    if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
-    if (tid == 0) sh.cursor = 0u;
-    __syncthreads();
-
-    // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
-    // the slice's region of the pair's list: at the slice's element offset inside the pair
-    const uint64_t in_pair = it.offset - slices[pair_slice0[2 * pair]].offset;
-    stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh, ctl);
-    __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
-
-    // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
-    if (tid == 0) {
-        float tmn = INFINITY, tmx = -INFINITY;
-        uint32_t tnz = 0u, tnan = 0u;
-        double tsum = 0.0;
-        for (int j = 0; j < kWaves; ++j) {
-            tmn = fminf(tmn, sh.red_mn[j]);
-            tmx = fmaxf(tmx, sh.red_mx[j]);
-            tnz += sh.red_a[j];
-            tnan |= sh.red_b[j];
-            tsum += sh.red_d[j];
-        }
-        if (tnz) {
-            atomicAdd(&me->sum, tsum);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
-        }
-        atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)cnt);
-        if (tmn <= tmx) {
-            atomicMin(&me->min_enc, enc_f32(tmn));
-            atomicMax(&me->max_enc, enc_f32(tmx));
-        }
-        if (tnan) atomicOr(&me->nan_seen, 1u);
-    }
-    // the slice's histogram goes out as ONE row of plain, coalesced stores (16 KiB, empty bins included: nothing to zero
-    // beforehand, no read-modify-write at the memory side); the walk adds up the rows of a pair's slices
-    unsigned long long* row = lh + (uint64_t)blockIdx.x * kLogNB;
-    // (bin 0 holds no element: its word carries the length of the slice's list segment)
-    for (int b = tid; b < kLogNB; b += kThreads) row[b] = b == 0 ? (unsigned long long)sh.cursor : l_packed[b] & ~(1ull << 63);
-}
-
 // wave64 sum by DPP (row-local butterflies, then the two row broadcasts): ~6 VALU instead of six dependent ds_bpermute round
 // trips; the total arrives in lane 63 and is broadcast from there
 __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
@@ -485,11 +425,13 @@ __device__ __forceinline__ void walk_pair(
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
     int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const float* __restrict__ list_rescue,
-    const uint32_t* __restrict__ pred_t, float* __restrict__ tstat) {
+    const uint32_t* __restrict__ pred_t, float* __restrict__ tstat, unsigned long long* __restrict__ resc, uint32_t fused_cnt) {
+    // phase 3: FUSED — called by the streaming workgroup of a single-slice pair: the histogram is in LDS already (s_ge's memory,
+    // packed), the statistics in sh.f_*, the list (one segment of sh.cursor entries) was written by this workgroup.
     // phase 0: the walk of every pair.  phase 1 (only_missed): the pass behind k_octav_walk_sorted, see below.  phase 2: the
     // RESCUE walk — the pairs phase 0 / 1 could not finish (mode 3), over the values k_octav_rescue_gather collected for them
     // from a second read of those pairs alone: the bins of the pair's exact bracket (rescue_bm), one list (list_rescue).
-    const bool only_missed = phase == 1, rescue = phase == 2;
+    const bool only_missed = phase == 1, rescue = phase == 2, fused = phase == 3;
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const int w = tid / kWave;
@@ -499,7 +441,7 @@ __device__ __forceinline__ void walk_pair(
     // the next batches and leave the state the compaction route starts from.  No pair missed (the steady state): nothing to do.
     if (only_missed && (ctl->iters == 0u || me->mode != 1u)) return;
     if (rescue && (me->mode != 3u || me->done)) return;
-    const unsigned long long n_pair = me->n_elems;
+    const unsigned long long n_pair = fused ? (unsigned long long)fused_cnt : me->n_elems;
     if (n_pair == 0ull) return;   // an empty pair: nothing was streamed
     const bool small = n_pair <= (unsigned long long)kSmallCap;
     const uint32_t tensor = pair % n_tensors;
@@ -508,7 +450,7 @@ __device__ __forceinline__ void walk_pair(
     {
         constexpr int kPerT = kLogNB / kThreads;
         const int hi = kLogNB - 1 - (int)tid * kPerT;
-        const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
+        const uint32_t sl0 = fused ? 0u : pair_slice0[2 * pair], sl1 = fused ? 0u : pair_slice0[2 * pair + 1];
         uint32_t cnt[kPerT];
         unsigned long long mant[kPerT];
 #pragma unroll
@@ -516,7 +458,25 @@ __device__ __forceinline__ void walk_pair(
             cnt[qq] = 0u;
             mant[qq] = 0ull;
         }
-        for (uint32_t sl = sl0; sl < sl1; ++sl) {
+        if (fused) {   // the slice's histogram, still in LDS (bit 63: the gather flag)
+            const unsigned long long* lp = reinterpret_cast<const unsigned long long*>(s_ge);
+#pragma unroll
+            for (int qq = 0; qq < kPerT; ++qq) {
+                const unsigned long long v = lp[hi - qq] & ~(1ull << 63);
+                cnt[qq] = (uint32_t)(v >> kPackShift);
+                mant[qq] = v & kPackMask;
+            }
+        }
+        if (rescue) {   // the suffix totals the first walk left for this pair
+            const double* rs = reinterpret_cast<const double*>(resc + (uint64_t)pair * kRescRow);
+            const uint32_t* rn = reinterpret_cast<const uint32_t*>(resc + (uint64_t)pair * kRescRow + kLogNB);
+#pragma unroll
+            for (int qq = 0; qq < kPerT; ++qq) {
+                n_ge[hi - qq] = rn[hi - qq];
+                s_ge[hi - qq] = rs[hi - qq];
+            }
+        }
+        for (uint32_t sl = sl0; sl < sl1 && !rescue; ++sl) {
             const unsigned long long* row = lh + (uint64_t)sl * kLogNB;
 #pragma unroll
             for (int qq = 0; qq < kPerT; ++qq) {
@@ -525,12 +485,14 @@ __device__ __forceinline__ void walk_pair(
                 mant[qq] += v & kPackMask;
             }
         }
+        if (!rescue) {
 #pragma unroll
-        for (int qq = 0; qq < kPerT; ++qq) {
-            const int b = hi - qq;
-            if (b == 0) cnt[qq] = 0u, mant[qq] = 0ull;   // bin 0 holds no element (its row words are the segment lengths)
-            n_ge[b] = cnt[qq];
-            s_ge[b] = bin_sum(mant[qq], cnt[qq], b);
+            for (int qq = 0; qq < kPerT; ++qq) {
+                const int b = hi - qq;
+                if (b == 0) cnt[qq] = 0u, mant[qq] = 0ull;   // bin 0 holds no element (its row words are the segment lengths)
+                n_ge[b] = cnt[qq];
+                s_ge[b] = bin_sum(mant[qq], cnt[qq], b);
+            }
         }
         // the pair's gathered values: one list segment per slice, at the slice's element offset inside the pair
         if (rescue) {   // one list: what the rescue's gather pass wrote
@@ -538,11 +500,17 @@ __device__ __forceinline__ void walk_pair(
                 sh.seg_off[0] = 0u;
                 sh.seg_len[0] = me->len[0];
             }
+        } else if (fused) {
+            if (tid == 0) {
+                sh.seg_off[0] = 0u;
+                sh.seg_len[0] = sh.cursor;
+            }
         } else if (tid < sl1 - sl0) {
             sh.seg_off[tid] = (uint32_t)(slices[sl0 + tid].offset - slices[sl0].offset);
             sh.seg_len[tid] = (uint32_t)lh[(uint64_t)(sl0 + tid) * kLogNB];
         }
-        suffix_in_place(n_ge, s_ge, sh);
+        if (rescue) __syncthreads();
+        else suffix_in_place(n_ge, s_ge, sh);
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
@@ -555,11 +523,11 @@ __device__ __forceinline__ void walk_pair(
         sh.n_elems = me->n_elems;
         sh.route = 2u;
     } else if (tid == 0) {
-        const double sum_out = me->sum;
-        const unsigned long long nz_out = me->cnt_gt;
-        const unsigned long long n = me->n_elems;
-        const float gmn = dec_f32(me->min_enc), gmx = dec_f32(me->max_enc);
-        const bool nanseen = me->nan_seen != 0u;
+        const double sum_out = fused ? sh.f_sum : me->sum;
+        const unsigned long long nz_out = fused ? (unsigned long long)sh.f_nz : me->cnt_gt;
+        const unsigned long long n = n_pair;
+        const float gmn = fused ? sh.f_mn : dec_f32(me->min_enc), gmx = fused ? sh.f_mx : dec_f32(me->max_enc);
+        const bool nanseen = fused ? sh.f_nan != 0u : me->nan_seen != 0u;
         // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
         const float ud = (dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
         // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
@@ -594,7 +562,8 @@ __device__ __forceinline__ void walk_pair(
         const unsigned long long n_elems = sh.n_elems;
         // the list (bit patterns of |x|) goes into registers, 1024 values per ROW (one 16-byte vector per thread); every
         // segment starts a new row; a list of more rows than the registers hold is re-read in pieces every iteration
-        const uint32_t n_seg = rescue ? 1u : __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
+        const uint32_t n_seg = (rescue || fused) ? 1u : __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
+        if (fused) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the list is this workgroup's own global stores (one CU, one L1)
         uint32_t n_rows = 0u, L = 0u;
         for (uint32_t j = 0; j < n_seg; ++j) {
             const uint32_t len = __builtin_amdgcn_readfirstlane(sh.seg_len[j]);
@@ -660,7 +629,7 @@ __device__ __forceinline__ void walk_pair(
         if (tid == 0) {
             g_prof_iters_add(blockIdx.x, 0u);
             DPL_PROF_L(L);
-            if (phase == 0) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
+            if (phase == 0 || fused) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
         }
         while (!done && !bad) {
             // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1), i.e. d = u - bits(s) - 1 below
@@ -812,6 +781,14 @@ __device__ __forceinline__ void walk_pair(
             }
         }
     }
+    if (rescued) {   // the rescue walk starts from these suffix totals (it has no histogram of its own)
+        double* rs = reinterpret_cast<double*>(resc + (uint64_t)pair * kRescRow);
+        uint32_t* rn = reinterpret_cast<uint32_t*>(resc + (uint64_t)pair * kRescRow + kLogNB);
+        for (int b = tid; b < kLogNB; b += kThreads) {
+            rs[b] = s_ge[b];
+            rn[b] = n_ge[b];
+        }
+    }
     DPL_PROF_T(pt5);
     DPL_PROF_ADD(3, pt4, pt5);
     if (tid == 0) {
@@ -843,18 +820,109 @@ __device__ __forceinline__ void walk_pair(
     }
 }
 
+// K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
+// then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
+// A slice that is a WHOLE pair (all but the largest tensors) is walked right here (fuse != 0): its histogram is still in LDS
+// (converted in place into the suffix totals), its list still in L2 — no histogram row goes out and comes back, no second
+// launch has to find a slot beside the next batch's streaming kernel.
+struct FusedArgs {
+    uint32_t* vis_w;
+    uint32_t* rescue_bm;
+    uint32_t* missed;
+    float* tstat;
+    unsigned long long* resc;
+    int dynamic_sym, max_iters, fail_every, fuse;
+};
+__global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
+    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
+    unsigned long long* __restrict__ lh, const PredRows pred, uint32_t n_tensors,
+    const uint64_t* __restrict__ pair_base, const uint32_t* __restrict__ pair_slice0, float* __restrict__ list0,
+    dpl_octav_state* __restrict__ ctl, const FusedArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
+    __shared__ Shared sh;
+
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    const uint32_t pair = it.slot, n_sl = it.reserved, cnt = it.count;
+    dpl_octav_state* me = st + pair;
+    const float* pg = segs[it.seg] + it.offset;
+    const bool small = n_sl == 1u && cnt <= kSmallCap;    // the walk holds the pair's whole window in registers: no prediction
+    const uint32_t tensor = pair % n_tensors;
+    // empty histogram; bit 63 of a bin's word = "gather this bin's values": the pair's prediction row
+    // (a small pair gathers its whole window)
+    const uint32_t* prow = pred.row(pair, tensor);
+    for (int b = tid; b < kLogNB; b += kThreads) {
+        const uint32_t f = small ? 1u : (prow[b >> 5] >> (b & 31)) & 1u;
+        l_packed[b] = (unsigned long long)f << 63;
+    }
+    if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
+    if (tid == 0) sh.cursor = 0u;
+    __syncthreads();
+
+    // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
+    // the slice's region of the pair's list: at the slice's element offset inside the pair
+    const uint64_t in_pair = it.offset - slices[pair_slice0[2 * pair]].offset;
+    stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh, ctl);
+    __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
+
+    // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
+    if (tid == 0) {
+        float tmn = INFINITY, tmx = -INFINITY;
+        uint32_t tnz = 0u, tnan = 0u;
+        double tsum = 0.0;
+        for (int j = 0; j < kWaves; ++j) {
+            tmn = fminf(tmn, sh.red_mn[j]);
+            tmx = fmaxf(tmx, sh.red_mx[j]);
+            tnz += sh.red_a[j];
+            tnan |= sh.red_b[j];
+            tsum += sh.red_d[j];
+        }
+        if (tnz) {
+            atomicAdd(&me->sum, tsum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)tnz);
+        }
+        atomicAdd(reinterpret_cast<unsigned long long*>(&me->n_elems), (unsigned long long)cnt);
+        if (tmn <= tmx) {
+            atomicMin(&me->min_enc, enc_f32(tmn));
+            atomicMax(&me->max_enc, enc_f32(tmx));
+        }
+        if (tnan) atomicOr(&me->nan_seen, 1u);
+        sh.f_sum = tsum;
+        sh.f_nz = tnz;
+        sh.f_nan = tnan;
+        sh.f_mn = tmn;
+        sh.f_mx = tmx;
+    }
+    if (fa.fuse && n_sl == 1u) {
+        // ------------------------------------------------------------------ 3. the pair's walk, here and now
+        // s_ge takes the histogram's own 16 KiB (a thread reads its eight packed words before it writes its eight doubles over
+        // them), n_ge the queues' space (all flushed)
+        __syncthreads();
+        walk_pair(pair, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl, nullptr, pair_slice0,
+                  pred, fa.vis_w, n_tensors, pair_base, list0, slices, fa.dynamic_sym, fa.max_iters, fa.fail_every, 3, fa.rescue_bm,
+                  fa.missed, nullptr, pred.t, fa.tstat, fa.resc, cnt);
+        return;
+    }
+    // the slice's histogram goes out as ONE row of plain, coalesced stores (16 KiB, empty bins included: nothing to zero
+    // beforehand, no read-modify-write at the memory side); the walk adds up the rows of a pair's slices
+    unsigned long long* row = lh + (uint64_t)blockIdx.x * kLogNB;
+    // (bin 0 holds no element: its word carries the length of the slice's list segment)
+    for (int b = tid; b < kLogNB; b += kThreads) row[b] = b == 0 ? (unsigned long long)sh.cursor : l_packed[b] & ~(1ull << 63);
+}
+
 __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const PredRows pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const float* __restrict__ list0, const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every,
     int phase, uint32_t* __restrict__ rescue_bm, uint32_t* __restrict__ missed, const uint32_t* __restrict__ pred_t,
-    float* __restrict__ tstat) {
+    float* __restrict__ tstat, unsigned long long* __restrict__ resc) {
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
     walk_pair(pair_order ? pair_order[blockIdx.x] : blockIdx.x, s_ge, n_ge, sh, st, ctl, lh, pair_slice0, pred, vis_w, n_tensors,
-              pair_base, list0, slices, dynamic_sym, max_iters, fail_every, phase, rescue_bm, missed, nullptr, pred_t, tstat);
+              pair_base, list0, slices, dynamic_sym, max_iters, fail_every, phase, rescue_bm, missed, nullptr, pred_t, tstat, resc, 0u);
 }
 
 // The rescue walk (phase 2): a small persistent grid over the list of rescued pairs — usually empty, and a launch that has
@@ -863,14 +931,14 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const unsigned long long* __restrict__ lh,
     const uint32_t* __restrict__ pair_slice0, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
     const dpl_work_item* __restrict__ slices, int dynamic_sym, int max_iters, int fail_every, uint32_t* __restrict__ rescue_bm,
-    uint32_t* __restrict__ missed, const float* __restrict__ list_rescue) {
+    uint32_t* __restrict__ missed, const float* __restrict__ list_rescue, unsigned long long* __restrict__ resc) {
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
     const uint32_t n_missed = ctl->len[0];
     for (uint32_t e = blockIdx.x; e < n_missed; e += gridDim.x) {
         walk_pair(missed[3 * e], s_ge, n_ge, sh, st, ctl, lh, pair_slice0, PredRows{nullptr, nullptr, nullptr}, nullptr, n_tensors, pair_base, nullptr, slices,
-                  dynamic_sym, max_iters, fail_every, 2, rescue_bm, missed, list_rescue, nullptr, nullptr);
+                  dynamic_sym, max_iters, fail_every, 2, rescue_bm, missed, list_rescue, nullptr, nullptr, resc, 0u);
         __syncthreads();
     }
 }
@@ -887,13 +955,13 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
 __global__ __launch_bounds__(kThreads) void k_octav_sort(
     const dpl_work_item* __restrict__ slices, const uint32_t* __restrict__ pair_slice0, const unsigned long long* __restrict__ lh,
     const PredRows pred, uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0,
-    const uint32_t* __restrict__ slice_chunk0, uint16_t* __restrict__ dir) {
+    const uint32_t* __restrict__ slice_chunk0, uint16_t* __restrict__ dir, int fuse) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[kChunk];
     __shared__ uint32_t cnt[kMaxFlag], off[kMaxFlag + 1];
     __shared__ unsigned long long bp[kLogWords];   // per word: bitmap (low half) | ranks below the word (high half)
     const uint32_t tid = threadIdx.x;
     const dpl_work_item it = slices[blockIdx.x];
-    if (it.reserved == 1u && it.count <= kSmallCap) return;   // a small pair (whole window gathered): walked from registers
+    if (it.reserved == 1u && (fuse || it.count <= kSmallCap)) return;   // walked by its streaming workgroup / a small pair (registers)
     const uint32_t len = (uint32_t)lh[(uint64_t)blockIdx.x * kLogNB];
     if (len == 0u) return;
     const uint32_t pair = it.slot, tensor = pair % n_tensors;
@@ -1711,12 +1779,12 @@ static int check_job(const char* who, const dpl_octav_oneread_job* j) {
     }
     if (!j->d_slices || !j->d_pair_slice0 || !j->d_slice_chunk0 || !j->d_pair_spans || !j->d_pair_base || !j->d_pair_order ||
         !j->d_seg_ptrs || !j->d_states || !j->d_lh || !j->d_pred || !j->d_list0 || !j->d_list1 || !j->d_dir || !j->d_rescue_bm ||
-        !j->d_missed || !j->d_vis || !j->d_pred_pair || !j->d_use_probe || !j->d_tstat) {
+        !j->d_missed || !j->d_vis || !j->d_pred_pair || !j->d_use_probe || !j->d_tstat || !j->d_resc) {
         snprintf(g_err, sizeof(g_err), "%s: null buffer in the job", who);
         return -1;
     }
-    if (j->n_small < 0 || j->n_small > j->n_pairs) {
-        snprintf(g_err, sizeof(g_err), "%s: bad small-pair count", who);
+    if (j->n_small < 0 || j->n_small > j->n_pairs || j->n_multi < 0 || j->n_multi > j->n_pairs) {
+        snprintf(g_err, sizeof(g_err), "%s: bad small-pair / multi-slice-pair count", who);
         return -1;
     }
     return 0;
@@ -1750,7 +1818,10 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
                        j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
-                       (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0, j->d_states + j->n_pairs);
+                       (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0, j->d_states + j->n_pairs,
+                       FusedArgs{j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords, j->d_rescue_bm, j->d_missed, j->d_tstat,
+                                 reinterpret_cast<unsigned long long*>(j->d_resc), j->dynamic_sym, j->max_iters, g_exact_fail_every,
+                                 j->fuse});
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
 }
@@ -1769,24 +1840,29 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     auto walk = [&](unsigned grid, const uint32_t* order, int phase) {
         hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                            d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
-                           g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_pred, j->d_tstat);
+                           g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_pred, j->d_tstat,
+                           reinterpret_cast<unsigned long long*>(j->d_resc));
     };
-    const int64_t n_big = j->n_pairs - j->n_small;   // d_pair_order: largest first, so the small pairs are its last n_small entries
+    // d_pair_order: largest first — the multi-slice pairs are its first n_multi entries, the small pairs its last n_small.
+    // fuse: the streaming kernel has walked every single-slice pair itself; what is left here are the multi-slice ones.
+    const int64_t n_big = j->fuse ? j->n_multi : j->n_pairs - j->n_small;
+    const int64_t n_small = j->fuse ? 0 : j->n_small;
+    const int64_t n_walk = j->fuse ? j->n_multi : j->n_pairs;
     if (!j->sorted) {   // every pair walked from registers by one workgroup
-        walk((unsigned)j->n_pairs, j->d_pair_order, 0);
+        if (n_walk > 0) walk((unsigned)n_walk, j->d_pair_order, 0);
         DPL_LAUNCH_CHECK("k_octav_walk");
     } else {
         if (n_big > 0) {
             hipLaunchKernelGGL(k_octav_sort, dim3((unsigned)j->n_slices), dim3(kThreads), 0, st, j->d_slices, j->d_pair_slice0, lh, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
-                               (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slice_chunk0, j->d_dir);
+                               (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slice_chunk0, j->d_dir, j->fuse);
             DPL_LAUNCH_CHECK("k_octav_sort");
             hipLaunchKernelGGL(k_octav_walk_sorted, dim3((unsigned)n_big), dim3(kWave), 0, st, j->d_states, ctl, j->d_pair_order, lh,
                                j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe}, d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices,
                                j->d_slice_chunk0, j->d_dir, j->dynamic_sym, j->max_iters, g_exact_fail_every, j->d_pred, j->d_tstat);
             DPL_LAUNCH_CHECK("k_octav_walk_sorted");
         }
-        if (j->n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
-            walk((unsigned)j->n_small, j->d_pair_order + n_big, 0);
+        if (n_small > 0) {   // whole window gathered, at most 20 480 values: walked from registers
+            walk((unsigned)n_small, j->d_pair_order + n_big, 0);
             DPL_LAUNCH_CHECK("k_octav_walk");
         }
         if (n_big > 0) {        // the pairs the sorted walk marked: their bracket, their place on the rescue list
@@ -1800,7 +1876,7 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
         return e;
     hipLaunchKernelGGL(k_octav_walk_rescue, dim3(kRescueGrid), dim3(kThreads), 0, st, j->d_states, ctl, lh, j->d_pair_slice0,
                        (uint32_t)j->n_tensors, j->d_pair_base, j->d_slices, j->dynamic_sym, j->max_iters, g_rescue_fail_every,
-                       j->d_rescue_bm, j->d_missed, j->d_list1);
+                       j->d_rescue_bm, j->d_missed, j->d_list1, reinterpret_cast<unsigned long long*>(j->d_resc));
     DPL_LAUNCH_CHECK("k_octav_walk_rescue");
     return j->compaction_inline ? dpl_octav_oneread_compaction(j, s) : 0;
 }

@@ -153,6 +153,9 @@ class TensorSetPlan:
                     dir=torch.empty(int(per_slice.sum()) * _hip.lib().dpl_octav_dir_row(), dtype=torch.int16, device=self.device),
                     # pairs that gather their whole window (the last entries of the largest-first pair order): no sort
                     n_small=self.batch * sum(1 for e in self.elems if e <= small),
+                    # pairs of more than one slice (the first entries of the largest-first pair order): the others are walked
+                    # by their streaming workgroup
+                    n_multi=self.batch * sum(1 for e in self.elems if e > _hip.lib().dpl_octav_slice_cap()),
                     slices=_upload_struct_array(arr, n, self.device), n_slices=n,
                     pair_slice0=torch.frombuffer(bytearray(bytes(ps)), dtype=torch.int32).to(self.device),
                     lh=torch.empty(n, 2048, dtype=torch.int64, device=self.device),    # one histogram row per slice
@@ -166,7 +169,8 @@ class TensorSetPlan:
                     tstat=torch.zeros(self.T, 8, dtype=torch.float32, device=self.device),
                     # rescue of the pairs a walk could not finish: their exact bracket, the work list of the re-read
                     rescue_bm=torch.empty(self.n_pairs, 64, dtype=torch.int32, device=self.device),
-                    missed=torch.empty(self.n_pairs, 3, dtype=torch.int32, device=self.device))
+                    missed=torch.empty(self.n_pairs, 3, dtype=torch.int32, device=self.device),
+                    resc=torch.empty(self.n_pairs, 3072, dtype=torch.int64, device=self.device))
         return self._octav_one or None
 
     def octav_reset(self):
@@ -359,7 +363,7 @@ _PREDICT = {"learned": 0, "probe": 1, "auto": 2}
 
 
 def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, write_epoch, reset_epoch, sorted_walk, dyn,
-                 compaction_inline=1):
+                 compaction_inline=1, rescue=None):
     """The C ABI's dpl_octav_oneread_job for one batch of `plan` (all device pointers; the tensors stay alive in the caller)."""
     spans, base, order, _, l1 = plan.octav_scratch()
     w = plan.work("octav", per_image=True)
@@ -376,7 +380,11 @@ def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, wri
     j.predict = _PREDICT[os.environ.get("DPL_OCTAV_PREDICT", "auto")]
     j.probe_z = float(os.environ.get("DPL_PROBE_Z", "0"))
     j.d_list0, j.d_list1, j.d_dir = l0.data_ptr(), l1.data_ptr(), res["dir"].data_ptr()
-    j.d_rescue_bm, j.d_missed, j.d_vis = res["rescue_bm"].data_ptr(), res["missed"].data_ptr(), res["vis"].data_ptr()
+    rescue = rescue or res            # (the pipeline's two batches in flight have their own rescue buffers)
+    j.d_rescue_bm, j.d_missed, j.d_resc = rescue["rescue_bm"].data_ptr(), rescue["missed"].data_ptr(), rescue["resc"].data_ptr()
+    j.d_vis, j.n_multi = res["vis"].data_ptr(), res["n_multi"]
+    # DPL_OCTAV_FUSE=0: every pair walked by dpl_octav_oneread_finish (the pre-round-3 schedule; A/B and tests)
+    j.fuse = 0 if os.environ.get("DPL_OCTAV_FUSE", "1") == "0" else 1
     j.write_epoch, j.reset_epoch, j.sorted, j.dynamic_sym, j.max_iters = write_epoch, reset_epoch, sorted_walk, dyn, _OCTAV_MAX_ITERS
     j.compaction_inline = compaction_inline
     return j
@@ -444,6 +452,9 @@ class OctavPipeline:
                                  lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
                                  l0=l0 if j == 0 else torch.empty_like(l0),
                                  pred_pair=res["pred_pair"] if j == 0 else torch.zeros_like(res["pred_pair"]),
+                                 rescue_bm=res["rescue_bm"] if j == 0 else torch.empty_like(res["rescue_bm"]),
+                                 missed=res["missed"] if j == 0 else torch.empty_like(res["missed"]),
+                                 resc=res["resc"] if j == 0 else torch.empty_like(res["resc"]),
                                  done=None, refs=None, pending=False, k=-1))
             plan._octav_pipe_sets = sets
         return sets
@@ -453,7 +464,7 @@ class OctavPipeline:
         ep, first = divmod(k, _ONEREAD_EPOCH)
         job = _oneread_job(plan, res, plan._octav_pipe_pred[k % 4], plan._octav_pipe_states[k % 4], st["lh"], plan._octav_pipe_pred[k % 4],
                            st["pred_pair"], plan._octav_pipe_use[k % 4], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
-                           self.dyn)    # (prepare reads neither tensors nor the walk choice)
+                           self.dyn, rescue=st)    # (prepare reads neither tensors nor the walk choice)
         _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
         st["prepared"] = k
 
@@ -528,7 +539,7 @@ class OctavPipeline:
             self._prepare(plan, res, cur, k, main.cuda_stream)
         job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
                                         plan._octav_pipe_use[k % 4], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
-                                        compaction_inline=0)
+                                        compaction_inline=0, rescue=cur)
         _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
         _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
         streamed = torch.cuda.Event()

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 13
+#define DPL_ABI_VERSION 14
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -154,6 +154,7 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  *   k_octav_oneread — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one pair): the slice's only HBM
  *     read yields the pair's statistics, the slice's exact log-scale histogram row and the values of the bins the exact
  *     iteration is PREDICTED to visit (appended to the pair's list);
+ *   (job.fuse: a slice that is a whole pair is walked by its streaming workgroup right away — no histogram row, no second launch)
  *   k_octav_walk — one workgroup per pair: per-bin totals = the sum of the pair's slice rows, suffix totals, s_0, then the
  *     reference's iteration on (exact totals of the bins above) + (listed values of the iterate's bin), every iterate
  *     VERIFIED to lie in a gathered bin (for long lists: k_octav_sort + k_octav_walk_sorted, one wave per pair over runs
@@ -197,6 +198,7 @@ typedef struct dpl_octav_oneread_job {
     const uint64_t* d_pair_base;     /* [n_pairs]: element offset of the pair's region in the lists (a region holds the pair's element count) */
     const uint32_t* d_pair_order;    /* [n_pairs]: pair indices, largest first; its last n_small entries gather their whole window */
     int64_t n_pairs, n_tensors, n_small;
+    int64_t n_multi;                 /* pairs of more than one slice (the first n_multi entries of d_pair_order) */
     const dpl_work_item* d_items;    /* the balanced partition of the same pairs (compaction route), as for dpl_octav_run_compact */
     int64_t n_items;
     const uint32_t* d_block_begin;
@@ -213,6 +215,7 @@ typedef struct dpl_octav_oneread_job {
     uint16_t* d_dir;                 /* [n_chunks, dpl_octav_dir_row()]: per sorted run the position of each rank's first value */
     uint32_t* d_rescue_bm;           /* [n_pairs, 64]: exact bracket of a rescued pair */
     uint32_t* d_missed;              /* [n_pairs, 3]: (pair, first unit, units) of the rescued pairs */
+    uint64_t* d_resc;                /* [n_pairs, 3072]: suffix totals of a rescued pair (2048 fp64 sums, 2048 u32 counts): what its second walk starts from */
     /* carried across batches */
     uint32_t* d_vis;                 /* [2, n_tensors, 64] epoch accumulators; walks add to d_vis[write_epoch], cleared first when reset_epoch != 0 */
     float* d_tstat;                  /* [n_tensors, 8]: what each tensor's prediction from earlier batches would have cost lately (zeroed by the caller once) */
@@ -222,6 +225,9 @@ typedef struct dpl_octav_oneread_job {
     int32_t predict;                 /* 0: every tensor predicts from earlier batches, 1: every pair from a sample of itself, 2: chosen per
                                         tensor and batch on the device (by what the first would have listed / missed in the last batches) */
     float probe_z;                   /* width of the sample's brackets in standard deviations; 0: the default (3) */
+    int32_t fuse;                    /* 1: k_octav_oneread walks every single-slice pair itself (histogram still in LDS, list in L2);
+                                        dpl_octav_oneread_finish then walks the multi-slice pairs only.  0: every pair is walked by finish */
+    int32_t reserved;
     int32_t compaction_inline;       /* 1: dpl_octav_oneread_finish ends with dpl_octav_oneread_compaction; 0: the caller reads d_states[n_pairs].cnt_le
                                         when the batch is done and calls it only when that is non-zero */
 } dpl_octav_oneread_job;

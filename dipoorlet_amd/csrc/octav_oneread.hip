@@ -418,6 +418,7 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 // handed back zeroed), s_0, then the reference's iteration — totals of the bins above the iterate's bin (exact integers)
 // + the listed values of that bin (integer mantissa sums) — verifying that every iterate lands in a gathered bin.  Records
 // the bins it stepped into (or, when it left the gathered set, the pair's bracket) for the next batches.
+template <int kVecT>
 __device__ __forceinline__ void walk_pair(
     const uint32_t pair, double* s_ge, uint32_t* n_ge, Shared& sh,
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl,
@@ -572,7 +573,7 @@ __device__ __forceinline__ void walk_pair(
         }
         // the first kVec rows stay in registers for the whole walk; the rows beyond (the 3 % lists of the largest pairs) are
         // streamed kOver at a time in every iteration — requested before the resident rows are scanned, consumed after
-        f4 v[kVec], ov[kOver];
+        f4 v[kVecT], ov[kOver];
         const float* lp = (rescue ? list_rescue : list0) + pair_base[pair];
         auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
             constexpr int kN = decltype(count)::value;
@@ -605,7 +606,7 @@ __device__ __forceinline__ void walk_pair(
                 dst[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
             }
         };
-        load_rows(v, std::integral_constant<int, kVec>{}, 0u);
+        load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
         auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
         // all waves count their share of the list; ONE wave takes the step (fp64 totals, the division, the bin look-ups — some
         // hundred instructions that would otherwise issue four times over on a CU whose issue slots are what this kernel runs
@@ -646,11 +647,11 @@ __device__ __forceinline__ void walk_pair(
                 c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
                 ds += in ? d : 0u;
             };
-            if (n_rows > (uint32_t)kVec) load_rows(ov, std::integral_constant<int, kOver>{}, (uint32_t)kVec);
+            if (n_rows > (uint32_t)kVecT) load_rows(ov, std::integral_constant<int, kOver>{}, (uint32_t)kVecT);
             {
-                const uint32_t rows = min(n_rows, (uint32_t)kVec);
+                const uint32_t rows = min(n_rows, (uint32_t)kVecT);
 #pragma unroll
-                for (int u = 0; u < kVec; ++u) {
+                for (int u = 0; u < kVecT; ++u) {
                     if ((uint32_t)u < rows) {   // uniform
                         in1(v[u].x);
                         in1(v[u].y);
@@ -661,7 +662,7 @@ __device__ __forceinline__ void walk_pair(
                 dsum += (unsigned long long)wave_sum_dpp(ds);   // < 64 * 80 * 2^17
                 ds = 0u;
             }
-            for (uint32_t r0 = (uint32_t)kVec; r0 < n_rows; r0 += (uint32_t)kOver) {
+            for (uint32_t r0 = (uint32_t)kVecT; r0 < n_rows; r0 += (uint32_t)kOver) {
 #pragma unroll
                 for (int u = 0; u < kOver; ++u) {   // (rows past the list's end were loaded as zeros)
                     in1(ov[u].x);
@@ -899,7 +900,7 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
         // s_ge takes the histogram's own 16 KiB (a thread reads its eight packed words before it writes its eight doubles over
         // them), n_ge the queues' space (all flushed)
         __syncthreads();
-        walk_pair(pair, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl, nullptr, pair_slice0,
+        walk_pair<kVec>(pair, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl, nullptr, pair_slice0,
                   pred, fa.vis_w, n_tensors, pair_base, list0, slices, fa.dynamic_sym, fa.max_iters, fa.fail_every, 3, fa.rescue_bm,
                   fa.missed, nullptr, pred.t, fa.tstat, fa.resc, cnt);
         return;
@@ -911,7 +912,11 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     for (int b = tid; b < kLogNB; b += kThreads) row[b] = b == 0 ? (unsigned long long)sh.cursor : l_packed[b] & ~(1ull << 63);
 }
 
-__global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
+// kVecT = 16: any pair (four workgroups per CU).  kVecT = 32 (two per CU): the multi-slice pairs the fused schedule leaves to this
+// kernel — their lists (2.8 % of 802 816 elements: 22 k values) then sit in registers whole instead of being streamed from L2 in
+// every iteration beyond the first 16 Ki values.
+template <int kVecT>
+__global__ __launch_bounds__(kThreads, kVecT > 16 ? 2 : DPL_WALK_OCC) void k_octav_walk(
     dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl, const uint32_t* __restrict__ pair_order,
     const unsigned long long* __restrict__ lh, const uint32_t* __restrict__ pair_slice0, const PredRows pred,
     uint32_t* __restrict__ vis_w, uint32_t n_tensors, const uint64_t* __restrict__ pair_base,
@@ -921,7 +926,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk(
     __shared__ double s_ge[kLogNB];
     __shared__ uint32_t n_ge[kLogNB];
     __shared__ Shared sh;
-    walk_pair(pair_order ? pair_order[blockIdx.x] : blockIdx.x, s_ge, n_ge, sh, st, ctl, lh, pair_slice0, pred, vis_w, n_tensors,
+    walk_pair<kVecT>(pair_order ? pair_order[blockIdx.x] : blockIdx.x, s_ge, n_ge, sh, st, ctl, lh, pair_slice0, pred, vis_w, n_tensors,
               pair_base, list0, slices, dynamic_sym, max_iters, fail_every, phase, rescue_bm, missed, nullptr, pred_t, tstat, resc, 0u);
 }
 
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
     __shared__ Shared sh;
     const uint32_t n_missed = ctl->len[0];
     for (uint32_t e = blockIdx.x; e < n_missed; e += gridDim.x) {
-        walk_pair(missed[3 * e], s_ge, n_ge, sh, st, ctl, lh, pair_slice0, PredRows{nullptr, nullptr, nullptr}, nullptr, n_tensors, pair_base, nullptr, slices,
+        walk_pair<kVec>(missed[3 * e], s_ge, n_ge, sh, st, ctl, lh, pair_slice0, PredRows{nullptr, nullptr, nullptr}, nullptr, n_tensors, pair_base, nullptr, slices,
                   dynamic_sym, max_iters, fail_every, 2, rescue_bm, missed, list_rescue, nullptr, nullptr, resc, 0u);
         __syncthreads();
     }
@@ -1838,7 +1843,7 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(j->d_lh);
     dpl_octav_state* ctl = j->d_states + j->n_pairs;
     auto walk = [&](unsigned grid, const uint32_t* order, int phase) {
-        hipLaunchKernelGGL(k_octav_walk, dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_octav_walk<kVec>), dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                            d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
                            g_exact_fail_every, phase, j->d_rescue_bm, j->d_missed, j->d_pred, j->d_tstat,
                            reinterpret_cast<unsigned long long*>(j->d_resc));
@@ -1849,7 +1854,14 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const int64_t n_small = j->fuse ? 0 : j->n_small;
     const int64_t n_walk = j->fuse ? j->n_multi : j->n_pairs;
     if (!j->sorted) {   // every pair walked from registers by one workgroup
-        if (n_walk > 0) walk((unsigned)n_walk, j->d_pair_order, 0);
+        if (n_walk > 0 && j->fuse)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_octav_walk<2 * kVec>), dim3((unsigned)n_walk), dim3(kThreads), 0, st, j->d_states, ctl,
+                               j->d_pair_order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe}, d_vis_w,
+                               (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
+                               g_exact_fail_every, 0, j->d_rescue_bm, j->d_missed, j->d_pred, j->d_tstat,
+                               reinterpret_cast<unsigned long long*>(j->d_resc));
+        else if (n_walk > 0)
+            walk((unsigned)n_walk, j->d_pair_order, 0);
         DPL_LAUNCH_CHECK("k_octav_walk");
     } else {
         if (n_big > 0) {

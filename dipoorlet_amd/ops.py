@@ -296,7 +296,10 @@ _OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
 # batches per prediction epoch of the one-read form: a batch gathers the bins the walks of the current and the previous epoch
 # stepped into (8-16 batches of history)
 _ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.30"))
-_ONEREAD_SORT_SHARE = float(os.environ.get("DPL_ONEREAD_SORT_SHARE", "0.05"))
+# (round 3: with the single-slice pairs walked by their streaming workgroups, only the multi-slice pairs' lists reach the walk
+# kernels, and k_octav_walk<32> holds 32 Ki values in registers: sorted runs pay beyond ~12 % listed; measured at 4.3 % on the
+# ViT-B/16 set 0.51 vs 0.49, at 5.8 % on the ResNet-50 set 0.51 vs 0.48)
+_ONEREAD_SORT_SHARE = float(os.environ.get("DPL_ONEREAD_SORT_SHARE", "0.12"))
 _ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
 
 
@@ -495,8 +498,7 @@ class OctavPipeline:
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
         self.max_share = max(self.max_share, share)
         # which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short, sorted
-        # runs beyond ~5 % of the elements (measured, ResNet-50 shapes: 2.8 % listed 0.59 vs 0.55 of the roofline, 9 % listed
-        # 0.38 vs 0.43, 24 % listed 0.20 vs 0.32)
+        # runs beyond _ONEREAD_SORT_SHARE of the elements
         if share > _ONEREAD_SORT_SHARE * 1.2:
             plan._octav_sorted = 1
         elif share < _ONEREAD_SORT_SHARE * 0.8:

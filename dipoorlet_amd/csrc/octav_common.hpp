@@ -56,9 +56,9 @@ __device__ __forceinline__ double log_bin_scale(int b) {   // 2^(e - 150) for th
     return __longlong_as_double((long long)(e - 150 + 1023) << 52);
 }
 
-// One 64-bit LDS atomic per element: the bin word holds the count in bits 44..63 and the mantissa sum in bits
-// 0..43 (a sub-span has < 2^20 elements, an explicit mantissa is < 2^23: neither field can overflow into the other).
-constexpr int kPackShift = 44;
+// One 64-bit LDS atomic per element: the bin word holds the count in bits 43..62 and the mantissa sum in bits
+// 0..42 (a sub-span has < 2^20 elements, an explicit mantissa is < 2^23: neither field can overflow into the other).
+constexpr int kPackShift = 43;   // count: bits 43..62 (a slice has < 2^20 elements), bit 63 stays free for the gather flag
 constexpr unsigned long long kPackMask = (1ull << kPackShift) - 1ull;
 
 

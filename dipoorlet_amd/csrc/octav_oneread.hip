@@ -63,10 +63,10 @@ constexpr int kVec = DPL_RES_VEC;                               // 16-byte vecto
 constexpr int kOver = 4;                                         // rows of a list beyond the resident ones streamed per step of an iteration
 constexpr uint32_t kSmallCap = 20480;                           // pairs this small gather their whole window (no prediction)
 #ifndef DPL_SLICE_CAP
-#define DPL_SLICE_CAP 520192
+#define DPL_SLICE_CAP 1044480
 #endif
 constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
-static_assert(kCap < (1u << 19) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed field below the flag bit");
+static_assert(kCap < (1u << 20) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed field below the flag bit");
 constexpr int kRareTiles = (int)(kCap / (kWaves * 1024u)) + 1;   // tiles of a slice one wave walks (+ the ragged one)
 #ifndef DPL_QUEUE_CAP
 #define DPL_QUEUE_CAP 832

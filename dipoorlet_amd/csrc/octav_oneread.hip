@@ -7,26 +7,35 @@
 // cross-workgroup round trips per slice against ~16 us of residency a CU can afford at HBM rate.
 //
 // So nothing waits here.  The values the exact iteration needs are the ones in the histogram bins its iterates fall
-// into; WHICH bins is predicted from the previous batches (the bins the same tensor's iterates visited, OR-ed over the
-// images of two alternating epochs of batches, neighbours that hold next to nothing and the sparse tail added) and every
-// iterate of the exact walk is VERIFIED against the set that was gathered.  A pair whose iterate leaves the gathered bins
-// (first batch of a run, a distribution shift) publishes its bracket for the next batches and finishes on the compaction
-// route of octav_kernels.hip.  Results are the reference's iterate sequence either way; only the speed depends on the
-// prediction.
+// into; WHICH bins is predicted — per tensor and batch either from the previous batches (the bins the same tensor's iterates
+// visited, OR-ed over the images of two alternating epochs of batches, neighbours that hold next to nothing and the sparse
+// tail added: the narrowest prediction while the images are alike) or from a strided sample of the pair itself (k_octav_probe:
+// wider, costs a read of 1/16 of the pair, indifferent to how the images differ) — and every iterate of the exact walk is
+// VERIFIED against the set that was gathered.  A pair whose iterate leaves the gathered bins is RESCUED on the device: its
+// exact bracket from the histogram, a re-read of that pair alone by many workgroups, a second walk.  Results are the
+// reference's iterate sequence either way; only the speed depends on the prediction.
 //
-// Kernels (DESIGN.md 3c):
+// Kernels (DESIGN.md 3c, 3d):
 //   k_octav_oneread      one 256-thread workgroup per SLICE (<= kCap elements of one (image, tensor) pair): the slice's
 //                        only HBM read; per element min / max and ONE returning 64-bit LDS add on the bin's word of an
 //                        exact log-scale histogram (64 bins per octave: count + integer mantissa sum) whose bit 63 says
 //                        "gather"; gathered values -> dense per-wave LDS queues -> the slice's own region of the pair's
-//                        list (LDS cursor, no global atomic); the histogram leaves as one row per slice.
-//   k_octav_walk         one workgroup per pair: rows -> suffix totals in LDS -> s_0 -> the exact iteration with the list
-//                        in registers (totals of the bins above the iterate's bin: exact integers; listed values of that
-//                        bin: integer mantissa sums), every iterate verified, visited bins recorded for the next batches.
-//   k_octav_sort + k_octav_walk_sorted   the walk for LONG lists (images that differ widen the prediction): a slice's
-//                        list sorted by bin rank in 8192-value runs, then one WAVE per pair looking up one rank per
-//                        iteration.
-//   k_octav_oneread_init state + prediction snapshot (bitmap of at most 255 bins + per-word rank prefix) of a batch.
+//                        list (LDS cursor, no global atomic).  A slice that is a whole pair (kCap = 1 044 480: every pair
+//                        of the ResNet-50 / ViT-B/16 sets) is then WALKED by the same workgroup (walk_pair, phase 3):
+//                        histogram converted in place into suffix totals, list read back from L2.  Otherwise the
+//                        histogram leaves as one row per slice for k_octav_walk.
+//   walk_pair            the exact walk of one pair: suffix totals -> s_0 -> the reference's iteration with the list in
+//                        registers (totals of the bins above the iterate's bin: exact integers; listed values of that
+//                        bin: integer mantissa sums), every iterate verified; records the bins stepped into for the next
+//                        batches and what the tensor's prediction from earlier batches would have cost (the choice);
+//                        a pair that leaves the gathered set: its bracket + suffix totals for the rescue.
+//   k_octav_walk<16|32>  walk_pair for multi-slice pairs (one workgroup per pair); k_octav_walk_rescue: a persistent grid
+//                        over the rescued pairs (octav_kernels.hip: k_octav_rescue_gather re-reads them first).
+//   k_octav_sort + k_octav_walk_sorted   the walk for LONG lists of multi-slice pairs: a slice's list sorted by bin rank in
+//                        8192-value runs, then one WAVE per pair looking up one rank per iteration.
+//   k_octav_probe        the pair's own prediction row from a strided sample (128 bytes of every 2 KiB).
+//   k_octav_oneread_init state + the tensors' prediction snapshot (bitmap of at most 255 bins + per-word rank prefix) of a
+//                        batch + the choice per tensor.
 // No workgroup ever waits for another; what crosses kernels crosses launches.
 #include <type_traits>
 #include "common.hpp"

@@ -403,21 +403,21 @@ def _walk_sorted(plan):
 
 
 class OctavPipeline:
-    """OCTAV over a RUN of batches in the one-read form with the two halves of a batch on two HIP streams: the streaming
-    kernel of batch i + 1 (HBM-bound, the caller's stream) runs beside the per-pair walk of batch i (latency-bound: ~20
-    dependent iterations per pair, a side stream).  Same kernels, same results as octav_batch(form='oneread').
+    """OCTAV over a RUN of batches in the one-read form on two HIP streams.  Same kernels, same results as
+    octav_batch(form='oneread').
 
         pipe = OctavPipeline(dynamic_sym)
         rows = [pipe.submit(plan, tensors) for ...]     # [B, T, 3] each, NOT valid yet
         pipe.sync()                                     # rows are valid for work on the caller's stream
 
-    Each plan keeps two sets of per-batch scratch (states, histogram rows, prediction snapshot, gather list) so that
-    batch i + 1 can stream while batch i walks.  The walk leaves the number of pairs it could not finish (a bin outside the
-    prediction: every multi-slice pair of a plan's first batch, rare afterwards) in the set's control block; that count is
-    copied to pinned memory and read when the set comes up for reuse two submits later (or in sync()), and only then, if it
-    is non-zero, is the compaction route launched for that batch — in steady state no no-op launches queue up behind the
-    streaming kernel.  The activations of a batch, its pointer table and its result stay referenced from the set until
-    then.  The host therefore runs at most two batches ahead of the device.
+    Caller's stream: the pairs' own predictions where the tensor needs them (k_octav_probe) and the streaming kernel, which
+    also walks every single-slice pair.  Side stream, behind the streaming kernel of batch i and beside that of batch i + 1:
+    the walk of the multi-slice pairs, the rescue of the pairs a walk could not finish (on the device, no host round trip),
+    the result rows, the state and the choice of prediction for batch i + 2.  Each plan keeps two sets of per-batch scratch.
+    The control block of a batch (listed values, rescued pairs, pairs left for the compaction route) is copied to pinned
+    memory and read when the set comes up for reuse two submits later (or in sync()): statistics, the choice of walk for long
+    lists, and — only when the count is non-zero — the launch of the compaction route for that batch.  The activations of a
+    batch, its pointer table and its result stay referenced from the set until then; the host runs at most two batches ahead.
     A tensor set the one-read form cannot take (a pair above 64 slices) runs octav_batch on the caller's stream instead."""
 
     def __init__(self, dynamic_sym, device=None):

@@ -602,3 +602,40 @@ def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk):
         warnings.simplefilter("ignore")
         for t in range(len(sizes)):
             assert _close(a[1, t, 0].item(), O.octav_scale(x[t][1].cpu().numpy(), 1))
+
+
+def test_octav_oneread_schedules_and_predictions_agree(dev, monkeypatch):
+    """The one-read form's variants walk the same exact integer sums: the walk inside the streaming kernel (DPL_OCTAV_FUSE=1,
+    the default) or in its own kernel (=0); the prediction from earlier batches, from a sample of the pair itself, or chosen
+    per tensor (DPL_OCTAV_PREDICT) — bit-identical rows over a run of batches whose images differ in scale (so that the
+    prediction from earlier batches misses and pairs are rescued), through the pipeline and on one stream."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(41)
+    B, sizes = 3, [150528, 40000, 802816, 1000, 200704, 1200007]
+    batches = [[torch.from_numpy((rng.standard_normal((B, n)) * (1 + 0.3 * t) * (1 + 0.25 * k)).astype(np.float32)
+                                 * (1 if t % 2 else np.float32(1)) ).clamp_(min=0 if t % 2 else -1e30).to(dev)
+                for t, n in enumerate(sizes)] for k in range(4)]
+    ref = None
+    for fuse in ("1", "0"):
+        for predict in ("auto", "probe", "learned"):
+            monkeypatch.setenv("DPL_OCTAV_FUSE", fuse)
+            monkeypatch.setenv("DPL_OCTAV_PREDICT", predict)
+            plan = ops.TensorSetPlan(sizes, B, dev)
+            pipe = ops.OctavPipeline(False, dev)
+            rows = [pipe.submit(plan, b) for b in batches]
+            pipe.sync()
+            torch.cuda.synchronize()
+            got = np.stack([r.cpu().numpy() for r in rows])
+            plan1 = ops.TensorSetPlan(sizes, B, dev)
+            single = np.stack([ops.octav_batch(plan1, b, False).cpu().numpy() for b in batches])
+            assert np.array_equal(got, single), (fuse, predict)
+            if ref is None:
+                ref = got
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    for t in range(len(sizes)):
+                        assert _close(got[3, 1, t, 0], O.octav_scale(batches[3][t][1].cpu().numpy(), 1)), t
+            else:
+                assert np.array_equal(got, ref), (fuse, predict)
+            if predict == "learned":   # differing scales: the earlier batches' bins do not cover the later ones -> rescues
+                assert pipe.fallback_pairs > 0

@@ -166,6 +166,7 @@ struct Shared {
     uint32_t rare_tiles[kWaves * kRareTiles];   // streaming kernel: tiles holding a non-zero value outside the window
     uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
     uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
+    uint32_t cheapw[kLogWords], thinw[kLogWords];   // walk: bins holding next to nothing / the sparse tail (bitmaps)
     uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
     double f_sum;                 // streaming kernel -> its own walk (a single-slice pair): the statistics it just published
     uint32_t f_nz, f_nan;
@@ -521,6 +522,30 @@ __device__ __forceinline__ void walk_pair(
         }
         if (rescue) __syncthreads();
         else suffix_in_place(n_ge, s_ge, sh);
+        // what the publication below adds to the bins the walk steps into: bins that hold next to nothing (cheap) and the sparse
+        // tail (thin) — per bitmap word, by the threads that own the bins (eight consecutive bins: one word), while the walk's
+        // list is on its way; a loop over all bins per word at publication time was a quarter of a small pair's walk
+        if (tid < (uint32_t)kLogWords) {
+            sh.cheapw[tid] = 0u;
+            sh.thinw[tid] = 0u;
+        }
+        __syncthreads();
+        if (!rescue) {
+            const uint32_t cheap_n = (uint32_t)(n_pair >> DPL_CHEAP_SHIFT), thin_n = (uint32_t)(n_pair >> DPL_THIN_SHIFT);
+            uint32_t cb = 0u, tb = 0u;
+            uint32_t above = hi + 1 < kLogNB ? n_ge[hi + 1] : 0u;
+#pragma unroll
+            for (int qq = 0; qq < kPerT; ++qq) {
+                const int b = hi - qq;
+                const uint32_t here = n_ge[b];
+                const bool valid = b > 0 && b < kLogNB - 1;
+                cb |= (valid && here - above <= cheap_n ? 1u : 0u) << (b & 31);
+                tb |= (valid && here != 0u && here <= thin_n ? 1u : 0u) << (b & 31);
+                above = here;
+            }
+            atomicOr(&sh.cheapw[hi >> 5], cb);
+            atomicOr(&sh.thinw[hi >> 5], tb);
+        }
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
@@ -746,26 +771,14 @@ __device__ __forceinline__ void walk_pair(
             rescued = sh.route == 2u;
         }
         if (tid < (uint32_t)kLogWords) {
-            // neighbours: bin j-1 / j+1 of a published bin j join when they hold <= 0.2 % of the pair
-            const uint32_t cheap = (uint32_t)(sh.n_elems >> DPL_CHEAP_SHIFT);
+            // neighbours: bin j-1 / j+1 of a published bin j join when they hold <= 0.05 % of the pair (sh.cheapw)
             const uint32_t mine = sh.pub[tid];
             const uint32_t up = (mine << 1) | (tid > 0 ? sh.pub[tid - 1] >> 31 : 0u);                    // j + 1 candidates
             const uint32_t dn = (mine >> 1) | (tid + 1 < (uint32_t)kLogWords ? sh.pub[tid + 1] << 31 : 0u);   // j - 1 candidates
-            uint32_t cand = (up | dn) & ~mine, add = 0u;
-            while (cand) {
-                const int bit = __ffs(cand) - 1;
-                cand &= cand - 1u;
-                const int j = (int)tid * 32 + bit;
-                if (j > 0 && j < kLogNB - 1 && n_ge[j] - n_ge[j + 1] <= cheap) add |= 1u << bit;
-            }
-            // the sparse tail, wholesale: every bin from which on no more than 1/128 of the pair lies above — that is where
-            // the late iterates land, and where they scatter most from image to image
-            const uint32_t thin = (uint32_t)(sh.n_elems >> DPL_THIN_SHIFT);
-            uint32_t tail = 0u;
-            for (int bit = 0; bit < 32; ++bit) {
-                const int j = (int)tid * 32 + bit;
-                if (j > 0 && j < kLogNB - 1 && n_ge[j] != 0u && n_ge[j] <= thin) tail |= 1u << bit;
-            }
+            const uint32_t add = (up | dn) & ~mine & sh.cheapw[tid];
+            // the sparse tail, wholesale: every bin from which on no more than 1/512 of the pair lies above — that is where
+            // the late iterates land, and where they scatter most from image to image (sh.thinw)
+            const uint32_t tail = sh.thinw[tid];
             const uint32_t out = mine | add | tail;
             if (out) atomicOr(vis_w + tensor * kLogWords + tid, out);
             if (rescued) rescue_bm[(uint64_t)pair * kLogWords + tid] = out;
@@ -853,6 +866,7 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     __shared__ Shared sh;
 
     const uint32_t tid = threadIdx.x;
+    DPL_PROF_T(kt0);
     const dpl_work_item it = slices[blockIdx.x];
     const uint32_t pair = it.slot, n_sl = it.reserved, cnt = it.count;
     dpl_octav_state* me = st + pair;
@@ -875,6 +889,8 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     const uint64_t in_pair = it.offset - slices[pair_slice0[2 * pair]].offset;
     stream_slice(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + in_pair), sh, ctl);
     __syncthreads();   // every LDS histogram atomic of the slice has landed; the per-wave statistics are in sh
+    DPL_PROF_T(kt1);
+    DPL_PROF_ADD(4, kt0, kt1);
 
     // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
     if (tid == 0) {
@@ -912,6 +928,8 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
         walk_pair<kVec>(pair, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl, nullptr, pair_slice0,
                   pred, fa.vis_w, n_tensors, pair_base, list0, slices, fa.dynamic_sym, fa.max_iters, fa.fail_every, 3, fa.rescue_bm,
                   fa.missed, nullptr, pred.t, fa.tstat, fa.resc, cnt);
+        DPL_PROF_T(kt2);
+        DPL_PROF_ADD(5, kt1, kt2);
         return;
     }
     // the slice's histogram goes out as ONE row of plain, coalesced stores (16 KiB, empty bins included: nothing to zero

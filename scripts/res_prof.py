@@ -51,4 +51,6 @@ for i, nm in enumerate(names):
 for lo, hi in ((0, 384), (384, 864), (864, 1952), (1952, 3936)):
     q = p[lo:hi] / n
     print(f"  slots {lo:4d}-{hi:4d}: rows {q[:, 0].mean():8.0f}  list {q[:, 1].mean():8.0f}  walk {q[:, 2].mean():8.0f}  publish {q[:, 3].mean():8.0f}  "
-          f"iters {q[:, 7].mean():.1f}  list {q[:, 6].mean():.0f}")
+          f"iters {q[:, 7].mean():.1f}  list {q[:, 6].mean():.0f}   | stream {q[:, 4].mean():9.0f}  fused walk total {q[:, 5].mean():8.0f}")
+print(f"  sums over workgroups (ticks): stream {p[:, 4].sum() / n:.3e}  fused walk {p[:, 5].sum() / n:.3e}  -> walk share of workgroup time "
+      f"{p[:, 5].sum() / max(1.0, p[:, 4].sum() + p[:, 5].sum()):.3f}")

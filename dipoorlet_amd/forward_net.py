@@ -23,7 +23,7 @@ from .dist_helper import shard_range
 from .platform_settings import platform_setting_table
 from .utils import logger
 
-DEFAULT_BATCH = 16
+DEFAULT_BATCH = 32   # images per forward (the batch bench.py measures the statistics kernels at)
 
 
 class ActivationSession:

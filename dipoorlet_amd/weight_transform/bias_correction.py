@@ -31,7 +31,9 @@ def _channel_mean_diff(fp_chunks, q_chunks, is_conv):
     """bias_correction.py:10-13 — mean(fp - q) over every axis but the channel one (axis 1 of a Conv output
     [n, C, spatial...]; the last axis of a Gemm output [n, C]): one fused kernel per chunk pair, fp64 sums."""
     acc, cnt = None, 0
+    dev = torch.device("cuda", torch.cuda.current_device())
     for a, b in zip(fp_chunks, q_chunks):
+        a, b = a.to(dev, non_blocking=True), b.to(dev, non_blocking=True)   # (no-ops unless the frontier is kept on the host)
         if not is_conv:
             a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
         acc = ops.channel_diff_sum(a.contiguous(), b.contiguous(), acc)
@@ -93,10 +95,14 @@ def _frontier_peak_elems(graph, session):
 class _Frontier:
     """Activations of every live tensor for the whole calibration set, as lists of per-chunk tensors."""
 
-    def __init__(self, session, graph):
+    def __init__(self, session, graph, on_host=False):
         self.sess, self.graph = session, graph
         self.env = {}
         self.ref = {}
+        # on_host: the live activations of the whole set do not fit the HBM budget — chunks wait in (pinned) host memory and
+        # come back to the device one at a time when a node consumes them: slower (PCIe both ways), same values
+        self.on_host = on_host
+        self.dev = torch.device("cuda", torch.cuda.current_device())
         for node in graph.graph.node:
             if node.name in session._folded:
                 continue
@@ -110,14 +116,14 @@ class _Frontier:
         outs = [[] for _ in node.output]
         for c in range(n_chunks):
             self.sess.batch = chunk_sizes[c]
-            args = [None if i == "" else (self.sess.consts[i] if i in self.sess.consts else self.env[i][c])
+            args = [None if i == "" else (self.sess.consts[i] if i in self.sess.consts else self.env[i][c].to(self.dev))
                     for i in node.input]
             while args and args[-1] is None:
                 args.pop()
             r = _OPS[node.op_type](self.sess, node, *args)
             r = list(r) if isinstance(r, (list, tuple)) else [r]
             for k, v in enumerate(r[:len(outs)]):
-                outs[k].append(v)
+                outs[k].append(v.cpu() if self.on_host else v)
         for o, v in zip(node.output, outs):
             if o != "":
                 self.env[o] = v
@@ -152,13 +158,16 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
     # die in the allocator halfway through (the other ranks would be left at the next barrier).
     need = 4.0 * N * (_frontier_peak_elems(graph, s_fp) + _frontier_peak_elems(graph_q, s_q))
     budget = float(getattr(args, "resident_gb", 160.0) or 160.0) * 1e9
-    if need > budget:
-        raise MemoryError(f"--bc keeps the live activations of all {N} images of both networks in HBM: about {need / 1e9:.0f} GB "
-                          f"at the widest point of this graph, over the {budget / 1e9:.0f} GB budget (--resident_gb); "
-                          f"lower -N for --bc or raise --resident_gb")
-    fp, qf = _Frontier(s_fp, graph), _Frontier(s_q, graph_q)
+    on_host = need > budget
+    if on_host:
+        logger.warning("--bc: the live activations of all %d images of both networks are about %.0f GB at the widest point of "
+                       "this graph, over the %.0f GB budget (--resident_gb): keeping them in host memory between nodes",
+                       N, need / 1e9, budget / 1e9)
+    fp, qf = _Frontier(s_fp, graph, on_host), _Frontier(s_q, graph_q, on_host)
     for n in graph.network_inputs:
         chunks = [load_input_batch(args.input_dir, [n], shapes, i, j, dev)[n] for i, j in bounds]
+        if on_host:
+            chunks = [t.cpu() for t in chunks]
         fp.env[n] = chunks
         qf.env[n] = chunks
     fp_nodes = {n.name: n for n in graph.graph.node}
@@ -179,8 +188,9 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
             logger.info("Update bias for node: {}".format(node.name))
             diff = update_conv_node_bias(graph_bc, node, keep_fp[out], qf.env[out])
             shape = [1, -1] + [1] * (qf.env[out][0].dim() - 2)
+            d_host = diff.reshape(shape).cpu() if on_host else None
             for t in qf.env[out]:  # the bias is additive in the output: fix the computed q output in place
-                t.add_(diff.reshape(shape))
+                t.add_(d_host if on_host else diff.reshape(shape))
         for env_ref, o in ((fp, fp_node.output[0]), (qf, out)):   # drop the extra hold
             env_ref.ref[o] -= 1
             if env_ref.ref[o] == 0:

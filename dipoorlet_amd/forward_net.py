@@ -228,9 +228,26 @@ def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_residen
         allr = _np32(torch.cat(rows)) if rows else np.zeros((0, run.T, 2), np.float32)
         return {n: {"max": list(allr[:, t, 1]), "min": list(allr[:, t, 0])} for t, n in enumerate(run.names)}
     acc = ops.CalibAccumulators(run.T, run.device, int(getattr(args, "bins", 2048)))
+    # the range kernel of batch i runs on a side stream beside the network forward of batch i + 1 (one is HBM-bound, the
+    # other mostly compute-bound library work); a batch's tensors stay referenced until its kernel has run
+    main = torch.cuda.current_stream(run.device)
+    side = torch.cuda.Stream(run.device)
+    side.wait_stream(main)                      # the accumulators' initialisation
+    in_flight = []
     for b, tensors in run.forward(keep=keep_resident):
-        with run.timed("statistics"):
-            acc.minmax_accumulate(run.plan(b), tensors)
+        produced = torch.cuda.Event()
+        produced.record(main)
+        side.wait_event(produced)
+        with torch.cuda.stream(side):
+            with run.timed("statistics"):
+                acc.minmax_accumulate(run.plan(b), tensors)
+            done = torch.cuda.Event()
+            done.record(side)
+        in_flight.append((done, tensors))
+        while len(in_flight) > 2:               # at most two batches ahead of the statistics
+            in_flight.pop(0)[0].synchronize()
+    main.wait_stream(side)
+    in_flight.clear()
     gmin, gmax = acc.finalize_minmax()
     run.acc = acc
     lo, hi = _np32(gmin), _np32(gmax)

@@ -136,3 +136,26 @@ def test_header_compiles_as_plain_c_and_cpp():
         pytest.skip("no gcc on this box")
     subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Werror", hdr], check=True)
     subprocess.run(["g++", "-fsyntax-only", "-x", "c++", "-Wall", "-Werror", hdr], check=True)
+
+
+def test_oneread_job_struct_layout_matches_the_header(tmp_path):
+    """dpl_octav_oneread_job crosses the boundary by pointer: the ctypes mirror must have the C compiler's layout — every
+    field's offset and the total size, taken from a C program that includes the header."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    fields = [f[0] for f in _hip.OctavOnereadJob._fields_]
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dipoorlet_hip.h"\nint main(void) {\n'
+                   + "".join(f'  printf("{f} %zu\\n", offsetof(dpl_octav_oneread_job, {f}));\n' for f in fields)
+                   + '  printf("sizeof %zu\\n", sizeof(dpl_octav_oneread_job));\n'
+                   + '  printf("state %zu %zu %zu\\n", sizeof(dpl_octav_state), offsetof(dpl_octav_state, mode), offsetof(dpl_octav_state, len));\n'
+                   + "  return 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(line.split(None, 1) for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for f in fields:
+        assert int(out[f]) == getattr(_hip.OctavOnereadJob, f).offset, f
+    assert int(out["sizeof"]) == C.sizeof(_hip.OctavOnereadJob)
+    assert out["state"].split() == [str(C.sizeof(_hip.OctavState)), str(_hip.OctavState.mode.offset), str(_hip.OctavState.len0.offset)]

@@ -641,11 +641,15 @@ __device__ __forceinline__ void walk_pair(
             }
         };
         load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
-        auto marked = [&](int j) { return j > 0 && j < kLogNB - 1 && ((sh.bm[j >> 5] >> (j & 31)) & 1u); };
-        // all waves count their share of the list; ONE wave takes the step (fp64 totals, the division, the bin look-ups — some
-        // hundred instructions that would otherwise issue four times over on a CU whose issue slots are what this kernel runs
-        // out of) and hands the next iterate to the others through LDS: two barriers per iteration.  Which wave: by workgroup,
-        // so that the stepping waves of the workgroups sharing a CU do not all sit on the same SIMD
+        // Every wave takes the step itself from the four partial sums (one barrier and two LDS round trips per iteration instead
+        // of two and five): inside the streaming kernel the LDS pipeline is full of the other workgroups' histogram atomics and
+        // a round trip costs several hundred cycles.  The gathered-bin bitmap sits in registers (lane l: word l).
+        const uint32_t bm_reg = sh.bm[lane];
+        auto marked = [&](int j) {
+            return j > 0 && j < kLogNB - 1 && (((uint32_t)__builtin_amdgcn_readlane((int)bm_reg, j >> 5) >> (j & 31)) & 1u);
+        };
+        // all waves count their share of the list and leave their partial sums in LDS; which wave records the bins entered: by
+        // workgroup
         const int stepper = (int)(blockIdx.x & (kWaves - 1));
         int jb = log_bin(s);
         bad = marked(jb) ? 0u : 1u;
@@ -655,9 +659,10 @@ __device__ __forceinline__ void walk_pair(
         auto enter = [&](int j) {   // exact totals of the bins above bin j; bin j goes on record
             n_above = (j + 1 < kLogNB) ? (unsigned long long)n_ge[j + 1] : 0ull;
             s_above = (j + 1 < kLogNB) ? s_ge[j + 1] : 0.0;
-            if (lane == 0) sh.pub[j >> 5] |= 1u << (j & 31);   // (only the stepping wave enters bins)
+            if (lane == 0 && w == stepper) sh.pub[j >> 5] |= 1u << (j & 31);   // (every wave enters; one records)
         };
-        if (!bad && w == stepper) enter(jb);
+        if (!bad) enter(jb);
+        uint32_t par = 0u;   // alternating slots: a wave may write iteration k + 1's partials while another still reads k's
         uint32_t done = 0u;
         DPL_PROF_T(pt2);
         DPL_PROF_ADD(1, pt1, pt2);
@@ -709,17 +714,18 @@ __device__ __forceinline__ void walk_pair(
                 ds = 0u;
             }
             if (lane == 0) {
-                sh.part_c[0][w] = c;
-                sh.part_m[0][w] = dsum + (unsigned long long)c * (unsigned long long)(lo1 & 0x7FFFFFu);   // sum of explicit mantissas
+                sh.part_c[par][w] = c;
+                sh.part_m[par][w] = dsum + (unsigned long long)c * (unsigned long long)(lo1 & 0x7FFFFFu);   // sum of explicit mantissas
             }
             __syncthreads();
-            if (w == stepper) {
+            {
                 unsigned long long tc = 0ull, tm = 0ull;
 #pragma unroll
                 for (int j = 0; j < kWaves; ++j) {
-                    tc += sh.part_c[0][j];
-                    tm += sh.part_m[0][j];
+                    tc += sh.part_c[par][j];
+                    tm += sh.part_m[par][j];
                 }
+                par ^= 1u;
                 const unsigned long long tg = n_above + tc;
                 const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
                 const OctavStep qs = octav_step(ts, tg, n_elems - tg, ud, s, iters, max_iters);
@@ -735,19 +741,6 @@ __device__ __forceinline__ void walk_pair(
                         enter(jb);
                     }
                 }
-                if (lane == 0) {
-                    sh.w_s = s;
-                    sh.jb = jb;
-                    sh.bad = done | (bad << 1);
-                }
-            }
-            __syncthreads();
-            if (w != stepper) {
-                s = sh.w_s;
-                jb = sh.jb;
-                const uint32_t fl = sh.bad;
-                done = fl & 1u;
-                bad = fl >> 1;
             }
         }
         DPL_PROF_T(pt3);

@@ -167,6 +167,7 @@ struct Shared {
     uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
     uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
     uint32_t cheapw[kLogWords], thinw[kLogWords];   // walk: bins holding next to nothing / the sparse tail (bitmaps)
+    uint32_t would_list;          // walk: values the tensor's prediction from earlier batches would have listed of this pair
     uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
     double f_sum;                 // streaming kernel -> its own walk (a single-slice pair): the statistics it just published
     uint32_t f_nz, f_nan;
@@ -179,6 +180,36 @@ struct Shared {
     double s_above;
     unsigned long long n_above, n_elems;
 };
+
+// wave64 inclusive prefix sums by DPP (Hillis-Steele inside each row of 16, then the two row broadcasts): VALU only — the
+// ds_bpermute form (__shfl_up) is six dependent trips through the LDS pipeline per value, which inside the streaming kernel is
+// full of the other workgroups' histogram atomics
+__device__ __forceinline__ uint32_t scan_u32_dpp(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+__device__ __forceinline__ double scan_f64_dpp(double v) {
+#define DPL_SCAN_STEP(ctrl, rmask, bound)                                                                              \
+    {                                                                                                                  \
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);                                      \
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, ctrl, rmask, 0xF, bound);       \
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), ctrl, rmask, 0xF, bound); \
+        v += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));                                   \
+    }
+    DPL_SCAN_STEP(0x111, 0xF, true)
+    DPL_SCAN_STEP(0x112, 0xF, true)
+    DPL_SCAN_STEP(0x114, 0xF, true)
+    DPL_SCAN_STEP(0x118, 0xF, true)
+    DPL_SCAN_STEP(0x142, 0xA, false)
+    DPL_SCAN_STEP(0x143, 0xC, false)
+#undef DPL_SCAN_STEP
+    return v;
+}
 
 // Raw per-bin (count, scaled sum) in n_ge / s_ge -> suffix totals in place (N_ge[j], S_ge[j] = everything in bins >= j).
 // Thread t owns the 8 bins below 2047 - 8 t; all 256 threads; the raw values were written by their owners.
@@ -193,17 +224,8 @@ __device__ __forceinline__ void suffix_in_place(uint32_t* n_ge, double* s_ge, Sh
         ln += n_ge[hi - q];
         ls += s_ge[hi - q];
     }
-    double is = ls;
-    uint32_t in = ln;
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const double ts = __shfl_up(is, o, kWave);
-        const uint32_t tn = __shfl_up(in, o, kWave);
-        if (lane >= (uint32_t)o) {
-            is += ts;
-            in += tn;
-        }
-    }
+    const double is = scan_f64_dpp(ls);
+    const uint32_t in = scan_u32_dpp(ln);
     if (lane == kWave - 1) {
         sh.red_d[w] = is;
         sh.red_a[w] = in;
@@ -529,10 +551,13 @@ __device__ __forceinline__ void walk_pair(
             sh.cheapw[tid] = 0u;
             sh.thinw[tid] = 0u;
         }
+        if (tid == 0) sh.would_list = 0u;
         __syncthreads();
         if (!rescue) {
             const uint32_t cheap_n = (uint32_t)(n_pair >> DPL_CHEAP_SHIFT), thin_n = (uint32_t)(n_pair >> DPL_THIN_SHIFT);
-            uint32_t cb = 0u, tb = 0u;
+            // (also: what the tensor's prediction from earlier batches would have listed of this pair — the selection statistics)
+            const uint32_t lw = pred_t ? pred_t[tensor * kPredRow + (hi >> 5)] : 0u;
+            uint32_t cb = 0u, tb = 0u, wl = 0u;
             uint32_t above = hi + 1 < kLogNB ? n_ge[hi + 1] : 0u;
 #pragma unroll
             for (int qq = 0; qq < kPerT; ++qq) {
@@ -541,10 +566,12 @@ __device__ __forceinline__ void walk_pair(
                 const bool valid = b > 0 && b < kLogNB - 1;
                 cb |= (valid && here - above <= cheap_n ? 1u : 0u) << (b & 31);
                 tb |= (valid && here != 0u && here <= thin_n ? 1u : 0u) << (b & 31);
+                wl += (valid && ((lw >> (b & 31)) & 1u)) ? here - above : 0u;
                 above = here;
             }
             atomicOr(&sh.cheapw[hi >> 5], cb);
             atomicOr(&sh.thinw[hi >> 5], tb);
+            if (wl) atomicAdd(&sh.would_list, wl);
         }
     }
     // the bins whose values were gathered (the walk may only step into these)
@@ -779,14 +806,7 @@ __device__ __forceinline__ void walk_pair(
             // whether it would have covered the bins this walk needed: k_octav_oneread_init chooses per tensor between that
             // prediction and the one from a sample of the pair itself (k_octav_probe)
             const uint32_t lw = pred_t[tensor * kPredRow + tid];
-            uint32_t c = 0u, bits = lw;
-            while (bits) {
-                const int bit = __ffs(bits) - 1;
-                bits &= bits - 1u;
-                const int j = (int)tid * 32 + bit;
-                if (j > 0 && j < kLogNB - 1) c += n_ge[j] - n_ge[j + 1];
-            }
-            const uint32_t would_list = wave_sum_dpp(c);
+            const uint32_t would_list = sh.would_list;
             const bool would_miss = __builtin_amdgcn_ballot_w64((mine & ~lw) != 0u) != 0ull;
             if (tid == 0) {
                 float* ts = tstat + (size_t)tensor * kTstatRow;

@@ -1493,6 +1493,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     if (sp.count <= (uint64_t)kSmallCap) return;   // gathers its whole window: no prediction row is read
     if (!use_probe[tensor]) return;                // this batch, the tensor's pairs gather by its row from earlier batches
     uint32_t* row = pred_p + (uint64_t)pair * kPredRow;
+    DPL_PROF_T(qp0);
     for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
     __syncthreads();
     // ---- the sample: chunk g (32 floats = 128 bytes, one L2 line: 64-byte chunks fetched whole lines for half the use —
@@ -1599,6 +1600,8 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
             if (var_e > 0.0) deff = (float)fmin(fmax(1.0 + (31.0 / 3.0) * (var_c / (4.0 * var_e) - 1.0), 1.0), 64.0);
         }
     }
+    DPL_PROF_T(qp1);
+    DPL_PROF_ADD(0, qp0, qp1);
     // ---- per-bin (count, sum, sum of squares) -> suffix sums (thread t owns the 8 bins below 2047 - 8 t; everything in bins >= j)
     {
         constexpr int kPerT = kLogNB / kThreads;
@@ -1660,6 +1663,8 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     }
     if (tid < (uint32_t)kLogWords) sh.bm[tid] = 0u;
     __syncthreads();
+    DPL_PROF_T(qp2);
+    DPL_PROF_ADD(1, qp1, qp2);
     // ---- the iteration on the sample, with its uncertainty (one thread: ~20 steps of a few dozen operations)
 #ifdef DPL_PROBE_NOWALK
     if (tid == 0) sh.bm[20] = 0xFFu;
@@ -1711,6 +1716,8 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     }
 #endif
     __syncthreads();
+    DPL_PROF_T(qp3);
+    DPL_PROF_ADD(2, qp2, qp3);
     // ---- the row: at most kMaxFlag - 1 bins (lowest first) + per word the number of gathered bins below it (wave 0)
     if (tid < (uint32_t)kLogWords) {
         uint32_t x = sh.bm[tid];

@@ -493,9 +493,24 @@ def main():
             pass
         return None
     traffic = measured_traffic("k_abs_hist")
+
+    def mse_batch_traffic():
+        """HBM bytes of ONE mse batch: every k_octav_* kernel of the profiled run, per launch of the streaming kernel."""
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r03", "traffic.json"))
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from summarize_prof import source_sha
+            with open(tj) as f:
+                tr = json.load(f)
+            if tr.get("source_sha") != source_sha() or tr.get("batch") != B:
+                return None
+            ks = {k: v for k, v in tr["kernels"].items() if k.startswith("k_octav_")}
+            n = ks["k_octav_oneread"]["launches"]
+            return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / n
+        except Exception:
+            return None
     if mse is not None:
-        t1, t2 = measured_traffic("k_octav_oneread"), measured_traffic("k_octav_walk")
-        mse["roofline"]["traffic"] = (t1 + t2) if (t1 is not None and t2 is not None) else None
+        mse["roofline"]["traffic"] = mse_batch_traffic()
     images = N_HIST * world * a.steps
     hist_rate = images / dt_hist
     headline_mse = a.algo == "mse" and mse is not None

@@ -1565,12 +1565,24 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
 #endif
         }
     }
-    m = wave_sum(m);
+    // (wave sums by DPP: the ds_bpermute form of ten reductions was a fifth of a small pair's time here)
+#define DPL_FSTEP(ctrl, rmask, bound) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bound))
+    auto fsum = [](float v) {
+        DPL_FSTEP(0xB1, 0xF, true);     // quad_perm [1,0,3,2]
+        DPL_FSTEP(0x4E, 0xF, true);     // quad_perm [2,3,0,1]
+        DPL_FSTEP(0x141, 0xF, true);    // row_half_mirror
+        DPL_FSTEP(0x140, 0xF, true);    // row_mirror: every lane holds its row's sum
+        DPL_FSTEP(0x142, 0xA, false);   // row_bcast15 -> rows 1, 3
+        DPL_FSTEP(0x143, 0xC, false);   // row_bcast31 -> rows 2, 3
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    };
+#undef DPL_FSTEP
+    m = wave_sum_dpp(m);
     mn = wave_min(mn);
-    const double w_cs = wave_sum((double)c_sum), w_cq = wave_sum((double)c_sq), w_es = wave_sum((double)e_sum), w_eq = wave_sum((double)e_sq);
-    const double w_os = wave_sum((double)o_sum);
-    o_cnt = wave_sum(o_cnt);
-    c_n = wave_sum(c_n);
+    const double w_cs = fsum(c_sum), w_cq = fsum(c_sq), w_es = fsum(e_sum), w_eq = fsum(e_sq);
+    const double w_os = fsum(o_sum);
+    o_cnt = wave_sum_dpp(o_cnt);
+    c_n = wave_sum_dpp(c_n);
     if (lane == 0) {
         red_de[w][6] = (double)c_n;
         red_de[w][0] = w_cs;

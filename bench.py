@@ -345,8 +345,8 @@ def main():
                                      "batches_walked_sorted": pipe.sorted_batches,
                                      "source": os.environ.get("DPL_OCTAV_PREDICT", "auto"),
                                      "tensors_predicted_from_own_sample": pipe.probe_tensors / max(1, pipe.batches * T),
-                                     # 1024-element tiles holding a non-zero value outside the 2^-18 .. 2^14 window (read twice)
-                                     "tiles_read_twice_share": pipe.tiles_reread / max(1, pipe.batches * B * sum((e + 1023) // 1024 for e in plan.elems))}
+                                     # 1024-element tiles holding a non-zero value outside the 2^-18 .. 2^14 window (summed apart)
+                                     "tiles_with_values_outside_window_share": pipe.tiles_reread / max(1, pipe.batches * B * sum((e + 1023) // 1024 for e in plan.elems))}
             return obj
 
         if len(pool) < min_pool and rank == 0:

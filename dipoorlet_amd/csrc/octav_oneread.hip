@@ -76,7 +76,6 @@ constexpr uint32_t kSmallCap = 20480;                           // pairs this sm
 #endif
 constexpr uint32_t kCap = DPL_SLICE_CAP;                        // elements of a slice (streamed tile by tile)
 static_assert(kCap < (1u << 20) && kCap % 4096u == 0u, "a slice's bin counts must fit the packed field below the flag bit");
-constexpr int kRareTiles = (int)(kCap / (kWaves * 1024u)) + 1;   // tiles of a slice one wave walks (+ the ragged one)
 #ifndef DPL_QUEUE_CAP
 #define DPL_QUEUE_CAP 832
 #endif
@@ -163,7 +162,8 @@ struct Shared {
     unsigned long long part_m[2][kWaves];   // walk: the waves' partial (count, mantissa sum), two alternating slots
     uint32_t part_c[2][kWaves];
     float red_mn[kWaves], red_mx[kWaves];
-    uint32_t rare_tiles[kWaves * kRareTiles];   // streaming kernel: tiles holding a non-zero value outside the window
+    double low_sum;               // streaming kernel: non-zero values outside the window: their sum, count, a NaN among them
+    uint32_t low_cnt, low_nan;
     uint32_t bm[kLogWords];       // walker: the gathered bins, then this pair's bracket
     uint32_t pub[kLogWords];      // bins published for the next batch (bracket + cheap neighbours)
     uint32_t cheapw[kLogWords], thinw[kLogWords];   // walk: bins holding next to nothing / the sparse tail (bitmaps)
@@ -279,8 +279,6 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
     const uint32_t lane = tid & (kWave - 1);
     const int w = tid / kWave;
     float mn = INFINITY, mx = -INFINITY;
-    uint32_t nan = 0u, nz = 0u;
-    double sum = 0.0;
     // the wave's survivor queue: dense (ballot + mbcnt positions), `tail` entries in use (wave-uniform)
     const lptr_u32 wq = (lptr_u32)(lds_raw + kLdsA) + (uint32_t)w * kQueueCap;
     uint32_t tail = 0u;
@@ -311,7 +309,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
     // VALU instructions per element — cost 95 us of a 680 us kernel that is bound by instruction issue; the atomics
     // themselves 4 us).  A zero or a value outside the window adds to a per-LANE dummy word behind the histogram instead of
     // being masked off (no exec juggling, no same-address pile-up: lane l's dummy lies in bank pair l); its flag is never
-    // set.  The rare non-zero value outside the window (or NaN) leaves a per-lane mark that is looked at once per tile.
+    // set.  A non-zero value outside the window (or NaN) leaves a per-lane mark that is looked at once per tile.
     // `issue` starts the four adds of a vector; `append` (a vector later: the returns have arrived by then) puts the flagged
     // elements at the wave's queue tail (position = tail + the number of flagged lanes below: ballot + v_mbcnt).
     uint32_t rare = 0u;
@@ -353,9 +351,6 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
         if (tail > (uint32_t)(kQueueCap - 256)) flush();   // (rare: see flush)
 #endif
     };
-    // A tile in which some lane marked such a value is only noted (its base, per wave) and looked at again after the
-    // slice has been streamed — the hot loop carries no code for it.  A wave has at most kCap / (waves * 1024) tiles.
-    uint32_t* rare_list = sh.rare_tiles + (size_t)w * kRareTiles;
     uint32_t rare_n = 0u;
     for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
         if (tail > (uint32_t)kQueueTop) {   // the regular flush: BEFORE the tile is consumed, AFTER all of it has arrived
@@ -385,48 +380,50 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
 #pragma unroll
         for (int u = 4 - kAppendLag; u < 4; ++u) append(t[u], r[u]);
         if (__any((rare & 0x7FFFFFFFu) != 0u)) {   // (a lone sign bit is -0.0: nothing to account for)
-            if (lane == 0) rare_list[rare_n] = base;
+            // Non-zero values outside the window (and NaNs) are accumulated directly — from the tile's registers, behind this
+            // wave-uniform branch, into three words of LDS (one set of atomics per wave and tile): rare on convolutional
+            // activations, every tile of an attention-probability tensor (round 3: such tiles used to be noted and read a
+            // second time after the slice; 5.8 % of the tiles of the ViT-B/16 set)
+            double fs = 0.0;
+            uint32_t c = 0u, nn = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xs[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t a = __float_as_uint(xs[e]) & 0x7FFFFFFFu;
+                    const uint32_t tt = (a >> kLogShift) - (kLogKey0 + 1u);
+                    const bool o = !(tt < (uint32_t)(kLogNB - 1)) && a != 0u;
+                    const float f = __uint_as_float(a);
+                    const bool pos = o && f > 0.0f;
+                    fs += pos ? (double)f : 0.0;
+                    c += pos ? 1u : 0u;
+                    nn |= (o && f != f) ? 1u : 0u;
+                }
+            }
+            const uint32_t ct = (uint32_t)__builtin_amdgcn_readlane((int)scan_u32_dpp(c), kWave - 1);
+            const unsigned long long fb = (unsigned long long)__double_as_longlong(scan_f64_dpp(fs));
+            const double ft = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fb >> 32), kWave - 1) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fb, kWave - 1)));
+            const bool any_nan = __any(nn != 0u);
+            if (lane == 0) {
+                if (ct) {
+                    atomicAdd(&sh.low_cnt, ct);
+                    atomicAdd(&sh.low_sum, ft);
+                }
+                if (any_nan) atomicOr(&sh.low_nan, 1u);
+            }
             ++rare_n;
         }
         rare = 0u;
     });
-    // the noted tiles again (cold): non-zero values outside the window, and NaNs, are accumulated directly
-    for (uint32_t r = 0; r < rare_n; ++r) {
-        const uint32_t base = __builtin_amdgcn_readfirstlane(rare_list[r]);
-        const bool aligned = (((uintptr_t)pg) & 15u) == 0;
-        f4 t[4];
-        load_tile(pg, base, cnt, aligned, t);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float xs[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint32_t a = __float_as_uint(xs[e]) & 0x7FFFFFFFu;
-                const uint32_t tt = (a >> kLogShift) - (kLogKey0 + 1u);
-                if (!(tt < (uint32_t)(kLogNB - 1)) && a != 0u) {
-                    const float f = __uint_as_float(a);
-                    if (f > 0.0f) {
-                        sum += (double)f;
-                        ++nz;
-                    }
-                    nan |= (f != f);
-                }
-            }
-        }
-    }
     if (tail != 0u) flush();
-    if (rare_n != 0u && lane == 0) atomicAdd(&ctl->reserved, rare_n);   // (statistics: tiles read a second time)
-    // per-wave totals of the directly accumulated statistics
+    if (rare_n != 0u && lane == 0) atomicAdd(&ctl->reserved, rare_n);   // (statistics: tiles holding values outside the window)
+    // per-wave ranges (the values outside the window are in sh.low_*)
     const float wmn = wave_min(mn), wmx = wave_max(mx);
-    const uint32_t wnz = wave_sum(nz);
-    const double wsum = wave_sum(sum);
-    const uint32_t wnan = __any(nan) ? 1u : 0u;
     if (lane == 0) {
         sh.red_mn[w] = wmn;
         sh.red_mx[w] = wmx;
-        sh.red_a[w] = wnz;
-        sh.red_b[w] = wnan;
-        sh.red_d[w] = wsum;
     }
 }
 
@@ -894,7 +891,12 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
         l_packed[b] = (unsigned long long)f << 63;
     }
     if (tid < (uint32_t)kWave) l_packed[kLogNB + tid] = 0ull;
-    if (tid == 0) sh.cursor = 0u;
+    if (tid == 0) {
+        sh.cursor = 0u;
+        sh.low_sum = 0.0;
+        sh.low_cnt = 0u;
+        sh.low_nan = 0u;
+    }
     __syncthreads();
 
     // ------------------------------------------------------------------ 1. the slice's only HBM read, tile by tile
@@ -908,14 +910,11 @@ __global__ __launch_bounds__(kThreads, DPL_RES_OCC) void k_octav_oneread(
     // ------------------------------------------------------------------ 2. publish the slice (nothing waits for it)
     if (tid == 0) {
         float tmn = INFINITY, tmx = -INFINITY;
-        uint32_t tnz = 0u, tnan = 0u;
-        double tsum = 0.0;
+        const uint32_t tnz = sh.low_cnt, tnan = sh.low_nan;
+        const double tsum = sh.low_sum;
         for (int j = 0; j < kWaves; ++j) {
             tmn = fminf(tmn, sh.red_mn[j]);
             tmx = fmaxf(tmx, sh.red_mx[j]);
-            tnz += sh.red_a[j];
-            tnan |= sh.red_b[j];
-            tsum += sh.red_d[j];
         }
         if (tnz) {
             atomicAdd(&me->sum, tsum);

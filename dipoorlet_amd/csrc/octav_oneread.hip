@@ -100,7 +100,8 @@ constexpr int kPredRow = 2 * kLogWords;
 constexpr uint32_t kChunk = 8192;
 constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows are 16-byte aligned
 // Per tensor, what its prediction from earlier batches would have cost lately (floats, halved every batch):
-// [0] values it would have listed, [1] elements walked, [2] walks it would not have covered, [3] walks, [4] current choice
+// [0] values it would have listed, [1] elements walked, [2] walks it would not have covered, [3] walks, [4] current choice,
+// [5] / [6] values listed / elements walked while the tensor's pairs predicted from their own sample, [7] that share, remembered
 constexpr int kTstatRow = 8;
 constexpr int kRescRow = kLogNB + kLogNB / 2;   // u64 words of a rescued pair's row: 2048 suffix sums (fp64) + 2048 suffix counts (u32)
 #ifndef DPL_PROBE_RATE
@@ -693,7 +694,13 @@ __device__ __forceinline__ void walk_pair(
         if (tid == 0) {
             g_prof_iters_add(blockIdx.x, 0u);
             DPL_PROF_L(L);
-            if (phase == 0 || fused) atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
+            if (phase == 0 || fused) {
+                atomicAdd(&ctl->sum, (double)L);   // the batch's gathered values: what the caller's form choice looks at
+                if (!small && tstat && pred.use && pred.use[tensor]) {   // ... and what the pair's own sample made it list
+                    atomicAdd(tstat + (size_t)tensor * kTstatRow + 5, (float)L);
+                    atomicAdd(tstat + (size_t)tensor * kTstatRow + 6, (float)n_elems);
+                }
+            }
         }
         while (!done && !bad) {
             // values of bin jb above s: bit patterns in (bits(s), lower edge of bin jb + 1), i.e. d = u - bits(s) - 1 below
@@ -1412,15 +1419,21 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
             // narrowest there is when the images are alike) or the one from a sample of the pair itself (k_octav_probe: wider,
             // costs a read of 1 / kProbeRate of the pair, but does not care how the images differ).  Judged by what the
             // first would have cost in the last batches' walks; with hysteresis; no history: the sample.
+            // What the sample costs is MEASURED too (the values its pairs listed while the tensor was on it): on independent
+            // values ~6 % of the elements, on the spatially smooth feature maps of a convolutional network — where the 32
+            // neighbours of a chunk carry little more than one of them — 20 % and more; remembered in ts[7] while the tensor is on
+            // the other prediction.
             float* ts = tstat + t * kTstatRow;
             const float listed = ts[0], elems = ts[1], misses = ts[2], walks = ts[3];
+            if (ts[6] > 0.0f) ts[7] = ts[5] / ts[6];
+            const float own = fminf(fmaxf(ts[7] > 0.0f ? ts[7] + 0.02f : 0.08f, 0.05f), 0.5f);   // + its read of 1/16 of the pair
             uint32_t probe = ts[4] != 0.0f ? 1u : 0u;
             if (walks < 0.5f) {
                 probe = 1u;
-            } else if (probe) {   // (measured, ResNet-50 shapes: the sample costs what a prediction listing ~8 % costs)
-                if (listed < 0.055f * elems && misses < 0.04f * walks) probe = 0u;
+            } else if (probe) {
+                if (listed < 0.7f * own * elems && misses < 0.04f * walks) probe = 0u;
             } else {
-                if (listed > 0.080f * elems || misses > 0.08f * walks) probe = 1u;
+                if (listed > 1.0f * own * elems || misses > 0.08f * walks) probe = 1u;
             }
             if (predict == 0) probe = 0u;   // forced: earlier batches only
             if (predict == 1) probe = 1u;   // forced: the pair's own sample
@@ -1429,6 +1442,8 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
             ts[2] = 0.5f * misses;
             ts[3] = 0.5f * walks;
             ts[4] = probe ? 1.0f : 0.0f;
+            ts[5] *= 0.5f;
+            ts[6] *= 0.5f;
             use_probe[t] = probe;
         }
     }
@@ -1510,11 +1525,11 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     float mn = INFINITY;
     uint32_t m = 0u;
     // the 16 values of a chunk are neighbours (one token, one row of a feature map): not independent draws.  The variance of
-    // the sample mean is therefore taken BETWEEN groups of neighbours (each lane's four) and compared with what independent
-    // draws would give — the design effect of cluster sampling, extrapolated to the chunk's 16; every iterate's variance is
-    // scaled by it.
-    float c_sum = 0.0f, c_sq = 0.0f, e_sum = 0.0f, e_sq = 0.0f;   // per lane: sums over its groups of 4 / over elements of |x|
-    uint32_t c_n = 0u;        // groups of 4 counted
+    // the sample mean is therefore taken BETWEEN chunks and compared with what independent draws would give — the design effect
+    // of cluster sampling (an extrapolation from each lane's four neighbours overstated it threefold on feature maps, whose
+    // correlation falls off within the chunk); every iterate's variance is scaled by it.
+    float c_sum = 0.0f, c_sq = 0.0f, e_sum = 0.0f, e_sq = 0.0f;   // per lane: chunk sums (first lane of a chunk) / element sums of |x|
+    uint32_t c_n = 0u;        // chunks counted
     uint32_t o_cnt = 0u;      // non-zero values outside the binned window (a softmax output: most of them) ...
     float o_sum = 0.0f;       // ... and their sum
     auto eat = [&](float x) {
@@ -1555,12 +1570,18 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
 #ifndef DPL_PROBE_NODEFF
             if (u & 1) continue;                         // (every other load: an estimate of a ratio of variances)
             const float a0 = fabsf(v[u].x), a1 = fabsf(v[u].y), a2 = fabsf(v[u].z), a3 = fabsf(v[u].w);
-            const float cs = (a0 + a1) + (a2 + a3);     // the lane's four neighbours: a cluster of the sample
+            float cs = (a0 + a1) + (a2 + a3);
             e_sum += cs;
             e_sq += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-            c_sum += cs;
-            c_sq += cs * cs;
-            c_n += g0 + (uint32_t)u * (kThreads / kChunkLanes) < n_chunks ? 1u : 0u;
+            // the chunk's sum (its 8 lanes) in every one of them: two quad permutes and a half-row mirror
+            cs += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cs), 0xB1, 0xF, 0xF, true));
+            cs += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cs), 0x4E, 0xF, 0xF, true));
+            cs += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(cs), 0x141, 0xF, 0xF, true));
+            if ((tid & (kChunkLanes - 1u)) == 0u) {
+                c_sum += cs;
+                c_sq += cs * cs;
+                c_n += g0 + (uint32_t)u * (kThreads / kChunkLanes) < n_chunks ? 1u : 0u;
+            }
 #endif
         }
     }
@@ -1603,12 +1624,11 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
             for (int i = 0; i < 7; ++i) t[i] += red_de[q][i];
         out_sum = (float)t[4];
         out_cnt = (float)t[5];
-        const double nc = t[6], ne = 4.0 * t[6];
+        const double nc = t[6], ne = 32.0 * t[6];
         if (nc > 1.0) {
-            const double var_c = t[1] / nc - (t[0] / nc) * (t[0] / nc);     // variance of the sums of 4 neighbours
+            const double var_c = t[1] / nc - (t[0] / nc) * (t[0] / nc);     // variance of the chunks' sums (32 neighbours each)
             const double var_e = t[3] / ne - (t[2] / ne) * (t[2] / ne);     // variance of the elements
-            // clusters of 4: deff_4 = 1 + 3 rho; the sample's clusters hold 32: deff_32 = 1 + 31 rho
-            if (var_e > 0.0) deff = (float)fmin(fmax(1.0 + (31.0 / 3.0) * (var_c / (4.0 * var_e) - 1.0), 1.0), 64.0);
+            if (var_e > 0.0) deff = (float)fmin(fmax(var_c / (32.0 * var_e), 1.0), 64.0);
         }
     }
     DPL_PROF_T(qp1);

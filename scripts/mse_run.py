@@ -17,6 +17,13 @@ if which == "vit":
     elems, B = [int(e) for e in sess.elems_per_image], 8
     gen = torch.Generator(device=dev); gen.manual_seed(1)
     pool = [[t.reshape(B, -1) for t in sess.run({"input": torch.randn(B, 3, 224, 224, generator=gen, device=dev)})] for _ in range(npool)]
+elif which == "resnet50_real":     # ResNet-50 run by the repo's executor (random weights, random images): real layer statistics
+    sess = models.resnet50().make_session()
+    elems, B = [int(e) for e in sess.elems_per_image], 32
+    gen = torch.Generator(device=dev); gen.manual_seed(1)
+    scale = lambda k: 1.0 + jit * (2.0 * torch.rand(B, 1, 1, 1, generator=gen, device=dev) - 1.0)
+    pool = [[t.reshape(B, -1) for t in sess.run({"input": torch.randn(B, 3, 224, 224, generator=gen, device=dev) * scale(k)})]
+            for k in range(npool)]
 else:
     spec = resnet50_tensors()
     elems, B = [e for _, e, _ in spec], 32

@@ -101,13 +101,15 @@ constexpr uint32_t kChunk = 8192;
 constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows are 16-byte aligned
 // Per tensor, what its prediction from earlier batches would have cost lately (floats, halved every batch):
 // [0] values it would have listed, [1] elements walked, [2] walks it would not have covered, [3] walks, [4] current choice,
-// [5] / [6] values listed / elements walked while the tensor's pairs predicted from their own sample, [7] that share, remembered
-constexpr int kTstatRow = 8;
+// [5] / [6] values listed / elements walked while the tensor's pairs predicted from their own sample, [7] that share, remembered,
+// [8] the tensor's bracket width z (0: the default), [9] / [10] walks that left the sample's bins / walks on the sample
+constexpr int kTstatRow = 12;
 constexpr int kRescRow = kLogNB + kLogNB / 2;   // u64 words of a rescued pair's row: 2048 suffix sums (fp64) + 2048 suffix counts (u32)
 #ifndef DPL_PROBE_RATE
 #define DPL_PROBE_RATE 16
 #endif
 constexpr uint32_t kProbeRate = DPL_PROBE_RATE;   // k_octav_probe reads one 64-byte chunk of every kProbeRate
+constexpr float kProbeZ = 3.0f;                  // default width of the sample's brackets, in standard deviations
 constexpr uint32_t kProbeThin = 64;               // sampled values above a bracket's lower end below which the whole tail is gathered
 
 // LDS: [A: packed histogram 16 KiB, bit 63 of a word = gather flag | one dummy word per lane][B: the waves' survivor queues 13 KiB]
@@ -699,6 +701,7 @@ __device__ __forceinline__ void walk_pair(
                 if (!small && tstat && pred.use && pred.use[tensor]) {   // ... and what the pair's own sample made it list
                     atomicAdd(tstat + (size_t)tensor * kTstatRow + 5, (float)L);
                     atomicAdd(tstat + (size_t)tensor * kTstatRow + 6, (float)n_elems);
+                    atomicAdd(tstat + (size_t)tensor * kTstatRow + 10, 1.0f);
                 }
             }
         }
@@ -836,6 +839,7 @@ __device__ __forceinline__ void walk_pair(
             me->done = 1u;
             me->mode = 2u;
         } else if (bad && rescued) {
+            if (!rescue && tstat && pred.use && pred.use[tensor]) atomicAdd(tstat + (size_t)tensor * kTstatRow + 9, 1.0f);
             // restart from s_0 (in me->s) on the pair's exact bracket: its units go on the rescue's work list
             me->mode = 3u;
             me->done = 0u;
@@ -1444,6 +1448,18 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
             ts[4] = probe ? 1.0f : 0.0f;
             ts[5] *= 0.5f;
             ts[6] *= 0.5f;
+            // The brackets' width follows the misses it produces (the variance model errs where neighbours are correlated: on
+            // feature maps z = 3 gave 0.5 % misses and 19 % listed): aimed at 2 – 6 % of the walks leaving the gathered bins —
+            // a miss costs a re-read of that pair, a wider bracket costs every pair
+            if (ts[10] >= 8.0f) {
+                float z = ts[8] > 0.0f ? ts[8] : kProbeZ;
+                const float rate = ts[9] / ts[10];
+                if (rate < 0.02f) z *= 0.92f;
+                else if (rate > 0.06f) z *= 1.08f;
+                ts[8] = fminf(fmaxf(z, 1.5f), 4.0f);
+            }
+            ts[9] *= 0.5f;
+            ts[10] *= 0.5f;
             use_probe[t] = probe;
         }
     }
@@ -1479,11 +1495,10 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
 // Nothing here needs to be exact: the walk verifies every iterate against what was gathered and a pair whose iterate
 // falls outside is rescued (re-read alone).  One workgroup per pair; a tensor whose pairs use the prediction from earlier
 // batches (use_probe == 0) only copies that row.
-constexpr float kProbeZ = 3.0f;
 __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     const dpl_span* __restrict__ pair_spans, const float* const* __restrict__ segs, const uint32_t* __restrict__ pred_t,
     const uint32_t* __restrict__ use_probe, uint32_t* __restrict__ pred_p, uint32_t n_tensors, int dynamic_sym, int max_iters,
-    float z, const uint32_t* __restrict__ pair_order) {
+    float z, const uint32_t* __restrict__ pair_order, const float* __restrict__ tstat) {
     // 24 KiB of LDS per workgroup (six per CU): the packed sample histogram, overlaid after the conversion by the suffix sums
     // of the values and of their squares (fp32: nothing here has to be exact), and the suffix counts
     __shared__ __attribute__((aligned(16))) unsigned long long packed[kLogNB];
@@ -1506,6 +1521,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     const dpl_span sp = pair_spans[pair];
     if (sp.count <= (uint64_t)kSmallCap) return;   // gathers its whole window: no prediction row is read
     if (!use_probe[tensor]) return;                // this batch, the tensor's pairs gather by its row from earlier batches
+    if (tstat && tstat[(size_t)tensor * kTstatRow + 8] > 0.0f) z = tstat[(size_t)tensor * kTstatRow + 8];   // the tensor's own width
     uint32_t* row = pred_p + (uint64_t)pair * kPredRow;
     DPL_PROF_T(qp0);
     for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
@@ -1892,7 +1908,7 @@ int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_probe");
     hipLaunchKernelGGL(k_octav_probe, dim3((unsigned)j->n_pairs), dim3(kThreads), 0, (hipStream_t)s, j->d_pair_spans, j->d_seg_ptrs,
                        j->d_pred, j->d_use_probe, j->d_pred_pair, (uint32_t)j->n_tensors, j->dynamic_sym, j->max_iters,
-                       j->probe_z > 0.0f ? j->probe_z : kProbeZ, j->d_pair_order);
+                       j->probe_z > 0.0f ? j->probe_z : kProbeZ, j->d_pair_order, j->probe_z > 0.0f ? nullptr : j->d_tstat);
     DPL_LAUNCH_CHECK("k_octav_probe");
     return 0;
 }

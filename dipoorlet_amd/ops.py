@@ -166,7 +166,7 @@ class TensorSetPlan:
                     # batch's choice per tensor, and what the choice is made from
                     pred_pair=torch.zeros(self.n_pairs, 128, dtype=torch.int32, device=self.device),
                     use_probe=torch.zeros(self.T, dtype=torch.int32, device=self.device),
-                    tstat=torch.zeros(self.T, 8, dtype=torch.float32, device=self.device),
+                    tstat=torch.zeros(self.T, 12, dtype=torch.float32, device=self.device),
                     # rescue of the pairs a walk could not finish: their exact bracket, the work list of the re-read
                     rescue_bm=torch.empty(self.n_pairs, 64, dtype=torch.int32, device=self.device),
                     missed=torch.empty(self.n_pairs, 3, dtype=torch.int32, device=self.device),

@@ -218,13 +218,13 @@ typedef struct dpl_octav_oneread_job {
     uint64_t* d_resc;                /* [n_pairs, 3072]: suffix totals of a rescued pair (2048 fp64 sums, 2048 u32 counts): what its second walk starts from */
     /* carried across batches */
     uint32_t* d_vis;                 /* [2, n_tensors, 64] epoch accumulators; walks add to d_vis[write_epoch], cleared first when reset_epoch != 0 */
-    float* d_tstat;                  /* [n_tensors, 8]: what each tensor's prediction from earlier batches would have cost lately (zeroed by the caller once) */
+    float* d_tstat;                  /* [n_tensors, 12]: what each tensor's prediction from earlier batches would have cost lately (zeroed by the caller once) */
     int32_t write_epoch, reset_epoch;
     int32_t sorted;                  /* 0: lists scanned whole from registers (short lists), 1: sorted runs */
     int32_t dynamic_sym, max_iters;
     int32_t predict;                 /* 0: every tensor predicts from earlier batches, 1: every pair from a sample of itself, 2: chosen per
                                         tensor and batch on the device (by what the first would have listed / missed in the last batches) */
-    float probe_z;                   /* width of the sample's brackets in standard deviations; 0: the default (3) */
+    float probe_z;                   /* width of the sample's brackets in standard deviations; 0: the default (3, then adapted per tensor to the misses it produces) */
     int32_t fuse;                    /* 1: k_octav_oneread walks every single-slice pair itself (histogram still in LDS, list in L2);
                                         dpl_octav_oneread_finish then walks the multi-slice pairs only.  0: every pair is walked by finish */
     int32_t reserved;

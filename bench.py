@@ -49,6 +49,7 @@ def parse():
     p.add_argument("--mse-jitter", default="0.03,0.1", help="extra one-sweep mse objects with per-image contrast jitter (comma list; '' = none)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
     p.add_argument("--e2e-images", type=int, default=1024, help="N of the end-to-end CLI object (real .onnx + .bin files, fresh process; 0 skips it)")
+    p.add_argument("--real-images", type=int, default=2048, help="N of the mse objects over executor-produced ResNet-50 activations (0 skips them)")
     p.add_argument("--vit-images", type=int, default=256, help="N of the ViT-B/16 mse object (0 skips it)")
     p.add_argument("--fq-reps", type=int, default=3, help="timed passes of the fake-quant object (0 skips it)")
     p.add_argument("--dry-run", action="store_true",
@@ -256,7 +257,7 @@ def main():
     # what earlier sweeps learned (octav_reset) inside the timed region, so the first batches run without a prediction as they
     # do in a fresh process.  The pool holds more distinct batches than the prediction remembers (2 epochs of
     # DPL_ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
-    mse, mse_jitter, vit_mse = None, {}, None
+    mse, mse_jitter, vit_mse, mse_real = None, {}, None, {}
     if a.mse_steps > 0:
         import ctypes
         form = os.environ.get("DPL_OCTAV_FORM", "oneread")
@@ -358,6 +359,26 @@ def main():
             mse_jitter[f"{jit:g}"] = run_mse(jp, 1, jit)
             del jp
             torch.cuda.empty_cache()
+        # The same sweep over activations the repo's executor PRODUCES for ResNet-50 (random weights, random images): real layer
+        # statistics — spatially smooth feature maps, where a strided sample of 32 neighbours at a time carries little and the
+        # tensors settle on the prediction from earlier batches — alike, and with every image's input scaled by its own factor
+        if a.real_images > 0:
+            from dipoorlet_amd import models
+            rsess = models.resnet50().make_session()
+            assert [int(e) for e in rsess.elems_per_image] == elems
+            for jit in (0.0, 0.3):
+                gen = torch.Generator(device=dev)
+                gen.manual_seed(777 + rank)
+                rpool = []
+                for _ in range(min_pool):
+                    x = torch.randn(B, 3, 224, 224, generator=gen, device=dev)
+                    if jit:
+                        x = x * (1.0 + jit * (2.0 * torch.rand(B, 1, 1, 1, generator=gen, device=dev) - 1.0))
+                    rpool.append([t.reshape(B, -1) for t in rsess.run({"input": x})])
+                mse_real[f"{jit:g}"] = run_mse(rpool, 1, jit, n_images=a.real_images, net="ResNet-50 (executor-produced activations)")
+                del rpool
+                torch.cuda.empty_cache()
+            del rsess
         # BASELINE configs[4]'s workload on one GPU: ViT-B/16 activations produced by the repo's own graph executor (every node
         # output exposed: 557 tensors, LayerNorm / erf-GELU / attention-probability tensors among them; the attention logits are
         # scaled up so that most probabilities lie below the OCTAV window, as in a trained network), N = 256 in batches of 8
@@ -537,7 +558,7 @@ def main():
                      {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                       "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes,
                       "avg_kernel_ms": hist_kern_ms}),
-        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "e2e": e2e,
+        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "mse_feature_maps": mse_real or None, "e2e": e2e,
     }
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:

@@ -102,7 +102,8 @@ constexpr int kDirRow = kMaxFlag + 8;   // uint16 entries; a multiple of 8: rows
 // Per tensor, what its prediction from earlier batches would have cost lately (floats, halved every batch):
 // [0] values it would have listed, [1] elements walked, [2] walks it would not have covered, [3] walks, [4] current choice,
 // [5] / [6] values listed / elements walked while the tensor's pairs predicted from their own sample, [7] that share, remembered,
-// [8] the tensor's bracket width z (0: the default), [9] / [10] walks that left the sample's bins / walks on the sample
+// [8] the tensor's bracket width z (0: the default), [9] / [10] walks that left the sample's bins / walks on the sample,
+// [11] != 0: the tensor's pairs are sampled at twice the default rate
 constexpr int kTstatRow = 12;
 constexpr int kRescRow = kLogNB + kLogNB / 2;   // u64 words of a rescued pair's row: 2048 suffix sums (fp64) + 2048 suffix counts (u32)
 #ifndef DPL_PROBE_RATE
@@ -1430,7 +1431,7 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
             float* ts = tstat + t * kTstatRow;
             const float listed = ts[0], elems = ts[1], misses = ts[2], walks = ts[3];
             if (ts[6] > 0.0f) ts[7] = ts[5] / ts[6];
-            const float own = fminf(fmaxf(ts[7] > 0.0f ? ts[7] + 0.02f : 0.08f, 0.05f), 0.5f);   // + its read of 1/16 of the pair
+            const float own = fminf(fmaxf(ts[7] > 0.0f ? ts[7] + (ts[11] != 0.0f ? 0.04f : 0.02f) : 0.08f, 0.05f), 0.5f);   // + the sample's read
             uint32_t probe = ts[4] != 0.0f ? 1u : 0u;
             if (walks < 0.5f) {
                 probe = 1u;
@@ -1460,6 +1461,9 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
             }
             ts[9] *= 0.5f;
             ts[10] *= 0.5f;
+            // twice the sample where the sample's own lists stay long (feature maps: 12 % at 1/16 -> 9 % at 1/8 for 6 % more reading)
+            if (ts[11] == 0.0f && ts[7] > 0.09f) ts[11] = 1.0f;
+            else if (ts[11] != 0.0f && ts[7] > 0.0f && ts[7] < 0.045f) ts[11] = 0.0f;
             use_probe[t] = probe;
         }
     }
@@ -1522,6 +1526,9 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     if (sp.count <= (uint64_t)kSmallCap) return;   // gathers its whole window: no prediction row is read
     if (!use_probe[tensor]) return;                // this batch, the tensor's pairs gather by its row from earlier batches
     if (tstat && tstat[(size_t)tensor * kTstatRow + 8] > 0.0f) z = tstat[(size_t)tensor * kTstatRow + 8];   // the tensor's own width
+    // ... and its sampling rate: one chunk of every kProbeRate, or twice that where the chunks' neighbours are so alike that
+    // the brackets stay wide (what counts there is the number of LINES touched)
+    const uint32_t rate = (tstat && tstat[(size_t)tensor * kTstatRow + 11] > 0.0f) ? kProbeRate / 2u : kProbeRate;
     uint32_t* row = pred_p + (uint64_t)pair * kPredRow;
     DPL_PROF_T(qp0);
     for (int b = tid; b < kLogNB; b += kThreads) packed[b] = 0ull;
@@ -1537,7 +1544,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     gptr_f4 pv = (gptr_f4)(p0 + head);
     constexpr uint32_t kChunkLanes = 8u;                         // lanes (16 bytes each) per chunk: 128 bytes = one L2 line
     constexpr uint32_t kChunkElems = kChunkLanes * 4u;
-    const uint32_t n_chunks = n / (kChunkElems * kProbeRate);    // whole windows only (the last partial one is skipped)
+    const uint32_t n_chunks = n / (kChunkElems * rate);          // whole windows only (the last partial one is skipped)
     float mn = INFINITY;
     uint32_t m = 0u;
     // the 16 values of a chunk are neighbours (one token, one row of a feature map): not independent draws.  The variance of
@@ -1571,9 +1578,9 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
 #ifdef DPL_PROBE_FIXSLOT
             const uint32_t slot = 0u;
 #else
-            const uint32_t slot = ((g * 0x9E3779B1u) >> 16) % kProbeRate;   // where in its window chunk g lies
+            const uint32_t slot = ((g * 0x9E3779B1u) >> 16) % rate;   // where in its window chunk g lies
 #endif
-            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + ((size_t)g * kProbeRate + slot) * kChunkLanes + (tid & (kChunkLanes - 1u)))
+            v[u] = g < n_chunks ? __builtin_nontemporal_load(pv + ((size_t)g * rate + slot) * kChunkLanes + (tid & (kChunkLanes - 1u)))
                                 : f4{0.f, 0.f, 0.f, 0.f};
             m += g < n_chunks ? 4u : 0u;
         }
@@ -1719,7 +1726,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     if (tid == 0) {
         const float ud = (dynamic_sym && fabsf(smn) < 1e-6f) ? 4.0f : 1.0f;
         const float c = (float)(1.0 / 65536.0 / 3.0) / ud;
-        const float fpc = 1.0f - 1.0f / (float)kProbeRate;     // finite population: the sample is a fixed share of the pair
+        const float fpc = 1.0f - 1.0f / (float)rate;           // finite population: the sample is a fixed share of the pair
         auto mark = [&](int a, int b) {   // bins a .. b
             a = max(a, 1);
             b = min(b, kLogNB - 2);

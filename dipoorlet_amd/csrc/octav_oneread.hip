@@ -109,7 +109,7 @@ constexpr int kRescRow = kLogNB + kLogNB / 2;   // u64 words of a rescued pair's
 #ifndef DPL_PROBE_RATE
 #define DPL_PROBE_RATE 16
 #endif
-constexpr uint32_t kProbeRate = DPL_PROBE_RATE;   // k_octav_probe reads one 64-byte chunk of every kProbeRate
+constexpr uint32_t kProbeRate = DPL_PROBE_RATE;   // k_octav_probe reads one 128-byte chunk of every kProbeRate (or kProbeRate / 2)
 constexpr float kProbeZ = 3.0f;                  // default width of the sample's brackets, in standard deviations
 constexpr uint32_t kProbeThin = 64;               // sampled values above a bracket's lower end below which the whole tail is gathered
 
@@ -1490,11 +1490,12 @@ __global__ void k_octav_oneread_init(dpl_octav_state* st, int64_t n_pairs, uint3
 
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_octav_probe: the prediction of a pair FROM THE PAIR ITSELF — one 64-byte chunk of every kProbeRate (a strided sample:
+// k_octav_probe: the prediction of a pair FROM THE PAIR ITSELF — one 128-byte chunk of every kProbeRate (a strided sample:
 // every channel and every region of the feature map contributes), binned like the full pass (count, sum per bin) plus a
 // sum of squares; then the iteration is walked on the SAMPLE's histogram (linear inside a bin) carrying the sampling
 // variance of every iterate along: Var(s_{k+1}) ~ Var(tail mean above s_k) / (sampled tail count) + F'(s_k)^2 Var(s_k).
-// Gathered: the bins within kProbeZ standard deviations of every sampled iterate, and — from the first iterate on whose
+// Gathered: the bins within z standard deviations (kProbeZ, then per tensor whatever keeps 2 - 6 % of the walks leaving them)
+// of every sampled iterate, and — from the first iterate on whose
 // lower end fewer than kProbeThin sampled values lie — everything above (the late iterates' tail holds next to nothing).
 // Nothing here needs to be exact: the walk verifies every iterate against what was gathered and a pair whose iterate
 // falls outside is rescued (re-read alone).  One workgroup per pair; a tensor whose pairs use the prediction from earlier

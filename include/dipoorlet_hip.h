@@ -169,9 +169,10 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
  * below it: a gathered bin's RANK) comes from one of two sources, chosen per tensor and batch on the device (job.predict):
  *   - what the same tensor's walks stepped into in earlier batches (two alternating epoch accumulators in d_vis, snapshot
  *     d_pred taken by dpl_octav_oneread_prepare): the narrowest there is while the images are alike, useless when they differ;
- *   - a strided SAMPLE of the pair itself (dpl_octav_oneread_probe, k_octav_probe: 64 bytes of every 1 KiB binned like the
+ *   - a strided SAMPLE of the pair itself (dpl_octav_oneread_probe, k_octav_probe: 128 bytes of every 2 KiB — of every KiB where the tensor's samples stay wide — binned like the
  *     full pass, the iteration walked on the sample's histogram with the sampling variance of every iterate carried along;
- *     gathered: the bins within 3 standard deviations of each sampled iterate + the sparse tail): costs a read of 1/16 of
+ *     gathered: the bins within z standard deviations of each sampled iterate (z = 3, then adapted per tensor to the misses it
+ *     produces) + the sparse tail): costs a read of 1/16 of
  *     the pair and about twice the gathered values, but does not depend on any other image.
  * Pairs of at most dpl_octav_small_pair() elements gather their whole window.
  *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples

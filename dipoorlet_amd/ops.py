@@ -109,9 +109,12 @@ class TensorSetPlan:
 
     def octav_scratch(self):
         """(pair_spans, pair_base u64 [B*T], pair_order, list0, list1): where each pair's data lives, and two tail lists of
-        the batch's size with the pair regions laid out in pair order (4-element aligned: 16-byte loads)."""
+        the batch's size with the pair regions laid out in pair order (32-element aligned: whole 128-byte lines)."""
         if getattr(self, "_octav_scratch", None) is None:
-            sizes = [((e + 3) // 4) * 4 for _ in range(self.batch) for e in self.elems]
+            # (a region starts on a 128-byte line: the streaming workgroup that walks a pair reads back the list it has just
+            # written, and no other workgroup of the launch may have pulled a line of it into the CU's L1 beforehand — which a
+            # neighbouring pair's last, straddling line would)
+            sizes = [((e + 31) // 32) * 32 for _ in range(self.batch) for e in self.elems]
             base = np.zeros(len(sizes), np.int64)
             base[1:] = np.cumsum(sizes)[:-1]
             tot = int(sum(sizes))

@@ -196,7 +196,9 @@ typedef struct dpl_octav_oneread_job {
     const uint32_t* d_pair_slice0;   /* [n_pairs, 2] */
     const uint32_t* d_slice_chunk0;  /* [n_slices]: first directory row of a slice = running sum of ceil(slice count / dpl_octav_sort_chunk()) */
     const dpl_span* d_pair_spans;    /* [n_pairs]: where each pair's data lives */
-    const uint64_t* d_pair_base;     /* [n_pairs]: element offset of the pair's region in the lists (a region holds the pair's element count) */
+    const uint64_t* d_pair_base;     /* [n_pairs]: element offset of the pair's region in the lists (a region holds the pair's element count);
+                                        job.fuse: multiples of 32 elements (a region must not share a 128-byte line with its neighbour: the
+                                        streaming workgroup reads back the list it has just written) */
     const uint32_t* d_pair_order;    /* [n_pairs]: pair indices, largest first; its last n_small entries gather their whole window */
     int64_t n_pairs, n_tensors, n_small;
     int64_t n_multi;                 /* pairs of more than one slice (the first n_multi entries of d_pair_order) */

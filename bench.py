@@ -491,6 +491,20 @@ def main():
                 e2e = {"command": "python -m dipoorlet_amd -M r50.onnx -I calib -N %d -A hist -D trt --calib_batch 32 --skip_profiling" % a.e2e_images,
                        "process_wall_s": wall, "images_per_s_process": a.e2e_images / wall,
                        "images_per_s_calibration": a.e2e_images / tm["tensor_calibration_wall_s"], "tensors": n_clips, "split": tm}
+                # the same files through `-A mse` (BASELINE configs[2]'s algorithm; a second fresh process, warm file cache)
+                tj2 = os.path.join(d, "timing_mse.json")
+                cmd2 = [c if c != "hist" else "mse" for c in cmd[:-1]] + [tj2]
+                cmd2[cmd2.index(os.path.join(d, "out"))] = os.path.join(d, "out_mse")
+                t0 = time.perf_counter()
+                r2 = subprocess.run(cmd2, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                wall2 = time.perf_counter() - t0
+                if r2.returncode == 0 and os.path.exists(tj2):
+                    with open(tj2) as f:
+                        tm2 = json.load(f)
+                    e2e["mse"] = {"process_wall_s": wall2, "images_per_s_calibration": a.e2e_images / tm2["tensor_calibration_wall_s"],
+                                  "split": tm2}
+                else:
+                    e2e["mse"] = {"error": (r2.stderr or r2.stdout)[-600:], "returncode": r2.returncode}
             else:
                 e2e = {"error": (r.stderr or r.stdout)[-600:], "returncode": r.returncode}
         finally:

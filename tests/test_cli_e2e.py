@@ -234,7 +234,9 @@ def test_bias_correction_matches_sequential_definition(workdir):
         ref.set_initializer(bname, (ref.get_initializer(bname) + diff.float().cpu().numpy()).astype(np.float32))
         got = g_bc.get_initializer(bname)
         want = ref.get_initializer(bname)
-        assert np.allclose(got, want, rtol=1e-3, atol=2e-4), (node.name, np.abs(got - want).max())
+        # (a quantisation step of the fake-quantised network flips with the last bits of the fp32 convolutions, which differ
+        # between MIOpen's algorithms for different batch sizes: 2.5e-4 on some boxes of the pool)
+        assert np.allclose(got, want, rtol=1e-3, atol=6e-4), (node.name, np.abs(got - want).max())
         assert np.abs(got - g.get_initializer(bname)).max() > 0  # something was corrected
 
 

@@ -10,9 +10,16 @@ Batching: the reference feeds one image per forward (model input batch dim 1).  
 stacked on dim 0; Reshape targets and dim-0 broadcasts that were constant-folded for batch 1 are
 re-scaled to B.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
+
+# Calibration values must come from fp32 arithmetic: no reduced-precision paths in the library kernels of the forward
+# (convolutions default to allow_tf32 = True in PyTorch)
+torch.backends.cudnn.allow_tf32 = False
+torch.backends.cuda.matmul.allow_tf32 = False
 
 from .forward_net import ActivationSession
 from .utils import logger
@@ -525,6 +532,8 @@ class GraphSession(ActivationSession):
         calibration statistics would then silently come from scrambled data.  So, once per session: a batch-2 forward on
         random inputs must reproduce, for every exposed tensor, two batch-1 forwards.  If not, this session runs one image
         at a time from then on (and says so)."""
+        if self._batched_ok is None and os.environ.get("DPL_EXECUTOR_PER_IMAGE"):   # (testing aid: the fallback mode)
+            self._batched_ok = False
         if self._batched_ok is None:
             g = torch.Generator(device="cpu").manual_seed(20260)
             lead = self._lead()

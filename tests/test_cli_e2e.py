@@ -234,9 +234,13 @@ def test_bias_correction_matches_sequential_definition(workdir):
         ref.set_initializer(bname, (ref.get_initializer(bname) + diff.float().cpu().numpy()).astype(np.float32))
         got = g_bc.get_initializer(bname)
         want = ref.get_initializer(bname)
-        # (a quantisation step of the fake-quantised network flips with the last bits of the fp32 convolutions, which differ
-        # between MIOpen's algorithms for different batch sizes: 2.5e-4 on some boxes of the pool)
-        assert np.allclose(got, want, rtol=1e-3, atol=6e-4), (node.name, np.abs(got - want).max())
+        # The two computations run the convolutions at different batch sizes (chunks of BATCH vs. all N images, or one image
+        # at a time when the executor's self-check rejects batching on a box): activations equal to 6e-7, but every flipped
+        # rounding step of the fake-quantised network moves a bias by ~4e-5 and the next layers' activations with it — the
+        # difference roughly doubles per corrected layer (seen: 2.5e-4 .. 1.2e-3 at the sixth).  Tight where the algorithm
+        # is decided, loose where only that sensitivity shows.
+        k = targets.index(node)
+        assert np.allclose(got, want, rtol=1e-3, atol=2e-4 * 2 ** k), (node.name, np.abs(got - want).max())
         assert np.abs(got - g.get_initializer(bname)).max() > 0  # something was corrected
 
 

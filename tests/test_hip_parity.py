@@ -25,7 +25,8 @@ def _close(a, b, tol=TOL):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     both_nan = np.isnan(a) & np.isnan(b)
-    return np.all(both_nan | (np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))))
+    with np.errstate(invalid="ignore"):
+        return np.all(both_nan | (a == b) | (np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))))   # (a == b: equal infinities)
 
 
 @pytest.fixture(scope="module")
@@ -639,3 +640,65 @@ def test_octav_oneread_schedules_and_predictions_agree(dev, monkeypatch):
                 assert np.array_equal(got, ref), (fuse, predict)
             if predict == "learned":   # differing scales: the earlier batches' bins do not cover the later ones -> rescues
                 assert pipe.fallback_pairs > 0
+
+
+@pytest.mark.parametrize("predict", ["auto", "probe", "learned"])
+def test_octav_special_values(dev, monkeypatch, predict):
+    """Values the histogram window (2^-18 .. 2^14) does not hold, and the ones IEEE sets apart: all zeros, signed zeros, NaN,
+    +-inf, denormals, tiny normals below the window mixed into ordinary data, a pair that lies below the window entirely,
+    values on the window's two edges, one huge outlier, a single non-zero — every form against the numpy oracle
+    (forward_net.py:315-330 on such data: NaN and inf propagate through the sums, 0 / 0 is NaN), the one-read form with each
+    prediction source, fused and unfused, and through the pipeline."""
+    from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_PREDICT", predict)
+    rng = np.random.default_rng(77)
+    n = 70001
+
+    def base():
+        return rng.standard_normal(n).astype(np.float32) * 2
+
+    def put(x, idx, v):
+        x = x.copy()
+        x[idx] = v
+        return x
+    some = rng.integers(0, n, 9)
+    mk = [
+        np.zeros(n, np.float32),                                                      # 0 / 0
+        np.where(rng.random(n) < 0.5, np.float32(0.0), np.float32(-0.0)).astype(np.float32),
+        put(base(), some, np.nan),
+        put(base(), some[:1], np.inf),
+        put(base(), some[:2], -np.inf),
+        put(np.maximum(base(), 0), some, np.float32(1e-40)),                           # denormals among ReLU outputs
+        put(base(), some, np.float32(2.0 ** -30)),                                     # normals below the window (exact power of two)
+        (rng.standard_normal(n) * 1e-7).astype(np.float32),                            # the whole pair below the window
+        put(put(base(), some[:3], np.float32(2.0 ** -18)), some[3:6], np.float32(2.0 ** 14)),   # both edges
+        put(base(), some[:1], np.float32(3e30)),                                       # one huge outlier
+        put(np.zeros(n, np.float32), some[:1], np.float32(0.75)),                      # a single non-zero
+        put(np.abs(base()), some, np.float32(1e-45)),                                  # smallest denormal; min >= 0: dynamic_sym
+    ]
+    B = 2
+    tensors = [torch.from_numpy(np.stack([x, x[::-1].copy()])).to(dev) for x in mk]
+    sizes = [n] * len(mk)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for dyn in (False, True):
+            want = np.array([[O.octav_scale(t[b].cpu().numpy(), O.octav_unsigned(t[b].cpu().numpy().min(), dyn)) for t in tensors]
+                             for b in range(B)], np.float64)
+            for fuse in ("1", "0"):
+                monkeypatch.setenv("DPL_OCTAV_FUSE", fuse)
+                plan = ops.TensorSetPlan(sizes, B, dev)
+                got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("oneread", "bracket", "compact", "full")}
+                for form, g in got.items():
+                    for t in range(len(mk)):
+                        for b in range(B):
+                            assert _close(g[b, t, 0], want[b, t]), (form, fuse, dyn, t, b, g[b, t], want[b, t])
+                            x = tensors[t][b].cpu().numpy()
+                            if not np.isnan(x).any():
+                                assert g[b, t, 1] == x.min() and g[b, t, 2] == x.max(), (form, t, b)
+                assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)
+                pipe = ops.OctavPipeline(dyn, dev)
+                plan2 = ops.TensorSetPlan(sizes, B, dev)
+                rows = [pipe.submit(plan2, tensors) for _ in range(3)]
+                pipe.sync()
+                for r in rows:
+                    assert np.array_equal(r.cpu().numpy(), got["oneread"], equal_nan=True), (fuse, dyn)

@@ -386,7 +386,7 @@ def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, wri
     j.predict = _PREDICT[os.environ.get("DPL_OCTAV_PREDICT", "auto")]
     j.probe_z = float(os.environ.get("DPL_PROBE_Z", "0"))
     j.d_list0, j.d_list1, j.d_dir = l0.data_ptr(), l1.data_ptr(), res["dir"].data_ptr()
-    rescue = rescue or res            # (the pipeline's two batches in flight have their own rescue buffers)
+    rescue = rescue or res            # (the pipeline's batches in flight have their own rescue buffers)
     j.d_rescue_bm, j.d_missed, j.d_resc = rescue["rescue_bm"].data_ptr(), rescue["missed"].data_ptr(), rescue["resc"].data_ptr()
     j.d_vis, j.n_multi = res["vis"].data_ptr(), res["n_multi"]
     # DPL_OCTAV_FUSE=0: every pair walked by dpl_octav_oneread_finish (the pre-round-3 schedule; A/B and tests)
@@ -394,6 +394,9 @@ def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, wri
     j.write_epoch, j.reset_epoch, j.sorted, j.dynamic_sym, j.max_iters = write_epoch, reset_epoch, sorted_walk, dyn, _OCTAV_MAX_ITERS
     j.compaction_inline = compaction_inline
     return j
+
+
+_PIPE_SETS = max(2, int(os.environ.get("DPL_OCTAV_PIPE_SETS", "3")))   # batches the host may run ahead of the device (OctavPipeline)
 
 
 def _walk_sorted(plan):
@@ -416,11 +419,12 @@ class OctavPipeline:
     Caller's stream: the pairs' own predictions where the tensor needs them (k_octav_probe) and the streaming kernel, which
     also walks every single-slice pair.  Side stream, behind the streaming kernel of batch i and beside that of batch i + 1:
     the walk of the multi-slice pairs, the rescue of the pairs a walk could not finish (on the device, no host round trip),
-    the result rows, the state and the choice of prediction for batch i + 2.  Each plan keeps two sets of per-batch scratch.
+    the result rows, the state and the choice of prediction for batch i + 3.  Each plan keeps three sets of per-batch scratch.
     The control block of a batch (listed values, rescued pairs, pairs left for the compaction route) is copied to pinned
-    memory and read when the set comes up for reuse two submits later (or in sync()): statistics, the choice of walk for long
+    memory and read when the set comes up for reuse three submits later (or in sync()): statistics, the choice of walk for long
     lists, and — only when the count is non-zero — the launch of the compaction route for that batch.  The activations of a
-    batch, its pointer table and its result stay referenced from the set until then; the host runs at most two batches ahead.
+    batch, its pointer table and its result stay referenced from the set until then; the host runs at most three batches ahead
+    (DPL_OCTAV_PIPE_SETS; with two the host waited for side-stream work that ends with the previous streaming kernel).
     A tensor set the one-read form cannot take (a pair above 64 slices) runs octav_batch on the caller's stream instead."""
 
     def __init__(self, dynamic_sym, device=None):
@@ -443,16 +447,21 @@ class OctavPipeline:
             _, _, _, l0, _ = plan.octav_scratch()
             nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
             off, csz = plan.n_pairs * C.sizeof(_hip.OctavState), C.sizeof(_hip.OctavState)    # the control block
-            # four state arrays in rotation (call k uses k % 4): the array for call k + 2 is initialised at the end of call k's
-            # side-stream work, while the one of call k must survive until the host has read k's count of unfinished pairs
-            plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(4)]
+            # S sets of per-batch scratch (call k uses set k % S) and 2 S state arrays in rotation (call k uses k % 2S): the array
+            # for call k + S is initialised at the end of call k's side-stream work, while the one of call k must survive until
+            # the host has read k's count of unfinished pairs (S submits later).  S = 3: with two sets the host, which reads
+            # the statistics of call k - S before it enqueues call k, waited for the side-stream work of call k - 2 — work that
+            # runs BESIDE the streaming kernel of call k - 1 and is often not done before that kernel's last tenth: the next
+            # batch was then enqueued after the kernel had ended (measured: 32 us of idle caller's stream per batch)
+            S = _PIPE_SETS
+            plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(2 * S)]
             plan._octav_pipe_failed = [x[off:off + csz] for x in plan._octav_pipe_states]
             # the prediction snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
-            # taken care of (two submits later), after the snapshot of call k + 2 has been written
-            plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(3)]
-            plan._octav_pipe_use = [res["use_probe"]] + [torch.zeros_like(res["use_probe"]) for _ in range(3)]
+            # taken care of (S submits later), after the snapshot of call k + S has been written
+            plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(2 * S - 1)]
+            plan._octav_pipe_use = [res["use_probe"]] + [torch.zeros_like(res["use_probe"]) for _ in range(2 * S - 1)]
             sets = []
-            for j in range(2):
+            for j in range(S):
                 sets.append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(),
                                  use_host=torch.zeros(plan.T, dtype=torch.int32).pin_memory(),
                                  lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
@@ -468,8 +477,9 @@ class OctavPipeline:
     def _prepare(self, plan, res, st, k, stream):
         """State array + prediction snapshot (in set `st`) for the plan's call number k."""
         ep, first = divmod(k, _ONEREAD_EPOCH)
-        job = _oneread_job(plan, res, plan._octav_pipe_pred[k % 4], plan._octav_pipe_states[k % 4], st["lh"], plan._octav_pipe_pred[k % 4],
-                           st["pred_pair"], plan._octav_pipe_use[k % 4], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
+        r = k % (2 * _PIPE_SETS)
+        job = _oneread_job(plan, res, plan._octav_pipe_pred[r], plan._octav_pipe_states[r], st["lh"], plan._octav_pipe_pred[r],
+                           st["pred_pair"], plan._octav_pipe_use[r], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
                            self.dyn, rescue=st)    # (prepare reads neither tensors nor the walk choice)
         _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
         st["prepared"] = k
@@ -478,13 +488,13 @@ class OctavPipeline:
         """Side stream: results of the set's batch -> its output rows, the set made ready for its next use, completion event."""
         side = self.side.cuda_stream
         _hip.check(_hip.lib().dpl_octav_finalize(_ptr(st["states"]), plan.n_pairs, _ptr(st["refs"][2]), side), "dpl_octav_finalize")
-        self._prepare(plan, res, st, st["k"] + 2, side)    # off the caller's stream: the set's next use is two calls away
+        self._prepare(plan, res, st, st["k"] + _PIPE_SETS, side)    # off the caller's stream: the set's next use is S calls away
         st["done"] = torch.cuda.Event()
         st["done"].record(self.side)
 
     def _settle(self, plan, res, st):
         """HOST: read the statistics the set's last batch left in pinned memory (the walk finished long ago: the set comes up
-        for reuse two submits later) and choose the walk of the plan's next batches.  Nothing is launched here: the pairs a
+        for reuse S submits later) and choose the walk of the plan's next batches.  Nothing is launched here: the pairs a
         walk could not finish are taken care of on the device, behind the walk, without the host (submit)."""
         if not st["pending"]:
             return
@@ -512,7 +522,7 @@ class OctavPipeline:
             self.fallback_batches += 1
         if ctl.cnt_le:
             # what neither the walk nor the rescue could finish (a bracket that cannot be formed: flat distributions, values
-            # beyond 2^14): the compaction route, launched only now that the count is known — the set's batch is two submits
+            # beyond 2^14): the compaction route, launched only now that the count is known — the set's batch is S submits
             # old, its tensors are still referenced — and its results written over the batch's output rows
             _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(st["job"]), C.c_void_p(self.side.cuda_stream)),
                        "dpl_octav_oneread_compaction")
@@ -527,7 +537,8 @@ class OctavPipeline:
         sets = self._sets(plan, res)
         k = res["calls"]
         res["calls"] = k + 1
-        cur = sets[k % 2]
+        cur = sets[k % _PIPE_SETS]
+        r = k % (2 * _PIPE_SETS)
         self._settle(plan, res, cur)
         if cur["done"] is not None:
             main.wait_event(cur["done"])        # everything that last used this set has finished
@@ -536,14 +547,14 @@ class OctavPipeline:
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         cur["refs"] = (list(tensors), tab, out)
         cur["k"] = k
-        cur["states"] = plan._octav_pipe_states[k % 4]
-        cur["pred"] = plan._octav_pipe_pred[k % 4]
+        cur["states"] = plan._octav_pipe_states[r]
+        cur["pred"] = plan._octav_pipe_pred[r]
         cur["sorted"] = _walk_sorted(plan)
         L = _hip.lib()
         if cur.get("prepared") != k:
             self._prepare(plan, res, cur, k, main.cuda_stream)
         job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
-                                        plan._octav_pipe_use[k % 4], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
+                                        plan._octav_pipe_use[r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
                                         compaction_inline=0, rescue=cur)
         _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
         _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
@@ -553,8 +564,8 @@ class OctavPipeline:
         # the walk and, behind it on the device, the rescue of the pairs it could not finish: no host round trip decides anything
         _hip.check(L.dpl_octav_oneread_finish(C.byref(job), C.c_void_p(self.side.cuda_stream)), "dpl_octav_oneread_finish")
         with torch.cuda.stream(self.side):
-            cur["failed"].copy_(plan._octav_pipe_failed[k % 4], non_blocking=True)    # (statistics only: _settle)
-            cur["use_host"].copy_(plan._octav_pipe_use[k % 4], non_blocking=True)
+            cur["failed"].copy_(plan._octav_pipe_failed[r], non_blocking=True)    # (statistics only: _settle)
+            cur["use_host"].copy_(plan._octav_pipe_use[r], non_blocking=True)
         self._finish(plan, res, cur)
         cur["pending"] = True
         if all(p is not plan for p, _ in self._touched):

@@ -480,6 +480,40 @@ __device__ __forceinline__ void walk_pair(
     const bool small = n_pair <= (unsigned long long)kSmallCap;
     const uint32_t tensor = pair % n_tensors;
     DPL_PROF_T(pt0);
+    // What the walk reads from global memory is requested HERE, before the histogram is turned into suffix totals: inside the
+    // streaming kernel a global load takes 1 - 2 us to come back and the walk used to wait for three of them one after the
+    // other (the prediction row, the tensor's row for the statistics, the list).
+    const float* lp = (rescue ? list_rescue : list0) + pair_base[pair];
+    f4 v[kVecT];
+    // a list of ONE segment at the start of the pair's region (a single-slice pair, a rescue list): rows straight from `len`,
+    // no look-up of the segment table in LDS — the pairs with the longest lists (a flat distribution: the output of an erf is
+    // uniform, every bin of its top octave holds 0.8 % of the pair, eight iterates list 6 - 10 % of it: 59 k values of
+    // ViT-B/16's 605 184-element MLP tensors, 43 rows beyond the registers streamed in every iteration) spent a trip through
+    // LDS per group of rows (ViT-B/16, batches of such images: - 2 ... - 8 %)
+    auto load_rows1 = [&](auto& dst, auto count, uint32_t row0, uint32_t len) {
+        constexpr int kN = decltype(count)::value;
+        const uint32_t voff = tid << 4;
+#pragma unroll
+        for (int u = 0; u < kN; ++u) {
+            const uint32_t e0 = (row0 + (uint32_t)u) << 10;
+            // buffer loads: zero fill past the list's end (one descriptor per row: the range check leaves the SGPR offset out,
+            // so the row offset goes into the base)
+            const int nbytes = e0 < len ? (int)(min(len - e0, 1024u) << 2) : 0;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(lp + (e0 < len ? e0 : 0u)), 0, nbytes, 0x00020000);
+            dst[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        }
+    };
+    uint32_t len_early = 0u;
+    if (fused) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the list is this workgroup's own global stores (one CU, one L1)
+        len_early = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cursor);
+        load_rows1(v, std::integral_constant<int, kVecT>{}, 0u, len_early);
+    }
+    uint32_t bm_early = 0u, lw_early = 0u;
+    if (!rescue) {
+        if (tid < (uint32_t)kLogWords) bm_early = small ? 0xFFFFFFFFu : pred.row(pair, tensor)[tid];
+        if (pred_t) lw_early = pred_t[tensor * kPredRow + ((kLogNB - 1 - (int)tid * (kLogNB / kThreads)) >> 5)];
+    }
     // per-bin totals = the sum of the pair's slice rows -> LDS (own bins per thread)
     {
         constexpr int kPerT = kLogNB / kThreads;
@@ -557,7 +591,7 @@ __device__ __forceinline__ void walk_pair(
         if (!rescue) {
             const uint32_t cheap_n = (uint32_t)(n_pair >> DPL_CHEAP_SHIFT), thin_n = (uint32_t)(n_pair >> DPL_THIN_SHIFT);
             // (also: what the tensor's prediction from earlier batches would have listed of this pair — the selection statistics)
-            const uint32_t lw = pred_t ? pred_t[tensor * kPredRow + (hi >> 5)] : 0u;
+            const uint32_t lw = lw_early;
             uint32_t cb = 0u, tb = 0u, wl = 0u;
             uint32_t above = hi + 1 < kLogNB ? n_ge[hi + 1] : 0u;
 #pragma unroll
@@ -577,7 +611,7 @@ __device__ __forceinline__ void walk_pair(
     }
     // the bins whose values were gathered (the walk may only step into these)
     if (tid < (uint32_t)kLogWords) {
-        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : small ? 0xFFFFFFFFu : pred.row(pair, tensor)[tid];
+        sh.bm[tid] = rescue ? rescue_bm[(uint64_t)pair * kLogWords + tid] : bm_early;
         sh.pub[tid] = 0u;
     }
     if (tid == 0 && rescue) {   // s_0 and the divisor are in the state since the first walk
@@ -626,18 +660,16 @@ __device__ __forceinline__ void walk_pair(
         // the list (bit patterns of |x|) goes into registers, 1024 values per ROW (one 16-byte vector per thread); every
         // segment starts a new row; a list of more rows than the registers hold is re-read in pieces every iteration
         const uint32_t n_seg = (rescue || fused) ? 1u : __builtin_amdgcn_readfirstlane(pair_slice0[2 * pair + 1] - pair_slice0[2 * pair]);
-        if (fused) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the list is this workgroup's own global stores (one CU, one L1)
-        uint32_t n_rows = 0u, L = 0u;
-        for (uint32_t j = 0; j < n_seg; ++j) {
+        uint32_t n_rows = fused ? (len_early + 1023u) >> 10 : 0u, L = fused ? len_early : 0u;
+        for (uint32_t j = 0; j < n_seg && !fused; ++j) {
             const uint32_t len = __builtin_amdgcn_readfirstlane(sh.seg_len[j]);
             n_rows += (len + 1023u) >> 10;
             L += len;
         }
         // the first kVec rows stay in registers for the whole walk; the rows beyond (the 3 % lists of the largest pairs) are
         // streamed kOver at a time in every iteration — requested before the resident rows are scanned, consumed after
-        f4 v[kVecT], ov[kOver];
-        const float* lp = (rescue ? list_rescue : list0) + pair_base[pair];
-        auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
+        f4 ov[kOver];
+        auto load_rows_segs = [&](auto& dst, auto count, uint32_t row0) {
             constexpr int kN = decltype(count)::value;
             uint32_t j = 0u, r = row0;   // segment and row inside it of row `row0`
             while (j < n_seg) {
@@ -668,7 +700,11 @@ __device__ __forceinline__ void walk_pair(
                 dst[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
             }
         };
-        load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
+        auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
+            if (n_seg == 1u) load_rows1(dst, count, row0, L);   // (uniform)
+            else load_rows_segs(dst, count, row0);
+        };
+        if (!fused) load_rows(v, std::integral_constant<int, kVecT>{}, 0u);   // (fused: requested at the top)
         // Every wave takes the step itself from the four partial sums (one barrier and two LDS round trips per iteration instead
         // of two and five): inside the streaming kernel the LDS pipeline is full of the other workgroups' histogram atomics and
         // a round trip costs several hundred cycles.  The gathered-bin bitmap sits in registers (lane l: word l).

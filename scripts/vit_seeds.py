@@ -1,3 +1,6 @@
+"""GPU: the ViT-B/16 `-A mse` run (N = 256 in batches of 8, cold, two-stream pipeline) over images drawn with different seeds: how
+many flat-distribution pairs (erf outputs: long lists) a batch holds moves its time by +- 8 %.  DPL_LIB=<other build>
+for an A/B on one box.  python scripts/vit_seeds.py"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import torch

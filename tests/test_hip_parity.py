@@ -564,13 +564,15 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
                 assert g[1] == x.min() and g[2] == x.max()
 
 
-@pytest.mark.parametrize("walk", ["group", "sorted", "auto"])
-def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk):
-    """(walk: as above; auto = chosen by the listed share.)  OctavPipeline (walk of batch i on a side stream beside the streaming kernel of batch i + 1, double-buffered
+@pytest.mark.parametrize("walk,sets", [("group", 3), ("sorted", 3), ("auto", 3), ("auto", 2), ("auto", 4)])
+def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk, sets):
+    """(walk: as above; auto = chosen by the listed share.  sets: how many batches the host runs ahead = sets of per-batch
+    scratch, ops._PIPE_SETS.)  OctavPipeline (walk of batch i on a side stream beside the streaming kernel of batch i + 1, double-buffered
     scratch) returns what octav_batch returns batch by batch — including the first batches, where every multi-slice pair
     takes the compaction route on the side stream — and the oracle's scales."""
     from dipoorlet_amd import ops
     monkeypatch.setenv("DPL_OCTAV_WALK", walk)
+    monkeypatch.setattr(ops, "_PIPE_SETS", sets)
     rng = np.random.default_rng(41)
     B, sizes = 4, [401408, 30000, 802816, 777, 200704]
     batches = []

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_BINS = 16384
 
 
@@ -58,7 +58,7 @@ class OctavOnereadJob(C.Structure):
                 ("d_list0", C.c_void_p), ("d_list1", C.c_void_p), ("d_dir", C.c_void_p), ("d_rescue_bm", C.c_void_p),
                 ("d_missed", C.c_void_p), ("d_resc", C.c_void_p), ("d_vis", C.c_void_p), ("d_tstat", C.c_void_p), ("write_epoch", C.c_int32),
                 ("reset_epoch", C.c_int32), ("sorted", C.c_int32), ("dynamic_sym", C.c_int32), ("max_iters", C.c_int32),
-                ("predict", C.c_int32), ("probe_z", C.c_float), ("fuse", C.c_int32), ("reserved", C.c_int32),
+                ("predict", C.c_int32), ("probe_z", C.c_float), ("fuse", C.c_int32), ("tail", C.c_int32),
                 ("compaction_inline", C.c_int32)]
 
 

@@ -173,6 +173,8 @@ struct Shared {
     uint32_t cheapw[kLogWords], thinw[kLogWords];   // walk: bins holding next to nothing / the sparse tail (bitmaps)
     uint32_t would_list;          // walk: values the tensor's prediction from earlier batches would have listed of this pair
     uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
+    uint32_t tail_j;              // exact-tail form (octav_tail.hpp): the bin at and above which values are listed (only ever raised)
+    uint32_t jwant;               // ... and the bin this pair asks the tensor's next batches to list from
     double f_sum;                 // streaming kernel -> its own walk (a single-slice pair): the statistics it just published
     uint32_t f_nz, f_nan;
     float f_mn, f_mx;
@@ -900,6 +902,8 @@ __device__ __forceinline__ void walk_pair(
         }
     }
 }
+
+#include "octav_tail.hpp"
 
 // K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
 // then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
@@ -1942,6 +1946,14 @@ int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const uint32_t* d_vis_o = j->d_vis + (int64_t)(1 - j->write_epoch) * vis_words;
     const int64_t init_n = (j->n_pairs + 1 > vis_words ? j->n_pairs + 1 : vis_words);
     if (j->predict < 0 || j->predict > 2) return fail_msg("dpl_octav_oneread_prepare: predict must be 0, 1 or 2");
+    if (j->tail) {   // exact-tail form: state + the tensors' threshold snapshot
+        if (j->n_multi != 0) return fail_msg("dpl_octav_oneread_prepare: the exact-tail form takes single-slice pairs only");
+        const int64_t n = j->n_pairs + 1 > j->n_tensors ? j->n_pairs + 1 : j->n_tensors;
+        hipLaunchKernelGGL(k_octav_tail_init, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, j->d_states, j->n_pairs, d_vis_w, d_vis_o,
+                           j->d_pred, j->n_tensors, j->reset_epoch);
+        DPL_LAUNCH_CHECK("k_octav_tail_init");
+        return 0;
+    }
     hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, j->d_states, j->n_pairs, d_vis_w,
                        d_vis_o, j->d_pred, vis_words, j->reset_epoch, j->d_tstat, j->d_use_probe, j->predict);
     DPL_LAUNCH_CHECK("k_octav_oneread_init");
@@ -1950,6 +1962,7 @@ int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* j, dpl_stream_t s) {
 
 int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_probe");
+    if (j->tail) return 0;   // the exact-tail form needs no prediction row
     hipLaunchKernelGGL(k_octav_probe, dim3((unsigned)j->n_pairs), dim3(kThreads), 0, (hipStream_t)s, j->d_pair_spans, j->d_seg_ptrs,
                        j->d_pred, j->d_use_probe, j->d_pred_pair, (uint32_t)j->n_tensors, j->dynamic_sym, j->max_iters,
                        j->probe_z > 0.0f ? j->probe_z : kProbeZ, j->d_pair_order, j->probe_z > 0.0f ? nullptr : j->d_tstat);
@@ -1959,6 +1972,15 @@ int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
 
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
+    if (j->tail) {
+        if (j->n_multi != 0) return fail_msg("dpl_octav_oneread_stream: the exact-tail form takes single-slice pairs only");
+        hipLaunchKernelGGL(k_octav_tail, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s, j->d_slices,
+                           j->d_seg_ptrs, j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs,
+                           TailArgs{j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords, j->d_pred, j->d_rescue_bm, j->d_missed,
+                                    reinterpret_cast<unsigned long long*>(j->d_resc), j->dynamic_sym, j->max_iters, g_exact_fail_every});
+        DPL_LAUNCH_CHECK("k_octav_tail");
+        return 0;
+    }
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
                        j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                        (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0, j->d_states + j->n_pairs,
@@ -1991,7 +2013,9 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const int64_t n_big = j->fuse ? j->n_multi : j->n_pairs - j->n_small;
     const int64_t n_small = j->fuse ? 0 : j->n_small;
     const int64_t n_walk = j->fuse ? j->n_multi : j->n_pairs;
-    if (!j->sorted) {   // every pair walked from registers by one workgroup
+    if (j->tail) {
+        // every pair was walked by its streaming workgroup; what is left is the rescue below
+    } else if (!j->sorted) {   // every pair walked from registers by one workgroup
         if (n_walk > 0 && j->fuse)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_octav_walk<2 * kVec>), dim3((unsigned)n_walk), dim3(kThreads), 0, st, j->d_states, ctl,
                                j->d_pair_order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe}, d_vis_w,

@@ -1,0 +1,578 @@
+// OCTAV ('-A mse', forward_net.py:323-330) in one read: EXACT TAIL, BOUNDED BULK (round 4).  Included by octav_oneread.hip
+// (shares its LDS layout, scans, the walk's counting idiom and the rescue of pairs a walk cannot finish).
+//
+// The reference's loop s' = sum_{|x|>s} |x| / (c #{|x|<=s} + #{|x|>s}) climbs from s_0 = mean of the non-zero |x| to the
+// LEAST fixed point of a step function F, and that fixed point is carried by the top few dozen ... few thousand values of
+// the pair: below it F is non-decreasing (dropping a value v raises F iff v < (1 - c) F), so whatever the early iterates
+// are — as long as none of them is ABOVE the reference's — the walk ends where the reference ends.  Hence:
+//   list    only |x| >= theta = the lower edge of histogram bin J (about 1 % of a pair; round 3 listed the bins of all ~10
+//           iterates: 3 - 8 %): a compare on the bin key, no returning atomic, no prediction bitmap;
+//   bulk    while the iterate t lies in a bin b < J:  t <- a LOWER BOUND of F(t) from the exact suffix totals alone:
+//               F(t) = (S_ge[b+1] + sum of the m values of bin b above t) / (c (n - N_ge[b+1] - m) + N_ge[b+1] + m),
+//           every such value lies in (t, edge[b+1]) and 0 <= m <= count[b]; with the values put at t the quotient is monotone
+//           in m, so F(t) >= min(q(0), q(count[b])).  By induction a bulk iterate never passes the reference's iterate of the
+//           same index;
+//   exact   from the first iterate in a bin >= J on: the reference's own step on exact totals (suffix totals of the bins above
+//           + the listed values of the iterate's bin, as walk_pair counts them);
+//   accept  iff every bulk step moved up by >= 2e-6 (the reference cannot have stopped there), no exact step moved down, the
+//           stop rule fired on an exact evaluation, >= 2 exact evaluations, <= max_iters evaluations in all (the reference is
+//           never behind: it converged too).  tests/octav_tail_model.py states the same rule in numpy and
+//           tests/test_octav_tail_model.py holds it to the oracle over > 10^4 random distributions and thresholds.
+//   else    the pair is RESCUED exactly as in round 3: its exact bracket from the histogram, a re-read of that pair alone
+//           (k_octav_rescue_gather), the verified walk (k_octav_walk_rescue), the compaction route behind that.
+// Where theta comes from: per tensor the LOWEST bin any of its pairs asked for in the last two epochs of batches (a pair asks
+// for the bin above which 1/128 of its elements lie: the fixed point of a thin-tailed — uniform — pair has ~0.3 % of the pair
+// above it, of a normal one 0.01 %), and it is RAISED ON THE FLY when a wave lists more than its budget (a brighter image, or
+// no history at all: the first batch of a run starts at bin 1): that wave alone takes the quantile of the workgroup's
+// histogram so far and publishes the new bin in LDS.  theta only ever rises inside a pair, so the list holds every value
+// >= the final theta; a theta that ends up too high costs a rescue, never a wrong result.
+#pragma once
+
+#ifndef DPL_TAIL_TAU_SHIFT
+#define DPL_TAIL_TAU_SHIFT 7      // a pair asks for the bin above which n >> 7 of its n elements lie
+#endif
+#ifndef DPL_TAIL_BUDGET_SHIFT
+#define DPL_TAIL_BUDGET_SHIFT 6   // a wave may list kTailAllow0 + (elements it has seen >> 6) values before it raises theta
+#endif
+#ifndef DPL_TAIL_ALLOW0
+#define DPL_TAIL_ALLOW0 2048
+#endif
+#ifndef DPL_TAIL_OCC
+#define DPL_TAIL_OCC 4
+#endif
+constexpr int kTailTauShift = DPL_TAIL_TAU_SHIFT;
+constexpr int kTailBudgetShift = DPL_TAIL_BUDGET_SHIFT;
+constexpr uint32_t kTailAllow0 = DPL_TAIL_ALLOW0;
+
+struct TailArgs {
+    uint32_t* vis_w;             // [T, kLogWords]: word 0 of a tensor's row = kLogNB - (lowest bin its pairs asked for this epoch); 0: none
+    const uint32_t* pred;        // [T, kPredRow]: word 0 = the snapshot (both epochs); 0: no history
+    uint32_t* rescue_bm;
+    uint32_t* missed;
+    unsigned long long* resc;
+    int dynamic_sym, max_iters, fail_every;
+};
+
+// One pair, streamed: min / max, the exact log-scale histogram (ONE non-returning 64-bit LDS add per element) and the values
+// at or above the current threshold bin -> the wave's dense LDS queue -> the pair's list.  Leaves the per-wave ranges in
+// sh.red_*, the number of listed values in sh.cursor, the final threshold bin in sh.tail_j.
+__device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
+                                                      Shared& sh, dpl_octav_state* __restrict__ ctl, const bool adaptive) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const lptr_u64 l_packed = (lptr_u64)(lds_raw);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    float mn = INFINITY, mx = -INFINITY;
+    const lptr_u32 wq = (lptr_u32)(lds_raw + kLdsA) + (uint32_t)w * kQueueCap;
+    uint32_t tail = 0u;          // entries in the wave's queue
+    uint32_t mine = 0u;          // values this wave has listed
+    uint32_t seen = 0u;          // elements this wave has consumed
+    // what the wave may list before it looks at the histogram: 1 / 128 of its share of the pair, at least 256 values (a first
+    // look needs something to look at), at most kTailAllow0
+    uint32_t slack = min(max(cnt >> 9, 256u), kTailAllow0);
+    uint32_t backoff = 512u;     // a raise that could not move the threshold (an atom at the top: saturating activations) doubles it
+    uint32_t raises = 0u;
+    int jm1 = (int)__builtin_amdgcn_readfirstlane((int)sh.tail_j) - 1;   // listed: bin key t = bin - 1 >= jm1
+    auto flush = [&]() {
+        typedef __attribute__((address_space(1))) uint32_t* gptr_u32;
+        gptr_u32 gdst = (gptr_u32)dst;
+        uint32_t base = 0u;
+        if (lane == 0) base = __hip_atomic_fetch_add((lptr_u32)&sh.cursor, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        for (uint32_t i = lane; i < tail; i += kWave) gdst[base + i] = wq[i] & 0x7FFFFFFFu;
+        tail = 0u;
+    };
+    // The threshold of a wave that lists too much: the bin above which 1 / 2^kTailTauShift of what the workgroup has seen so
+    // far lies, from a snapshot of the LDS histogram (the other waves keep adding to it: nothing here has to be exact).  Lane l
+    // owns the 32 bins below kLogNB - 32 l (lane 0: the highest).
+    auto raise = [&]() {
+        const uint32_t b0 = (uint32_t)kLogNB - 32u * (lane + 1u);
+        uint32_t tot = 0u;
+#pragma unroll 8
+        for (int k = 0; k < 32; ++k) tot += (uint32_t)(l_packed[b0 + (uint32_t)k] >> kPackShift);
+        const uint32_t incl = scan_u32_dpp(tot);   // everything in bins >= the lane's lowest
+        const uint32_t target = max((4u * seen) >> kTailTauShift, 16u);
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(incl >= target);
+        int jn = 1;
+        if (mm != 0ull) {
+            const int L = (int)__builtin_ctzll(mm);   // the first lane (highest bins) whose cumulative count reaches the target
+            uint32_t run = incl - tot, found = 0u;
+            int jl = (int)b0;
+#pragma unroll 8
+            for (int k = 31; k >= 0; --k) {
+                run += (uint32_t)(l_packed[b0 + (uint32_t)k] >> kPackShift);
+                const bool hit = !found && run >= target;
+                jl = hit ? (int)b0 + k : jl;
+                found |= hit ? 1u : 0u;
+            }
+            jn = __builtin_amdgcn_readlane(jl, L);
+        }
+        jn = min(max(jn, 1), kLogNB - 2);
+        if (jn - 1 > jm1) {
+            if (lane == 0) atomicMax(&sh.tail_j, (uint32_t)jn);
+            jm1 = jn - 1;
+        } else {
+            backoff = min(backoff * 2u, 1u << 20);
+        }
+        ++raises;
+    };
+    uint32_t rare = 0u;
+    constexpr uint32_t kWin = (uint32_t)(kLogNB - 1);
+    const lptr_u64 dummy = l_packed + kLogNB + lane;
+    // per element: the bin key (14 bits of exponent and top mantissa, relative to the window), ONE LDS add {count += 1, mantissa
+    // sum += 23 explicit bits} on the bin's word (zeros and values outside the window: the lane's dummy word), and the threshold
+    // test on the key itself (signed: below the window is negative; above it — values >= 2^14, inf, NaN — passes and is harmless:
+    // such a pair leaves for the compaction route anyway)
+    auto add1 = [&](uint32_t bits) -> bool {
+        const uint32_t t = ((bits >> kLogShift) & 0x3FFFu) - (kLogKey0 + 1u);
+        const bool in = t < kWin;
+        const lptr_u64 slot = in ? l_packed + t + 1u : dummy;
+        rare |= in ? 0u : bits;
+        (void)__hip_atomic_fetch_add(slot, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int32_t)t >= jm1;
+    };
+    auto put = [&](uint32_t bits, bool f) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
+        if (m != 0ull) {   // (uniform; about every other element slot of a wave at 1 % listed)
+            const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, tail));
+            if (f) wq[pos] = bits;
+            const uint32_t k = (uint32_t)__builtin_popcountll(m);
+            tail += k;
+            mine += k;
+        }
+    };
+    uint32_t rare_n = 0u;
+    for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
+        if (tail > (uint32_t)kQueueTop) {   // the regular flush: BEFORE the tile is consumed, AFTER all of it has arrived (stream_slice)
+            asm volatile("" ::"v"(t[3].w));
+            flush();
+        }
+        // the workgroup's threshold (another wave may have raised it), and this wave's own budget
+        jm1 = max(jm1, (int)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((lptr_u32)&sh.tail_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - 1);
+        if (adaptive && mine > slack + (seen >> kTailBudgetShift)) {   // (a small pair lists its whole window: no budget)
+            raise();
+            const uint32_t base_allow = seen >> kTailBudgetShift;
+            slack = max(slack, mine + backoff > base_allow ? mine + backoff - base_allow : 0u);
+        }
+        seen += full ? 1024u : min(1024u, cnt - base);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (full) {
+                mn = fminf(mn, fminf(fminf(t[u].x, t[u].y), fminf(t[u].z, t[u].w)));
+                mx = fmaxf(mx, fmaxf(fmaxf(t[u].x, t[u].y), fmaxf(t[u].z, t[u].w)));
+            } else {   // padding is +0.0: in no histogram bin, never listed; only min / max must skip it
+                const uint32_t e = base + (uint32_t)u * 256u + lane * 4u;
+                if (e + 0 < cnt) mn = fminf(mn, t[u].x), mx = fmaxf(mx, t[u].x);
+                if (e + 1 < cnt) mn = fminf(mn, t[u].y), mx = fmaxf(mx, t[u].y);
+                if (e + 2 < cnt) mn = fminf(mn, t[u].z), mx = fmaxf(mx, t[u].z);
+                if (e + 3 < cnt) mn = fminf(mn, t[u].w), mx = fmaxf(mx, t[u].w);
+            }
+            const uint32_t b0 = __float_as_uint(t[u].x), b1 = __float_as_uint(t[u].y), b2 = __float_as_uint(t[u].z), b3 = __float_as_uint(t[u].w);
+            const bool f0 = add1(b0), f1 = add1(b1), f2 = add1(b2), f3 = add1(b3);
+            put(b0, f0);
+            put(b1, f1);
+            put(b2, f2);
+            put(b3, f3);
+            if (tail > (uint32_t)(kQueueCap - 256)) flush();   // (a pair that lists most of what it reads: a small pair, a cold start)
+        }
+        if (__any((rare & 0x7FFFFFFFu) != 0u)) {   // non-zero values outside the window (and NaNs): summed directly, as stream_slice does
+            double fs = 0.0;
+            uint32_t c = 0u, nn = 0u;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float xs[4] = {t[u].x, t[u].y, t[u].z, t[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t a = __float_as_uint(xs[e]) & 0x7FFFFFFFu;
+                    const uint32_t tt = (a >> kLogShift) - (kLogKey0 + 1u);
+                    const bool o = !(tt < (uint32_t)(kLogNB - 1)) && a != 0u;
+                    const float f = __uint_as_float(a);
+                    const bool pos = o && f > 0.0f;
+                    fs += pos ? (double)f : 0.0;
+                    c += pos ? 1u : 0u;
+                    nn |= (o && f != f) ? 1u : 0u;
+                }
+            }
+            const uint32_t ct = (uint32_t)__builtin_amdgcn_readlane((int)scan_u32_dpp(c), kWave - 1);
+            const unsigned long long fb = (unsigned long long)__double_as_longlong(scan_f64_dpp(fs));
+            const double ft = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(fb >> 32), kWave - 1) << 32) |
+                                                               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fb, kWave - 1)));
+            const bool any_nan = __any(nn != 0u);
+            if (lane == 0) {
+                if (ct) {
+                    atomicAdd(&sh.low_cnt, ct);
+                    atomicAdd(&sh.low_sum, ft);
+                }
+                if (any_nan) atomicOr(&sh.low_nan, 1u);
+            }
+            ++rare_n;
+        }
+        rare = 0u;
+    });
+    if (tail != 0u) flush();
+    if (lane == 0) {
+        if (rare_n != 0u) atomicAdd(&ctl->reserved, rare_n);   // (statistics: tiles holding values outside the window)
+        if (raises != 0u) atomicAdd(&ctl->iters, raises);      // (statistics: thresholds raised on the fly)
+    }
+    const float wmn = wave_min(mn), wmx = wave_max(mx);
+    if (lane == 0) {
+        sh.red_mn[w] = wmn;
+        sh.red_mx[w] = wmx;
+    }
+}
+
+// The walk of one pair by the workgroup that has just streamed it: histogram (still in LDS) -> suffix totals in place, s_0,
+// bounded bulk steps, exact steps over the list (registers), acceptance; results / rescue request -> the pair's state.
+template <int kVecT>
+__device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t tensor, double* s_ge, uint32_t* n_ge, Shared& sh,
+                                          dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl,
+                                          const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
+                                          const TailArgs& fa, const uint32_t cnt) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & (kWave - 1);
+    const int w = tid / kWave;
+    dpl_octav_state* me = st + pair;
+    const unsigned long long n_pair = (unsigned long long)cnt;
+    const bool small = cnt <= kSmallCap;
+    // the list: this workgroup's own global stores (one CU, one L1), requested before the histogram is turned into suffix totals
+    const float* lp = list0 + pair_base[pair];
+    f4 v[kVecT];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cursor);
+    const uint32_t n_rows = (L + 1023u) >> 10;
+    auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
+        constexpr int kN = decltype(count)::value;
+        const uint32_t voff = tid << 4;
+#pragma unroll
+        for (int u = 0; u < kN; ++u) {
+            const uint32_t e0 = (row0 + (uint32_t)u) << 10;
+            const int nbytes = e0 < L ? (int)(min(L - e0, 1024u) << 2) : 0;   // buffer loads: zero fill past the list's end
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(lp + (e0 < L ? e0 : 0u)), 0, nbytes, 0x00020000);
+            dst[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        }
+    };
+    load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
+    // per-bin totals -> suffix totals (thread t owns the 8 bins below 2047 - 8 t; the packed words are read before the doubles
+    // are written over them)
+    {
+        constexpr int kPerT = kLogNB / kThreads;
+        const int hi = kLogNB - 1 - (int)tid * kPerT;
+        const unsigned long long* lpk = reinterpret_cast<const unsigned long long*>(s_ge);
+        uint32_t c[kPerT];
+        unsigned long long m[kPerT];
+#pragma unroll
+        for (int q = 0; q < kPerT; ++q) {
+            const unsigned long long x = lpk[hi - q];
+            c[q] = (uint32_t)(x >> kPackShift);
+            m[q] = x & kPackMask;
+        }
+#pragma unroll
+        for (int q = 0; q < kPerT; ++q) {
+            const int b = hi - q;
+            if (b == 0) c[q] = 0u, m[q] = 0ull;   // bin 0 holds no element
+            n_ge[b] = c[q];
+            s_ge[b] = bin_sum(m[q], c[q], b);
+        }
+        if (tid == 0) sh.jwant = 1u;
+        suffix_in_place(n_ge, s_ge, sh);
+        // what this pair asks the tensor's next batches to list: the bin above which n >> kTailTauShift elements lie
+        const uint32_t want = max((uint32_t)(n_pair >> kTailTauShift), 1u);
+        uint32_t above = hi + 1 < kLogNB ? n_ge[hi + 1] : 0u;
+#pragma unroll
+        for (int q = 0; q < kPerT; ++q) {
+            const int b = hi - q;
+            const uint32_t here = n_ge[b];
+            if (b >= 1 && here >= want && above < want) sh.jwant = (uint32_t)b;   // (N_ge is monotone: one bin at most)
+            above = here;
+        }
+    }
+    if (tid == 0) {
+        const double sum_out = sh.f_sum;
+        const unsigned long long nz_out = (unsigned long long)sh.f_nz;
+        const float gmn = sh.f_mn, gmx = sh.f_mx;
+        const bool nanseen = sh.f_nan != 0u;
+        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+        const float ud = (fa.dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+        // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
+        const float s0 = nanseen ? __uint_as_float(0x7FC00000u)
+            : __fdiv_rn((float)(sum_out + s_ge[1]), (float)(long long)(nz_out + n_ge[1]));
+        uint32_t route = 2u;                                         // 2: walk
+        if (s0 != s0 || fa.max_iters <= 0) route = 0u;               // 0: finished (NaN is a fixed point)
+        else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB))) route = 1u;   // 1: values >= 2^14 / inf: compaction route
+        sh.s0 = s0;
+        sh.ud = ud;
+        sh.n_elems = n_pair;
+        sh.route = route;
+        me->s = s0;
+        me->unsigned_div = ud;
+        me->iters = 0u;
+        me->sum = 0.0;
+        me->cnt_gt = 0ull;
+        me->cnt_le = 0ull;
+        me->len[0] = 0u;
+        me->len[1] = 0u;
+        me->cur = 2u;
+        atomicAdd(&ctl->sum, (double)L);   // the batch's listed values (statistics)
+    }
+    __syncthreads();
+    const uint32_t route = __builtin_amdgcn_readfirstlane(sh.route);
+    uint32_t bad = route == 1u ? 1u : 0u;
+    float s = sh.s0;
+    uint32_t evals = 0u, exact = 0u, stopped = 0u;
+    if (route == 2u) {
+        const float ud = sh.ud;
+        const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
+        const int J = (int)__builtin_amdgcn_readfirstlane((int)sh.tail_j);
+        const int max_iters = fa.max_iters;
+        if (fa.fail_every > 0 && pair % (uint32_t)fa.fail_every == 0u) bad = 1u;   // test hook: the rescue path
+        // ---- bulk: lower bounds of F from the suffix totals (every thread the same; LDS broadcasts)
+        int jb = log_bin(s);
+        while (!bad && jb < J) {
+            if (jb < 1) {
+                bad = 1u;   // below the binned window
+                break;
+            }
+            const uint32_t nb = n_ge[jb], nb1 = n_ge[jb + 1];
+            const double A = s_ge[jb + 1];
+            if (nb1 == 0u) {
+                bad = 1u;
+                break;
+            }
+            const double d0 = c * (double)(long long)(n_pair - nb1) + (double)nb1;
+            const double dm = c * (double)(long long)(n_pair - nb) + (double)nb;
+            const double nm = A + (double)(nb - nb1) * (double)s;
+            const float q0 = __fdiv_rn((float)A, (float)d0), qm = __fdiv_rn((float)nm, (float)dm);
+            const float lb = __fmul_rn(fminf(q0, qm), 0.99999952316284180f);   // (1 - 2^-21: below every rounding above)
+            if (!(__fsub_rn(lb, s) >= 2e-6f)) {
+                bad = 1u;   // the bound does not move up: the fixed point is in this bin, or the pair is degenerate
+                break;
+            }
+            s = lb;
+            ++evals;
+            if ((int)evals >= max_iters) {
+                bad = 1u;
+                break;
+            }
+            jb = log_bin(s);
+        }
+        // ---- exact: the reference's step; count / sum of the values above s = suffix totals of the bins above + listed values of bin jb
+        if (!bad && jb > kLogNB - 2) bad = 1u;
+        unsigned long long n_above = 0ull;
+        double s_above = 0.0;
+        auto enter = [&](int j) {
+            n_above = (unsigned long long)n_ge[j + 1];
+            s_above = s_ge[j + 1];
+        };
+        if (!bad) enter(jb);
+        uint32_t par = 0u;
+        f4 ov[kOver];
+        while (!bad && !stopped) {
+            const uint32_t lo1 = __float_as_uint(s) + 1u;
+            const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
+            uint32_t cc = 0u;   // (wave-uniform)
+            unsigned long long dsum = 0ull;
+            uint32_t ds = 0u;
+            auto in1 = [&](float f) {
+                const uint32_t d = __float_as_uint(f) - lo1;
+                const bool in = d < span;
+                cc += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                ds += in ? d : 0u;
+            };
+            if (n_rows > (uint32_t)kVecT) load_rows(ov, std::integral_constant<int, kOver>{}, (uint32_t)kVecT);
+            {
+                const uint32_t rows = min(n_rows, (uint32_t)kVecT);
+#pragma unroll
+                for (int u = 0; u < kVecT; ++u) {
+                    if ((uint32_t)u < rows) {   // uniform
+                        in1(v[u].x);
+                        in1(v[u].y);
+                        in1(v[u].z);
+                        in1(v[u].w);
+                    }
+                }
+                dsum += (unsigned long long)wave_sum_dpp(ds);
+                ds = 0u;
+            }
+            for (uint32_t r0 = (uint32_t)kVecT; r0 < n_rows; r0 += (uint32_t)kOver) {   // a list beyond the registers (a cold start)
+#pragma unroll
+                for (int u = 0; u < kOver; ++u) {
+                    in1(ov[u].x);
+                    in1(ov[u].y);
+                    in1(ov[u].z);
+                    in1(ov[u].w);
+                }
+                if (r0 + (uint32_t)kOver < n_rows) load_rows(ov, std::integral_constant<int, kOver>{}, r0 + (uint32_t)kOver);
+                dsum += (unsigned long long)wave_sum_dpp(ds);
+                ds = 0u;
+            }
+            if (lane == 0) {
+                sh.part_c[par][w] = cc;
+                sh.part_m[par][w] = dsum + (unsigned long long)cc * (unsigned long long)(lo1 & 0x7FFFFFu);
+            }
+            __syncthreads();
+            unsigned long long tc = 0ull, tm = 0ull;
+#pragma unroll
+            for (int j = 0; j < kWaves; ++j) {
+                tc += sh.part_c[par][j];
+                tm += sh.part_m[par][j];
+            }
+            par ^= 1u;
+            const unsigned long long tg = n_above + tc;
+            const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+            const double denom = c * (double)(long long)(n_pair - tg) + (double)(long long)tg;
+            const float s1 = __fdiv_rn((float)ts, (float)denom);
+            ++evals;
+            ++exact;
+            if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
+                stopped = 1u;   // forward_net.py:328-329: keeps the previous s
+            } else if (!(s1 >= s)) {
+                bad = 1u;       // moved down (or NaN): not the climb this form relies on
+            } else {
+                s = s1;
+                if ((int)evals >= max_iters) {
+                    bad = 1u;   // the cap: which iterate the reference stopped on is not known here
+                } else {
+                    const int jn = log_bin(s);
+                    if (jn > kLogNB - 2) {
+                        bad = 1u;
+                    } else if (jn != jb) {
+                        jb = jn;
+                        enter(jb);
+                    }
+                }
+            }
+        }
+        // at least two exact evaluations behind a bounded start (none needed when every step was exact: a small pair)
+        if (!bad && !(stopped && (exact >= 2u || evals == exact))) bad = 1u;
+    }
+    // ---- history: the bin this pair asked for (whatever became of its walk)
+    if (tid == 0 && !small && route != 0u) atomicMax(fa.vis_w + (size_t)tensor * kLogWords, (uint32_t)kLogNB - sh.jwant);
+    // ---- a pair this form could not finish is RESCUED (as walk_pair does): exact bracket, re-read of the pair alone, verified walk
+    bool rescued = false;
+    if (bad && !small && route == 2u) {
+        if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
+        __syncthreads();
+        if (tid == 0) sh.route = bracket_marks(n_ge, s_ge, sh.pub, sh.s0, sh.ud, sh.n_elems).route;
+        __syncthreads();
+        rescued = sh.route == 2u;
+        if (rescued) {
+            if (tid < (uint32_t)kLogWords) fa.rescue_bm[(uint64_t)pair * kLogWords + tid] = sh.pub[tid];
+            double* rs = reinterpret_cast<double*>(fa.resc + (uint64_t)pair * kRescRow);
+            uint32_t* rn = reinterpret_cast<uint32_t*>(fa.resc + (uint64_t)pair * kRescRow + kLogNB);
+            for (int b = tid; b < kLogNB; b += kThreads) {
+                rs[b] = s_ge[b];
+                rn[b] = n_ge[b];
+            }
+        }
+    }
+    if (tid == 0) {
+        if (route == 0u) {
+            me->done = 1u;
+            me->mode = 2u;
+        } else if (bad && rescued) {
+            me->mode = 3u;   // restart from s_0 (in me->s) on the pair's exact bracket: its units go on the rescue's work list
+            me->done = 0u;
+            me->len[0] = 0u;
+            const uint32_t nu = (uint32_t)((n_pair + kRescueUnit - 1) / kRescueUnit);
+            const uint32_t e = atomicAdd(&ctl->len[0], 1u), u0 = atomicAdd(&ctl->len[1], nu);
+            fa.missed[3 * e] = pair;
+            fa.missed[3 * e + 1] = u0;
+            fa.missed[3 * e + 2] = nu;
+        } else if (bad) {
+            me->mode = 1u;   // restart from s_0 on the compaction route: state as k_octav_update<true> leaves it
+            me->done = 0u;
+            me->len[0] = 0u;
+            atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+        } else {
+            me->s = s;
+            me->iters = evals;
+            me->done = 1u;
+            me->mode = 2u;
+        }
+    }
+}
+
+// One workgroup per pair (largest first): the pair's only HBM read, then its walk.
+__global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
+    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
+    uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0, dpl_octav_state* __restrict__ ctl,
+    const TailArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    const uint32_t pair = it.slot, cnt = it.count;
+    dpl_octav_state* me = st + pair;
+    const float* pg = segs[it.seg] + it.offset;
+    const uint32_t tensor = pair % n_tensors;
+    const bool small = cnt <= kSmallCap;   // lists its whole window: every step exact
+    for (int b = tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
+    if (tid == 0) {
+        const uint32_t hist = small ? 0u : fa.pred[(size_t)tensor * kPredRow];   // kLogNB - bin; 0: none (a cold start lists from bin 1 and raises)
+        sh.tail_j = (hist >= 1u && hist < (uint32_t)kLogNB) ? (uint32_t)kLogNB - hist : 1u;
+        sh.cursor = 0u;
+        sh.low_sum = 0.0;
+        sh.low_cnt = 0u;
+        sh.low_nan = 0u;
+    }
+    __syncthreads();
+    stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair]), sh, ctl, !small);
+    __syncthreads();   // every LDS histogram add has landed; the per-wave ranges are in sh
+    if (tid == 0) {
+        float tmn = INFINITY, tmx = -INFINITY;
+        const uint32_t tnz = sh.low_cnt, tnan = sh.low_nan;
+        const double tsum = sh.low_sum;
+        for (int j = 0; j < kWaves; ++j) {
+            tmn = fminf(tmn, sh.red_mn[j]);
+            tmx = fmaxf(tmx, sh.red_mx[j]);
+        }
+        // the pair's statistics (what the rescue / the compaction route and dpl_octav_finalize read)
+        me->n_elems = (unsigned long long)cnt;
+        if (tmn <= tmx) {
+            me->min_enc = enc_f32(tmn);
+            me->max_enc = enc_f32(tmx);
+        }
+        if (tnan) me->nan_seen = 1u;
+        sh.f_sum = tsum;
+        sh.f_nz = tnz;
+        sh.f_nan = tnan;
+        sh.f_mn = tmn;
+        sh.f_mx = tmx;
+    }
+    __syncthreads();
+    walk_tail<kVec>(pair, tensor, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl,
+                    pair_base, list0, fa, cnt);
+}
+
+// State + threshold snapshot of a batch: pred[t][0] = what the tensor's pairs asked for in the current and the previous epoch.
+__global__ void k_octav_tail_init(dpl_octav_state* st, int64_t n_pairs, uint32_t* vis_w, const uint32_t* vis_o, uint32_t* pred,
+                                  int64_t n_tensors, int zero_w) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_tensors) {
+        const uint32_t mine = zero_w ? 0u : vis_w[i * kLogWords];
+        if (zero_w) vis_w[i * kLogWords] = 0u;
+        pred[i * kPredRow] = max(mine, vis_o[i * kLogWords]);
+    }
+    if (i > n_pairs) return;  // slot n_pairs is the control block
+    dpl_octav_state z;
+    z.sum = 0.0;
+    z.cnt_gt = 0;
+    z.cnt_le = 0;
+    z.min_enc = 0xFFFFFFFFu;
+    z.max_enc = 0u;
+    z.nan_seen = 0u;
+    z.done = 0u;
+    z.s = 0.0f;
+    z.unsigned_div = 1.0f;
+    z.iters = 0u;
+    z.mode = 2u;
+    z.n_elems = 0ull;
+    z.len[0] = 0u;
+    z.len[1] = 0u;
+    z.cur = 2u;
+    z.reserved = 0u;
+    st[i] = z;
+}

@@ -177,21 +177,17 @@ class TensorSetPlan:
         return self._octav_one or None
 
     def octav_reset(self):
-        """Cold start of the one-read OCTAV form: what the plan learned from earlier batches (bins visited, choice of walk) is
-        forgotten — the state of a plan that has never run.  Call between independent calibration runs that share a plan
-        (after OctavPipeline.sync())."""
+        """Cold start of the one-read OCTAV forms: what the plan learned from earlier batches (bins visited / thresholds asked
+        for, choice of walk) is forgotten — the state of a plan that has never run.  Call between independent calibration runs
+        that share a plan (after OctavPipeline.sync())."""
         one = getattr(self, "_octav_one", None)
         if one:
             one["vis"].zero_()
             one["pred"].zero_()
             one["tstat"].zero_()
             one["calls"] = 0
-        for st in getattr(self, "_octav_pipe_sets", None) or []:
-            if st["pending"]:
-                raise _hip.DipoorletHipError("octav_reset with batches in flight: call OctavPipeline.sync() first")
-            st["prepared"] = None
-            st["k"] = -1
-        self.__dict__.pop("_octav_sorted", None)
+        for pipe in list(getattr(self, "_octav_pipes", ())):
+            pipe._forget(self)
 
     def seg_table(self, tensors):
         """Device table of base pointers for this launch (cached per pointer tuple)."""
@@ -295,9 +291,9 @@ class CalibAccumulators:
 _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 
-_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3}
-# batches per prediction epoch of the one-read form: a batch gathers the bins the walks of the current and the previous epoch
-# stepped into (8-16 batches of history)
+_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3, "tail": 3}
+# batches per prediction epoch of the one-read forms: a batch lists by what the walks of the current and the previous epoch
+# asked for (8-16 batches of history)
 _ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.30"))
 # (round 3: with the single-slice pairs walked by their streaming workgroups, only the multi-slice pairs' lists reach the walk
 # kernels, and k_octav_walk<32> holds 32 Ki values in registers: sorted runs pay beyond ~12 % listed; measured at 4.3 % on the
@@ -306,26 +302,39 @@ _ONEREAD_SORT_SHARE = float(os.environ.get("DPL_ONEREAD_SORT_SHARE", "0.12"))
 _ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
 
 
+def _default_form():
+    """DPL_OCTAV_FORM, else 'tail' (round 4: exact tail / bounded bulk; csrc/octav_tail.hpp)."""
+    return os.environ.get("DPL_OCTAV_FORM", "tail")
+
+
+def _tail_ok(res):
+    """The exact-tail form takes tensor sets whose pairs are all one slice (<= dpl_octav_slice_cap() elements per image and
+    tensor: every pair of the ResNet-50 and ViT-B/16 sets); others run the round-3 one-read form."""
+    return res is not None and res["n_multi"] == 0
+
+
 def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):
     """OCTAV for every (image, tensor) pair of one batch -> fp32 device tensor [B, T, 3] = (s, min, max).
 
-    Four forms computing the SAME iterate sequence (forward_net.py:323-330):
-      'oneread' (default)  ONE read, one launch: statistics, exact log-scale histogram and the values of the bins the
-                           iterates are predicted to visit (from the same tensor in the previous batches of this plan)
-                           in a single pass; the exact iteration verifies every iterate against what was gathered and
-                           mispredicted pairs (all of them in a plan's first batch) finish on the compaction route
-                           (csrc/octav_oneread.hip).  A tensor set with a pair too large for it uses 'bracket'
+    Forms (all end on the reference's result, forward_net.py:323-330):
+      'tail' (default)     ONE read, one launch: statistics, exact log-scale histogram and the values at or above a threshold
+                           bin (~1 % of a pair); the early iterates are taken as lower bounds from the histogram, the late
+                           ones exactly from the list; a walk that does not end on two exact evaluations is rescued by the
+                           exact two-read route (csrc/octav_tail.hpp).  Single-slice pairs only: other sets use 'oneread'
+      'oneread'            ONE read: the values of the bins ALL iterates are predicted to visit are listed, every iterate is
+                           evaluated exactly and verified (csrc/octav_oneread.hip); a set with a pair too large: 'bracket'
       'bracket'            two reads: statistics + exact log-scale histogram, bracket walk, gather of the marked
                            bins, exact per-pair iteration; pairs it cannot serve finish on the compaction route
       'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists
       'full'               every evaluation re-reads the full data (21 passes)
     `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default."""
     if form is None:
-        form = ("compact" if compact else "full") if compact is not None else os.environ.get("DPL_OCTAV_FORM", "oneread")
+        form = ("compact" if compact else "full") if compact is not None else _default_form()
     mode = _OCTAV_MODE[form]
     res = plan.octav_oneread_scratch() if mode == 3 else None
     if mode == 3 and res is None:
         mode = 2
+    tail = 1 if (form == "tail" and _tail_ok(res)) else 0
     w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
     nbytes = (n_pairs + 1) * C.sizeof(_hip.OctavState)  # + control block
@@ -340,7 +349,7 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
         res["calls"] = k + 1
         epoch, first = divmod(k, _ONEREAD_EPOCH)
         job = _oneread_job(plan, res, tab, states, res["lh"], res["pred"], res["pred_pair"], res["use_probe"], l0, epoch % 2,
-                           1 if first == 0 else 0, _walk_sorted(plan), dyn)
+                           1 if first == 0 else 0, _walk_sorted(plan), dyn, tail=tail)
         _hip.check(L.dpl_octav_run_oneread(C.byref(job), _stream()), "dpl_octav_run_oneread")
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
@@ -369,7 +378,7 @@ _PREDICT = {"learned": 0, "probe": 1, "auto": 2}
 
 
 def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, write_epoch, reset_epoch, sorted_walk, dyn,
-                 compaction_inline=1, rescue=None):
+                 compaction_inline=1, rescue=None, tail=0):
     """The C ABI's dpl_octav_oneread_job for one batch of `plan` (all device pointers; the tensors stay alive in the caller)."""
     spans, base, order, _, l1 = plan.octav_scratch()
     w = plan.work("octav", per_image=True)
@@ -391,6 +400,7 @@ def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, wri
     j.d_vis, j.n_multi = res["vis"].data_ptr(), res["n_multi"]
     # DPL_OCTAV_FUSE=0: every pair walked by dpl_octav_oneread_finish (the pre-round-3 schedule; A/B and tests)
     j.fuse = 0 if os.environ.get("DPL_OCTAV_FUSE", "1") == "0" else 1
+    j.tail = tail
     j.write_epoch, j.reset_epoch, j.sorted, j.dynamic_sym, j.max_iters = write_epoch, reset_epoch, sorted_walk, dyn, _OCTAV_MAX_ITERS
     j.compaction_inline = compaction_inline
     return j
@@ -400,7 +410,7 @@ _PIPE_SETS = max(2, int(os.environ.get("DPL_OCTAV_PIPE_SETS", "3")))   # batches
 
 
 def _walk_sorted(plan):
-    """1: the plan's next one-read batch walks sorted runs, 0: whole lists from registers (DPL_OCTAV_WALK = sorted | group
+    """1: the plan's next 'oneread' batch walks sorted runs, 0: whole lists from registers (DPL_OCTAV_WALK = sorted | group
     forces one; default: by the share of values the plan's last batches listed, see OctavPipeline._settle)."""
     forced = os.environ.get("DPL_OCTAV_WALK", "auto")
     if forced in ("sorted", "group"):
@@ -409,41 +419,44 @@ def _walk_sorted(plan):
 
 
 class OctavPipeline:
-    """OCTAV over a RUN of batches in the one-read form on two HIP streams.  Same kernels, same results as
-    octav_batch(form='oneread').
+    """OCTAV over a RUN of batches in a one-read form ('tail', or 'oneread') on two HIP streams.  Same kernels, same results
+    as octav_batch.
 
         pipe = OctavPipeline(dynamic_sym)
         rows = [pipe.submit(plan, tensors) for ...]     # [B, T, 3] each, NOT valid yet
         pipe.sync()                                     # rows are valid for work on the caller's stream
 
-    Caller's stream: the pairs' own predictions where the tensor needs them (k_octav_probe) and the streaming kernel, which
-    also walks every single-slice pair.  Side stream, behind the streaming kernel of batch i and beside that of batch i + 1:
-    the walk of the multi-slice pairs, the rescue of the pairs a walk could not finish (on the device, no host round trip),
-    the result rows, the state and the choice of prediction for batch i + 3.  Each plan keeps three sets of per-batch scratch.
-    The control block of a batch (listed values, rescued pairs, pairs left for the compaction route) is copied to pinned
-    memory and read when the set comes up for reuse three submits later (or in sync()): statistics, the choice of walk for long
-    lists, and — only when the count is non-zero — the launch of the compaction route for that batch.  The activations of a
-    batch, its pointer table and its result stay referenced from the set until then; the host runs at most three batches ahead
-    (DPL_OCTAV_PIPE_SETS; with two the host waited for side-stream work that ends with the previous streaming kernel).
-    A tensor set the one-read form cannot take (a pair above 64 slices) runs octav_batch on the caller's stream instead."""
+    Caller's stream: the streaming kernel, which also walks every single-slice pair ('oneread': + the pairs' own predictions
+    where the tensor needs them, k_octav_probe).  Side stream, behind the streaming kernel of batch i and beside that of batch
+    i + 1: the rescue of the pairs a walk could not finish (on the device, no host round trip; 'oneread': + the walk of the
+    multi-slice pairs), the result rows, the state and the threshold / prediction snapshot for batch i + 3.
+    The pipeline OWNS its rotation state per plan (three sets of per-batch scratch, six state arrays and snapshots, the call
+    counter): two pipelines may run the same plan (they share only what the plan has learned: bits OR-ed / maxima taken into
+    plan-level accumulators).  The control block of a batch (listed values, rescued pairs, pairs left for the compaction route)
+    is copied to pinned memory and read when the set comes up for reuse three submits later (or in sync()): statistics, the
+    choice of walk for long lists, and — only when the count is non-zero — the launch of the compaction route for that batch.
+    The activations of a batch, its pointer table and its result stay referenced from the set until then; the host runs at
+    most three batches ahead (DPL_OCTAV_PIPE_SETS; with two the host waited for side-stream work that ends with the previous
+    streaming kernel).  A tensor set the one-read forms cannot take (a pair above 64 slices) runs octav_batch on the caller's
+    stream instead."""
 
     def __init__(self, dynamic_sym, device=None):
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
+        self._plans = {}          # id(plan) -> this pipeline's rotation state for the plan
         self._touched = []
         # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
         self.reset_stats()
 
     def reset_stats(self):
         self.batches = self.fallback_batches = self.fallback_pairs = self.sorted_batches = self.compaction_pairs = 0
-        self.probe_tensors = self.tiles_reread = 0
-        self.list_share = self.max_share = 0.0    # gathered values / elements (running mean / maximum over the settled batches)
+        self.probe_tensors = self.tiles_reread = self.raises = 0
+        self.list_share = self.max_share = 0.0    # listed values / elements (running mean / maximum over the settled batches)
 
-    @staticmethod
-    def _sets(plan, res):
-        sets = getattr(plan, "_octav_pipe_sets", None)
-        if sets is None:
+    def _state(self, plan, res):
+        ps = self._plans.get(id(plan))
+        if ps is None:
             _, _, _, l0, _ = plan.octav_scratch()
             nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
             off, csz = plan.n_pairs * C.sizeof(_hip.OctavState), C.sizeof(_hip.OctavState)    # the control block
@@ -454,68 +467,90 @@ class OctavPipeline:
             # runs BESIDE the streaming kernel of call k - 1 and is often not done before that kernel's last tenth: the next
             # batch was then enqueued after the kernel had ended (measured: 32 us of idle caller's stream per batch)
             S = _PIPE_SETS
-            plan._octav_pipe_states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(2 * S)]
-            plan._octav_pipe_failed = [x[off:off + csz] for x in plan._octav_pipe_states]
-            # the prediction snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
-            # taken care of (S submits later), after the snapshot of call k + S has been written
-            plan._octav_pipe_pred = [res["pred"]] + [torch.zeros_like(res["pred"]) for _ in range(2 * S - 1)]
-            plan._octav_pipe_use = [res["use_probe"]] + [torch.zeros_like(res["use_probe"]) for _ in range(2 * S - 1)]
-            sets = []
+            first = not getattr(plan, "_octav_pipes", None)    # the first pipeline on a plan uses the plan's own scratch
+            states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(2 * S)]
+            ps = dict(plan=plan, calls=0, states=states, failed=[x[off:off + csz] for x in states],
+                      # the snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
+                      # taken care of (S submits later), after the snapshot of call k + S has been written
+                      pred=[torch.zeros_like(res["pred"]) for _ in range(2 * S)],
+                      use=[torch.zeros_like(res["use_probe"]) for _ in range(2 * S)], sets=[])
             for j in range(S):
-                sets.append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(),
-                                 use_host=torch.zeros(plan.T, dtype=torch.int32).pin_memory(),
-                                 lh=res["lh"] if j == 0 else torch.empty_like(res["lh"]),
-                                 l0=l0 if j == 0 else torch.empty_like(l0),
-                                 pred_pair=res["pred_pair"] if j == 0 else torch.zeros_like(res["pred_pair"]),
-                                 rescue_bm=res["rescue_bm"] if j == 0 else torch.empty_like(res["rescue_bm"]),
-                                 missed=res["missed"] if j == 0 else torch.empty_like(res["missed"]),
-                                 resc=res["resc"] if j == 0 else torch.empty_like(res["resc"]),
-                                 done=None, refs=None, pending=False, k=-1))
-            plan._octav_pipe_sets = sets
-        return sets
+                own = first and j == 0
+                ps["sets"].append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(),
+                                       use_host=torch.zeros(plan.T, dtype=torch.int32).pin_memory(),
+                                       lh=res["lh"] if own else torch.empty_like(res["lh"]),
+                                       l0=l0 if own else torch.empty_like(l0),
+                                       pred_pair=res["pred_pair"] if own else torch.zeros_like(res["pred_pair"]),
+                                       rescue_bm=res["rescue_bm"] if own else torch.empty_like(res["rescue_bm"]),
+                                       missed=res["missed"] if own else torch.empty_like(res["missed"]),
+                                       resc=res["resc"] if own else torch.empty_like(res["resc"]),
+                                       done=None, refs=None, pending=False, k=-1, prepared=None))
+            self._plans[id(plan)] = ps
+            if getattr(plan, "_octav_pipes", None) is None:
+                import weakref
+                plan._octav_pipes = weakref.WeakSet()
+            plan._octav_pipes.add(self)
+        return ps
 
-    def _prepare(self, plan, res, st, k, stream):
-        """State array + prediction snapshot (in set `st`) for the plan's call number k."""
+    def _forget(self, plan):
+        """plan.octav_reset(): this pipeline's rotation for the plan starts over (nothing may be in flight)."""
+        ps = self._plans.get(id(plan))
+        if ps is None:
+            return
+        for st in ps["sets"]:
+            if st["pending"]:
+                raise _hip.DipoorletHipError("octav_reset with batches in flight: call OctavPipeline.sync() first")
+            st["prepared"] = None
+            st["k"] = -1
+        ps["calls"] = 0
+        ps.pop("sorted", None)
+
+    def _prepare(self, plan, res, ps, st, k, stream, tail):
+        """State array + threshold / prediction snapshot (in set `st`) for this pipeline's call number k on the plan."""
         ep, first = divmod(k, _ONEREAD_EPOCH)
         r = k % (2 * _PIPE_SETS)
-        job = _oneread_job(plan, res, plan._octav_pipe_pred[r], plan._octav_pipe_states[r], st["lh"], plan._octav_pipe_pred[r],
-                           st["pred_pair"], plan._octav_pipe_use[r], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
-                           self.dyn, rescue=st)    # (prepare reads neither tensors nor the walk choice)
+        job = _oneread_job(plan, res, ps["pred"][r], ps["states"][r], st["lh"], ps["pred"][r],
+                           st["pred_pair"], ps["use"][r], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
+                           self.dyn, rescue=st, tail=tail)    # (prepare reads neither tensors nor the walk choice)
         _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
         st["prepared"] = k
 
-    def _finish(self, plan, res, st):
+    def _finish(self, plan, res, ps, st):
         """Side stream: results of the set's batch -> its output rows, the set made ready for its next use, completion event."""
         side = self.side.cuda_stream
         _hip.check(_hip.lib().dpl_octav_finalize(_ptr(st["states"]), plan.n_pairs, _ptr(st["refs"][2]), side), "dpl_octav_finalize")
-        self._prepare(plan, res, st, st["k"] + _PIPE_SETS, side)    # off the caller's stream: the set's next use is S calls away
+        self._prepare(plan, res, ps, st, st["k"] + _PIPE_SETS, side, st["tail"])    # off the caller's stream: the set's next use is S calls away
         st["done"] = torch.cuda.Event()
         st["done"].record(self.side)
 
-    def _settle(self, plan, res, st):
+    def _settle(self, plan, res, ps, st):
         """HOST: read the statistics the set's last batch left in pinned memory (the walk finished long ago: the set comes up
-        for reuse S submits later) and choose the walk of the plan's next batches.  Nothing is launched here: the pairs a
-        walk could not finish are taken care of on the device, behind the walk, without the host (submit)."""
+        for reuse S submits later) and choose the walk of the plan's next batches.  Nothing is launched here unless pairs are
+        left for the compaction route: the pairs a walk could not finish are rescued on the device, without the host (submit)."""
         if not st["pending"]:
             return
         st["pending"] = False
         st["done"].synchronize()
         ctl = _hip.OctavState.from_buffer_copy(st["failed"].numpy().tobytes())
-        # gathered values; pairs rescued by a re-read of the pair + pairs that ended on the compaction route
+        # listed values; pairs rescued by a re-read of the pair + pairs that ended on the compaction route
         listed, failed = float(ctl.sum), int(ctl.len0) + int(ctl.cnt_le)
         self.compaction_pairs += int(ctl.cnt_le)
-        self.probe_tensors += int(st["use_host"].sum().item())     # tensors whose pairs predicted from a sample of themselves
+        if st["tail"]:
+            self.raises += int(ctl.iters)                              # thresholds raised on the fly (waves that listed beyond their budget)
+        else:
+            self.probe_tensors += int(st["use_host"].sum().item())     # tensors whose pairs predicted from a sample of themselves
         self.tiles_reread += int(ctl.reserved)                     # 1024-element tiles holding a non-zero value outside the window
         self.batches += 1
         share = listed / max(1, plan.batch * sum(plan.elems))
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
         self.max_share = max(self.max_share, share)
-        # which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short, sorted
-        # runs beyond _ONEREAD_SORT_SHARE of the elements
-        if share > _ONEREAD_SORT_SHARE * 1.2:
-            plan._octav_sorted = 1
-        elif share < _ONEREAD_SORT_SHARE * 0.8:
-            plan._octav_sorted = 0
+        # 'oneread': which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short,
+        # sorted runs beyond _ONEREAD_SORT_SHARE of the elements
+        if not st["tail"]:
+            if share > _ONEREAD_SORT_SHARE * 1.2:
+                plan._octav_sorted = 1
+            elif share < _ONEREAD_SORT_SHARE * 0.8:
+                plan._octav_sorted = 0
         self.sorted_batches += st["sorted"]
         if failed:
             self.fallback_pairs += failed
@@ -526,47 +561,52 @@ class OctavPipeline:
             # old, its tensors are still referenced — and its results written over the batch's output rows
             _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(st["job"]), C.c_void_p(self.side.cuda_stream)),
                        "dpl_octav_oneread_compaction")
-            self._finish(plan, res, st)
+            self._finish(plan, res, ps, st)
 
     def submit(self, plan, tensors):
-        form = os.environ.get("DPL_OCTAV_FORM", "oneread")
-        res = plan.octav_oneread_scratch() if form == "oneread" else None
+        form = _default_form()
+        res = plan.octav_oneread_scratch() if form in ("oneread", "tail") else None
         if res is None:
-            return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form == "oneread" else form)
+            return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form in ("oneread", "tail") else form)
+        tail = 1 if (form == "tail" and _tail_ok(res)) else 0
         main = torch.cuda.current_stream(plan.device)
-        sets = self._sets(plan, res)
-        k = res["calls"]
-        res["calls"] = k + 1
+        ps = self._state(plan, res)
+        sets = ps["sets"]
+        k = ps["calls"]
+        ps["calls"] = k + 1
         cur = sets[k % _PIPE_SETS]
         r = k % (2 * _PIPE_SETS)
-        self._settle(plan, res, cur)
+        self._settle(plan, res, ps, cur)
         if cur["done"] is not None:
             main.wait_event(cur["done"])        # everything that last used this set has finished
-        _, base, order, _, _ = plan.octav_scratch()
         tab = plan.seg_table(tensors)
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         cur["refs"] = (list(tensors), tab, out)
         cur["k"] = k
-        cur["states"] = plan._octav_pipe_states[r]
-        cur["pred"] = plan._octav_pipe_pred[r]
-        cur["sorted"] = _walk_sorted(plan)
+        cur["tail"] = tail
+        cur["states"] = ps["states"][r]
+        cur["pred"] = ps["pred"][r]
+        cur["sorted"] = 0 if tail else _walk_sorted(plan)
         L = _hip.lib()
         if cur.get("prepared") != k:
-            self._prepare(plan, res, cur, k, main.cuda_stream)
+            self._prepare(plan, res, ps, cur, k, main.cuda_stream, tail)
         job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
-                                        plan._octav_pipe_use[r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
-                                        compaction_inline=0, rescue=cur)
-        _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
+                                        ps["use"][r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
+                                        compaction_inline=0, rescue=cur, tail=tail)
+        if not tail:
+            _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
         _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
         streamed = torch.cuda.Event()
         streamed.record(main)
         self.side.wait_event(streamed)
-        # the walk and, behind it on the device, the rescue of the pairs it could not finish: no host round trip decides anything
+        # the rescue of the pairs a walk could not finish ('oneread': behind the walk of the multi-slice pairs), on the device: no
+        # host round trip decides anything
         _hip.check(L.dpl_octav_oneread_finish(C.byref(job), C.c_void_p(self.side.cuda_stream)), "dpl_octav_oneread_finish")
         with torch.cuda.stream(self.side):
-            cur["failed"].copy_(plan._octav_pipe_failed[r], non_blocking=True)    # (statistics only: _settle)
-            cur["use_host"].copy_(plan._octav_pipe_use[r], non_blocking=True)
-        self._finish(plan, res, cur)
+            cur["failed"].copy_(ps["failed"][r], non_blocking=True)    # (statistics only: _settle)
+            if not tail:
+                cur["use_host"].copy_(ps["use"][r], non_blocking=True)
+        self._finish(plan, res, ps, cur)
         cur["pending"] = True
         if all(p is not plan for p, _ in self._touched):
             self._touched.append((plan, res))
@@ -576,11 +616,12 @@ class OctavPipeline:
         """Settle every outstanding batch (host waits for the walks), order the caller's stream after the side stream and
         let go of the batches' tensors."""
         for plan, res in self._touched:
-            for st in sorted(plan._octav_pipe_sets, key=lambda q: q["k"]):
-                self._settle(plan, res, st)
+            ps = self._plans[id(plan)]
+            for st in sorted(ps["sets"], key=lambda q: q["k"]):
+                self._settle(plan, res, ps, st)
         torch.cuda.current_stream(self.device).wait_stream(self.side)
         for plan, _ in self._touched:
-            for st in plan._octav_pipe_sets:
+            for st in self._plans[id(plan)]["sets"]:
                 st["refs"] = None
         self._touched = []
 

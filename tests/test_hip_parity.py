@@ -138,13 +138,24 @@ def _octav(ops, plan, tensors, dyn, form, states=None):
         again = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
         assert np.array_equal(got, again, equal_nan=True)
         assert _same_steps(first, got)
+    if form == "tail":
+        # the exact-tail form: the first call of a plan has no threshold history (lists from the bottom of the window and raises
+        # the threshold on the fly), the later ones start from what the earlier calls asked for.  Where the list starts decides
+        # which early iterates are bounds and which are exact, not where the walk ends: same fixed point, up to the stop rule
+        # (|s' - s| < 1e-6) firing one step apart
+        first = got
+        got = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
+        again = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
+        for a in (first, again):
+            assert np.array_equal(a[..., 1:], got[..., 1:], equal_nan=True)
+            assert _close(a[..., 0], got[..., 0])
     return got
 
 
-@pytest.mark.parametrize("form", ["oneread", "bracket", "compact", "full"])
+@pytest.mark.parametrize("form", ["tail", "oneread", "bracket", "compact", "full"])
 def test_octav_golden(dev, kl, form):
-    """All four forms (one-read, two-read bracket, tail compaction, full re-reads): same iterate
-    sequence."""
+    """All forms against the reference's own outputs: exact tail / bounded bulk (the default), and the four that walk the
+    reference's iterate sequence (one-read, two-read bracket, tail compaction, full re-reads)."""
     from dipoorlet_amd import ops
     meta, g = kl
     for c in meta["cases"]:
@@ -181,13 +192,14 @@ def test_octav_non_monotone_pairs_fall_back_to_full_passes(dev):
     f = ops.octav_batch(plan, tensors, False, form="full").cpu().numpy()
     k = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
     r = _octav(ops, plan, tensors, False, "oneread")
+    e = _octav(ops, plan, tensors, False, "tail")      # (refuses such pairs: the rescue / the compaction route finishes them)
     for t in range(len(sizes)):
         for b in range(B):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
-            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s) and _close(r[b, t, 0], s), \
-                (t, b, a[b, t], f[b, t], k[b, t], r[b, t], s)
+            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s) and _close(r[b, t, 0], s) \
+                and _close(e[b, t, 0], s), (t, b, a[b, t], f[b, t], k[b, t], r[b, t], e[b, t], s)
 
 
 def test_batched_tensor_set_vs_golden_pipeline_stats(dev, golden_dir):
@@ -418,7 +430,7 @@ def test_empty_and_tiny_spans(dev):
                 assert _close(oc[b, t, 0], s), (t, b, oc[b, t], s)
 
 
-@pytest.mark.parametrize("form", ["oneread", "bracket"])
+@pytest.mark.parametrize("form", ["tail", "oneread", "bracket"])
 def test_octav_bracket_routes(dev, form):
     """The histogram forms on data that exercises each route: ordinary tensors (bracket), a flat distribution whose
     bracket explodes, values beyond the 2^14 window, a huge dynamic range, all in one batched launch."""
@@ -442,7 +454,7 @@ def test_octav_bracket_routes(dev, form):
             assert _close(got[b, t, 0], s), (t, b, got[b, t], s)
 
 
-@pytest.mark.parametrize("form", ["oneread", "bracket"])
+@pytest.mark.parametrize("form", ["tail", "oneread", "bracket"])
 def test_octav_exact_walk_restart_path(dev, form, monkeypatch):
     _restart_path(dev, form)
     if form == "oneread":      # ... and with the sorted-run walk, whose misses a second kernel takes care of
@@ -475,17 +487,18 @@ def _restart_path(dev, form):
         return got, ctl
 
     got, ctl = hooked(0)
-    if form == "oneread":
+    if form in ("oneread", "tail"):
         # the one-read form RESCUES a rejected pair (its exact bracket, a re-read of that pair alone, a second walk); only
         # the pairs that gather their whole window anyway (here: the 1000-element tensor) go straight to the compaction route
         assert int(ctl.len0) + int(ctl.cnt_le) >= plan.n_pairs // 2 and int(ctl.len0) >= plan.n_pairs // 4
         assert int(ctl.len1) >= int(ctl.len0)                # units of the re-read
         got2, ctl2 = hooked(2)                               # ... and when the rescue walk rejects them too: compaction route
         assert int(ctl2.cnt_le) >= plan.n_pairs // 2
-        assert _same_steps(got2, want)
+        assert _same_steps(got2, want) if form == "oneread" else _close(got2[..., 0], want[..., 0])
     else:
         assert int(ctl.cnt_le) == plan.n_pairs // 2          # control block: pairs that took the compaction route
-    assert _same_steps(got, want)
+    # (exact tail: a rescued pair walks the reference's whole iterate sequence, an accepted one only its end: same fixed point)
+    assert _same_steps(got, want) if form != "tail" else (_close(got[..., 0], want[..., 0]) and np.array_equal(got[..., 1:], want[..., 1:]))
     for t in range(len(sizes)):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
@@ -564,13 +577,15 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
                 assert g[1] == x.min() and g[2] == x.max()
 
 
-@pytest.mark.parametrize("walk,sets", [("group", 3), ("sorted", 3), ("auto", 3), ("auto", 2), ("auto", 4)])
-def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk, sets):
-    """(walk: as above; auto = chosen by the listed share.  sets: how many batches the host runs ahead = sets of per-batch
-    scratch, ops._PIPE_SETS.)  OctavPipeline (walk of batch i on a side stream beside the streaming kernel of batch i + 1, double-buffered
-    scratch) returns what octav_batch returns batch by batch — including the first batches, where every multi-slice pair
-    takes the compaction route on the side stream — and the oracle's scales."""
+@pytest.mark.parametrize("form,walk,sets", [("tail", "auto", 3), ("tail", "auto", 2), ("tail", "auto", 4), ("oneread", "group", 3),
+                                            ("oneread", "sorted", 3), ("oneread", "auto", 3), ("oneread", "auto", 2), ("oneread", "auto", 4)])
+def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, sets):
+    """(form: the exact-tail form — the default — or the round-3 one-read form; walk: as above, auto = chosen by the listed share.
+    sets: how many batches the host runs ahead = sets of per-batch scratch, ops._PIPE_SETS.)  OctavPipeline (rescue / walk of
+    batch i on a side stream beside the streaming kernel of batch i + 1, rotating scratch) returns what the two-read form
+    returns batch by batch — including the first batches, which run without any history — and the oracle's scales."""
     from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", form)
     monkeypatch.setenv("DPL_OCTAV_WALK", walk)
     monkeypatch.setattr(ops, "_PIPE_SETS", sets)
     rng = np.random.default_rng(41)
@@ -590,7 +605,8 @@ def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk, sets):
     for k, (o, w) in enumerate(zip(outs, want)):
         got = o.cpu().numpy()
         assert np.array_equal(got[:, :, 1:], w[:, :, 1:]), k
-        assert np.allclose(got[:, :, 0], w[:, :, 0], rtol=2e-7, atol=0), k
+        # (one-read: the reference's iterate sequence, up to the order of atomically merged sums; exact tail: its fixed point)
+        assert np.allclose(got[:, :, 0], w[:, :, 0], rtol=2e-7, atol=0) if form == "oneread" else _close(got[:, :, 0], w[:, :, 0]), k
     # a second run on the same plan (prediction warmed up), interleaved with a ragged plan
     plan2 = ops.TensorSetPlan(sizes, 2, dev)
     x = [torch.from_numpy(np.stack([(rng.standard_normal(n) * (1 + t)).astype(np.float32) for _ in range(B)])).to(dev)
@@ -599,8 +615,12 @@ def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, walk, sets):
     b = pipe.submit(plan2, [v[:2].contiguous() for v in x])
     c = pipe.submit(plan, x)
     pipe.sync()
-    assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
-    assert np.array_equal(a.cpu().numpy()[:2], b.cpu().numpy())
+    if form == "oneread":
+        assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
+        assert np.array_equal(a.cpu().numpy()[:2], b.cpu().numpy())
+    else:
+        assert np.array_equal(a.cpu().numpy()[..., 1:], c.cpu().numpy()[..., 1:]) and _close(a.cpu().numpy()[..., 0], c.cpu().numpy()[..., 0])
+        assert _close(a.cpu().numpy()[:2, :, 0], b.cpu().numpy()[..., 0])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for t in range(len(sizes)):
@@ -613,6 +633,7 @@ def test_octav_oneread_schedules_and_predictions_agree(dev, monkeypatch):
     per tensor (DPL_OCTAV_PREDICT) — bit-identical rows over a run of batches whose images differ in scale (so that the
     prediction from earlier batches misses and pairs are rescued), through the pipeline and on one stream."""
     from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", "oneread")
     rng = np.random.default_rng(41)
     B, sizes = 3, [150528, 40000, 802816, 1000, 200704, 1200007]
     batches = [[torch.from_numpy((rng.standard_normal((B, n)) * (1 + 0.3 * t) * (1 + 0.25 * k)).astype(np.float32)
@@ -690,6 +711,8 @@ def test_octav_special_values(dev, monkeypatch, predict):
                 monkeypatch.setenv("DPL_OCTAV_FUSE", fuse)
                 plan = ops.TensorSetPlan(sizes, B, dev)
                 got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("oneread", "bracket", "compact", "full")}
+                if fuse == "1":     # (the exact-tail form has no unfused variant)
+                    got["tail"] = _octav(ops, ops.TensorSetPlan(sizes, B, dev), tensors, dyn, "tail")
                 for form, g in got.items():
                     for t in range(len(mk)):
                         for b in range(B):
@@ -698,9 +721,134 @@ def test_octav_special_values(dev, monkeypatch, predict):
                             if not np.isnan(x).any():
                                 assert g[b, t, 1] == x.min() and g[b, t, 2] == x.max(), (form, t, b)
                 assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)
-                pipe = ops.OctavPipeline(dyn, dev)
-                plan2 = ops.TensorSetPlan(sizes, B, dev)
-                rows = [pipe.submit(plan2, tensors) for _ in range(3)]
-                pipe.sync()
-                for r in rows:
-                    assert np.array_equal(r.cpu().numpy(), got["oneread"], equal_nan=True), (fuse, dyn)
+                for pform in ("oneread", "tail") if fuse == "1" else ("oneread",):
+                    monkeypatch.setenv("DPL_OCTAV_FORM", pform)
+                    pipe = ops.OctavPipeline(dyn, dev)
+                    plan2 = ops.TensorSetPlan(sizes, B, dev)
+                    rows = [pipe.submit(plan2, tensors) for _ in range(3)]
+                    pipe.sync()
+                    for r in rows:
+                        if pform == "oneread":
+                            assert np.array_equal(r.cpu().numpy(), got["oneread"], equal_nan=True), (fuse, dyn)
+                        else:
+                            assert np.array_equal(r.cpu().numpy()[..., 1:], got["tail"][..., 1:], equal_nan=True)
+                            assert _close(r.cpu().numpy()[..., 0], got["tail"][..., 0]), (fuse, dyn)
+                monkeypatch.delenv("DPL_OCTAV_FORM")
+
+
+def test_octav_tail_randomised_shapes_and_distributions(dev):
+    """The exact-tail form over odd sizes (not multiples of 4, around the small-pair threshold, up to the one-slice cap) and
+    distributions (discrete-valued, sparse, constant, huge / tiny scale, heavy tails, saturating, per-channel scales with the
+    hot channels first / last): against the numpy oracle and the two-read form, both `dynamic_sym` settings, cold and warm."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(20264)
+    sizes = [1, 3, 17, 1023, 1025, 4099, 16383, 20480, 20481, 50001, 131071, 300003, 605184, 1044480]
+
+    def draw(kind, n):
+        if kind == 0:
+            return rng.standard_normal(n) * 10 ** rng.uniform(-3, 3)
+        if kind == 1:
+            return np.maximum(rng.standard_normal(n) - rng.uniform(-1, 1), 0) * 10 ** rng.uniform(-2, 2)
+        if kind == 2:
+            return rng.integers(-8, 9, n) * 0.25                         # discrete values: many ties
+        if kind == 3:
+            return np.where(rng.random(n) < 0.02, rng.standard_normal(n) * 5, 0.0)
+        if kind == 4:
+            return np.full(n, rng.uniform(0.1, 3.0))                     # constant
+        if kind == 5:
+            return rng.standard_t(2.5, n)                                # heavy tails
+        if kind == 6:
+            return np.abs(rng.standard_normal(n)) + 1e-7                 # |min| < 1e-6: dynamic_sym trigger
+        if kind == 7:
+            return np.clip(rng.standard_normal(n) * 3, 0, 6)             # saturating: an atom at the maximum
+        if kind == 8:
+            return rng.uniform(-1, 1, n)                                 # thin tail: the fixed point holds 0.3 % of the pair
+        if kind == 9:                                                    # channel-major, the hot channels first / last
+            c = 16
+            sc = np.ones((c, 1))
+            sc[:2 if rng.random() < 0.5 else -2] = 12.0
+            return (rng.standard_normal((c, n // c + 1)) * sc).ravel()[:n]
+        return rng.lognormal(0, 2.0, n) * rng.choice([-1, 1], n)
+    B = 2
+    elems, tensors, raw = [], [], []
+    for t, n in enumerate(sizes):
+        data = np.stack([draw((t + 3 * b) % 11, n) for b in range(B)]).astype(np.float32)
+        raw.append(data)
+        elems.append(n)
+        tensors.append(torch.from_numpy(data).to(dev))
+    plan = ops.TensorSetPlan(elems, B, dev)
+    for dyn in (False, True):
+        got = _octav(ops, plan, tensors, dyn, "tail")
+        ref = ops.octav_batch(ops.TensorSetPlan(elems, B, dev), tensors, dyn, form="bracket").cpu().numpy()
+        assert np.array_equal(got[..., 1:], ref[..., 1:]) and _close(got[..., 0], ref[..., 0])
+        for t, n in enumerate(sizes):
+            for b in range(B):
+                x = raw[t][b]
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    s = O.octav_scale(x, O.octav_unsigned(x.min(), dyn))
+                g = got[b, t]
+                assert _close(g[0], s), (n, b, dyn, g, s)
+                assert g[1] == x.min() and g[2] == x.max()
+
+
+def test_octav_tail_thresholds_follow_the_images(dev):
+    """What the exact-tail form lists and how often it has to be rescued, over a run of batches through the pipeline: images
+    alike (thresholds from the earlier batches: ~1 % listed, next to no rescues), then images that differ in scale by +-30 %
+    (a brighter image raises its threshold on the fly; a dimmer one may need the rescue) — results equal to the oracle's
+    either way."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(91)
+    B, sizes = 4, [401408, 100352, 802816, 25088, 200704]
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    for jitter in (0.0, 0.3):
+        batches = []
+        for k in range(6):
+            f = 1.0 + jitter * (2.0 * rng.random((B, 1)) - 1.0)
+            batches.append([torch.from_numpy((np.maximum(rng.standard_normal((B, n)), 0 if t % 2 else -1e30) * (1 + t) * f).astype(np.float32)).to(dev)
+                            for t, n in enumerate(sizes)])
+        plan.octav_reset()
+        pipe = ops.OctavPipeline(False, dev)
+        rows = [pipe.submit(plan, x) for x in batches]
+        pipe.sync()
+        assert pipe.batches == len(batches) and pipe.compaction_pairs == 0
+        if jitter == 0.0:
+            assert pipe.fallback_pairs <= 2 and pipe.list_share < 0.03, (pipe.fallback_pairs, pipe.list_share)
+        else:
+            assert pipe.fallback_pairs <= plan.n_pairs and pipe.max_share < 0.08, (pipe.fallback_pairs, pipe.max_share)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for k in (0, 5):
+                got = rows[k].cpu().numpy()
+                for t in range(len(sizes)):
+                    for b in (0, B - 1):
+                        x = batches[k][t][b].cpu().numpy()
+                        assert _close(got[b, t, 0], O.octav_scale(x, 1)), (jitter, k, t, b)
+                        assert got[b, t, 1] == x.min() and got[b, t, 2] == x.max()
+
+
+@pytest.mark.parametrize("form", ["tail", "oneread"])
+def test_two_pipelines_share_a_plan(dev, monkeypatch, form):
+    """An OctavPipeline owns its rotation state (scratch sets, state arrays, snapshots, call counter) per plan: two pipelines —
+    calibration and profiling, or two threads — may run the same TensorSetPlan interleaved without corrupting each other
+    (re-entrant ops, no hidden mutable state on the plan)."""
+    from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", form)
+    rng = np.random.default_rng(77)
+    B, sizes = 2, [200704, 30000, 802816]
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    batches = [[torch.from_numpy((rng.standard_normal((B, n)) * (1 + t + 0.2 * k)).astype(np.float32)).to(dev) for t, n in enumerate(sizes)]
+               for k in range(8)]
+    p1, p2 = ops.OctavPipeline(False, dev), ops.OctavPipeline(False, dev)
+    r1, r2 = [], []
+    for k, x in enumerate(batches):          # p2 runs the batches in reverse order, interleaved with p1
+        r1.append(p1.submit(plan, x))
+        r2.append(p2.submit(plan, batches[len(batches) - 1 - k]))
+    p1.sync()
+    p2.sync()
+    torch.cuda.synchronize()
+    want = [ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), x, False, form="bracket").cpu().numpy() for x in batches]
+    for k in range(len(batches)):
+        for got in (r1[k].cpu().numpy(), r2[len(batches) - 1 - k].cpu().numpy()):
+            assert np.array_equal(got[..., 1:], want[k][..., 1:]), k
+            assert _close(got[..., 0], want[k][..., 0]), k

@@ -204,7 +204,9 @@ def test_config4_vit_b16_real_shapes_hist_and_mse():
     single = ops.octav_batch(ops.TensorSetPlan(elems, B, dev), batches[2], False).cpu().numpy()   # a fresh plan, one stream
     got = [r.cpu().numpy() for r in rows]
     assert np.isfinite(got[2]).all()
-    np.testing.assert_allclose(got[2][:, :, 0], single[:, :, 0], rtol=2.4e-7)
+    # (a cold plan on one stream against the third batch of a pipelined run: the exact-tail form's list starts at different bins,
+    # its walk ends on the same fixed point — up to the stop rule |s' - s| < 1e-6 firing one step apart)
+    np.testing.assert_allclose(got[2][:, :, 0], single[:, :, 0], rtol=1e-5)
     assert np.array_equal(got[2][:, :, 1:], single[:, :, 1:])
     rng = np.random.default_rng(11)
     picks = [(int(rng.integers(0, 3)), t, int(rng.integers(0, B))) for t in softmax]

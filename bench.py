@@ -15,8 +15,11 @@ The same JSON line carries, as `"mse"`, BASELINE configs[2]: the `-A mse` (OCTAV
 batches of 32 through ops.octav_batch (one-read form) + the per-tensor clip — timed the same way over `--mse-steps` sweeps.
 
 `value` is whole-job images/s of the hist sweep; `roofline` is the hist kernel's (duration by HIP events on the launch
-stream inside the timed region); `cpu_baseline` times the CPU oracle (a port of the reference's arithmetic) on a bounded
-sample of the same activations on the host cores of this box, rank 0, N = 1 only.
+stream inside the timed region) and carries the other objects' headline scalars (`roofline.mse` = configs[2], `.mse_jitter`,
+`.mse_feature_maps`, `.mse_vit`, `.fake_quant`, `.e2e`); `cpu_baseline` times the CPU oracle (a port of the reference's
+arithmetic) on a bounded sample of the same activations on the host cores of this box, rank 0, N = 1 only.
+TWO lines are printed: `{"details": {...}}` (every object in full: workload strings, prediction statistics, the e2e split)
+and then the record's line (< 2 KB).
 
 Multi-GPU: launched by torch.distributed.run (one rank per GPU) — or, when started plainly with --gpus N > 1, this script
 starts the N ranks itself as child processes (before anything touches the GPU) and relays rank 0's line.  Images are
@@ -210,14 +213,22 @@ def main():
     n_hist_batches = N_HIST // B
     hist_ev = []
 
+    coll_ev = []
+
     def hist_sweep(timed):
         acc.reset_minmax()
         for b in range(n_hist_batches):                                   # pass 1
             acc.minmax_accumulate(plan, pool[b % len(pool)])
         gmin, gmax = acc.finalize_minmax()
         if use_dist:                                                      # the algorithm's exchange after pass 1
+            if timed:     # the collectives' own time (events on the stream the backend enqueues on: what the merge costs a sweep)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
             dist.all_reduce(gmin, op=dist.ReduceOp.MIN)
             dist.all_reduce(gmax, op=dist.ReduceOp.MAX)
+            if timed:
+                c1.record()
+                coll_ev.append((c0, c1))
             acc.set_minmax(gmin.clone(), gmax.clone())
         acc.hist_prepare()
         for b in range(n_hist_batches):                                   # pass 2
@@ -229,7 +240,13 @@ def main():
                 e1.record()
                 hist_ev.append((e0, e1))
         if use_dist:                                                      # ... and after pass 2
+            if timed:
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
             dist.all_reduce(acc.hist, op=dist.ReduceOp.SUM)
+            if timed:
+                c1.record()
+                coll_ev.append((c0, c1))
         return acc.hist_percentile(0.99999)
 
     for _ in range(a.warmup):
@@ -249,6 +266,8 @@ def main():
     else:
         per_rank_rates = [N_HIST * a.steps / dt_local]
     hist_kern_ms = sum(s.elapsed_time(e) for s, e in hist_ev) / max(1, len(hist_ev))
+    # RCCL's three all-reduces of a sweep (MIN + MAX of the ranges, SUM of the [T, bins] int64 histograms), milliseconds per sweep
+    coll_ms = round(sum(s.elapsed_time(e) for s, e in coll_ev) / max(1, a.steps), 4) if coll_ev else None
     hist_checksum = int(acc.hist.sum().item())        # = elements x images x ranks when every rank's counts arrived
     clip_checksum = float(clip.double().abs().sum().item())
 
@@ -260,8 +279,8 @@ def main():
     mse, mse_jitter, vit_mse, mse_real = None, {}, None, {}
     if a.mse_steps > 0:
         import ctypes
-        form = os.environ.get("DPL_OCTAV_FORM", "oneread")
-        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form == "oneread"
+        form = ops._default_form()
+        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form in ("oneread", "tail")
         pipe = ops.OctavPipeline(False, dev) if pipeline else None
         min_pool = 2 * ops._ONEREAD_EPOCH + 1
         # DPL_BENCH_FAIL_EVERY=n (a tuning aid, not the headline workload): the C ABI's test hook makes every n-th pair's walk
@@ -330,7 +349,7 @@ def main():
                    "workload": f"{net} activation set (T={T} tensors, {E} fp32 elems/img), -A mse (OCTAV per image and tensor), N={n_images} images per GPU in "
                                f"batches of {B}, form '{form}', every sweep a cold run, {len(mpool)} distinct resident batches"
                                + (f", per-image contrast jitter +-{jit:g}" if jit else ""),
-                   "roofline": {"bound": "hbm", "kernel": f"OCTAV batch, form '{form}'" + (" (k_octav_oneread of batch i+1 beside k_octav_walk of batch i)"
+                   "roofline": {"bound": "hbm", "kernel": f"OCTAV batch, form '{form}'" + (" (streaming kernel of batch i+1 beside the rescue of batch i)"
                                                                                    if pipe is not None else ""),
                                 "achieved": mse_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mse_ach / HBM_PEAK_GBPS,
                                 "traffic": None, "bytes_per_launch": mse_bytes, "avg_batch_ms": mse_ms},
@@ -344,8 +363,9 @@ def main():
                                      "pairs_per_batch": plan.n_pairs,
                                      "listed_share_of_elements": pipe.list_share, "listed_share_max": pipe.max_share,
                                      "batches_walked_sorted": pipe.sorted_batches,
-                                     "source": os.environ.get("DPL_OCTAV_PREDICT", "auto"),
+                                     "source": os.environ.get("DPL_OCTAV_PREDICT", "auto") if form == "oneread" else "threshold history",
                                      "tensors_predicted_from_own_sample": pipe.probe_tensors / max(1, pipe.batches * T),
+                                     "thresholds_raised_per_batch": pipe.raises / max(1, pipe.batches),
                                      # 1024-element tiles holding a non-zero value outside the 2^-18 .. 2^14 window (summed apart)
                                      "tiles_with_values_outside_window_share": pipe.tiles_reread / max(1, pipe.batches * B * sum((e + 1023) // 1024 for e in plan.elems))}
             return obj
@@ -515,40 +535,79 @@ def main():
     achieved = kernel_bytes / (hist_kern_ms * 1e-3) / 1e9 if hist_kern_ms > 0 else 0.0
     # HBM bytes per launch by the PMC counters (scripts/profile_gpu.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     # this very script).  Quoted only when the record was measured on the kernel sources this run uses (sha over csrc/), else null.
-    def measured_traffic(kernel):
-        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r03", "traffic.json"))
+    def traffic_record():
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r04", "traffic.json"))
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             from summarize_prof import source_sha
             with open(tj) as f:
                 tr = json.load(f)
             if tr.get("source_sha") == source_sha() and tr.get("batch") == B:
-                return tr["kernels"][kernel]["hbm_bytes_per_launch"]
+                return tr["kernels"]
         except Exception:
             pass
         return None
-    traffic = measured_traffic("k_abs_hist")
+    tk = traffic_record()
+    traffic = tk["k_abs_hist"]["hbm_bytes_per_launch"] if tk and "k_abs_hist" in tk else None
 
     def mse_batch_traffic():
         """HBM bytes of ONE mse batch: every k_octav_* kernel of the profiled run, per launch of the streaming kernel."""
-        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r03", "traffic.json"))
-        try:
-            sys.path.insert(0, os.path.join(ROOT, "scripts"))
-            from summarize_prof import source_sha
-            with open(tj) as f:
-                tr = json.load(f)
-            if tr.get("source_sha") != source_sha() or tr.get("batch") != B:
-                return None
-            ks = {k: v for k, v in tr["kernels"].items() if k.startswith("k_octav_")}
-            n = ks["k_octav_oneread"]["launches"]
-            return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / n
-        except Exception:
+        if not tk:
             return None
+        ks = {k: v for k, v in tk.items() if k.startswith("k_octav_")}
+        main = "k_octav_tail" if "k_octav_tail" in ks else "k_octav_oneread"
+        if main not in ks:
+            return None
+        return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / ks[main]["launches"]
     if mse is not None:
         mse["roofline"]["traffic"] = mse_batch_traffic()
     images = N_HIST * world * a.steps
     hist_rate = images / dt_hist
     headline_mse = a.algo == "mse" and mse is not None
+
+    def brief(o):
+        """The scalars of an mse object the record must carry (the whole object goes to the `details` line)."""
+        if not o:
+            return None
+        r, p = o["roofline"], o.get("prediction") or {}
+        b = {"frac": round(r["frac"], 4), "ms_per_batch": round(r["avg_batch_ms"], 4), "images_per_s": round(o["value"], 1),
+             "sample_ok": o["sample_ok"]}
+        if r.get("traffic"):
+            b["traffic_ratio"] = round(r["traffic"] / r["bytes_per_launch"], 4)
+        if p:
+            b.update(listed=round(p["listed_share_of_elements"], 4), rescued_per_batch=round(p["pairs_missed"] / max(1, p["batches"]), 2),
+                     compaction_pairs=p["pairs_compaction"])
+        return b
+    hist_roof = {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes, "avg_kernel_ms": hist_kern_ms}
+    full = {
+        "hist": {"images_per_s": hist_rate, "ms_per_step": dt_hist / a.steps * 1e3, "roofline": hist_roof,
+                 "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9, "hist_checksum": hist_checksum,
+                 "hist_checksum_expected": E * N_HIST * world, "clip_checksum": clip_checksum, "collectives_ms_per_sweep": coll_ms},
+        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse,
+        "mse_feature_maps": mse_real or None, "e2e": e2e,
+    }
+    # The record's line: BASELINE.json's metric on its headline configuration, every headline scalar inside `roofline` / `config`
+    # (the driver keeps those objects whole), under 2 KB.  Everything else (workload strings, prediction statistics, the e2e split)
+    # is the `details` line printed BEFORE it.
+    roof = dict(mse["roofline"] if headline_mse else hist_roof)
+    roof["mse"] = brief(mse)                                                     # BASELINE configs[2]: -A mse, N = 4096, images alike
+    roof["mse_jitter"] = {k: brief(v) for k, v in mse_jitter.items()} or None    # ... with per-image contrast jitter
+    roof["mse_feature_maps"] = {k: brief(v) for k, v in mse_real.items()} or None   # ... executor-produced ResNet-50 activations
+    roof["mse_vit"] = brief(vit_mse)                                             # configs[4]'s workload on one GPU
+    if fake_quant:
+        roof["fake_quant"] = {m: {"frac": round(fake_quant[m]["frac"], 4),
+                                  "frac_50MB_and_more": round(fake_quant[m]["tensors_of_50MB_and_more"]["frac"], 4)}
+                              for m in ("per_tensor", "per_channel")}
+        if "set_launch" in fake_quant:
+            roof["fake_quant"]["set_launch"] = {m: round(v["frac"], 4) for m, v in fake_quant["set_launch"].items()}
+    if e2e and "error" not in e2e:
+        roof["e2e"] = {"hist_calib_images_per_s": round(e2e["images_per_s_calibration"], 1),
+                       "hist_forward_steady_images_per_s": round(e2e["split"].get("forward_steady_images_per_s", 0.0), 1)}
+        if "mse" in e2e and "error" not in e2e["mse"]:
+            roof["e2e"].update(mse_calib_images_per_s=round(e2e["mse"]["images_per_s_calibration"], 1),
+                               mse_forward_steady_images_per_s=round(e2e["mse"]["split"].get("forward_steady_images_per_s", 0.0), 1),
+                               mse_statistics_gpu_s=round(e2e["mse"]["split"].get("statistics_gpu_s", 0.0), 4))
     out = {
         # BASELINE.json's metric; images/s is `value`, the achieved HBM GB/s of the dominant kernel is `roofline.achieved`
         "metric": "calibration images/sec (whole node) + achieved HBM GB/s, ResNet-50 ONNX N=%d, -A %s"
@@ -557,29 +616,31 @@ def main():
         "steps": a.mse_steps if headline_mse else a.steps, "warmup": a.warmup,
         "ms_per_step": mse["ms_per_step"] if headline_mse else dt_hist / a.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": (mse["workload"] if headline_mse else
+        "config": {"workload": (f"ResNet-50 activation set (T={T}, {E} fp32 elems/img), -A mse (OCTAV), N={N_MSE} per GPU in batches of {B}, cold sweeps"
+                                if headline_mse else
                                 f"ResNet-50 ONNX activation set (T={T} tensors, {E} fp32 elems/img), -A hist --bins {a.bins}, "
-                                f"N={N_HIST} images per GPU in {n_hist_batches} batches of {B}: range pass + histogram pass + "
-                                f"percentile clip per step"),
+                                f"N={N_HIST} images per GPU in {n_hist_batches} batches of {B}: range pass + histogram pass + percentile clip per step"),
                    "batch": B, "bins": a.bins, "algo": a.algo, "images_per_step_per_gpu": N_MSE if headline_mse else N_HIST,
-                   "resident_pool_batches": n_pool, "device": devname},
-        "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9,
-        "per_gpu_images_per_s": hist_rate / world, "per_rank_images_per_s": per_rank_rates,
-        "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
-        "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if use_dist else None,
-        "hist_checksum": hist_checksum, "hist_checksum_expected": E * N_HIST * world, "clip_checksum": clip_checksum,
-        "roofline": (mse["roofline"] if headline_mse else
-                     {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes,
-                      "avg_kernel_ms": hist_kern_ms}),
-        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "mse_feature_maps": mse_real or None, "e2e": e2e,
+                   "resident_pool_batches": n_pool, "device": devname,
+                   "hist_checksum_ok": hist_checksum == E * N_HIST * world,
+                   "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
+                   "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if use_dist else None,
+                   "per_rank_images_per_s": [round(r, 1) for r in per_rank_rates],
+                   "collectives_ms_per_sweep": coll_ms},
+        "roofline": roof,
     }
     if rank == 0:
         if world == 1 and a.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(a.algo, a.bins, cpu_sample, a.cpu_seconds)
+            cb = cpu_baseline(a.algo, a.bins, cpu_sample, a.cpu_seconds)
+            full["cpu_baseline"] = dict(cb)
+            cb["sample"] = cb["sample"][:160]
+            out["cpu_baseline"] = cb
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps({"details": full}), flush=True)
+        line = json.dumps(out)
+        assert len(line) < 4000, len(line)
+        print(line, flush=True)
     if use_dist:
         dist.destroy_process_group()
 

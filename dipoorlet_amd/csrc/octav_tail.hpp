@@ -40,9 +40,29 @@
 #ifndef DPL_TAIL_OCC
 #define DPL_TAIL_OCC 4
 #endif
+#ifndef DPL_TAIL_QUEUE_CAP
+#define DPL_TAIL_QUEUE_CAP 512    // entries of a wave's survivor queue (flushed above 256): 8 KiB per workgroup, which the walk's suffix counts reuse
+#endif
+#ifndef DPL_TAIL_VEC
+#define DPL_TAIL_VEC 16           // 16-byte vectors per thread the walk keeps the list in (1024 values each); longer lists are streamed from L2
+#endif
+constexpr int kTailQueueCap = DPL_TAIL_QUEUE_CAP;
+constexpr int kTailLdsB = kWaves * kTailQueueCap * 4;
+static_assert(kTailQueueCap >= 512 && kTailLdsB >= kLogNB * 4, "a vector may add 256 survivors past the flush mark; the walk keeps its suffix counts in the queues' space");
+constexpr int kTailVec = DPL_TAIL_VEC;
 constexpr int kTailTauShift = DPL_TAIL_TAU_SHIFT;
 constexpr int kTailBudgetShift = DPL_TAIL_BUDGET_SHIFT;
 constexpr uint32_t kTailAllow0 = DPL_TAIL_ALLOW0;
+
+#ifdef DPL_RES_PROF
+// (stamps taken inside a branch are kept in registers and added at the end: an add is a global read-modify-write, and one in the
+// middle of the walk would be measured by the next stamp)
+#define DPL_PROF_KEEP(slot, a, b) prof_keep[slot] = (b) - (a)
+#define DPL_PROF_FLUSH() do { if (threadIdx.x == 0) { g_res_prof[(blockIdx.x & 4095u) * 8 + 1] += prof_keep[1]; g_res_prof[(blockIdx.x & 4095u) * 8 + 2] += prof_keep[2]; } } while (0)
+#else
+#define DPL_PROF_KEEP(slot, a, b) do {} while (0)
+#define DPL_PROF_FLUSH() do {} while (0)
+#endif
 
 struct TailArgs {
     uint32_t* vis_w;             // [T, kLogWords]: word 0 of a tensor's row = kLogNB - (lowest bin its pairs asked for this epoch); 0: none
@@ -64,7 +84,7 @@ __device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ 
     const uint32_t lane = tid & (kWave - 1);
     const int w = tid / kWave;
     float mn = INFINITY, mx = -INFINITY;
-    const lptr_u32 wq = (lptr_u32)(lds_raw + kLdsA) + (uint32_t)w * kQueueCap;
+    const lptr_u32 wq = (lptr_u32)(lds_raw + kLdsA) + (uint32_t)w * kTailQueueCap;
     uint32_t tail = 0u;          // entries in the wave's queue
     uint32_t mine = 0u;          // values this wave has listed
     uint32_t seen = 0u;          // elements this wave has consumed
@@ -129,9 +149,17 @@ __device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ 
         const bool in = t < kWin;
         const lptr_u64 slot = in ? l_packed + t + 1u : dummy;
         rare |= in ? 0u : bits;
+#if !defined(DPL_TAIL_ABL_NOHIST)   // (ablation builds, timing only: scripts/tail_ablate.sh)
         (void)__hip_atomic_fetch_add(slot, (1ull << kPackShift) | (unsigned long long)(bits & 0x7FFFFFu), __ATOMIC_RELAXED,
                                      __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        asm volatile("" ::"v"(slot));
+#endif
+#if defined(DPL_TAIL_ABL_NOLIST)
+        return false;
+#else
         return (int32_t)t >= jm1;
+#endif
     };
     auto put = [&](uint32_t bits, bool f) {
         const unsigned long long m = __builtin_amdgcn_ballot_w64(f);
@@ -145,7 +173,7 @@ __device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ 
     };
     uint32_t rare_n = 0u;
     for_each_tile<kThreads>(pg, cnt, [&](const f4 (&t)[4], uint32_t base, bool full) {
-        if (tail > (uint32_t)kQueueTop) {   // the regular flush: BEFORE the tile is consumed, AFTER all of it has arrived (stream_slice)
+        if (tail > (uint32_t)(kTailQueueCap - 256)) {   // the regular flush: BEFORE the tile is consumed, AFTER all of it has arrived (stream_slice)
             asm volatile("" ::"v"(t[3].w));
             flush();
         }
@@ -175,7 +203,10 @@ __device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ 
             put(b1, f1);
             put(b2, f2);
             put(b3, f3);
-            if (tail > (uint32_t)(kQueueCap - 256)) flush();   // (a pair that lists most of what it reads: a small pair, a cold start)
+            if (tail > (uint32_t)(kTailQueueCap - 256)) flush();   // (a pair that lists most of what it reads: a small pair, a cold start)
+#ifdef DPL_TAIL_FENCE
+            DPL_SCHED_FENCE();
+#endif
         }
         if (__any((rare & 0x7FFFFFFFu) != 0u)) {   // non-zero values outside the window (and NaNs): summed directly, as stream_slice does
             double fs = 0.0;
@@ -236,6 +267,9 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
     dpl_octav_state* me = st + pair;
     const unsigned long long n_pair = (unsigned long long)cnt;
     const bool small = cnt <= kSmallCap;
+#ifdef DPL_RES_PROF
+    unsigned long long prof_keep[3] = {0ull, 0ull, 0ull};
+#endif
     // the list: this workgroup's own global stores (one CU, one L1), requested before the histogram is turned into suffix totals
     const float* lp = list0 + pair_base[pair];
     f4 v[kVecT];
@@ -254,6 +288,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
         }
     };
     load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
+    DPL_PROF_T(wt0);
     // per-bin totals -> suffix totals (thread t owns the 8 bins below 2047 - 8 t; the packed words are read before the doubles
     // are written over them)
     {
@@ -321,6 +356,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
     uint32_t bad = route == 1u ? 1u : 0u;
     float s = sh.s0;
     uint32_t evals = 0u, exact = 0u, stopped = 0u;
+    DPL_PROF_T(wt1);
     if (route == 2u) {
         const float ud = sh.ud;
         const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
@@ -357,6 +393,8 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
             }
             jb = log_bin(s);
         }
+        DPL_PROF_T(wt2);
+        DPL_PROF_KEEP(1, wt1, wt2);
         // ---- exact: the reference's step; count / sum of the values above s = suffix totals of the bins above + listed values of bin jb
         if (!bad && jb > kLogNB - 2) bad = 1u;
         unsigned long long n_above = 0ull;
@@ -446,7 +484,10 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
         }
         // at least two exact evaluations behind a bounded start (none needed when every step was exact: a small pair)
         if (!bad && !(stopped && (exact >= 2u || evals == exact))) bad = 1u;
+        DPL_PROF_T(wt3);
+        DPL_PROF_KEEP(2, wt2, wt3);
     }
+    DPL_PROF_T(wt4);
     // ---- history: the bin this pair asked for (whatever became of its walk)
     if (tid == 0 && !small && route != 0u) atomicMax(fa.vis_w + (size_t)tensor * kLogWords, (uint32_t)kLogNB - sh.jwant);
     // ---- a pair this form could not finish is RESCUED (as walk_pair does): exact bracket, re-read of the pair alone, verified walk
@@ -492,6 +533,14 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
             me->mode = 2u;
         }
     }
+    DPL_PROF_T(wt5);
+    DPL_PROF_ADD(0, wt0, wt1);
+    DPL_PROF_FLUSH();
+    DPL_PROF_ADD(3, wt4, wt5);
+    if (tid == 0) {
+        g_prof_iters_add(blockIdx.x, evals);
+        DPL_PROF_L(L);
+    }
 }
 
 // One workgroup per pair (largest first): the pair's only HBM read, then its walk.
@@ -503,6 +552,7 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
+    DPL_PROF_T(kt0);
     const dpl_work_item it = slices[blockIdx.x];
     const uint32_t pair = it.slot, cnt = it.count;
     dpl_octav_state* me = st + pair;
@@ -521,6 +571,7 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     __syncthreads();
     stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair]), sh, ctl, !small);
     __syncthreads();   // every LDS histogram add has landed; the per-wave ranges are in sh
+    DPL_PROF_T(kt1);
     if (tid == 0) {
         float tmn = INFINITY, tmx = -INFINITY;
         const uint32_t tnz = sh.low_cnt, tnan = sh.low_nan;
@@ -543,8 +594,25 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
         sh.f_mx = tmx;
     }
     __syncthreads();
-    walk_tail<kVec>(pair, tensor, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl,
+#if defined(DPL_TAIL_ABL_NOWALK)
+    if (tid == 0) {
+        me->done = 1u;
+        me->s = sh.f_mx;
+    }
+#if defined(DPL_TAIL_ABL_DELAY)   // a stand-in for the walk's latency: DPL_TAIL_ABL_DELAY ticks spent by every wave (1) or by wave 0 alone (2: the others exit)
+    if (DPL_TAIL_ABL_WHO == 2 && tid >= kWave) return;
+    {
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        while (__builtin_readcyclecounter() - t0 < (unsigned long long)DPL_TAIL_ABL_DELAY) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
+    return;
+#endif
+    walk_tail<kTailVec>(pair, tensor, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl,
                     pair_base, list0, fa, cnt);
+    DPL_PROF_T(kt2);
+    DPL_PROF_ADD(4, kt0, kt1);
+    DPL_PROF_ADD(5, kt1, kt2);
 }
 
 // State + threshold snapshot of a batch: pred[t][0] = what the tensor's pairs asked for in the current and the previous epoch.

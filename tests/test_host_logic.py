@@ -2,6 +2,8 @@
 with the reference's files), scale/zero-point derivation, sharding, and the world_size-2 merge over gloo."""
 import json
 import os
+
+import pytest
 import types
 import warnings
 
@@ -252,20 +254,21 @@ def pytest_approx(v):
     return pytest.approx(v, rel=1e-6, abs=1e-12)
 
 
-def test_bench_dry_run_two_ranks_gloo():
-    """bench.py --gpus 2 --dry-run: the launcher (fresh child processes before anything touches a GPU), the rendezvous on
-    127.0.0.1 and the collectives of one hist sweep (all-reduce MIN / MAX of the ranges, SUM of the histograms) on
-    stand-in CPU tensors over gloo — the multi-GPU plumbing the driver's N > 1 runs go through."""
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_dry_run_gloo(world):
+    """bench.py --gpus W --dry-run (W = 2 and the node's 8): the launcher (fresh child processes before anything touches a
+    GPU), the rendezvous on 127.0.0.1 and the collectives of one hist sweep (all-reduce MIN / MAX of the ranges, SUM of the
+    histograms) on stand-in CPU tensors over gloo — the multi-GPU plumbing the driver's N > 1 runs go through."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["backend"] == "gloo"
-    assert line["hist_checksum"] == line["hist_checksum_expected"] == 123 * 2048 * 3
-    assert line["range"] == [-2.0, 2.0]                      # MIN / MAX over the two ranks' ranges
-    assert line["world_size_seen_by_backend"] == 2 and len(line["per_rank_ok"]) == 2 and all(line["per_rank_ok"])
+    assert line["dry_run"] is True and line["n_gpus"] == world and line["backend"] == "gloo"
+    assert line["hist_checksum"] == line["hist_checksum_expected"] == 123 * 2048 * world * (world + 1) // 2
+    assert line["range"] == [-float(world), float(world)]    # MIN / MAX over the ranks' ranges
+    assert line["world_size_seen_by_backend"] == world and len(line["per_rank_ok"]) == world and all(line["per_rank_ok"])

@@ -75,7 +75,21 @@ def main(argv=None):
         raise
 
 
+def _process_age_s():
+    """Seconds since this process was created (interpreter start-up and imports included)."""
+    try:
+        with open("/proc/self/stat") as f:
+            start_ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/uptime") as f:
+            up = float(f.read().split()[0])
+        return up - start_ticks / os.sysconf("SC_CLK_TCK")
+    except Exception:   # noqa: BLE001
+        return None
+
+
 def _main(argv=None):
+    t_enter = time.time()
+    age_at_enter = _process_age_s()       # interpreter + imports (torch, the package) up to here
     args = build_parser().parse_args(argv)
     if args.quant_format == "QOP":
         raise SystemExit("--quant_format QOP (onnxruntime's QOperator export, dipoorlet/utils.py:415-435) is not built: "
@@ -86,7 +100,11 @@ def _main(argv=None):
         dist_helper.init_from_mpi()
     else:
         dist_helper.init_default()
+    t_dist = time.time()
     rank, world = dist.get_rank(), dist.get_world_size()
+    if __import__("torch").cuda.is_available():      # the HIP context (first touch of the device), timed on its own
+        __import__("torch").cuda.synchronize()
+    t_ctx = time.time()
     if args.output_dir is None:
         args.output_dir = os.path.join(os.path.abspath(os.path.dirname(args.model)), "results")
     if args.model_type is not None:      # __main__.py:71-73 (the onnxruntime transformer optimiser step is not run:
@@ -113,9 +131,15 @@ def _main(argv=None):
         from .forward_net import CalibrationRun
         tm = CalibrationRun.last.timing() if CalibrationRun.last is not None else {}
         tm.update(tensor_calibration_wall_s=time.time() - t_cal, load_model_wall_s=t_cal - start, act_quant=args.act_quant,
-                  calib_batch=args.calib_batch, world_size=world)
+                  calib_batch=args.calib_batch, world_size=world,
+                  # the fixed costs of a fresh process, itemised: interpreter + imports, process group, HIP context (the
+                  # first batch's MIOpen algorithm search is forward_first_batch_gpu_s above)
+                  startup={"interpreter_and_imports_s": age_at_enter, "process_group_init_s": t_dist - t_enter,
+                           "process_group_backend": dist.get_backend(), "hip_context_s": t_ctx - t_dist,
+                           "until_calibration_starts_s": t_cal - t_enter})
         with open(args.timing_json, "w") as f:
             json.dump(tm, f)
+        CalibrationRun.last = None     # (a run pins its session, accumulators and every plan's scratch)
     tensor_range = copy.deepcopy(act_clip_val)
     save_clip_val(act_clip_val, weight_clip_val, args, act_fname=f"act_clip_val.json.rank{rank}",
                   weight_fname=f"weight_clip_val.json.rank{rank}")

@@ -26,6 +26,10 @@ def _backend():
     forced = os.environ.get("DPL_DIST_BACKEND")
     if forced:
         return forced
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        # one rank: every merge is the identity and only barriers remain; RCCL's communicator set-up (0.3 - 1 s of a fresh
+        # process) buys nothing, gloo's is milliseconds
+        return "gloo"
     return "nccl" if torch.cuda.is_available() and torch.cuda.device_count() > 0 else "gloo"
 
 
@@ -41,7 +45,12 @@ def init_default():
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend=_backend())
+        if int(os.environ["WORLD_SIZE"]) == 1 and not os.environ.get("DPL_DIST_BACKEND"):
+            # one rank: an in-process store — no TCP rendezvous (a port still in TIME_WAIT from the previous run of a script
+            # cost a fresh process 1.3 s of bind retries)
+            dist.init_process_group(backend="gloo", store=dist.HashStore(), rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend=_backend())
     _bind_device()
 
 

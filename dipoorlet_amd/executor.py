@@ -420,7 +420,7 @@ def _resize(s, node, x, roi=None, scales=None, sizes=None):
 @op("FakeQuant")
 def _fake_quant(s, node, x):
     q = s.graph._qdq[node.name]
-    if not x.is_cuda:          # shape-inference pass on the host: values are irrelevant there
+    if not x.is_cuda:          # shape-inference pass (host or meta tensors): values are irrelevant there
         return x
     return q.apply(x.contiguous())
 
@@ -454,11 +454,34 @@ class GraphSession(ActivationSession):
                 self._folded.add(node.name)
         self._infer()
 
+    def _infer_meta(self):
+        """The shape pass WITHOUT running anything: floating-point tensors on torch's 'meta' device (shapes only), integer
+        constants — the shape arithmetic of exported graphs — on the host.  A graph whose shapes depend on values this pass does
+        not have (or an op without a meta kernel) raises; the caller then runs the real batch-1 forward."""
+        real_consts, real_device = self.consts, self.device
+        try:
+            self.device = torch.device("cpu")
+            self.consts = {k: (torch.empty_like(v, device="meta") if v.is_floating_point() else v.cpu()) for k, v in real_consts.items()}
+            feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32, device="meta")
+                     for n in self.input_names}
+            return self._forward(feeds, 1)
+        finally:
+            self.consts, self.device = real_consts, real_device
+
     def _infer(self):
-        """One batch-1 forward on zeros fixes every tensor's per-image shape (replaces onnx shape inference)."""
-        feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
-                                device=self.device) for n in self.input_names}
-        env = self._forward(feeds, 1)
+        """Every tensor's per-image shape (replaces onnx shape inference): a pass over meta tensors where the graph allows
+        it — a real batch-1 forward on the device makes MIOpen load / choose kernels for a batch size no calibration batch
+        uses: 0.2 - 0.3 s of a fresh process — else one batch-1 forward on zeros."""
+        env = None
+        if os.environ.get("DPL_INFER_META", "1") != "0":
+            try:
+                env = self._infer_meta()
+            except Exception:   # noqa: BLE001
+                env = None
+        if env is None:
+            feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
+                                    device=self.device) for n in self.input_names}
+            env = self._forward(feeds, 1)
         names, elems = [], []
         self.shape1 = {}
         for n in self.input_names:

@@ -76,15 +76,36 @@ def load_input_batch(input_dir, input_names, shapes, idx0, idx1, device):
     return {n: h.to(device, non_blocking=True).reshape(full) for n, (h, full) in staged.items()}
 
 
+WALL = {}    # host wall seconds of the calibration phase's parts (reported by --timing_json): where a run's time goes outside the GPU
+
+
+class wall:
+    """with wall("name"): ... — adds the block's host wall seconds to WALL[name]."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        import time
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        import time
+        WALL[self.name] = WALL.get(self.name, 0.0) + time.perf_counter() - self.t0
+
+
 class CalibrationRun:
     """One rank's sweep(s) over its shard of the calibration set."""
-    last = None    # the most recent run of this process (its timing() is what --timing_json reports)
+    last = None    # the most recent run of this process WHEN --timing_json asks for it (its timing() is what gets reported;
+                   # __main__ clears it once written: a run pins its session, accumulators and every plan's scratch)
 
     def __init__(self, onnx_graph, args):
-        CalibrationRun.last = self
+        if getattr(args, "timing_json", None):
+            CalibrationRun.last = self
         self.graph = onnx_graph
         self.args = args
-        self.session = onnx_graph.make_session(args)
+        with wall("session_build_s"):      # weights to the device, node schedule
+            self.session = onnx_graph.make_session(args)
         self.names = list(self.session.tensor_names)
         self.elems = [int(e) for e in self.session.elems_per_image]
         self.T = len(self.names)
@@ -120,7 +141,7 @@ class CalibrationRun:
     def timing(self):
         """HOST (synchronises): {'ingest_s', 'forward_gpu_s', 'statistics_gpu_s', 'images'} of this rank so far."""
         torch.cuda.synchronize()
-        out = {"images": self.n_images(), "ingest_host_s": self.ingest_s}
+        out = {"images": self.n_images(), "ingest_host_s": self.ingest_s, "host_wall": {k: round(v, 4) for k, v in WALL.items()}}
         for k, evs in self._events.items():
             out[k + "_gpu_s"] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
         fw = [a.elapsed_time(b) * 1e-3 for a, b in self._events["forward"]]
@@ -234,6 +255,7 @@ def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_residen
     side = torch.cuda.Stream(run.device)
     side.wait_stream(main)                      # the accumulators' initialisation
     in_flight = []
+    t_loop = __import__("time").perf_counter()
     for b, tensors in run.forward(keep=keep_resident):
         produced = torch.cuda.Event()
         produced.record(main)
@@ -248,9 +270,11 @@ def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_residen
             in_flight.pop(0)[0].synchronize()
     main.wait_stream(side)
     in_flight.clear()
+    WALL["pass1_loop_s"] = WALL.get("pass1_loop_s", 0.0) + __import__("time").perf_counter() - t_loop
     gmin, gmax = acc.finalize_minmax()
     run.acc = acc
-    lo, hi = _np32(gmin), _np32(gmax)
+    with wall("results_to_host_s"):
+        lo, hi = _np32(gmin), _np32(gmax)
     return {n: {"max": [hi[t]], "min": [lo[t]]} for t, n in enumerate(run.names)}
 
 
@@ -279,11 +303,14 @@ def hist_pass(run, gmin, gmax, bins):
         acc = run.acc = ops.CalibAccumulators(run.T, run.device, bins)
     acc.set_minmax(gmin, gmax)
     acc.hist_prepare()
-    for b, tensors in run.second_pass():
-        with run.timed("statistics"):
-            acc.abs_hist_accumulate(run.plan(b), tensors)
-    run.release()
-    status = acc.range_status()["status"]
+    with wall("pass2_loop_s"):
+        for b, tensors in run.second_pass():
+            with run.timed("statistics"):
+                acc.abs_hist_accumulate(run.plan(b), tensors)
+    with wall("release_resident_s"):
+        run.release()
+    with wall("results_to_host_s"):
+        status = acc.range_status()["status"]
     for t, n in enumerate(run.names):
         if status[t] == 1:
             raise ValueError(f"supplied range of [0, {gmax[t].item()}] is not finite (tensor {n})")
@@ -299,11 +326,18 @@ def forward_net_octav(onnx_graph, args, run=None):
     dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
     rows = []
     pipe = ops.OctavPipeline(dynamic_sym, run.device)    # the walk of batch i runs beside the forward / streaming pass of batch i + 1
+    t_loop = __import__("time").perf_counter()
     for b, tensors in run.forward():
-        rows.append(pipe.submit(run.plan(b), tensors))
-    pipe.sync()
+        # (timed: what the caller's stream spends on the batch — the streaming kernel, which also walks the pairs; the rescue of the
+        # few pairs it could not finish runs on the pipeline's side stream beside the next forward)
+        with run.timed("statistics"):
+            rows.append(pipe.submit(run.plan(b), tensors))
+    with run.timed("statistics"):
+        pipe.sync()
+    WALL["pass1_loop_s"] = WALL.get("pass1_loop_s", 0.0) + __import__("time").perf_counter() - t_loop
     run.octav_rows = torch.cat(rows) if rows else torch.zeros(0, run.T, 3, device=run.device)
-    r = _np32(run.octav_rows)
+    with wall("results_to_host_s"):
+        r = _np32(run.octav_rows)
     return {n: {"optimal_s": list(r[:, t, 0]), "min": list(r[:, t, 1]), "max": list(r[:, t, 2])}
             for t, n in enumerate(run.names)}
 

@@ -668,9 +668,9 @@ def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None):
     """
     _require_cuda(x, "x")
     # (a graph walk issues one of these per tensor: no conversion calls when the parameters already are what the kernel takes)
-    if not (scale.is_cuda and scale.dtype == torch.float32 and scale.dim() == 1 and scale.is_contiguous()):
+    if not (scale.device == x.device and scale.dtype == torch.float32 and scale.dim() == 1 and scale.is_contiguous()):
         scale = scale.to(device=x.device, dtype=torch.float32).contiguous().reshape(-1)
-    if not (zero_point.is_cuda and zero_point.dtype == torch.int32 and zero_point.dim() == 1 and zero_point.is_contiguous()):
+    if not (zero_point.device == x.device and zero_point.dtype == torch.int32 and zero_point.dim() == 1 and zero_point.is_contiguous()):
         zero_point = zero_point.to(device=x.device, dtype=torch.int32).contiguous().reshape(-1)
     nch = scale.numel()
     if zero_point.numel() != nch:

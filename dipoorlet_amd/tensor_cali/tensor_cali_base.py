@@ -5,6 +5,9 @@ from . import basic_algorithm as _algo
 def tensor_calibration(onnx_graph, args):
     """-> (activation clip ranges from the algorithm registered under args.act_quant, per-channel weight ranges).
     Every rank calls this; the activation statistics are merged over ranks inside the algorithm."""
-    ranges = {"weight": _algo.find_clip_val_minmax_weight(onnx_graph, args)}
-    ranges["act"] = _algo.tensor_cali_dispatcher(args.act_quant, onnx_graph, args)
+    from ..forward_net import wall
+    with wall("weight_ranges_s"):
+        ranges = {"weight": _algo.find_clip_val_minmax_weight(onnx_graph, args)}
+    with wall("activation_algorithm_s"):
+        ranges["act"] = _algo.tensor_cali_dispatcher(args.act_quant, onnx_graph, args)
     return ranges["act"], ranges["weight"]

@@ -220,3 +220,84 @@ def test_config4_vit_b16_real_shapes_hist_and_mse():
             s = O.octav_scale(xk, 1)
         assert _close(got[b][k, t, 0], s), (names[t], b, k, got[b][k, t], s)
         assert got[b][k, t, 1] == xk.min() and got[b][k, t, 2] == xk.max()
+
+
+def test_config4_vit_b16_bc_and_fake_quant_forward_at_real_shapes(tmp_path):
+    """BASELINE configs[4]'s OTHER half at its real shapes: ViT-B/16 through the CLI with `-A mse --bc` (N = 8, batches of 4),
+    then, from the files the run wrote:
+      * the patch-embedding Conv's corrected bias = its bias + mean(fp_out - q_out) over (N, H, W) of the ORIGINAL network
+        (the first corrected node: nothing upstream has changed), oracle: np_oracle.bias_correction_delta
+        (bias_correction.py:9-13);
+      * the head Gemm's corrected bias = its bias + mean(fp_out - q_out) with every upstream bias already corrected
+        (bias_correction.py:42-53: node by node in topological order) — evaluated on the corrected network the run saved, with
+        the head's own bias put back;
+      * the fake-quant forward (quantize.py:197-239): ten sampled FakeQuant nodes of the quantised network, executor input
+        -> output against np_oracle.fake_quant_qdq, bit for bit."""
+    import types
+
+    from dipoorlet_amd import models
+    from dipoorlet_amd.__main__ import main
+    from dipoorlet_amd.executor import GraphSession
+    from dipoorlet_amd.forward_net import load_input_batch
+    from dipoorlet_amd.graph import ONNXGraph
+    from dipoorlet_amd.quantize import quant_graph
+    from dipoorlet_amd.utils import load_clip_val
+    dev = torch.device("cuda:0")
+    N, CB = 8, 4
+    g = models.vit_b16(seed=5, attn_gain=10.0)
+    g.output_dir = str(tmp_path)
+    g.save_onnx_model("vit")
+    os.makedirs(tmp_path / "calib" / "input")
+    rng = np.random.default_rng(19)
+    for i in range(N):
+        rng.standard_normal(3 * 224 * 224).astype(np.float32).tofile(tmp_path / "calib" / "input" / f"{i}.bin")
+    out = tmp_path / "out"
+    rc = main(["-M", str(tmp_path / "vit.onnx"), "-I", str(tmp_path / "calib"), "-N", str(N), "-A", "mse", "-D", "trt", "-O", str(out),
+               "--calib_batch", str(CB), "--bc", "--skip_profiling"])
+    assert rc == 0 and os.path.exists(out / "update_bias_model.onnx")
+    args = types.SimpleNamespace(output_dir=str(out), deploy="trt", skip_layers=[], input_dir=str(tmp_path / "calib"), data_num=N)
+    a, w = load_clip_val(args)
+    g0 = ONNXGraph.load(str(tmp_path / "vit.onnx"))
+    g_bc = ONNXGraph.load(str(out / "update_bias_model.onnx"))
+    targets = [n for n in g0.graph.node if n.op_type in ("Conv", "Gemm")]
+    first, last = targets[0], targets[-1]
+    assert first.op_type == "Conv" and last.op_type == "Gemm" and len(targets) >= 2
+    inp = load_input_batch(args.input_dir, g0.network_inputs, {"input": g0.get_tensor_shape("input")}, 0, N, dev)
+
+    def clip():
+        return {k: [np.copy(v[0]), np.copy(v[1])] for k, v in {**a, **w}.items()}
+
+    def per_image(t):
+        return [x[None] for x in t.cpu().numpy()]
+    s_fp = g0.make_session()
+    with torch.no_grad():
+        # ---- the first corrected node: the original network on both sides
+        gq0, _ = quant_graph(g0, clip(), args)
+        fp_o = s_fp.run_named(inp, [first.output[0]])[0]
+        q_o = gq0.make_session().run_named(inp, [first.output[0]])[0]
+        want = O.bias_correction_delta(per_image(fp_o), per_image(q_o), True)
+        got = g_bc.get_initializer(first.input[2]).astype(np.float64) - g0.get_initializer(first.input[2]).astype(np.float64)
+        assert np.abs(got).max() > 0
+        assert np.allclose(got, want, rtol=1e-3, atol=2e-5 + 1e-3 * np.abs(want).max()), np.abs(got - want).max()
+        # ---- the last one: every upstream bias corrected, its own put back
+        g_ref = ONNXGraph()
+        g_ref.copy_from(g_bc)
+        g_ref.set_initializer(last.input[2], g0.get_initializer(last.input[2]).astype(np.float32))
+        gq1, _ = quant_graph(g_ref, clip(), args)
+        fp_o = s_fp.run_named(inp, [last.output[0]])[0]
+        q_o = gq1.make_session().run_named(inp, [last.output[0]])[0]
+        want = O.bias_correction_delta(per_image(fp_o), per_image(q_o), False)
+        got = g_bc.get_initializer(last.input[2]).astype(np.float64) - g0.get_initializer(last.input[2]).astype(np.float64)
+        assert np.abs(got).max() > 0
+        assert np.allclose(got, want, rtol=1e-3, atol=2e-5 + 1e-3 * np.abs(want).max()), np.abs(got - want).max()
+        # ---- the fake-quant forward of the corrected, quantised network: ten activation FakeQuant nodes, input -> output
+        gq, _ = quant_graph(g_bc, clip(), args)
+        sq = GraphSession(gq, device=dev, expose_fake_quant=True)
+        fq = [n for n in gq.graph.node if n.op_type == "FakeQuant" and n.input[0] not in sq.consts]
+        assert len(fq) >= 10
+        picks = [fq[i] for i in sorted(rng.choice(len(fq), 10, replace=False))]
+        for n in picks:
+            x, y = sq.run_named(inp, [n.input[0], n.output[0]])
+            q = gq._qdq[n.name]
+            ref = O.fake_quant_qdq(x.cpu().numpy(), q.scale, q.zero_point, axis=q.axis if q.scale.size > 1 else None, signed=q.symmetric)
+            assert np.array_equal(y.cpu().numpy(), ref), (n.name, np.abs(y.cpu().numpy() - ref).max())

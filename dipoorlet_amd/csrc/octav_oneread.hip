@@ -175,6 +175,11 @@ struct Shared {
     uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
     uint32_t tail_j;              // exact-tail form (octav_tail.hpp): the bin at and above which values are listed (only ever raised)
     uint32_t jwant;               // ... and the bin this pair asks the tensor's next batches to list from
+    // ... wave 0 walks alone; what it hands to the others (and to the pair's state) at the joints of the walk
+    float t_s, w_s0, w_ud;
+    int w_jb;
+    uint32_t w_evals, w_exact, w_path, w_bad, w_route, w_lkn, w_lkc;
+    double w_lks;
     double f_sum;                 // streaming kernel -> its own walk (a single-slice pair): the statistics it just published
     uint32_t f_nz, f_nan;
     float f_mn, f_mx;

@@ -44,7 +44,7 @@
 #define DPL_TAIL_QUEUE_CAP 512    // entries of a wave's survivor queue (flushed above 256): 8 KiB per workgroup, which the walk's suffix counts reuse
 #endif
 #ifndef DPL_TAIL_VEC
-#define DPL_TAIL_VEC 16           // 16-byte vectors per thread the walk keeps the list in (1024 values each); longer lists are streamed from L2
+#define DPL_TAIL_VEC 12           // 16-byte vectors per thread the walk keeps the list in (1024 values each); longer lists are streamed from L2
 #endif
 constexpr int kTailQueueCap = DPL_TAIL_QUEUE_CAP;
 constexpr int kTailLdsB = kWaves * kTailQueueCap * 4;
@@ -254,10 +254,25 @@ __device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ 
     }
 }
 
-// The walk of one pair by the workgroup that has just streamed it: histogram (still in LDS) -> suffix totals in place, s_0,
-// bounded bulk steps, exact steps over the list (registers), acceptance; results / rescue request -> the pair's state.
+// The walk of one pair by the workgroup that has just streamed it.  What it costs is the time a streaming slot stands still and
+// the VALU cycles it takes from the streaming waves of the same SIMDs (every instruction of a walk that all four waves execute is
+// paid four times: measured, the round-3 shape spent 100 us of every SIMD per batch on walks), so:
+//   * ONE wave walks; the others only join for what is parallel — the totals above every group of 8 bins, the compaction of a
+//     long list — and otherwise wait at a barrier, which costs no issue slot;
+//   * the histogram stays PACKED in LDS: per group of 8 bins (one thread) the totals above the group (3 KiB); the suffix totals at a
+//     bin are looked up lazily — eight lanes read the group's eight words, a DPP sum — about fifteen times per walk, instead of
+//     converting all 2048 bins to fp64 suffix totals up front;
+//   * bounded steps go on past the list's first bin until the values still above the iterate fit one wave's registers (kSurvCap);
+//     they are then compacted through LDS once (a list that fits is loaded that way to begin with): an exact step is 20 compares
+//     per lane and a DPP sum, no exchange, no barrier;
+//   * lists beyond that (a cold start, a pair much brighter than its tensor's history) take the round-3 shape: rows spread over
+//     the workgroup, partial sums exchanged through LDS.
+constexpr int kSurvVec = 5;                          // 16-byte vectors per lane a wave holds the surviving values in
+constexpr uint32_t kSurvCap = kSurvVec * 4 * kWave;  // 1280 values
+static_assert(kTailLdsB >= 3072 + (int)kSurvCap * 4, "group totals (3 KiB) + the survivors' staging area share the queues' space");
+
 template <int kVecT>
-__device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t tensor, double* s_ge, uint32_t* n_ge, Shared& sh,
+__device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t tensor, unsigned char* lds_raw, Shared& sh,
                                           dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl,
                                           const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
                                           const TailArgs& fa, const uint32_t cnt) {
@@ -270,12 +285,20 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
 #ifdef DPL_RES_PROF
     unsigned long long prof_keep[3] = {0ull, 0ull, 0ull};
 #endif
-    // the list: this workgroup's own global stores (one CU, one L1), requested before the histogram is turned into suffix totals
+    const unsigned long long* packed = reinterpret_cast<const unsigned long long*>(lds_raw);   // the histogram: intact to the end
+    uint32_t* tn = reinterpret_cast<uint32_t*>(lds_raw + kLdsA);                                // [256] counts above a group
+    double* ts = reinterpret_cast<double*>(lds_raw + kLdsA + 1024);                             // [256] sums above a group
+    uint32_t* surv = reinterpret_cast<uint32_t*>(lds_raw + kLdsA + 3072);                       // [kSurvCap] survivors' staging
+    // the list: this workgroup's own global stores (one CU, one L1), requested before anything else
     const float* lp = list0 + pair_base[pair];
-    f4 v[kVecT];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cursor);
     const uint32_t n_rows = (L + 1023u) >> 10;
+    const bool fits = L <= kSurvCap;
+    // ONE register array, two layouts: the workgroup's rows of 1024 values (a list that does not fit a wave), or — in its first
+    // kSurvVec vectors, wave 0 only — all surviving values (entry (u * 64 + lane) * 4 ...)
+    f4 v[kVecT];
+    static_assert(kVecT >= kSurvVec, "the survivors live in the rows' registers");
     auto load_rows = [&](auto& dst, auto count, uint32_t row0) {
         constexpr int kN = decltype(count)::value;
         const uint32_t voff = tid << 4;
@@ -287,126 +310,298 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
             dst[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
         }
     };
-    load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
-    DPL_PROF_T(wt0);
-    // per-bin totals -> suffix totals (thread t owns the 8 bins below 2047 - 8 t; the packed words are read before the doubles
-    // are written over them)
-    {
-        constexpr int kPerT = kLogNB / kThreads;
-        const int hi = kLogNB - 1 - (int)tid * kPerT;
-        const unsigned long long* lpk = reinterpret_cast<const unsigned long long*>(s_ge);
-        uint32_t c[kPerT];
-        unsigned long long m[kPerT];
+    if (fits) {
+        if (w == 0) {
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)lp, 0, (int)(L << 2), 0x00020000);
 #pragma unroll
-        for (int q = 0; q < kPerT; ++q) {
-            const unsigned long long x = lpk[hi - q];
-            c[q] = (uint32_t)(x >> kPackShift);
-            m[q] = x & kPackMask;
+            for (int u = 0; u < kSurvVec; ++u)
+                v[u] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((uint32_t)u * kWave + lane) << 4, 0, 0));
         }
+    } else {
+        load_rows(v, std::integral_constant<int, kVecT>{}, 0u);
+    }
+    DPL_PROF_T(wt0);
+    // ---- totals above every group of 8 bins (thread t: bins 2040 - 8 t .. 2047 - 8 t, one exponent: integer sums, ONE conversion)
+    constexpr int kPerT = kLogNB / kThreads;
+    static_assert(kPerT == 8, "a thread owns eight bins: an eighth of an octave");
+    const int hi = kLogNB - 1 - (int)tid * kPerT;
+    {
+        uint32_t c[kPerT], cn = 0u;
+        unsigned long long cm = 0ull;
 #pragma unroll
         for (int q = 0; q < kPerT; ++q) {
-            const int b = hi - q;
-            if (b == 0) c[q] = 0u, m[q] = 0ull;   // bin 0 holds no element
-            n_ge[b] = c[q];
-            s_ge[b] = bin_sum(m[q], c[q], b);
+            const int bq = hi - q;
+            const unsigned long long x = bq == 0 ? 0ull : packed[bq];   // bin 0 holds no element
+            c[q] = (uint32_t)(x >> kPackShift);
+            cn += c[q];
+            cm += (x & kPackMask) + ((unsigned long long)c[q] << 23);   // full 24-bit mantissas
+        }
+        const double sd = (double)cm * log_bin_scale(hi);
+        const uint32_t in = scan_u32_dpp(cn);      // threads ascending = bins descending: everything in the groups at and above mine
+        const double is = scan_f64_dpp(sd);
+        if (lane == kWave - 1) {
+            sh.red_a[w] = in;
+            sh.red_d[w] = is;
         }
         if (tid == 0) sh.jwant = 1u;
-        suffix_in_place(n_ge, s_ge, sh);
+        __syncthreads();
+        uint32_t above_n = in - cn;
+        double above_s = is - sd;
+        for (int q = 0; q < w; ++q) {
+            above_n += sh.red_a[q];
+            above_s += sh.red_d[q];
+        }
+        tn[tid] = above_n;
+        ts[tid] = above_s;
         // what this pair asks the tensor's next batches to list: the bin above which n >> kTailTauShift elements lie
         const uint32_t want = max((uint32_t)(n_pair >> kTailTauShift), 1u);
-        uint32_t above = hi + 1 < kLogNB ? n_ge[hi + 1] : 0u;
+        uint32_t run = above_n;
 #pragma unroll
         for (int q = 0; q < kPerT; ++q) {
-            const int b = hi - q;
-            const uint32_t here = n_ge[b];
-            if (b >= 1 && here >= want && above < want) sh.jwant = (uint32_t)b;   // (N_ge is monotone: one bin at most)
-            above = here;
+            const uint32_t prev = run;
+            run += c[q];
+            if (hi - q >= 1 && run >= want && prev < want) sh.jwant = (uint32_t)(hi - q);   // (N_ge is monotone: one bin at most)
         }
+        __syncthreads();
     }
-    if (tid == 0) {
-        const double sum_out = sh.f_sum;
-        const unsigned long long nz_out = (unsigned long long)sh.f_nz;
-        const float gmn = sh.f_mn, gmx = sh.f_mx;
-        const bool nanseen = sh.f_nan != 0u;
-        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
-        const float ud = (fa.dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
-        // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
-        const float s0 = nanseen ? __uint_as_float(0x7FC00000u)
-            : __fdiv_rn((float)(sum_out + s_ge[1]), (float)(long long)(nz_out + n_ge[1]));
-        uint32_t route = 2u;                                         // 2: walk
-        if (s0 != s0 || fa.max_iters <= 0) route = 0u;               // 0: finished (NaN is a fixed point)
-        else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB))) route = 1u;   // 1: values >= 2^14 / inf: compaction route
-        sh.s0 = s0;
-        sh.ud = ud;
-        sh.n_elems = n_pair;
-        sh.route = route;
-        me->s = s0;
-        me->unsigned_div = ud;
-        me->iters = 0u;
-        me->sum = 0.0;
-        me->cnt_gt = 0ull;
-        me->cnt_le = 0ull;
-        me->len[0] = 0u;
-        me->len[1] = 0u;
-        me->cur = 2u;
-        atomicAdd(&ctl->sum, (double)L);   // the batch's listed values (statistics)
-    }
-    __syncthreads();
-    const uint32_t route = __builtin_amdgcn_readfirstlane(sh.route);
-    uint32_t bad = route == 1u ? 1u : 0u;
-    float s = sh.s0;
-    uint32_t evals = 0u, exact = 0u, stopped = 0u;
+    // The suffix totals at bin b, lazily (wave-uniform b): N_ge[b + 1], S_ge[b + 1] and the bin's own count.  Lanes 0 .. 7 read
+    // the eight words of b's group, masked to the bins above b; a DPP sum over the eight lanes.
+    uint32_t lk_n = 0u, lk_c = 0u;
+    double lk_s = 0.0;
+    auto look = [&](int b) {
+        const int t = (kLogNB - 1 - b) >> 3, g0 = kLogNB - kPerT - 8 * t;
+        const int bq = g0 + (int)(lane & 7u);
+        const unsigned long long x = bq == 0 ? 0ull : packed[bq];
+        const uint32_t c1 = (uint32_t)(x >> kPackShift);
+        const unsigned long long m1 = (x & kPackMask) + ((unsigned long long)c1 << 23);
+        uint32_t ci = bq > b ? c1 : 0u;
+        unsigned long long mi = bq > b ? m1 : 0ull;
+        const uint32_t cb = (uint32_t)__builtin_amdgcn_readlane((int)c1, b - g0);
+        // sum over lanes 0 .. 7 of the row (every group of eight lanes holds the same values): quad swaps + half-row mirror
+        uint32_t mlo = (uint32_t)mi & 0xFFFFFFu, mhi = (uint32_t)(mi >> 24);   // (two 24-bit halves: eight of them stay below 2^32)
+#define DPL_LK_STEP(ctrl)                                                                  \
+        ci += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ci, ctrl, 0xF, 0xF, true);     \
+        mlo += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mlo, ctrl, 0xF, 0xF, true);   \
+        mhi += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mhi, ctrl, 0xF, 0xF, true);
+        DPL_LK_STEP(0xB1)    // quad_perm [1,0,3,2]
+        DPL_LK_STEP(0x4E)    // quad_perm [2,3,0,1]
+        DPL_LK_STEP(0x141)   // row_half_mirror
+#undef DPL_LK_STEP
+        ci = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
+        const unsigned long long mt = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mlo) +
+                                      ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)mhi) << 24);
+        lk_n = tn[t] + ci;
+        lk_s = ts[t] + (double)mt * log_bin_scale(b);
+        lk_c = cb;
+    };
+    float s = 0.0f, s0 = 0.0f, ud = 1.0f;
+    uint32_t route = 2u, bad = 0u, evals = 0u, exact = 0u, stopped = 0u, path = 0u;
+    int jb = 0;
+    unsigned long long n_above = 0ull;
+    double s_above = 0.0;
+    double c = 0.0;
+    const int max_iters = fa.max_iters;
+    // one exact step from the count / mantissa sum of the values of bin jb above s; false: the walk is over
+    auto step = [&](unsigned long long tc, unsigned long long tm) {
+        const unsigned long long tg = n_above + tc;
+        const double tsum = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
+        const double denom = c * (double)(long long)(n_pair - tg) + (double)(long long)tg;
+        const float s1 = __fdiv_rn((float)tsum, (float)denom);
+        ++evals;
+        ++exact;
+        if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
+            stopped = 1u;   // forward_net.py:328-329: keeps the previous s
+            return false;
+        }
+        if (!(s1 >= s)) {
+            bad = 1u;       // moved down (or NaN): not the climb this form relies on
+            return false;
+        }
+        s = s1;
+        if ((int)evals >= max_iters) {
+            bad = 1u;       // the cap: which iterate the reference stopped on is not known here
+            return false;
+        }
+        const int jn = log_bin(s);
+        if (jn > kLogNB - 2) {
+            bad = 1u;
+            return false;
+        }
+        if (jn != jb) {
+            jb = jn;
+            look(jb);
+            n_above = (unsigned long long)lk_n;
+            s_above = lk_s;
+        }
+        return true;
+    };
+    // the exact steps of ONE wave over the survivors in its first kSurvVec vectors
+    auto walk_alone = [&]() {
+        for (;;) {
+            const uint32_t lo1 = __float_as_uint(s) + 1u;
+            const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
+            uint32_t cc = 0u, ds = 0u;   // cc: wave-uniform
+#pragma unroll
+            for (int u = 0; u < kSurvVec; ++u) {
+                const uint32_t b4[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y), __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t d = b4[e] - lo1;   // values of bin jb above s: d below `span` (anything at or below s wraps around)
+                    const bool in = d < span;
+                    cc += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in));
+                    ds += in ? d : 0u;
+                }
+            }
+            // (per lane at most 20 values below 2^17: the DPP sum of ds stays below 2^32)
+            const unsigned long long tm = (unsigned long long)wave_sum_dpp(ds) + (unsigned long long)cc * (unsigned long long)(lo1 & 0x7FFFFFu);
+            if (!step((unsigned long long)cc, tm)) break;
+        }
+    };
     DPL_PROF_T(wt1);
-    if (route == 2u) {
-        const float ud = sh.ud;
-        const double c = 1.0 / 65536.0 / 3.0 / (double)ud;
-        const int J = (int)__builtin_amdgcn_readfirstlane((int)sh.tail_j);
-        const int max_iters = fa.max_iters;
-        if (fa.fail_every > 0 && pair % (uint32_t)fa.fail_every == 0u) bad = 1u;   // test hook: the rescue path
-        // ---- bulk: lower bounds of F from the suffix totals (every thread the same; LDS broadcasts)
-        int jb = log_bin(s);
-        while (!bad && jb < J) {
-            if (jb < 1) {
-                bad = 1u;   // below the binned window
-                break;
-            }
-            const uint32_t nb = n_ge[jb], nb1 = n_ge[jb + 1];
-            const double A = s_ge[jb + 1];
-            if (nb1 == 0u) {
-                bad = 1u;
-                break;
-            }
-            const double d0 = c * (double)(long long)(n_pair - nb1) + (double)nb1;
-            const double dm = c * (double)(long long)(n_pair - nb) + (double)nb;
-            const double nm = A + (double)(nb - nb1) * (double)s;
-            const float q0 = __fdiv_rn((float)A, (float)d0), qm = __fdiv_rn((float)nm, (float)dm);
-            const float lb = __fmul_rn(fminf(q0, qm), 0.99999952316284180f);   // (1 - 2^-21: below every rounding above)
-            if (!(__fsub_rn(lb, s) >= 2e-6f)) {
-                bad = 1u;   // the bound does not move up: the fixed point is in this bin, or the pair is degenerate
-                break;
-            }
-            s = lb;
-            ++evals;
-            if ((int)evals >= max_iters) {
-                bad = 1u;
-                break;
-            }
+#ifdef DPL_RES_PROF
+    unsigned long long wt2m = wt1;   // (end of wave 0's bounded steps)
+#endif
+    if (w == 0) {
+        // ---- the pair's statistics (stream_tail left them per wave), s_0, the route
+        const float gmn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
+        const float gmx = fmaxf(fmaxf(sh.red_mx[0], sh.red_mx[1]), fmaxf(sh.red_mx[2], sh.red_mx[3]));
+        const bool nanseen = sh.low_nan != 0u;
+        // forward_net.py:319 — np.abs(data_min - 0) < 1e-6 (float32 compare) and 'dynamic_sym' in qi_params
+        ud = (fa.dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+        c = 1.0 / 65536.0 / 3.0 / (double)ud;
+        look(0);   // N_ge[1], S_ge[1]: the whole window
+        // forward_net.py:324 — sum(|x|) / count(|x| > 0): exact window totals + the out-of-window part
+        s0 = nanseen ? __uint_as_float(0x7FC00000u)
+                     : __fdiv_rn((float)(sh.low_sum + lk_s), (float)(long long)((unsigned long long)sh.low_cnt + lk_n));
+        if (s0 != s0 || max_iters <= 0) route = 0u;               // 0: finished (NaN is a fixed point)
+        else if (!(fmaxf(fabsf(gmn), fabsf(gmx)) < log_edge(kLogNB))) route = 1u;   // 1: values >= 2^14 / inf: compaction route
+        bad = route == 1u ? 1u : 0u;
+        s = s0;
+        if (route == 2u) {
+            const int J = (int)__builtin_amdgcn_readfirstlane((int)sh.tail_j);
+            if (fa.fail_every > 0 && pair % (uint32_t)fa.fail_every == 0u) bad = 1u;   // test hook: the rescue path
+            // ---- bounded steps: lower bounds of F from the suffix totals; past the list's first bin while more values lie above
+            // the iterate than a wave holds
             jb = log_bin(s);
+            while (!bad) {
+                if (jb < 1 || jb > kLogNB - 2) {
+                    bad = 1u;   // outside the binned window
+                    break;
+                }
+                look(jb);
+                const uint32_t nb1 = lk_n, nb = lk_n + lk_c;
+                if (jb >= J && (fits || nb <= kSurvCap)) break;   // exact from here on (lk_* hold the totals above bin jb)
+                bool moved = false;
+                float lb = s;
+                if (nb1 != 0u) {
+                    const double d0 = c * (double)(long long)(n_pair - nb1) + (double)nb1;
+                    const double dm = c * (double)(long long)(n_pair - nb) + (double)nb;
+                    const double nm = lk_s + (double)lk_c * (double)s;
+                    const float q0 = __fdiv_rn((float)lk_s, (float)d0), qm = __fdiv_rn((float)nm, (float)dm);
+                    lb = __fmul_rn(fminf(q0, qm), 0.99999952316284180f);   // (1 - 2^-21: below every rounding above)
+                    moved = __fsub_rn(lb, s) >= 2e-6f;
+                }
+                if (!moved) {
+                    if (jb < J) bad = 1u;   // below the list: the fixed point is down here, or the pair is degenerate
+                    break;                  // inside it: the bound has stopped moving, exact steps take over (the long way)
+                }
+                s = lb;
+                ++evals;
+                if ((int)evals >= max_iters) {
+                    bad = 1u;
+                    break;
+                }
+                jb = log_bin(s);
+            }
+            n_above = (unsigned long long)lk_n;
+            s_above = lk_s;
+            // 1: this wave finishes alone (the list fits its registers); 2: after a compaction; 3: the workgroup, rows + exchange
+            if (!bad) path = fits ? 1u : ((lk_n + lk_c <= kSurvCap && n_rows <= (uint32_t)kVecT) ? 2u : 3u);
+#ifdef DPL_RES_PROF
+            wt2m = __builtin_readcyclecounter();
+#endif
+            if (path == 1u) walk_alone();
         }
-        DPL_PROF_T(wt2);
-        DPL_PROF_KEEP(1, wt1, wt2);
-        // ---- exact: the reference's step; count / sum of the values above s = suffix totals of the bins above + listed values of bin jb
-        if (!bad && jb > kLogNB - 2) bad = 1u;
-        unsigned long long n_above = 0ull;
-        double s_above = 0.0;
-        auto enter = [&](int j) {
-            n_above = (unsigned long long)n_ge[j + 1];
-            s_above = s_ge[j + 1];
-        };
-        if (!bad) enter(jb);
+        if (lane == 0) {
+            sh.t_s = s;
+            sh.w_s0 = s0;
+            sh.w_ud = ud;
+            sh.w_jb = jb;
+            sh.w_evals = evals;
+            sh.w_path = path;
+            sh.w_bad = bad;
+            sh.w_route = route;
+            sh.w_lkn = lk_n;
+            sh.w_lkc = lk_c;
+            sh.w_lks = lk_s;
+        }
+    }
+    __syncthreads();   // (the other waves have been waiting here: no issue slot spent)
+    path = sh.w_path;
+    if (path == 2u) {
+        // ---- the values still above the iterate (bins >= jb), compacted through LDS by the whole workgroup: count, offsets, place
+        const uint32_t need = sh.w_lkn + sh.w_lkc;
+        const uint32_t edge = ((uint32_t)sh.w_jb + kLogKey0) << kLogShift;
+        uint32_t my = 0u;
+#pragma unroll
+        for (int u = 0; u < kVecT; ++u) {
+            if ((uint32_t)u < n_rows) {   // uniform
+                my += (__float_as_uint(v[u].x) >= edge ? 1u : 0u) + (__float_as_uint(v[u].y) >= edge ? 1u : 0u) +
+                      (__float_as_uint(v[u].z) >= edge ? 1u : 0u) + (__float_as_uint(v[u].w) >= edge ? 1u : 0u);
+            }
+        }
+        const uint32_t in = scan_u32_dpp(my);
+        if (lane == kWave - 1) sh.part_c[0][w] = in;
+        __syncthreads();
+        uint32_t pos = in - my, total = 0u;
+        for (int q = 0; q < kWaves; ++q) {
+            pos += q < w ? sh.part_c[0][q] : 0u;
+            total += sh.part_c[0][q];
+        }
+        const bool ok = total == need;   // (else the list does not hold what the histogram counted: cannot happen; rescued)
+        if (ok) {
+#pragma unroll
+            for (int u = 0; u < kVecT; ++u) {
+                if ((uint32_t)u < n_rows) {
+                    const uint32_t b4[4] = {__float_as_uint(v[u].x), __float_as_uint(v[u].y), __float_as_uint(v[u].z), __float_as_uint(v[u].w)};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (b4[e] >= edge) surv[pos++] = b4[e];
+                    }
+                }
+            }
+            for (uint32_t i = total + tid; i < kSurvCap; i += kThreads) surv[i] = 0u;
+        }
+        __syncthreads();
+        if (w == 0) {
+            if (!ok) {
+                bad = 1u;
+            } else {
+#pragma unroll
+                for (int u = 0; u < kSurvVec; ++u) v[u] = *reinterpret_cast<const f4*>(surv + (((uint32_t)u * kWave + lane) << 2));
+                walk_alone();
+            }
+            if (lane == 0) {
+                sh.t_s = s;
+                sh.w_evals = evals;
+                sh.w_bad = bad;
+            }
+        }
+        __syncthreads();
+    } else if (path == 3u) {
+        // ---- rows spread over the workgroup, partial sums through LDS, every wave takes the step (walk_pair's loop)
+        s = sh.t_s;
+        s0 = sh.w_s0;
+        ud = sh.w_ud;
+        c = 1.0 / 65536.0 / 3.0 / (double)ud;
+        jb = sh.w_jb;
+        evals = sh.w_evals;
+        n_above = (unsigned long long)sh.w_lkn;
+        s_above = sh.w_lks;
+        bad = 0u;
         uint32_t par = 0u;
         f4 ov[kOver];
-        while (!bad && !stopped) {
+        for (;;) {
             const uint32_t lo1 = __float_as_uint(s) + 1u;
             const uint32_t span = (((uint32_t)(jb + 1) + kLogKey0) << kLogShift) - lo1;
             uint32_t cc = 0u;   // (wave-uniform)
@@ -433,7 +628,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
                 dsum += (unsigned long long)wave_sum_dpp(ds);
                 ds = 0u;
             }
-            for (uint32_t r0 = (uint32_t)kVecT; r0 < n_rows; r0 += (uint32_t)kOver) {   // a list beyond the registers (a cold start)
+            for (uint32_t r0 = (uint32_t)kVecT; r0 < n_rows; r0 += (uint32_t)kOver) {   // a list beyond the registers
 #pragma unroll
                 for (int u = 0; u < kOver; ++u) {
                     in1(ov[u].x);
@@ -457,45 +652,62 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
                 tm += sh.part_m[par][j];
             }
             par ^= 1u;
-            const unsigned long long tg = n_above + tc;
-            const double ts = s_above + (double)(tm + (tc << 23)) * log_bin_scale(jb);
-            const double denom = c * (double)(long long)(n_pair - tg) + (double)(long long)tg;
-            const float s1 = __fdiv_rn((float)ts, (float)denom);
-            ++evals;
-            ++exact;
-            if (fabsf(__fsub_rn(s1, s)) < 1e-6f) {
-                stopped = 1u;   // forward_net.py:328-329: keeps the previous s
-            } else if (!(s1 >= s)) {
-                bad = 1u;       // moved down (or NaN): not the climb this form relies on
-            } else {
-                s = s1;
-                if ((int)evals >= max_iters) {
-                    bad = 1u;   // the cap: which iterate the reference stopped on is not known here
-                } else {
-                    const int jn = log_bin(s);
-                    if (jn > kLogNB - 2) {
-                        bad = 1u;
-                    } else if (jn != jb) {
-                        jb = jn;
-                        enter(jb);
-                    }
-                }
-            }
+            if (!step(tc, tm)) break;
         }
-        // at least two exact evaluations behind a bounded start (none needed when every step was exact: a small pair)
-        if (!bad && !(stopped && (exact >= 2u || evals == exact))) bad = 1u;
-        DPL_PROF_T(wt3);
-        DPL_PROF_KEEP(2, wt2, wt3);
+        if (tid == 0) {
+            sh.t_s = s;
+            sh.w_evals = evals;
+            sh.w_bad = bad;
+        }
+        // (exact / stopped of this path are every wave's own: the acceptance below is taken by wave 0 from its copies)
+        __syncthreads();
     }
+    // ---- acceptance (wave 0 holds exact / stopped of paths 1 and 2; every wave its own of path 3)
+    s = sh.t_s;
+    s0 = sh.w_s0;
+    ud = sh.w_ud;
+    evals = sh.w_evals;
+    route = sh.w_route;
+    bad = sh.w_bad;
+    if (w == 0 && lane == 0) {
+        // at least two exact evaluations behind a bounded start (none needed when every step was exact: a small pair)
+        if (route == 2u && !bad && !(stopped && (exact >= 2u || evals == exact))) bad = 1u;
+        sh.w_bad = bad;
+    }
+    __syncthreads();
+    bad = sh.w_bad;
+    DPL_PROF_T(wt3);
+    DPL_PROF_KEEP(1, wt1, wt2m);
+    DPL_PROF_KEEP(2, wt2m, wt3);
     DPL_PROF_T(wt4);
-    // ---- history: the bin this pair asked for (whatever became of its walk)
-    if (tid == 0 && !small && route != 0u) atomicMax(fa.vis_w + (size_t)tensor * kLogWords, (uint32_t)kLogNB - sh.jwant);
-    // ---- a pair this form could not finish is RESCUED (as walk_pair does): exact bracket, re-read of the pair alone, verified walk
+    // ---- a pair this form could not finish is RESCUED (as walk_pair does): exact bracket, re-read of the pair alone, verified
+    // walk.  The bracket walk wants the suffix totals of every bin: only now are they written out (over the packed histogram)
     bool rescued = false;
     if (bad && !small && route == 2u) {
+        double* s_ge = reinterpret_cast<double*>(lds_raw);
+        uint32_t* n_ge = reinterpret_cast<uint32_t*>(lds_raw + kLdsA);
+        {
+            uint32_t c8[kPerT];
+            unsigned long long m8[kPerT];
+#pragma unroll
+            for (int q = 0; q < kPerT; ++q) {
+                const unsigned long long x = packed[hi - q];
+                c8[q] = (uint32_t)(x >> kPackShift);
+                m8[q] = x & kPackMask;
+            }
+            __syncthreads();   // (n_ge overwrites the group totals and the staging area: every look is behind us)
+#pragma unroll
+            for (int q = 0; q < kPerT; ++q) {
+                const int bq = hi - q;
+                if (bq == 0) c8[q] = 0u, m8[q] = 0ull;
+                n_ge[bq] = c8[q];
+                s_ge[bq] = bin_sum(m8[q], c8[q], bq);
+            }
+        }
+        suffix_in_place(n_ge, s_ge, sh);
         if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
         __syncthreads();
-        if (tid == 0) sh.route = bracket_marks(n_ge, s_ge, sh.pub, sh.s0, sh.ud, sh.n_elems).route;
+        if (tid == 0) sh.route = bracket_marks(n_ge, s_ge, sh.pub, s0, ud, n_pair).route;
         __syncthreads();
         rescued = sh.route == 2u;
         if (rescued) {
@@ -509,29 +721,47 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
         }
     }
     if (tid == 0) {
+        // the pair's state: its statistics (what the rescue / the compaction route / dpl_octav_finalize read), and what became of it
+        const float gmn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
+        const float gmx = fmaxf(fmaxf(sh.red_mx[0], sh.red_mx[1]), fmaxf(sh.red_mx[2], sh.red_mx[3]));
+        dpl_octav_state z;
+        z.sum = 0.0;
+        z.cnt_gt = 0ull;
+        z.cnt_le = 0ull;
+        z.min_enc = gmn <= gmx ? enc_f32(gmn) : 0xFFFFFFFFu;
+        z.max_enc = gmn <= gmx ? enc_f32(gmx) : 0u;
+        z.nan_seen = sh.low_nan != 0u ? 1u : 0u;
+        z.unsigned_div = ud;
+        z.n_elems = n_pair;
+        z.len[0] = 0u;
+        z.len[1] = 0u;
+        z.cur = 2u;
+        z.reserved = 0u;
+        z.s = s0;          // (a restart begins at s_0)
+        z.iters = 0u;
+        z.done = 0u;
+        z.mode = 2u;
         if (route == 0u) {
-            me->done = 1u;
-            me->mode = 2u;
+            z.done = 1u;
         } else if (bad && rescued) {
-            me->mode = 3u;   // restart from s_0 (in me->s) on the pair's exact bracket: its units go on the rescue's work list
-            me->done = 0u;
-            me->len[0] = 0u;
+            z.mode = 3u;   // restart from s_0 on the pair's exact bracket: its units go on the rescue's work list
             const uint32_t nu = (uint32_t)((n_pair + kRescueUnit - 1) / kRescueUnit);
             const uint32_t e = atomicAdd(&ctl->len[0], 1u), u0 = atomicAdd(&ctl->len[1], nu);
             fa.missed[3 * e] = pair;
             fa.missed[3 * e + 1] = u0;
             fa.missed[3 * e + 2] = nu;
         } else if (bad) {
-            me->mode = 1u;   // restart from s_0 on the compaction route: state as k_octav_update<true> leaves it
-            me->done = 0u;
-            me->len[0] = 0u;
+            z.mode = 1u;   // restart from s_0 on the compaction route: state as k_octav_update<true> leaves it
             atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
         } else {
-            me->s = s;
-            me->iters = evals;
-            me->done = 1u;
-            me->mode = 2u;
+            z.s = s;
+            z.iters = evals;
+            z.done = 1u;
         }
+        *me = z;
+        atomicAdd(&ctl->sum, (double)L);   // the batch's listed values (statistics)
+        // history: the bin this pair asked for (whatever became of its walk)
+        if (!small && route != 0u) atomicMax(fa.vis_w + (size_t)tensor * kLogWords, (uint32_t)kLogNB - sh.jwant);
     }
     DPL_PROF_T(wt5);
     DPL_PROF_ADD(0, wt0, wt1);
@@ -555,7 +785,6 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     DPL_PROF_T(kt0);
     const dpl_work_item it = slices[blockIdx.x];
     const uint32_t pair = it.slot, cnt = it.count;
-    dpl_octav_state* me = st + pair;
     const float* pg = segs[it.seg] + it.offset;
     const uint32_t tensor = pair % n_tensors;
     const bool small = cnt <= kSmallCap;   // lists its whole window: every step exact
@@ -570,34 +799,12 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     }
     __syncthreads();
     stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair]), sh, ctl, !small);
-    __syncthreads();   // every LDS histogram add has landed; the per-wave ranges are in sh
+    __syncthreads();   // every LDS histogram add has landed; the per-wave ranges and the out-of-window sums are in sh
     DPL_PROF_T(kt1);
-    if (tid == 0) {
-        float tmn = INFINITY, tmx = -INFINITY;
-        const uint32_t tnz = sh.low_cnt, tnan = sh.low_nan;
-        const double tsum = sh.low_sum;
-        for (int j = 0; j < kWaves; ++j) {
-            tmn = fminf(tmn, sh.red_mn[j]);
-            tmx = fmaxf(tmx, sh.red_mx[j]);
-        }
-        // the pair's statistics (what the rescue / the compaction route and dpl_octav_finalize read)
-        me->n_elems = (unsigned long long)cnt;
-        if (tmn <= tmx) {
-            me->min_enc = enc_f32(tmn);
-            me->max_enc = enc_f32(tmx);
-        }
-        if (tnan) me->nan_seen = 1u;
-        sh.f_sum = tsum;
-        sh.f_nz = tnz;
-        sh.f_nan = tnan;
-        sh.f_mn = tmn;
-        sh.f_mx = tmx;
-    }
-    __syncthreads();
 #if defined(DPL_TAIL_ABL_NOWALK)
     if (tid == 0) {
-        me->done = 1u;
-        me->s = sh.f_mx;
+        st[pair].done = 1u;
+        st[pair].s = sh.red_mx[0];
     }
 #if defined(DPL_TAIL_ABL_DELAY)   // a stand-in for the walk's latency: DPL_TAIL_ABL_DELAY ticks spent by every wave (1) or by wave 0 alone (2: the others exit)
     if (DPL_TAIL_ABL_WHO == 2 && tid >= kWave) return;
@@ -608,8 +815,7 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
 #endif
     return;
 #endif
-    walk_tail<kTailVec>(pair, tensor, reinterpret_cast<double*>(lds_raw), reinterpret_cast<uint32_t*>(lds_raw + kLdsA), sh, st, ctl,
-                    pair_base, list0, fa, cnt);
+    walk_tail<kTailVec>(pair, tensor, lds_raw, sh, st, ctl, pair_base, list0, fa, cnt);
     DPL_PROF_T(kt2);
     DPL_PROF_ADD(4, kt0, kt1);
     DPL_PROF_ADD(5, kt1, kt2);

@@ -5,7 +5,8 @@ that was not obtained by evaluating every iterate of forward_net.py:323-330 exac
   histogram   64 bins per octave over 2^-18 .. 2^14, per bin an exact count and an exact sum (the kernel: integer mantissa
               sums) -> suffix totals N_ge[b], S_ge[b] = everything in bins >= b;
   list        every |x| whose bin is >= J (the gather threshold theta = lower edge of bin J, however it was chosen);
-  bulk phase  while the iterate t lies in a bin b < J: t <- a LOWER BOUND of F(t) that needs only the suffix totals:
+  bulk phase  while the iterate t lies in a bin b < J (and beyond, while more values lie above t than a wave's registers hold):
+              t <- a LOWER BOUND of F(t) that needs only the suffix totals:
                   F(t) = (S_ge[b+1] + sum of the m values of bin b above t) / (c (n - N_ge[b+1] - m) + N_ge[b+1] + m),
               each of the m values lies in (t, edge[b+1]) and 0 <= m <= count[b]: the quotient is monotone in m once the
               values are put at t, so F(t) >= min(q(0), q(count[b])).  F is non-decreasing below its least fixed point
@@ -80,7 +81,10 @@ class Hist:
 BULK_SHAVE = F32(0.99999952316284180)   # 1 - 2^-21: below the three fp32 roundings of a bound (csrc/octav_tail.hpp)
 
 
-def tail_walk(h, J, dynamic_sym=False, max_iters=20):
+SURV_CAP = 1280   # values one wave's registers hold (kSurvCap): bounded steps go on until what lies above the iterate fits
+
+
+def tail_walk(h, J, dynamic_sym=False, max_iters=20, surv_cap=SURV_CAP):
     """-> dict(status, s, evals, exact_evals, bulk_evals).  status: 'ok' (accepted), 'nan', or a rejection reason."""
     r = dict(status="ok", s=F32(np.nan), evals=0, exact_evals=0, bulk_evals=0)
     if h.n == 0:
@@ -104,22 +108,26 @@ def tail_walk(h, J, dynamic_sym=False, max_iters=20):
     J = max(1, min(int(J), LOG_NB - 1))
     t = s
     evals = 0
-    # ---- bulk phase: lower bounds from the suffix totals alone
+    # ---- bulk phase: lower bounds from the suffix totals alone; they go on past the list's first bin while more values lie above
+    # the iterate than one wave holds (the kernel then compacts them once and every exact step is cheap)
+    fits = int(h.n_ge[J]) <= surv_cap
     while True:
         b = log_bin(t)
-        if b >= J:
-            break
-        if b < 1:
-            r["status"] = "reject:below_window"
+        if b < 1 or b > LOG_NB - 2:
+            r["status"] = "reject:outside_window"
             return r
         A, nb1, nb = float(h.s_ge[b + 1]), int(h.n_ge[b + 1]), int(h.n_ge[b])
-        if nb1 == 0:
-            r["status"] = "reject:empty_above"
-            return r
-        q0 = F32(F32(A) / F32(c * (n - nb1) + nb1))
-        qm = F32(F32(A + (nb - nb1) * float(t)) / F32(c * (n - nb) + nb))
-        lb = F32(min(q0, qm) * BULK_SHAVE)
-        if not (F32(lb - t) >= F32(2e-6)):
+        if b >= J and (fits or nb <= surv_cap):
+            break
+        moved = False
+        if nb1 != 0:
+            q0 = F32(F32(A) / F32(c * (n - nb1) + nb1))
+            qm = F32(F32(A + (nb - nb1) * float(t)) / F32(c * (n - nb) + nb))
+            lb = F32(min(q0, qm) * BULK_SHAVE)
+            moved = bool(F32(lb - t) >= F32(2e-6))
+        if not moved:
+            if b >= J:
+                break                      # the bound has stopped moving inside the list: exact steps take over
             r["status"] = "reject:bulk_stall"
             return r
         t = lb

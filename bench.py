@@ -464,6 +464,26 @@ def main():
             fq[mode] = {"ms_per_batch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": T,
                         "tensors_of_50MB_and_more": {"launches": len(big), "ms": ms_big, "achieved": gbps_big,
                                                      "frac": gbps_big / HBM_PEAK_GBPS}}
+        # ... and the whole set in ONE launch (dpl_fake_quant_items: what a caller that holds every tensor of a forward uses)
+        ys = [torch.empty_like(x) for x in xs]
+        fq["set_launch"] = {}
+        for mode in ("per_tensor", "per_channel"):
+            prm = [((q[0], q[1], 1, -128, 127) if mode == "per_tensor" else (q[2], q[3], h * w, -128, 127))
+                   for q, (c, h, w) in zip(qp, shapes)]
+            fset = ops.FakeQuantSet(plan, prm)
+            tot = []
+            for rep in range(a.fq_reps + 1):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fset(xs, out=ys)
+                e1.record()
+                torch.cuda.synchronize()
+                if rep > 0:
+                    tot.append(e0.elapsed_time(e1))
+            ms = sum(tot) / len(tot)
+            gbps = 8 * E * B / (ms * 1e-3) / 1e9
+            fq["set_launch"][mode] = {"ms_per_batch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": 1}
+        del ys
         fake_quant = {"workload": f"ResNet-50 activation set, one batch of {B} images, fused QuantizeLinear -> DequantizeLinear, int8 grid",
                       "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "bytes_per_batch": 8 * E * B, **fq}
         del ybuf, xs, qp, xv, yv

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_BINS = 16384
 
 
@@ -47,6 +47,12 @@ class RoundStepParams(C.Structure):
                 ("reserved2", C.c_float)]
 
 
+class FakeQuantParams(C.Structure):
+    """dpl_fake_quant_params: one tensor's quantisation parameters for dpl_fake_quant_items."""
+    _fields_ = [("d_scale", C.c_void_p), ("d_zero_point", C.c_void_p), ("n_channels", C.c_int64), ("inner", C.c_int64),
+                ("qlo", C.c_int32), ("qhi", C.c_int32)]
+
+
 class OctavOnereadJob(C.Structure):
     """dpl_octav_oneread_job (include/dipoorlet_hip.h): one batch of the one-read OCTAV form."""
     _fields_ = [("d_slices", C.c_void_p), ("n_slices", C.c_int64), ("d_pair_slice0", C.c_void_p), ("d_slice_chunk0", C.c_void_p),
@@ -62,7 +68,7 @@ class OctavOnereadJob(C.Structure):
                 ("compaction_inline", C.c_int32)]
 
 
-assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 272
+assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 272 and C.sizeof(FakeQuantParams) == 40
 assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 80
 
 _P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
@@ -102,6 +108,7 @@ SIGNATURES = {
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    "dpl_fake_quant_items": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),
     "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
     "dpl_channel_diff_sum": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
     "dpl_cos_items_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),

@@ -330,79 +330,119 @@ __device__ __forceinline__ float fq_one(float x, float scale, float zp, float ql
     return __fmul_rn(__fsub_rn(q, zp), scale);
 }
 
-__global__ __launch_bounds__(kBlock) void k_fake_quant_tensor(const float* __restrict__ x, float* __restrict__ y,
-                                                               int64_t n, const float* __restrict__ scale_p,
-                                                               const int32_t* __restrict__ zp_p, float qlo,
-                                                               float qhi) {
-    const float scale = scale_p[0];
-    const float zp = (float)zp_p[0];
-    const int64_t nvec = n >> 2;
-    const f4* xv = reinterpret_cast<const f4*>(x);
-    f4* yv = reinterpret_cast<f4*>(y);
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
-        f4 v = __builtin_nontemporal_load(xv + i);
-        v.x = fq_one(v.x, scale, zp, qlo, qhi);
-        v.y = fq_one(v.y, scale, zp, qlo, qhi);
-        v.z = fq_one(v.z, scale, zp, qlo, qhi);
-        v.w = fq_one(v.w, scale, zp, qlo, qhi);
-        __builtin_nontemporal_store(v, yv + i);
+// One workgroup fake-quantises elements [e0, e0 + cnt) of a tensor viewed as [outer, n_channels, inner] (n_channels == 1: per
+// tensor).  A CONTIGUOUS chunk per workgroup (few large equal shares stream faster from HBM than a grid-stride walk), four
+// 16-byte vectors per lane in flight, non-temporal loads and stores (each byte is touched once).  The channel of a vector needs no
+// division in the loop: a lane's (column, channel) advance by a constant per step — 1024 elements = (1024 / inner) rows and
+// (1024 % inner) columns, both computed once per chunk on the scalar unit — with one conditional wrap each.
+__device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __restrict__ y, uint64_t e0, uint32_t cnt,
+                                        const float* __restrict__ scale_p, const int32_t* __restrict__ zp_p, uint32_t n_channels,
+                                        uint32_t inner, float qlo, float qhi) {
+    typedef __attribute__((address_space(1))) f4* gptr_f4w;
+    const uint32_t tid = threadIdx.x;
+    const float* xs = x + e0;
+    float* ys = y + e0;
+    const bool vec = ((((uintptr_t)xs | (uintptr_t)ys) & 15u) == 0u) && (n_channels == 1u || (inner & 3u) == 0u);
+    if (!vec) {   // unaligned views / rows that are no multiple of four long (7 x 7 maps): element by element, same bookkeeping
+        const uint64_t e = e0 + tid;
+        uint32_t col = (uint32_t)(e % inner), c = (uint32_t)((e / inner) % n_channels);
+        const uint32_t step_cols = (uint32_t)kBlock % inner, step_ch = ((uint32_t)kBlock / inner) % n_channels;
+        for (uint32_t i = tid; i < cnt; i += kBlock) {
+            ys[i] = fq_one(xs[i], scale_p[c], (float)zp_p[c], qlo, qhi);
+            col += step_cols;
+            c += step_ch;
+            if (col >= inner) {
+                col -= inner;
+                c += 1u;
+            }
+            if (c >= n_channels) c -= n_channels;
+        }
+        return;
     }
-    const int64_t t = (nvec << 2) + (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (t < n) y[t] = fq_one(x[t], scale, zp, qlo, qhi);
-}
-
-// Per-channel form, x viewed as [outer, n_channels, inner].  The channel of a 16-byte vector is one 32-bit
-// division per FOUR elements when rows are a multiple of four long (every conv activation / weight but 7x7 maps),
-// and the loop keeps four vectors per lane in flight like the per-tensor kernel.
-template <bool kVec>
-__global__ __launch_bounds__(kBlock) void k_fake_quant_channel(const float* __restrict__ x, float* __restrict__ y,
-                                                                uint32_t n, const float* __restrict__ scale_p,
-                                                                const int32_t* __restrict__ zp_p, uint32_t n_channels,
-                                                                uint32_t inner, float qlo, float qhi) {
-    const uint32_t stride = gridDim.x * kBlock;
-    if (kVec) {
-        const uint32_t nvec = n >> 2, inner4 = inner >> 2;
-        const f4* xv = reinterpret_cast<const f4*>(x);
-        f4* yv = reinterpret_cast<f4*>(y);
-        for (uint32_t i0 = blockIdx.x * kBlock + threadIdx.x; i0 < nvec; i0 += 4 * stride) {
+    const uint32_t nvec = cnt >> 2;
+    gptr_f4 xv = (gptr_f4)xs;
+    gptr_f4w yv = (gptr_f4w)ys;
+    if (n_channels == 1u) {
+        const float sc = scale_p[0], zp = (float)zp_p[0];
+        for (uint32_t i0 = tid; i0 < nvec; i0 += 4 * kBlock) {
             f4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + u * stride;
-                v[u] = i < nvec ? __builtin_nontemporal_load(xv + i) : f4{0.f, 0.f, 0.f, 0.f};
-            }
+            for (int u = 0; u < 4; ++u) v[u] = i0 + u * kBlock < nvec ? __builtin_nontemporal_load(xv + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + u * stride;
-                if (i < nvec) {
-                    const uint32_t c = (i / inner4) % n_channels;
-                    const float sc = scale_p[c], zp = (float)zp_p[c];
+                if (i0 + u * kBlock < nvec) {
                     v[u].x = fq_one(v[u].x, sc, zp, qlo, qhi);
                     v[u].y = fq_one(v[u].y, sc, zp, qlo, qhi);
                     v[u].z = fq_one(v[u].z, sc, zp, qlo, qhi);
                     v[u].w = fq_one(v[u].w, sc, zp, qlo, qhi);
-                    __builtin_nontemporal_store(v[u], yv + i);
+                    __builtin_nontemporal_store(v[u], yv + i0 + u * kBlock);
                 }
             }
         }
     } else {
-        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-            const uint32_t c = (i / inner) % n_channels;
-            y[i] = fq_one(x[i], scale_p[c], (float)zp_p[c], qlo, qhi);
+        // the lane's first vector: one division; then (col, c) advance by the per-step constants
+        const uint64_t e = e0 + 4ull * tid;
+        uint32_t col = (uint32_t)(e % inner), c = (uint32_t)((e / inner) % n_channels);
+        const uint32_t step_cols = (4u * kBlock) % inner, step_ch = ((4u * kBlock) / inner) % n_channels;
+        for (uint32_t i0 = tid; i0 < nvec; i0 += 4 * kBlock) {
+            f4 v[4];
+            float scu[4];
+            int32_t zpu[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                v[u] = i0 + u * kBlock < nvec ? __builtin_nontemporal_load(xv + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
+                scu[u] = scale_p[c];   // (requested with the data: a look-up at the point of use waits a cache round trip per vector)
+                zpu[u] = zp_p[c];
+                col += step_cols;
+                c += step_ch;
+                if (col >= inner) {
+                    col -= inner;
+                    c += 1u;
+                }
+                if (c >= n_channels) c -= n_channels;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * kBlock < nvec) {
+                    const float sc = scu[u], zp = (float)zpu[u];
+                    v[u].x = fq_one(v[u].x, sc, zp, qlo, qhi);
+                    v[u].y = fq_one(v[u].y, sc, zp, qlo, qhi);
+                    v[u].z = fq_one(v[u].z, sc, zp, qlo, qhi);
+                    v[u].w = fq_one(v[u].w, sc, zp, qlo, qhi);
+                    __builtin_nontemporal_store(v[u], yv + i0 + u * kBlock);
+                }
+            }
         }
+    }
+    const uint32_t t = (nvec << 2) + tid;   // (a chunk that is no multiple of four long: the tensor's last elements)
+    if (t < cnt) {
+        const uint32_t c = n_channels == 1u ? 0u : (uint32_t)(((e0 + t) / inner) % n_channels);
+        ys[t] = fq_one(xs[t], scale_p[c], (float)zp_p[c], qlo, qhi);
     }
 }
 
-// (tensors of 2^32 elements or more)
-__global__ __launch_bounds__(kBlock) void k_fake_quant_channel64(const float* __restrict__ x, float* __restrict__ y,
-                                                                  int64_t n, const float* __restrict__ scale_p,
-                                                                  const int32_t* __restrict__ zp_p, int64_t n_channels,
-                                                                  int64_t inner, float qlo, float qhi) {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const int64_t c = (i / inner) % n_channels;
-        y[i] = fq_one(x[i], scale_p[c], (float)zp_p[c], qlo, qhi);
+// one tensor: workgroup b takes elements [b * chunk, (b + 1) * chunk) (chunk a multiple of 1024)
+__global__ __launch_bounds__(kBlock) void k_fake_quant(const float* __restrict__ x, float* __restrict__ y, uint64_t n, uint64_t chunk,
+                                                        const float* __restrict__ scale_p, const int32_t* __restrict__ zp_p,
+                                                        uint32_t n_channels, uint32_t inner, float qlo, float qhi) {
+    const uint64_t e0 = (uint64_t)blockIdx.x * chunk;
+    if (e0 >= n) return;
+    const uint64_t cnt = n - e0 < chunk ? n - e0 : chunk;
+    fq_span(x, y, e0, (uint32_t)cnt, scale_p, zp_p, n_channels, inner, qlo, qhi);
+}
+
+// a whole tensor set in ONE launch: the balanced partition's items (item.seg = tensor, item.offset / count = the elements) over
+// the tensors' base pointers and a parameter row per tensor
+__global__ __launch_bounds__(kBlock) void k_fake_quant_items(const dpl_work_item* __restrict__ items, const uint32_t* __restrict__ bb,
+                                                              const float* const* __restrict__ seg_x, float* const* __restrict__ seg_y,
+                                                              const dpl_fake_quant_params* __restrict__ prm) {
+    uint32_t k0, k1;
+    block_items(bb, k0, k1);
+    for (uint32_t k = k0; k < k1; ++k) {
+        const dpl_work_item it = items[k];
+        const dpl_fake_quant_params p = prm[it.seg];
+        fq_span(seg_x[it.seg], seg_y[it.seg], it.offset, it.count, p.d_scale, p.d_zero_point, (uint32_t)p.n_channels, (uint32_t)p.inner,
+                (float)p.qlo, (float)p.qhi);
     }
 }
 
@@ -778,29 +818,28 @@ int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_mi
 int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
                    int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s) {
     if (n <= 0) return 0;
-    if (n_channels < 1 || inner < 1) return fail_msg("dpl_fake_quant: n_channels and inner must be >= 1");
-    int64_t blocks = (n / 4 + kBlock - 1) / kBlock;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    if (n_channels == 1) {
-        if (((uintptr_t)d_x | (uintptr_t)d_y) & 15u) return fail_msg("dpl_fake_quant: buffers must be 16-B aligned");
-        hipLaunchKernelGGL(k_fake_quant_tensor, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y, n,
-                           d_scale, d_zp, (float)qlo, (float)qhi);
-    } else {
-        if (n >= 0xFFFFFFFFll) {
-            hipLaunchKernelGGL(k_fake_quant_channel64, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x,
-                               d_y, n, d_scale, d_zp, n_channels, inner, (float)qlo, (float)qhi);
-        } else if ((inner & 3) == 0 && ((((uintptr_t)d_x | (uintptr_t)d_y) & 15u) == 0)) {
-            hipLaunchKernelGGL(k_fake_quant_channel<true>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x,
-                               d_y, (uint32_t)n, d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo,
-                               (float)qhi);
-        } else {
-            hipLaunchKernelGGL(k_fake_quant_channel<false>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x,
-                               d_y, (uint32_t)n, d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo,
-                               (float)qhi);
-        }
-    }
+    if (n_channels < 1 || inner < 1 || n_channels > 0xFFFFFFFFll || inner > 0xFFFFFFFFll)
+        return fail_msg("dpl_fake_quant: n_channels and inner must be in [1, 2^32)");
+    // contiguous chunks of at least 16 KiB, a multiple of 1024 elements (so that every chunk starts on a 16-byte boundary of an
+    // aligned tensor), at most 2^32 - 1024 elements, about 4096 workgroups for a large tensor
+    int64_t chunk = (n + 4095) / 4096;
+    chunk = ((chunk < 4096 ? 4096 : chunk) + 1023) / 1024 * 1024;
+    if (chunk > 0xFFFFFC00ll) chunk = 0xFFFFFC00ll;
+    const int64_t blocks = (n + chunk - 1) / chunk;
+    if (blocks > 0x7FFFFFFFll) return fail_msg("dpl_fake_quant: tensor too large");
+    hipLaunchKernelGGL(k_fake_quant, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y, (uint64_t)n, (uint64_t)chunk,
+                       d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo, (float)qhi);
     DPL_LAUNCH_CHECK("k_fake_quant");
+    return 0;
+}
+
+int dpl_fake_quant_items(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                         const float* const* d_seg_x, float* const* d_seg_y, const dpl_fake_quant_params* d_params, dpl_stream_t s) {
+    if (n_items <= 0) return 0;
+    if (int e = check_blocks("dpl_fake_quant_items", n_items, d_block_begin, n_blocks)) return e;
+    hipLaunchKernelGGL(k_fake_quant_items, dim3((unsigned)n_blocks), dim3(kBlock), 0, (hipStream_t)s, d_items, d_block_begin, d_seg_x,
+                       d_seg_y, d_params);
+    DPL_LAUNCH_CHECK("k_fake_quant_items");
     return 0;
 }
 

@@ -689,6 +689,46 @@ def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None):
     return y
 
 
+class FakeQuantSet:
+    """Fused QuantizeLinear -> DequantizeLinear over a WHOLE tensor set in one launch (dpl_fake_quant_items): for a caller that
+    holds every tensor of a forward (the profiling flow's fp-vs-quantised comparison, quant_acti over a set) — one launch
+    instead of one per Q/DQ pair, most of which are launch-bound.
+
+        fq = FakeQuantSet(plan, params)          # params[t] = (scale fp32 [1 | C], zero_point int32 [1 | C], inner, qlo, qhi)
+        ys = fq(xs)                              # or fq(xs, out=ys); xs[t]: [B, ...] contiguous fp32 as the plan describes
+
+    `inner` = elements per channel row of ONE tensor as laid out in memory ([B, C, H, W] with per-channel parameters on axis 1:
+    inner = H * W); ignored for per-tensor parameters."""
+
+    def __init__(self, plan, params):
+        if len(params) != plan.T:
+            raise _hip.DipoorletHipError(f"expected {plan.T} parameter rows, got {len(params)}")
+        self.plan = plan
+        self.keep = []
+        rows = (_hip.FakeQuantParams * plan.T)()
+        for t, (scale, zp, inner, qlo, qhi) in enumerate(params):
+            scale = scale.to(device=plan.device, dtype=torch.float32).contiguous().reshape(-1)
+            zp = zp.to(device=plan.device, dtype=torch.int32).contiguous().reshape(-1)
+            if scale.numel() != zp.numel():
+                raise _hip.DipoorletHipError("scale and zero_point lengths differ")
+            self.keep += [scale, zp]
+            rows[t] = _hip.FakeQuantParams(scale.data_ptr(), zp.data_ptr(), scale.numel(), int(inner) if scale.numel() > 1 else 1,
+                                           int(qlo), int(qhi))
+        self.d_params = _upload_struct_array(rows, plan.T, plan.device)
+        self.work = plan.work("hist")             # the balanced partition over the batch's tensors (slot = tensor)
+        self._out_cache = {}
+
+    def __call__(self, tensors, out=None):
+        plan = self.plan
+        tx = plan.seg_table(tensors)
+        if out is None:
+            out = [torch.empty_like(x) for x in tensors]
+        ty = plan.seg_table(out)
+        _hip.check(_hip.lib().dpl_fake_quant_items(*self.work.args(), _ptr(tx), _ptr(ty), _ptr(self.d_params), _stream()),
+                   "dpl_fake_quant_items")
+        return out
+
+
 def cos_accumulate(a, b, acc, slot=0):
     """acc[slot] += (sum a*b, sum a*a, sum b*b) in fp64 (utils.py:273-278 partial sums)."""
     _require_cuda(a, "a")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 15
+#define DPL_ABI_VERSION 16
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -256,10 +256,6 @@ int dpl_octav_run_oneread(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_test_hook_exact_fail_every(int every);
 int dpl_test_hook_rescue_fail_every(int every);
 /* d_out: fp32 [n_pairs,3] = (optimal_s, min, max) like the reference's per-image lists. */
-/* TEST HOOK: makes the exact walk of dpl_octav_run_bracket reject every `every`-th pair (0 = off) so that the
- * restart on the compaction route — taken in production only when an iterate leaves the bracket's bins — can be
- * exercised; returns the previous setting. */
-int dpl_test_hook_exact_fail_every(int every);
 int dpl_octav_finalize(const dpl_octav_state* d_states, int64_t n_pairs, float* d_out, dpl_stream_t s);
 
 /* ---- per-output-channel weight ranges: replaces np.min/np.max(tensor.reshape(C,-1), -1)
@@ -272,6 +268,20 @@ int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_mi
  *      n_channels == 1: per tensor.  Otherwise channel c = (i / inner) % n_channels. */
 int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
                    int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s);
+/* The same arithmetic over a WHOLE tensor set in one launch (a caller that holds every tensor of a forward: one launch instead
+ * of one per Q/DQ pair — 123 for ResNet-50, most of them launch-bound): d_items / d_block_begin = a partition of the tensors'
+ * elements (dpl_build_balanced_items over one span per tensor: item.seg = tensor, offset / count in elements; items are cut on
+ * multiples of 1024 elements inside a tensor), d_seg_x / d_seg_y = the tensors' input / output base pointers (may be equal:
+ * in place), d_params[tensor] = its quantisation parameters (all DEVICE memory). */
+typedef struct dpl_fake_quant_params {
+    const float* d_scale;          /* [n_channels] */
+    const int32_t* d_zero_point;   /* [n_channels] */
+    int64_t n_channels;            /* 1: per tensor */
+    int64_t inner;                 /* elements per channel row: channel c = (i / inner) % n_channels */
+    int32_t qlo, qhi;
+} dpl_fake_quant_params;
+int dpl_fake_quant_items(const dpl_work_item* d_items, int64_t n_items, const uint32_t* d_block_begin, int64_t n_blocks,
+                         const float* const* d_seg_x, float* const* d_seg_y, const dpl_fake_quant_params* d_params, dpl_stream_t s);
 
 /* ---- cosine-similarity partial sums (utils.py:273-278): d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a),
  *      sum(b*b) in fp64. */

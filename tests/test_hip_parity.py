@@ -852,3 +852,39 @@ def test_two_pipelines_share_a_plan(dev, monkeypatch, form):
         for got in (r1[k].cpu().numpy(), r2[len(batches) - 1 - k].cpu().numpy()):
             assert np.array_equal(got[..., 1:], want[k][..., 1:]), k
             assert _close(got[..., 0], want[k][..., 0]), k
+
+
+def test_fake_quant_set_launch_matches_per_tensor_launches(dev):
+    """dpl_fake_quant_items — a whole tensor set fake-quantised in ONE launch — against one dpl_fake_quant launch per tensor and
+    the oracle (ONNX opset-13 Q -> DQ, quantize.py:197-239), bit for bit: per-tensor and per-channel rows mixed, channel rows
+    that are / are not a multiple of four long (7 x 7 maps take the element-wise path), sizes that are no multiple of 1024 (a
+    workgroup's share ends inside a vector), uint8 and int8 grids with non-zero zero points, in place and out of place."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(61)
+    B = 3
+    shapes = [(16, 14, 14), (8, 7, 7), (5, 33, 3), (64, 56, 56), (1, 1000, 1), (12, 4, 4), (3, 224, 224)]
+    elems = [c * h * w for c, h, w in shapes]
+    plan = ops.TensorSetPlan(elems, B, dev)
+    xs, params, want = [], [], []
+    for t, (c, h, w) in enumerate(shapes):
+        x = (rng.standard_normal((B, c, h, w)) * (1 + t)).astype(np.float32)
+        per_channel = t % 2 == 0
+        signed = t % 3 != 0
+        qlo, qhi = (-128, 127) if signed else (0, 255)
+        nch = c if per_channel else 1
+        scale = (np.abs(rng.standard_normal(nch)) * 0.05 + 0.01).astype(np.float32)
+        zp = rng.integers(-5, 6, nch).astype(np.int32) if signed else rng.integers(0, 256, nch).astype(np.int32)
+        xs.append(torch.from_numpy(x).to(dev).reshape(B, -1))
+        params.append((torch.from_numpy(scale), torch.from_numpy(zp), h * w, qlo, qhi))
+        want.append(O.fake_quant_qdq(x, scale, zp, axis=1 if per_channel else None, signed=signed).reshape(B, -1))
+    fset = ops.FakeQuantSet(plan, params)
+    ys = fset(xs)
+    for t, (c, h, w) in enumerate(shapes):
+        sc, zp, inner, qlo, qhi = params[t]
+        one = ops.fake_quant(xs[t].view(B, c, h * w), sc, zp, qlo, qhi, axis=1 if sc.numel() > 1 else None)
+        assert np.array_equal(ys[t].cpu().numpy(), want[t]), t
+        assert np.array_equal(one.reshape(B, -1).cpu().numpy(), want[t]), t
+    again = [x.clone() for x in xs]
+    fset(again, out=again)                       # in place
+    for t in range(len(shapes)):
+        assert np.array_equal(again[t].cpu().numpy(), want[t]), t

@@ -76,7 +76,14 @@ struct TailArgs {
 // One pair, streamed: min / max, the exact log-scale histogram (ONE non-returning 64-bit LDS add per element) and the values
 // at or above the current threshold bin -> the wave's dense LDS queue -> the pair's list.  Leaves the per-wave ranges in
 // sh.red_*, the number of listed values in sh.cursor, the final threshold bin in sh.tail_j.
-__device__ __attribute__((noinline)) void stream_tail(const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
+// (Inlined: as a function of its own — round 3's stream_slice — its prologue saves two dozen callee-saved registers per lane to
+// scratch and restores them at the end: 97 MB written and 97 MB read per ResNet-50 batch, found in the WRITE_SIZE counter.)
+#ifdef DPL_TAIL_NOINLINE
+__device__ __attribute__((noinline)) void stream_tail(
+#else
+__device__ __forceinline__ void stream_tail(
+#endif
+const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
                                                       Shared& sh, dpl_octav_state* __restrict__ ctl, const bool adaptive) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const lptr_u64 l_packed = (lptr_u64)(lds_raw);

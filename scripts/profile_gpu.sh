@@ -1,18 +1,36 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): kernel-trace stats of the default bench line, then PMC passes (HBM traffic), each in its
-# own rocprofv3 run (never --pmc together with a trace domain).  Usage: scripts/profile_gpu.sh <tag>
+# Run on the GPU box (via gpurun): every number of the bench line from a committed duration.
+#   (i)   the default bench line: kernel-trace stats, then PMC passes (HBM traffic: FETCH_SIZE, WRITE_SIZE), each in its own
+#         rocprofv3 run (never --pmc together with a trace domain)
+#   (ii)  the +-10 % contrast-jitter mse sweep   (scripts/mse_run.py resnet50, DPL_BENCH_JITTER=0.1)
+#   (iii) the ViT-B/16 mse sweep                 (scripts/mse_run.py vit)
+# each of (ii), (iii): kernel stats + the two PMC passes -> traffic_<name>.json.  Usage: scripts/profile_gpu.sh <tag>
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --mse-jitter "" > $OUT/bench_stats.json 2> $OUT/stats.err
+BENCH="python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --mse-jitter"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH "" > $OUT/bench_stats.json 2> $OUT/stats.err
 python3 scripts/summarize_prof.py stats $OUT/stats $OUT/kernel_stats.md > /dev/null
+cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o bench -- python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --mse-jitter "" --fq-reps 0 --steps 2 --warmup 1 --mse-steps 1 > $OUT/bench_pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o bench -- $BENCH "" --fq-reps 0 --steps 2 --warmup 1 --mse-steps 1 > $OUT/bench_pmc_$C.json 2> $OUT/pmc_$C.err
   python3 scripts/summarize_prof.py pmc $OUT/pmc_$C $C $OUT/pmc_$C.json > /dev/null
 done
 python3 scripts/summarize_prof.py traffic $OUT/pmc_FETCH_SIZE.json $OUT/pmc_WRITE_SIZE.json $OUT/traffic.json
-cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 rm -rf $OUT/stats $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
-head -14 $OUT/kernel_stats.md; cat $OUT/traffic.json; tail -c 1500 $OUT/bench_stats.json
+sweep() {   # name, workload, batches, env...
+  N=$1; W=$2; NB=$3; shift 3
+  env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s_$N -o run -- python3 scripts/mse_run.py $W $NB 17 > $OUT/run_$N.log 2> $OUT/s_$N.err
+  python3 scripts/summarize_prof.py stats $OUT/s_$N $OUT/kernel_stats_$N.md > /dev/null
+  for C in FETCH_SIZE WRITE_SIZE; do
+    env "$@" rocprofv3 --pmc $C --output-format csv -d $OUT/p_${N}_$C -o run -- python3 scripts/mse_run.py $W $NB 17 > /dev/null 2> $OUT/p_${N}_$C.err
+    python3 scripts/summarize_prof.py pmc $OUT/p_${N}_$C $C $OUT/pmc_${N}_$C.json > /dev/null
+  done
+  python3 scripts/summarize_prof.py traffic $OUT/pmc_${N}_FETCH_SIZE.json $OUT/pmc_${N}_WRITE_SIZE.json $OUT/traffic_$N.json
+  rm -rf $OUT/s_$N $OUT/p_${N}_FETCH_SIZE $OUT/p_${N}_WRITE_SIZE $OUT/*.err
+}
+sweep jitter0.1 resnet50 64 DPL_BENCH_JITTER=0.1
+sweep vit vit 32 X=1
+head -12 $OUT/kernel_stats.md; cat $OUT/traffic.json | head -40; tail -c 1200 $OUT/bench_stats.json; tail -1 $OUT/run_jitter0.1.log $OUT/run_vit.log

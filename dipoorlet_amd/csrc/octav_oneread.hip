@@ -908,6 +908,9 @@ __device__ __forceinline__ void walk_pair(
     }
 }
 
+#ifndef DPL_TAIL_LDS_PAD
+#define DPL_TAIL_LDS_PAD 0   // (occupancy experiments: extra dynamic LDS per workgroup)
+#endif
 #include "octav_tail.hpp"
 
 // K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
@@ -1979,7 +1982,7 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
     if (j->tail) {
         if (j->n_multi != 0) return fail_msg("dpl_octav_oneread_stream: the exact-tail form takes single-slice pairs only");
-        hipLaunchKernelGGL(k_octav_tail, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kTailLdsB), (hipStream_t)s, j->d_slices,
+        hipLaunchKernelGGL(k_octav_tail, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kTailLdsB + DPL_TAIL_LDS_PAD), (hipStream_t)s, j->d_slices,
                            j->d_seg_ptrs, j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs,
                            TailArgs{j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords, j->d_pred, j->d_rescue_bm, j->d_missed,
                                     reinterpret_cast<unsigned long long*>(j->d_resc), j->dynamic_sym, j->max_iters, g_exact_fail_every});

@@ -590,13 +590,11 @@ def main():
         if not o:
             return None
         r, p = o["roofline"], o.get("prediction") or {}
-        b = {"frac": round(r["frac"], 4), "ms_per_batch": round(r["avg_batch_ms"], 4), "images_per_s": round(o["value"], 1),
-             "sample_ok": o["sample_ok"]}
+        b = {"frac": round(r["frac"], 4), "ms": round(r["avg_batch_ms"], 4), "ok": o["sample_ok"]}
         if r.get("traffic"):
             b["traffic_ratio"] = round(r["traffic"] / r["bytes_per_launch"], 4)
         if p:
-            b.update(listed=round(p["listed_share_of_elements"], 4), rescued_per_batch=round(p["pairs_missed"] / max(1, p["batches"]), 2),
-                     compaction_pairs=p["pairs_compaction"])
+            b.update(listed=round(p["listed_share_of_elements"], 4), rescued=round(p["pairs_missed"] / max(1, p["batches"]), 1))
         return b
     hist_roof = {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                  "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes, "avg_kernel_ms": hist_kern_ms}
@@ -610,42 +608,38 @@ def main():
     # The record's line: BASELINE.json's metric on its headline configuration, every headline scalar inside `roofline` / `config`
     # (the driver keeps those objects whole), under 2 KB.  Everything else (workload strings, prediction statistics, the e2e split)
     # is the `details` line printed BEFORE it.
-    roof = dict(mse["roofline"] if headline_mse else hist_roof)
+    roof = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (mse["roofline"] if headline_mse else hist_roof).items()}
     roof["mse"] = brief(mse)                                                     # BASELINE configs[2]: -A mse, N = 4096, images alike
     roof["mse_jitter"] = {k: brief(v) for k, v in mse_jitter.items()} or None    # ... with per-image contrast jitter
     roof["mse_feature_maps"] = {k: brief(v) for k, v in mse_real.items()} or None   # ... executor-produced ResNet-50 activations
     roof["mse_vit"] = brief(vit_mse)                                             # configs[4]'s workload on one GPU
     if fake_quant:
-        roof["fake_quant"] = {m: {"frac": round(fake_quant[m]["frac"], 4),
-                                  "frac_50MB_and_more": round(fake_quant[m]["tensors_of_50MB_and_more"]["frac"], 4)}
-                              for m in ("per_tensor", "per_channel")}
-        if "set_launch" in fake_quant:
-            roof["fake_quant"]["set_launch"] = {m: round(v["frac"], 4) for m, v in fake_quant["set_launch"].items()}
+        # per mode: frac of one launch per tensor over the set, ... over the tensors of >= 50 MB, ... of the set in ONE launch
+        roof["fake_quant"] = {m: [round(fake_quant[m]["frac"], 4), round(fake_quant[m]["tensors_of_50MB_and_more"]["frac"], 4),
+                                  round(fake_quant["set_launch"][m]["frac"], 4)] for m in ("per_tensor", "per_channel")}
+        roof["fake_quant"]["columns"] = "launch per tensor | tensors >= 50 MB | one set launch"
     if e2e and "error" not in e2e:
-        roof["e2e"] = {"hist_calib_images_per_s": round(e2e["images_per_s_calibration"], 1),
-                       "hist_forward_steady_images_per_s": round(e2e["split"].get("forward_steady_images_per_s", 0.0), 1)}
+        # images/s of calibration (fresh CLI process over .bin files) | of the network forward in steady state
+        roof["e2e"] = {"hist": [round(e2e["images_per_s_calibration"]), round(e2e["split"].get("forward_steady_images_per_s", 0.0))]}
         if "mse" in e2e and "error" not in e2e["mse"]:
-            roof["e2e"].update(mse_calib_images_per_s=round(e2e["mse"]["images_per_s_calibration"], 1),
-                               mse_forward_steady_images_per_s=round(e2e["mse"]["split"].get("forward_steady_images_per_s", 0.0), 1),
-                               mse_statistics_gpu_s=round(e2e["mse"]["split"].get("statistics_gpu_s", 0.0), 4))
+            roof["e2e"]["mse"] = [round(e2e["mse"]["images_per_s_calibration"]), round(e2e["mse"]["split"].get("forward_steady_images_per_s", 0.0))]
+            roof["e2e"]["mse_statistics_gpu_s"] = round(e2e["mse"]["split"].get("statistics_gpu_s", 0.0), 4)
     out = {
         # BASELINE.json's metric; images/s is `value`, the achieved HBM GB/s of the dominant kernel is `roofline.achieved`
         "metric": "calibration images/sec (whole node) + achieved HBM GB/s, ResNet-50 ONNX N=%d, -A %s"
                   % ((N_MSE, "mse") if headline_mse else (N_HIST, "hist")),
-        "value": mse["value"] if headline_mse else hist_rate, "unit": "images/s", "n_gpus": world,
+        "value": round(mse["value"] if headline_mse else hist_rate, 1), "unit": "images/s", "n_gpus": world,
         "steps": a.mse_steps if headline_mse else a.steps, "warmup": a.warmup,
-        "ms_per_step": mse["ms_per_step"] if headline_mse else dt_hist / a.steps * 1e3,
+        "ms_per_step": round(mse["ms_per_step"] if headline_mse else dt_hist / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": (f"ResNet-50 activation set (T={T}, {E} fp32 elems/img), -A mse (OCTAV), N={N_MSE} per GPU in batches of {B}, cold sweeps"
                                 if headline_mse else
-                                f"ResNet-50 ONNX activation set (T={T} tensors, {E} fp32 elems/img), -A hist --bins {a.bins}, "
-                                f"N={N_HIST} images per GPU in {n_hist_batches} batches of {B}: range pass + histogram pass + percentile clip per step"),
-                   "batch": B, "bins": a.bins, "algo": a.algo, "images_per_step_per_gpu": N_MSE if headline_mse else N_HIST,
-                   "resident_pool_batches": n_pool, "device": devname,
-                   "hist_checksum_ok": hist_checksum == E * N_HIST * world,
+                                f"ResNet-50 ONNX activation set (T={T}, {E} fp32 elems/img), -A hist --bins {a.bins}, N={N_HIST} per GPU in "
+                                f"{n_hist_batches} batches of {B}: range pass + histogram pass + percentile clip"),
+                   "device": devname, "hist_checksum_ok": hist_checksum == E * N_HIST * world,
                    "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
                    "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if use_dist else None,
-                   "per_rank_images_per_s": [round(r, 1) for r in per_rank_rates],
+                   "per_rank_images_per_s": [round(r) for r in per_rank_rates],
                    "collectives_ms_per_sweep": coll_ms},
         "roofline": roof,
     }
@@ -653,13 +647,14 @@ def main():
         if world == 1 and a.cpu_seconds > 0:
             cb = cpu_baseline(a.algo, a.bins, cpu_sample, a.cpu_seconds)
             full["cpu_baseline"] = dict(cb)
-            cb["sample"] = cb["sample"][:160]
-            out["cpu_baseline"] = cb
+            out["cpu_baseline"] = {"value": round(cb["value"], 2), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": cb["sample"].split(",")[0] + f", -A {a.algo}, C oracle + OpenMP",
+                                   "numpy_1_thread": round(cb["numpy_single_thread_images_per_s"], 2)}
         else:
             out["cpu_baseline"] = None
         print(json.dumps({"details": full}), flush=True)
         line = json.dumps(out)
-        assert len(line) < 4000, len(line)
+        assert len(line) < 2048, len(line)      # (the driver keeps the last 2 000 characters of stdout as `tail`)
         print(line, flush=True)
     if use_dist:
         dist.destroy_process_group()

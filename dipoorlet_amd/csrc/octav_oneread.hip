@@ -911,7 +911,11 @@ __device__ __forceinline__ void walk_pair(
 #ifndef DPL_TAIL_LDS_PAD
 #define DPL_TAIL_LDS_PAD 0   // (occupancy experiments: extra dynamic LDS per workgroup)
 #endif
+#ifdef DPL_TAIL_AB   // (A/B aid, scripts/ab_run.sh: another version of the header, kept untracked in scripts/ab/)
+#include "../../scripts/ab/octav_tail_prev.hpp"
+#else
 #include "octav_tail.hpp"
+#endif
 
 // K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
 // then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.

@@ -21,7 +21,7 @@
 //   else    the pair is RESCUED exactly as in round 3: its exact bracket from the histogram, a re-read of that pair alone
 //           (k_octav_rescue_gather), the verified walk (k_octav_walk_rescue), the compaction route behind that.
 // Where theta comes from: per tensor the LOWEST bin any of its pairs asked for in the last two epochs of batches (a pair asks
-// for the bin above which 1/128 of its elements lie: the fixed point of a thin-tailed — uniform — pair has ~0.3 % of the pair
+// for the bin above which 1/256 of its elements lie: the fixed point of a thin-tailed — uniform — pair has ~0.3 % of the pair
 // above it, of a normal one 0.01 %), and it is RAISED ON THE FLY when a wave lists more than its budget (a brighter image, or
 // no history at all: the first batch of a run starts at bin 1): that wave alone takes the quantile of the workgroup's
 // histogram so far and publishes the new bin in LDS.  theta only ever rises inside a pair, so the list holds every value
@@ -29,7 +29,7 @@
 #pragma once
 
 #ifndef DPL_TAIL_TAU_SHIFT
-#define DPL_TAIL_TAU_SHIFT 7      // a pair asks for the bin above which n >> 7 of its n elements lie
+#define DPL_TAIL_TAU_SHIFT 8      // a pair asks for the bin above which n >> 8 of its n elements lie (measured: 7 -> 8 -2 %, 9 the same with four times the rescues at +-30 %)
 #endif
 #ifndef DPL_TAIL_BUDGET_SHIFT
 #define DPL_TAIL_BUDGET_SHIFT 6   // a wave may list kTailAllow0 + (elements it has seen >> 6) values before it raises theta

@@ -84,9 +84,9 @@ def sweep(n_cases, seed, sizes):
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             want = O.octav_scale(x, O.octav_unsigned(x.min(), dyn))
-        # thresholds: the quantile the kernel asks for (1/128), one a history of brighter / dimmer images would leave
+        # thresholds: the quantile the kernel asks for (1/256), one a history of brighter / dimmer images would leave
         # (1/32 .. 1/1024), any bin at all, and bins around the fixed point itself (where a too-high threshold bites)
-        bins = {"tau": h.theta_bin(1.0 / 128), "hist": h.theta_bin(2.0 ** -rng.uniform(5, 10)),
+        bins = {"tau": h.theta_bin(1.0 / 256), "hist": h.theta_bin(2.0 ** -rng.uniform(5, 10)),
                 "any": int(rng.integers(1, M.LOG_NB - 1)),
                 "near": max(1, min(M.LOG_NB - 2, M.log_bin(want) + int(rng.integers(-40, 8)))) if np.isfinite(want) else 1}
         for mode, J in bins.items():

@@ -1115,11 +1115,14 @@ __global__ __launch_bounds__(kExactBlock, DPL_EXACT_WAVES) void k_octav_exact(dp
 int g_exact_fail_every = 0;   // dpl_test_hook_exact_fail_every
 int g_rescue_fail_every = 0;  // dpl_test_hook_rescue_fail_every
 
+#ifndef DPL_RESCUE_GRID
+#define DPL_RESCUE_GRID 512
+#endif
 // (octav_oneread.hip) gather pass of the rescue: see k_octav_rescue_gather
 int dpl_octav_rescue_gather_launch(const uint32_t* d_missed, dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans,
                                    const float* const* d_seg_ptrs, const uint32_t* d_bm_rows, const uint64_t* d_pair_base,
                                    float* d_list1, hipStream_t st) {
-    hipLaunchKernelGGL(k_octav_rescue_gather, dim3(512), dim3(kBlock), (size_t)kBlock * kQueueStride * sizeof(uint32_t), st,
+    hipLaunchKernelGGL(k_octav_rescue_gather, dim3(DPL_RESCUE_GRID), dim3(kBlock), (size_t)kBlock * kQueueStride * sizeof(uint32_t), st,
                        d_missed, d_states + n_pairs, d_states, d_pair_spans, d_seg_ptrs, d_bm_rows, d_pair_base, d_list1);
     DPL_LAUNCH_CHECK("k_octav_rescue_gather");
     return 0;

@@ -90,7 +90,10 @@ constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a
 #endif
 constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
 constexpr uint32_t kMaxCluster = 64;
-constexpr unsigned kRescueGrid = 512;   // workgroups of the rescue's persistent kernels
+#ifndef DPL_RESCUE_GRID
+#define DPL_RESCUE_GRID 512
+#endif
+constexpr unsigned kRescueGrid = DPL_RESCUE_GRID;   // workgroups of the rescue's persistent kernels
 // The prediction row of a tensor (d_pred): the bitmap of the bins to gather (kLogWords words, at most kMaxFlag bits set) and,
 // per word, the number of set bits in the words below it — the RANK of a gathered bin is a table index everywhere below.
 constexpr int kMaxFlag = 256;

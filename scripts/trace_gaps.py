@@ -8,7 +8,8 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         k = re.sub(r".*::(k_\w+).*", r"\1", r["Kernel_Name"])
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, r.get("Queue_Id", "?")))
 rows.sort()
-ones = [i for i, r in enumerate(rows) if r[2] == "k_octav_oneread"]
+main = "k_octav_tail" if any(r[2] == "k_octav_tail" for r in rows) else "k_octav_oneread"
+ones = [i for i, r in enumerate(rows) if r[2] == main]
 ones = ones[len(ones) // 2:]          # the second (warm) run
 gaps, between = [], defaultdict(list)
 for a, b in zip(ones[:-1], ones[1:]):
@@ -19,7 +20,7 @@ for a, b in zip(ones[:-1], ones[1:]):
         if r[3] == q:                 # same queue as the streaming kernel: the caller's stream
             between[r[2]].append((r[1] - r[0]) / 1e3)
 dur = [(rows[i][1] - rows[i][0]) / 1e3 for i in ones]
-print(f"k_octav_oneread: {len(ones)} launches, mean {sum(dur) / len(dur):.1f} us; gap to the next one: mean {sum(gaps) / len(gaps):.1f} us "
+print(f"{main}: {len(ones)} launches, mean {sum(dur) / len(dur):.1f} us; gap to the next one: mean {sum(gaps) / len(gaps):.1f} us "
       f"(min {min(gaps):.1f}, max {max(gaps):.1f})")
 for k, v in sorted(between.items()):
     print(f"  on the same queue in the gap: {k:28s} {len(v) / len(gaps):.2f} per batch, mean {sum(v) / len(v):.1f} us")

@@ -10,12 +10,15 @@ TAG=${1:-r04}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
+# counters for this library's kernels only (collecting them for every torch kernel made a torch.rand launch of the jittered set crash
+# inside the profiler)
+KERNELS="k_octav|k_abs_hist|k_minmax|k_hist|k_fake_quant"
 BENCH="python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --mse-jitter"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH "" > $OUT/bench_stats.json 2> $OUT/stats.err
 python3 scripts/summarize_prof.py stats $OUT/stats $OUT/kernel_stats.md > /dev/null
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o bench -- $BENCH "" --fq-reps 0 --steps 2 --warmup 1 --mse-steps 1 > $OUT/bench_pmc_$C.json 2> $OUT/pmc_$C.err
+  rocprofv3 --pmc $C --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/pmc_$C -o bench -- $BENCH "" --fq-reps 0 --steps 2 --warmup 1 --mse-steps 1 > $OUT/bench_pmc_$C.json 2> $OUT/pmc_$C.err
   python3 scripts/summarize_prof.py pmc $OUT/pmc_$C $C $OUT/pmc_$C.json > /dev/null
 done
 python3 scripts/summarize_prof.py traffic $OUT/pmc_FETCH_SIZE.json $OUT/pmc_WRITE_SIZE.json $OUT/traffic.json
@@ -25,7 +28,7 @@ sweep() {   # name, workload, batches, env...
   env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s_$N -o run -- python3 scripts/mse_run.py $W $NB 17 > $OUT/run_$N.log 2> $OUT/s_$N.err
   python3 scripts/summarize_prof.py stats $OUT/s_$N $OUT/kernel_stats_$N.md > /dev/null
   for C in FETCH_SIZE WRITE_SIZE; do
-    env "$@" rocprofv3 --pmc $C --output-format csv -d $OUT/p_${N}_$C -o run -- python3 scripts/mse_run.py $W $NB 17 > /dev/null 2> $OUT/p_${N}_$C.err
+    env "$@" rocprofv3 --pmc $C --kernel-include-regex "$KERNELS" --output-format csv -d $OUT/p_${N}_$C -o run -- python3 scripts/mse_run.py $W $NB 17 > /dev/null 2> $OUT/p_${N}_$C.err
     python3 scripts/summarize_prof.py pmc $OUT/p_${N}_$C $C $OUT/pmc_${N}_$C.json > /dev/null
   done
   python3 scripts/summarize_prof.py traffic $OUT/pmc_${N}_FETCH_SIZE.json $OUT/pmc_${N}_WRITE_SIZE.json $OUT/traffic_$N.json

@@ -342,8 +342,10 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
     const uint32_t tid = threadIdx.x;
     const float* xs = x + e0;
     float* ys = y + e0;
-    const bool vec = ((((uintptr_t)xs | (uintptr_t)ys) & 15u) == 0u) && (n_channels == 1u || (inner & 3u) == 0u);
-    if (!vec) {   // unaligned views / rows that are no multiple of four long (7 x 7 maps): element by element, same bookkeeping
+    // 16-byte vectors whatever the rows' length: a vector of a row that is no multiple of four long (7 x 7 maps: 49) may straddle two
+    // channels — it carries the parameters of both and picks per element (rows shorter than a vector: element by element)
+    const bool vec = ((((uintptr_t)xs | (uintptr_t)ys) & 15u) == 0u) && (n_channels == 1u || inner >= 4u);
+    if (!vec) {   // unaligned views / rows shorter than a vector: element by element, same bookkeeping
         const uint64_t e = e0 + tid;
         uint32_t col = (uint32_t)(e % inner), c = (uint32_t)((e / inner) % n_channels);
         const uint32_t step_cols = (uint32_t)kBlock % inner, step_ch = ((uint32_t)kBlock / inner) % n_channels;
@@ -362,37 +364,39 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
     const uint32_t nvec = cnt >> 2;
     gptr_f4 xv = (gptr_f4)xs;
     gptr_f4w yv = (gptr_f4w)ys;
-    if (n_channels == 1u) {
-        const float sc = scale_p[0], zp = (float)zp_p[0];
-        for (uint32_t i0 = tid; i0 < nvec; i0 += 4 * kBlock) {
-            f4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = i0 + u * kBlock < nvec ? __builtin_nontemporal_load(xv + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (i0 + u * kBlock < nvec) {
-                    v[u].x = fq_one(v[u].x, sc, zp, qlo, qhi);
-                    v[u].y = fq_one(v[u].y, sc, zp, qlo, qhi);
-                    v[u].z = fq_one(v[u].z, sc, zp, qlo, qhi);
-                    v[u].w = fq_one(v[u].w, sc, zp, qlo, qhi);
-                    __builtin_nontemporal_store(v[u], yv + i0 + u * kBlock);
-                }
-            }
-        }
-    } else {
-        // the lane's first vector: one division; then (col, c) advance by the per-step constants
+    // Two register sets in rotation (as stream_span): the NEXT four vectors of a lane — and, per channel, their parameters — are
+    // requested before the current four are computed and stored: eight loads in flight per lane, and a parameter look-up never
+    // sits between a vector's arrival and its use.
+    const bool per_channel = n_channels != 1u;
+    uint32_t col = 0u, c = 0u, step_cols = 0u, step_ch = 0u;
+    if (per_channel) {   // the lane's first vector: one division; then (col, c) advance by the per-step constants
         const uint64_t e = e0 + 4ull * tid;
-        uint32_t col = (uint32_t)(e % inner), c = (uint32_t)((e / inner) % n_channels);
-        const uint32_t step_cols = (4u * kBlock) % inner, step_ch = ((4u * kBlock) / inner) % n_channels;
-        for (uint32_t i0 = tid; i0 < nvec; i0 += 4 * kBlock) {
-            f4 v[4];
-            float scu[4];
-            int32_t zpu[4];
+        col = (uint32_t)(e % inner);
+        c = (uint32_t)((e / inner) % n_channels);
+        step_cols = (4u * kBlock) % inner;
+        step_ch = ((4u * kBlock) / inner) % n_channels;
+    }
+    const float sc1 = scale_p[0], zp1 = (float)zp_p[0];
+    const bool straddle = per_channel && (inner & 3u) != 0u;   // (uniform) a vector may end in the next channel's row
+    struct Set {
+        f4 v[4];
+        float sc[4], sc2[4];
+        int32_t zp[4], zp2[4];
+        uint32_t left[4];   // elements of the vector that still belong to the first channel's row (>= 4: all of them)
+    };
+    auto load = [&](Set& st, uint32_t i0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                v[u] = i0 + u * kBlock < nvec ? __builtin_nontemporal_load(xv + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
-                scu[u] = scale_p[c];   // (requested with the data: a look-up at the point of use waits a cache round trip per vector)
-                zpu[u] = zp_p[c];
+        for (int u = 0; u < 4; ++u) {
+            st.v[u] = i0 + u * kBlock < nvec ? __builtin_nontemporal_load(xv + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
+            if (per_channel) {   // (uniform)
+                st.sc[u] = scale_p[c];
+                st.zp[u] = zp_p[c];
+                if (straddle) {
+                    const uint32_t cn = c + 1u < n_channels ? c + 1u : 0u;
+                    st.sc2[u] = scale_p[cn];
+                    st.zp2[u] = zp_p[cn];
+                    st.left[u] = inner - col;
+                }
                 col += step_cols;
                 c += step_ch;
                 if (col >= inner) {
@@ -401,17 +405,47 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
                 }
                 if (c >= n_channels) c -= n_channels;
             }
+        }
+    };
+    auto eat = [&](Set& st, uint32_t i0) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (i0 + u * kBlock < nvec) {
-                    const float sc = scu[u], zp = (float)zpu[u];
-                    v[u].x = fq_one(v[u].x, sc, zp, qlo, qhi);
-                    v[u].y = fq_one(v[u].y, sc, zp, qlo, qhi);
-                    v[u].z = fq_one(v[u].z, sc, zp, qlo, qhi);
-                    v[u].w = fq_one(v[u].w, sc, zp, qlo, qhi);
-                    __builtin_nontemporal_store(v[u], yv + i0 + u * kBlock);
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * kBlock < nvec) {
+                const float sc = per_channel ? st.sc[u] : sc1, zp = per_channel ? (float)st.zp[u] : zp1;
+                if (straddle) {   // (uniform)
+                    const float scb = st.sc2[u], zpb = (float)st.zp2[u];
+                    const uint32_t l = st.left[u];
+                    st.v[u].x = fq_one(st.v[u].x, sc, zp, qlo, qhi);
+                    st.v[u].y = fq_one(st.v[u].y, l > 1u ? sc : scb, l > 1u ? zp : zpb, qlo, qhi);
+                    st.v[u].z = fq_one(st.v[u].z, l > 2u ? sc : scb, l > 2u ? zp : zpb, qlo, qhi);
+                    st.v[u].w = fq_one(st.v[u].w, l > 3u ? sc : scb, l > 3u ? zp : zpb, qlo, qhi);
+                } else {
+                    st.v[u].x = fq_one(st.v[u].x, sc, zp, qlo, qhi);
+                    st.v[u].y = fq_one(st.v[u].y, sc, zp, qlo, qhi);
+                    st.v[u].z = fq_one(st.v[u].z, sc, zp, qlo, qhi);
+                    st.v[u].w = fq_one(st.v[u].w, sc, zp, qlo, qhi);
                 }
+                __builtin_nontemporal_store(st.v[u], yv + i0 + u * kBlock);
             }
+        }
+    };
+    if (tid < nvec) {
+        Set A, B;
+        uint32_t i0 = tid;
+        load(A, i0);
+        for (;;) {
+            uint32_t nx = i0 + 4 * kBlock;
+            const bool hb = nx < nvec;
+            if (hb) load(B, nx);
+            eat(A, i0);
+            if (!hb) break;
+            i0 = nx;
+            nx = i0 + 4 * kBlock;
+            const bool ha = nx < nvec;
+            if (ha) load(A, nx);
+            eat(B, i0);
+            if (!ha) break;
+            i0 = nx;
         }
     }
     const uint32_t t = (nvec << 2) + tid;   // (a chunk that is no multiple of four long: the tensor's last elements)

@@ -42,7 +42,7 @@ def _upload_struct_array(arr, n, device):
 
 # Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
 # faster from HBM than many small items; the histogram wants a little more latency hiding).
-DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512, "fq": 1024, "fqc": 8192}   # measured optima per kernel family
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512, "fq": 1024}   # measured optima per kernel family
 
 
 def _blocks_for(kind):
@@ -91,7 +91,7 @@ class TensorSetPlan:
         return [(t, 0, e * self.batch, t) for t, e in enumerate(self.elems)]
 
     def work(self, kind, per_image=False):
-        """WorkSet for kernel family `kind` in {'minmax', 'hist', 'octav', 'cos', 'fq', 'fqc'}."""
+        """WorkSet for kernel family `kind` in {'minmax', 'hist', 'octav', 'cos', 'fq'}."""
         nb = None if self.chunk else max(1, min(_blocks_for(kind), (self.total + 4095) // 4096))
         key = (per_image, nb)
         w = self._work.get(key)
@@ -715,10 +715,9 @@ class FakeQuantSet:
             rows[t] = _hip.FakeQuantParams(scale.data_ptr(), zp.data_ptr(), scale.numel(), int(inner) if scale.numel() > 1 else 1,
                                            int(qlo), int(qhi))
         self.d_params = _upload_struct_array(rows, plan.T, plan.device)
-        # the balanced partition over the batch's tensors (slot = tensor).  Measured on the ResNet-50 set (scripts/fq_set_blocks.py):
-        # per-tensor rows stream best from few large shares (0.73 of 8 TB/s at 512 - 1024 workgroups, 0.70 at 8192); per-channel
-        # rows wait for their parameter look-ups and want many workgroups to hide that (0.24 at 512, 0.63 at 8192)
-        self.work = plan.work("fqc" if any(r.n_channels > 1 for r in rows) else "fq")
+        # the balanced partition over the batch's tensors (slot = tensor): 1024 workgroups, measured on the ResNet-50 set
+        # (scripts/fq_set_blocks.py: 512 .. 8192 within a few per cent for per-tensor and per-channel rows alike)
+        self.work = plan.work("fq")
         self._out_cache = {}
 
     def __call__(self, tensors, out=None):

@@ -9,7 +9,7 @@ xs = synth_activations(spec, B, dev, seed=1)
 ys = [torch.empty_like(x) for x in xs]
 shapes = resnet50_tensor_shapes()
 for nb in (512, 1024, 2048, 4096, 8192):
-    os.environ["DPL_BLOCKS_FQ"] = os.environ["DPL_BLOCKS_FQC"] = str(nb)
+    os.environ["DPL_BLOCKS_FQ"] = str(nb)
     plan = ops.TensorSetPlan(elems, B, dev)
     for mode in ("t", "c"):
         prm = [((torch.full((1,), .05), torch.zeros(1, dtype=torch.int32), 1, -128, 127) if mode == "t" else
@@ -22,3 +22,12 @@ for nb in (512, 1024, 2048, 4096, 8192):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         print(nb, mode, f"{ms:.3f} ms  {8 * sum(elems) * B / ms / 1e6 / 8000:.3f}")
+
+big = torch.randn(851_000_000, device=dev); out = torch.empty_like(big)
+for _ in range(2): out.copy_(big)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5): out.copy_(big)
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 5
+print(f"torch copy of 3.4 GB: {ms:.3f} ms  {8 * big.numel() / ms / 1e6 / 8000:.3f} of 8 TB/s (read + write)")

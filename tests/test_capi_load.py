@@ -159,3 +159,16 @@ def test_oneread_job_struct_layout_matches_the_header(tmp_path):
         assert int(out[f]) == getattr(_hip.OctavOnereadJob, f).offset, f
     assert int(out["sizeof"]) == C.sizeof(_hip.OctavOnereadJob)
     assert out["state"].split() == [str(C.sizeof(_hip.OctavState)), str(_hip.OctavState.mode.offset), str(_hip.OctavState.len0.offset)]
+
+
+def test_integration_md_job_struct_matches_the_binding():
+    """INTEGRATION.md §B writes dpl_octav_oneread_job out field by field for a maintainer who binds the C ABI by hand: the
+    listing must be the binding's (which test_job_struct_layout holds to the C compiler's)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = text[text.index("class Job(ctypes.Structure):"):text.index("assert ctypes.sizeof(Job)")]
+    listed = re.findall(r'\("(\w+)", (P|I64|I32|F32)\)', block)
+    kinds = {"P": C.c_void_p, "I64": C.c_int64, "I32": C.c_int32, "F32": C.c_float}
+    assert [(n, kinds[k]) for n, k in listed] == [(f[0], f[1]) for f in _hip.OctavOnereadJob._fields_]
+    assert "sizeof(Job) == %d" % C.sizeof(_hip.OctavOnereadJob) in text

@@ -16,7 +16,9 @@ batches of 32 through ops.octav_batch (one-read form) + the per-tensor clip — 
 
 `value` is whole-job images/s of the hist sweep; `roofline` is the hist kernel's (duration by HIP events on the launch
 stream inside the timed region) and carries the other objects' headline scalars (`roofline.mse` = configs[2], `.mse_jitter`,
-`.mse_feature_maps`, `.mse_vit`, `.fake_quant`, `.e2e`); `cpu_baseline` times the CPU oracle (a port of the reference's
+`.mse_feature_maps`, `.mse_vit`, `.fake_quant` = per mode [one launch per tensor over the set, ... over the tensors >= 50 MB,
+the set in one launch], `.e2e` = per algorithm [calibration images/s of a fresh CLI process, images/s of the network forward]);
+`cpu_baseline` times the CPU oracle (a port of the reference's
 arithmetic) on a bounded sample of the same activations on the host cores of this box, rank 0, N = 1 only.
 TWO lines are printed: `{"details": {...}}` (every object in full: workload strings, prediction statistics, the e2e split)
 and then the record's line (< 2 KB).
@@ -614,10 +616,9 @@ def main():
     roof["mse_feature_maps"] = {k: brief(v) for k, v in mse_real.items()} or None   # ... executor-produced ResNet-50 activations
     roof["mse_vit"] = brief(vit_mse)                                             # configs[4]'s workload on one GPU
     if fake_quant:
-        # per mode: frac of one launch per tensor over the set, ... over the tensors of >= 50 MB, ... of the set in ONE launch
+        # per mode: [frac of one launch per tensor over the set, ... over the tensors of >= 50 MB, ... of the set in ONE launch]
         roof["fake_quant"] = {m: [round(fake_quant[m]["frac"], 4), round(fake_quant[m]["tensors_of_50MB_and_more"]["frac"], 4),
                                   round(fake_quant["set_launch"][m]["frac"], 4)] for m in ("per_tensor", "per_channel")}
-        roof["fake_quant"]["columns"] = "launch per tensor | tensors >= 50 MB | one set launch"
     if e2e and "error" not in e2e:
         # images/s of calibration (fresh CLI process over .bin files) | of the network forward in steady state
         roof["e2e"] = {"hist": [round(e2e["images_per_s_calibration"]), round(e2e["split"].get("forward_steady_images_per_s", 0.0))]}
@@ -648,7 +649,7 @@ def main():
             cb = cpu_baseline(a.algo, a.bins, cpu_sample, a.cpu_seconds)
             full["cpu_baseline"] = dict(cb)
             out["cpu_baseline"] = {"value": round(cb["value"], 2), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                   "sample": cb["sample"].split(",")[0] + f", -A {a.algo}, C oracle + OpenMP",
+                                   "sample": cb["sample"].split(" (")[0] + f" of the same set, -A {a.algo}, C oracle + OpenMP",
                                    "numpy_1_thread": round(cb["numpy_single_thread_images_per_s"], 2)}
         else:
             out["cpu_baseline"] = None

@@ -226,18 +226,21 @@ def test_bias_correction_matches_sequential_definition(workdir):
     for node in targets:
         clip = {k: [np.copy(v[0]), np.copy(v[1])] for k, v in {**a, **w}.items()}
         gq, _ = quant_graph(ref, clip, args)
-        fp_o = s_fp.run_named(inp, [node.output[0]])[0].double()
-        q_o = gq.make_session().run_named(inp, [node.output[0]])[0].double()
+        # (in chunks of BATCH images, as bias_correction walks the set: the library picks its convolution kernels by shape, and
+        # the same shapes give the same activations on both sides)
+        def chunked(sess, name):
+            return torch.cat([sess.run_named({k: v[i:i + BATCH] for k, v in inp.items()}, [name])[0] for i in range(0, N, BATCH)]).double()
+        fp_o = chunked(s_fp, node.output[0])
+        q_o = chunked(gq.make_session(), node.output[0])
         d = (fp_o - q_o)
         diff = d.mean(dim=(0, 2, 3)) if node.op_type == "Conv" else d.mean(0)
         bname = node.input[2]
         want = (ref.get_initializer(bname) + diff.float().cpu().numpy()).astype(np.float32)
         got = g_bc.get_initializer(bname)
-        # The two computations run the convolutions at different batch sizes (chunks of BATCH vs. all N images, or one image
-        # at a time when the executor's self-check rejects batching on a box): activations equal to 6e-7, and a flipped
-        # rounding step of the fake-quantised network moves a bias by ~4e-5.  So that this sensitivity does not COMPOUND over
-        # the layers (and the bound can stay the same at every layer: a wrong correction at layer 5 must not pass), the
-        # sequential definition continues from the PRODUCT's corrected bias: every layer is checked on the same network.
+        # A flipped rounding step of the fake-quantised network moves a bias by ~4e-5.  So that this sensitivity does not
+        # COMPOUND over the layers (and the bound can stay the same at every layer: a wrong correction at layer 5 must not
+        # pass), both sides run the convolutions at the same batch sizes and the sequential definition continues from the
+        # PRODUCT's corrected bias: every layer is checked on the same network.
         assert np.allclose(got, want, rtol=1e-3, atol=2e-4), (node.name, np.abs(got - want).max())
         assert np.abs(got - g.get_initializer(bname)).max() > 0  # something was corrected
         ref.set_initializer(bname, got.astype(np.float32))

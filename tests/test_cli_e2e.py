@@ -237,11 +237,13 @@ def test_bias_correction_matches_sequential_definition(workdir):
         bname = node.input[2]
         want = (ref.get_initializer(bname) + diff.float().cpu().numpy()).astype(np.float32)
         got = g_bc.get_initializer(bname)
-        # A flipped rounding step of the fake-quantised network moves a bias by ~4e-5.  So that this sensitivity does not
-        # COMPOUND over the layers (and the bound can stay the same at every layer: a wrong correction at layer 5 must not
-        # pass), both sides run the convolutions at the same batch sizes and the sequential definition continues from the
-        # PRODUCT's corrected bias: every layer is checked on the same network.
-        assert np.allclose(got, want, rtol=1e-3, atol=2e-4), (node.name, np.abs(got - want).max())
+        # A flipped rounding step of the fake-quantised network moves a bias by ~4e-5 (the walk fixes a corrected layer's
+        # quantised output up in place, q_out + diff, where this definition recomputes conv + (bias + diff): equal to a few
+        # 1e-7, enough to flip a rounding here and there downstream; seen: up to 2.5e-4 at one layer on one box).  So that this
+        # sensitivity does not COMPOUND over the layers — the bound stays the same at every layer, a few per cent of a typical
+        # correction (1e-2 .. 1e-1): a wrong correction at layer 5 must not pass — both sides run the convolutions at the same
+        # batch sizes and the sequential definition continues from the PRODUCT's corrected bias.
+        assert np.allclose(got, want, rtol=1e-3, atol=4e-4), (node.name, np.abs(got - want).max())
         assert np.abs(got - g.get_initializer(bname)).max() > 0  # something was corrected
         ref.set_initializer(bname, got.astype(np.float32))
 

@@ -274,9 +274,13 @@ const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
 //     per lane and a DPP sum, no exchange, no barrier;
 //   * lists beyond that (a cold start, a pair much brighter than its tensor's history) take the round-3 shape: rows spread over
 //     the workgroup, partial sums exchanged through LDS.
-constexpr int kSurvVec = 5;                          // 16-byte vectors per lane a wave holds the surviving values in
-constexpr uint32_t kSurvCap = kSurvVec * 4 * kWave;  // 1280 values
-static_assert(kTailLdsB >= 3072 + (int)kSurvCap * 4, "group totals (3 KiB) + the survivors' staging area share the queues' space");
+#ifndef DPL_TAIL_SURV_VEC
+#define DPL_TAIL_SURV_VEC 5
+#endif
+constexpr int kSurvVec = DPL_TAIL_SURV_VEC;          // 16-byte vectors per lane a wave holds the surviving values in
+constexpr uint32_t kFitCap = kSurvVec * 4 * kWave;   // values one wave's registers hold (a list this short is loaded there whole)
+// ... and what the compaction's staging area holds (group totals, 3 KiB, + the staging area share the queues' space)
+constexpr uint32_t kSurvCap = kFitCap * 4 <= (uint32_t)(kTailLdsB - 3072) ? kFitCap : (uint32_t)(kTailLdsB - 3072) / 4;
 
 template <int kVecT>
 __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t tensor, unsigned char* lds_raw, Shared& sh,
@@ -301,7 +305,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cursor);
     const uint32_t n_rows = (L + 1023u) >> 10;
-    const bool fits = L <= kSurvCap;
+    const bool fits = L <= kFitCap;
     // ONE register array, two layouts: the workgroup's rows of 1024 values (a list that does not fit a wave), or — in its first
     // kSurvVec vectors, wave 0 only — all surviving values (entry (u * 64 + lane) * 4 ...)
     f4 v[kVecT];

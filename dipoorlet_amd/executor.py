@@ -469,11 +469,12 @@ class GraphSession(ActivationSession):
             self.consts, self.device = real_consts, real_device
 
     def _infer(self):
-        """Every tensor's per-image shape (replaces onnx shape inference): a pass over meta tensors where the graph allows
-        it — a real batch-1 forward on the device makes MIOpen load / choose kernels for a batch size no calibration batch
-        uses: 0.2 - 0.3 s of a fresh process — else one batch-1 forward on zeros."""
+        """Every tensor's per-image shape (replaces onnx shape inference): one batch-1 forward on zeros (0.3 s of a fresh
+        process on the device: MIOpen loads / chooses kernels for batch 1).  DPL_INFER_META=1: a pass over meta tensors instead —
+        no kernels, but the first meta call imports torch's reference decompositions (0.5 s measured: slower in a fresh
+        process; worth it where torch._refs is loaded anyway)."""
         env = None
-        if os.environ.get("DPL_INFER_META", "1") != "0":
+        if os.environ.get("DPL_INFER_META", "0") == "1":
             try:
                 env = self._infer_meta()
             except Exception:   # noqa: BLE001

@@ -57,3 +57,26 @@ def test_two_ranks_merge_to_the_world1_reference(tmp_path, golden_dir):
                 assert np.allclose(r0[key][name], v, rtol=1e-5, atol=1e-5), (key, name, r0[key][name], v)
             else:
                 assert r0[key][name] == v, (key, name, r0[key][name], v)  # bit-exact
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2` for real (not --dry-run): the self-launcher, the rendezvous, two ranks running the kernels of the hist
+    sweep and of the mse sweep (exact-tail form through ops.OctavPipeline) on the box's one GPU, the merge collectives inside
+    the timed region (gloo, because RCCL refuses two ranks on one device), max-over-ranks timing, rank 0's record line: the code
+    path of the driver's N = 2 / 4 / 8 runs above the backend string."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DPL_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--mse-steps", "1",
+                        "--e2e-images", "0", "--vit-images", "0", "--real-images", "0", "--fq-reps", "0", "--mse-jitter", "", "--pool", "5",
+                        "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    line = json.loads(lines[-1])
+    assert len(lines[-1]) < 2048 and "details" in json.loads(lines[-2])
+    assert line["n_gpus"] == 2 and line["config"]["world_size_seen_by_backend"] == 2 and line["config"]["backend"] == "gloo"
+    assert line["config"]["hist_checksum_ok"] is True and len(line["config"]["per_rank_images_per_s"]) == 2
+    assert line["config"]["collectives_ms_per_sweep"] > 0
+    assert line["roofline"]["mse"]["ok"] is True and line["value"] > 0

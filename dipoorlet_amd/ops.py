@@ -718,7 +718,6 @@ class FakeQuantSet:
         # the balanced partition over the batch's tensors (slot = tensor): 1024 workgroups, measured on the ResNet-50 set
         # (scripts/fq_set_blocks.py: 512 .. 8192 within a few per cent for per-tensor and per-channel rows alike)
         self.work = plan.work("fq")
-        self._out_cache = {}
 
     def __call__(self, tensors, out=None):
         plan = self.plan

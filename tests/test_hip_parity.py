@@ -888,3 +888,16 @@ def test_fake_quant_set_launch_matches_per_tensor_launches(dev):
     fset(again, out=again)                       # in place
     for t in range(len(shapes)):
         assert np.array_equal(again[t].cpu().numpy(), want[t]), t
+
+
+def test_octav_tail_soak_short():
+    """scripts/tail_soak.py for a few seconds: random tensor sets (sizes 1 .. 1 044 480, 16 distribution kinds, per-image scales up
+    to x 4, both dynamic_sym settings) through the pipeline in the exact-tail form — threshold history, raises on the fly, rescues,
+    the compaction route — every pair against the two-read form, a sample against the numpy oracle.  (The long runs:
+    profiles/r04/tail_soak.txt — 1.5 M pairs, 0 mismatches.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "tail_soak.py"), "8", "7"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    assert " 0 mismatches" in r.stdout

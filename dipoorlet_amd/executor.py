@@ -37,8 +37,31 @@ def op(*names):
 
 def _ints(v):
     if isinstance(v, torch.Tensor):
+        known = getattr(v, "_dpl_ints", None)   # integer constants carry their host values (_host_ints): no device read-back
+        if known is not None:
+            return list(known)
         return [int(x) for x in v.reshape(-1).tolist()]
     return [int(x) for x in np.asarray(v).reshape(-1).tolist()]
+
+
+def _host_ints(t, src=None):
+    """Tag a small constant with its values as Python numbers — integers (Reshape shapes, Gather indices, Slice bounds: the
+    shape arithmetic of exported graphs) and floating-point scalars (Clip bounds, Pad value, Resize scales) — so that the
+    ops reading them (_ints / _floats) do not synchronise the host with the device on every forward.  src: where to read
+    the values (a host copy or a list; default: t itself, one read-back now)."""
+    if not isinstance(t, torch.Tensor) or t.dtype == torch.bool:
+        return t
+    if t.is_floating_point():
+        if t.numel() <= 16:
+            t._dpl_floats = [float(x) for x in (src if isinstance(src, list) else (t if src is None else src).reshape(-1).tolist())]
+    elif t.numel() <= 4096:
+        t._dpl_ints = [int(x) for x in (src if isinstance(src, list) else (t if src is None else src).reshape(-1).tolist())]
+    return t
+
+
+def _floats(v):
+    known = getattr(v, "_dpl_floats", None)
+    return list(known) if known is not None else [float(x) for x in v.reshape(-1).tolist()]
 
 
 def _pads_nd(pads, nd):
@@ -134,8 +157,8 @@ def _hswish(s, node, x):
 
 @op("Clip")
 def _clip(s, node, x, lo=None, hi=None):
-    lo = node.attrs.get("min") if lo is None else float(lo)
-    hi = node.attrs.get("max") if hi is None else float(hi)
+    lo = node.attrs.get("min") if lo is None else _floats(lo)[0]
+    hi = node.attrs.get("max") if hi is None else _floats(hi)[0]
     return torch.clamp(x, min=lo, max=hi)
 
 
@@ -289,9 +312,9 @@ def _slice(s, node, x, starts=None, ends=None, axes=None, steps=None):
 @op("Gather")
 def _gather(s, node, x, idx):
     ax = int(node.attrs.get("axis", 0))
-    idx = idx.long()
     if idx.dim() == 0:
-        return x.select(ax, int(idx))
+        return x.select(ax, _ints(idx)[0])
+    idx = idx.long()
     return torch.index_select(x, ax, idx.reshape(-1)).reshape(x.shape[:ax] + tuple(idx.shape) + x.shape[ax + 1:])
 
 
@@ -369,7 +392,7 @@ def _cast(s, node, x):
 
 @op("Shape")
 def _shape(s, node, x):
-    return torch.tensor(list(x.shape), dtype=torch.int64, device=x.device)
+    return _host_ints(torch.tensor(list(x.shape), dtype=torch.int64, device=x.device), list(x.shape))
 
 
 @op("ConstantOfShape")
@@ -402,7 +425,7 @@ def _pad(s, node, x, pads=None, value=None, axes=None):
     nd = x.dim()
     _, fpad = _pads_nd(pads, nd)
     mode = node.attrs.get("mode", "constant")
-    v = float(value) if value is not None else float(node.attrs.get("value", 0.0))
+    v = _floats(value)[0] if value is not None else float(node.attrs.get("value", 0.0))
     return F.pad(x, fpad, mode=mode, value=v) if mode == "constant" else F.pad(x, fpad, mode=mode)
 
 
@@ -413,7 +436,7 @@ def _resize(s, node, x, roi=None, scales=None, sizes=None):
         scales = roi
     if sizes is not None and sizes.numel():
         return F.interpolate(x, size=_ints(sizes)[2:], mode={"linear": "bilinear"}.get(mode, mode))
-    sc = [float(v) for v in scales.reshape(-1).tolist()][2:]
+    sc = _floats(scales)[2:]
     return F.interpolate(x, scale_factor=sc, mode={"linear": "bilinear"}.get(mode, mode))
 
 
@@ -438,7 +461,7 @@ class GraphSession(ActivationSession):
         for name, arr in graph.initializer.items():
             a = np.array(arr, order="C")  # (np.ascontiguousarray would turn a 0-d scalar into shape (1,))
             t = torch.from_numpy(a.astype(np.float32)) if a.dtype == np.float16 else torch.from_numpy(a)
-            self.consts[name] = t.to(self.device)
+            self.consts[name] = _host_ints(t.to(self.device), t)
         missing = sorted({n.op_type for n in graph.graph.node if n.op_type not in _OPS})
         if missing:
             raise NotImplementedError(f"executor: unsupported ONNX ops {missing}")
@@ -509,7 +532,7 @@ class GraphSession(ActivationSession):
     def set_const(self, name, tensor):
         """Replace an initializer on the device (a weight updated by a weight transform) and refresh the folded
         fake-quantised copy that depends on it."""
-        self.consts[name] = tensor.to(self.device)
+        self.consts[name] = _host_ints(tensor.to(self.device))
         for node in self.graph.graph.node:
             if node.name in self._folded and node.input[0] == name:
                 self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, self.consts[name])

@@ -134,8 +134,12 @@ def _main(argv=None):
                   calib_batch=args.calib_batch, world_size=world,
                   # the fixed costs of a fresh process, itemised: interpreter + imports, process group, HIP context (the
                   # first batch's MIOpen algorithm search is forward_first_batch_gpu_s above)
-                  startup={"interpreter_and_imports_s": age_at_enter, "process_group_init_s": t_dist - t_enter,
-                           "process_group_backend": dist.get_backend(), "hip_context_s": t_ctx - t_dist,
+                  startup={"interpreter_and_imports_s": age_at_enter,
+                           "process_group_init_s": dist_helper.TIMES.get("group", t_dist - t_enter),
+                           "process_group_backend": dist.get_backend(),
+                           # first touch of the HIP runtime + the context (seconds longer right after a process that held
+                           # most of the HBM has exited: the driver is still releasing it)
+                           "hip_context_s": dist_helper.TIMES.get("device", 0.0) + (t_ctx - t_dist),
                            "until_calibration_starts_s": t_cal - t_enter})
         with open(args.timing_json, "w") as f:
             json.dump(tm, f)

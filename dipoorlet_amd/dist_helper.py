@@ -33,13 +33,22 @@ def _backend():
     return "nccl" if torch.cuda.is_available() and torch.cuda.device_count() > 0 else "gloo"
 
 
+TIMES = {}   # host seconds of the bootstrap's two parts (reported by --timing_json): "group" = the process group,
+             # "device" = the first touch of the HIP runtime (torch.cuda.is_available + set_device)
+
+
 def _bind_device():
+    import time
+    t0 = time.perf_counter()
     if torch.cuda.is_available() and torch.cuda.device_count() > 0:
         torch.cuda.set_device(dist.get_rank() % torch.cuda.device_count())
+    TIMES["device"] = time.perf_counter() - t0
 
 
 def init_default():
     """__main__.py:61-64 — env:// rendezvous as set up by torch.distributed.run."""
+    import time
+    t0 = time.perf_counter()
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -51,6 +60,7 @@ def init_default():
             dist.init_process_group(backend="gloo", store=dist.HashStore(), rank=0, world_size=1)
         else:
             dist.init_process_group(backend=_backend())
+    TIMES["group"] = time.perf_counter() - t0
     _bind_device()
 
 

@@ -8,7 +8,7 @@ spec = resnet50_tensors(); elems = [e for _, e, _ in spec]; B = 32
 xs = synth_activations(spec, B, dev, seed=1)
 ys = [torch.empty_like(x) for x in xs]
 shapes = resnet50_tensor_shapes()
-for nb in (512, 1024, 2048, 4096, 8192):
+for nb in ([int(v) for v in sys.argv[1].split(',')] if len(sys.argv) > 1 else (512, 1024, 2048, 4096, 8192)):
     os.environ["DPL_BLOCKS_FQ"] = str(nb)
     plan = ops.TensorSetPlan(elems, B, dev)
     for mode in ("t", "c"):

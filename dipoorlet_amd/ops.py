@@ -42,7 +42,7 @@ def _upload_struct_array(arr, n, device):
 
 # Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
 # faster from HBM than many small items; the histogram wants a little more latency hiding).
-DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512, "fq": 1024}   # measured optima per kernel family
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512, "fq": 65536}   # measured optima per kernel family
 
 
 def _blocks_for(kind):
@@ -715,8 +715,10 @@ class FakeQuantSet:
             rows[t] = _hip.FakeQuantParams(scale.data_ptr(), zp.data_ptr(), scale.numel(), int(inner) if scale.numel() > 1 else 1,
                                            int(qlo), int(qhi))
         self.d_params = _upload_struct_array(rows, plan.T, plan.device)
-        # the balanced partition over the batch's tensors (slot = tensor): 1024 workgroups, measured on the ResNet-50 set
-        # (scripts/fq_set_blocks.py: 512 .. 8192 within a few per cent for per-tensor and per-channel rows alike)
+        # the balanced partition over the batch's tensors (slot = tensor): 65536 workgroups of ~52 KB on the ResNet-50 set, so
+        # that the resident ones read and write a dense window as the dispatcher hands them out (scripts/fq_set_blocks.py: with
+        # 1024 resident workgroups of 3.3 MB each the read + write stream reaches 0.73 of 8 TB/s on some boxes of the pool and
+        # 0.60 - 0.62 on others; 65536: 0.70 - 0.73 on both kinds)
         self.work = plan.work("fq")
 
     def __call__(self, tensors, out=None):

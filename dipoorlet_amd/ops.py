@@ -42,7 +42,7 @@ def _upload_struct_array(arr, n, device):
 
 # Workgroups per launch for the balanced partition (tuned on MI355X: few, large, equal shares stream
 # faster from HBM than many small items; the histogram wants a little more latency hiding).
-DEFAULT_BLOCKS = {"minmax": 256, "hist": 512, "octav": 1024, "cos": 512, "fq": 65536}   # measured optima per kernel family
+DEFAULT_BLOCKS = {"minmax": 256, "hist": 768, "octav": 1024, "cos": 512, "fq": 65536}   # measured optima per kernel family
 
 
 def _blocks_for(kind):
@@ -419,16 +419,16 @@ def _walk_sorted(plan):
 
 
 class OctavPipeline:
-    """OCTAV over a RUN of batches in a one-read form ('tail', or 'oneread') on two HIP streams.  Same kernels, same results
-    as octav_batch.
+    """OCTAV over a RUN of batches in a one-read form ('tail', or 'oneread') on three HIP streams of its own.  Same kernels,
+    same results as octav_batch.
 
         pipe = OctavPipeline(dynamic_sym)
         rows = [pipe.submit(plan, tensors) for ...]     # [B, T, 3] each, NOT valid yet
         pipe.sync()                                     # rows are valid for work on the caller's stream
 
-    Caller's stream: the streaming kernel, which also walks every single-slice pair ('oneread': + the pairs' own predictions
-    where the tensor needs them, k_octav_probe).  Side stream, behind the streaming kernel of batch i and beside that of batch
-    i + 1: the rescue of the pairs a walk could not finish (on the device, no host round trip; 'oneread': + the walk of the
+    Lane streams (two, in rotation, each behind the caller's stream as of the submit): the streaming kernel, which also walks
+    every single-slice pair ('oneread': + the pairs' own predictions where the tensor needs them, k_octav_probe) — batch i + 1
+    starts while batch i drains.  Side stream, behind the streaming kernel of batch i and beside that of batch i + 1: the rescue of the pairs a walk could not finish (on the device, no host round trip; 'oneread': + the walk of the
     multi-slice pairs), the result rows, the state and the threshold / prediction snapshot for batch i + 3.
     The pipeline OWNS its rotation state per plan (three sets of per-batch scratch, six state arrays and snapshots, the call
     counter): two pipelines may run the same plan (they share only what the plan has learned: bits OR-ed / maxima taken into
@@ -444,6 +444,14 @@ class OctavPipeline:
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
+        # The streaming kernels of consecutive batches go to two streams of the pipeline's own in rotation (each behind the
+        # caller's stream as of its submit), so that batch i + 1 starts while batch i drains: the last workgroups of a batch are
+        # the pairs whose walks took longest (raised thresholds, long lists) and hold a few slots while the rest of the chip idles
+        # — same-box A/B (scripts/mse_run.py): images alike +- 0, +- 10 % jitter - 3.5 %, feature maps at +- 30 % - 5.5 %,
+        # ViT-B/16 - 0.7 %; three streams: + 3 ... 6 % (three kernels share the slots).  DPL_OCTAV_LANES=1: the caller's stream.
+        self.lanes = [torch.cuda.Stream(self.device) for _ in range(int(os.environ.get("DPL_OCTAV_LANES", "2")))]
+        if len(self.lanes) < 2:
+            self.lanes = []
         self._plans = {}          # id(plan) -> this pipeline's rotation state for the plan
         self._touched = []
         # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
@@ -574,6 +582,9 @@ class OctavPipeline:
         sets = ps["sets"]
         k = ps["calls"]
         ps["calls"] = k + 1
+        caller = main
+        if self.lanes:
+            main = self.lanes[k % len(self.lanes)]
         cur = sets[k % _PIPE_SETS]
         r = k % (2 * _PIPE_SETS)
         self._settle(plan, res, ps, cur)
@@ -581,6 +592,8 @@ class OctavPipeline:
             main.wait_event(cur["done"])        # everything that last used this set has finished
         tab = plan.seg_table(tensors)
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+        if main is not caller:
+            main.wait_stream(caller)            # the batch's activations and its pointer table are the caller's stream's work
         cur["refs"] = (list(tensors), tab, out)
         cur["k"] = k
         cur["tail"] = tail
@@ -620,6 +633,8 @@ class OctavPipeline:
             for st in sorted(ps["sets"], key=lambda q: q["k"]):
                 self._settle(plan, res, ps, st)
         torch.cuda.current_stream(self.device).wait_stream(self.side)
+        for lane in self.lanes:
+            torch.cuda.current_stream(self.device).wait_stream(lane)
         for plan, _ in self._touched:
             for st in self._plans[id(plan)]["sets"]:
                 st["refs"] = None

@@ -326,14 +326,14 @@ def forward_net_octav(onnx_graph, args, run=None):
     dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
     rows = []
     pipe = ops.OctavPipeline(dynamic_sym, run.device)    # the walk of batch i runs beside the forward / streaming pass of batch i + 1
+    # (timed: the streaming kernel of every batch — it also walks the pairs — by events on the pipeline's own stream that carries
+    # it, beside the next batch's forward; the rescue of the few pairs it could not finish runs on the pipeline's side stream)
+    pipe.record_events = bool(getattr(args, "timing_json", None))
     t_loop = __import__("time").perf_counter()
     for b, tensors in run.forward():
-        # (timed: what the caller's stream spends on the batch — the streaming kernel, which also walks the pairs; the rescue of the
-        # few pairs it could not finish runs on the pipeline's side stream beside the next forward)
-        with run.timed("statistics"):
-            rows.append(pipe.submit(run.plan(b), tensors))
-    with run.timed("statistics"):
-        pipe.sync()
+        rows.append(pipe.submit(run.plan(b), tensors))
+    pipe.sync()
+    run._events["statistics"] += pipe.events
     WALL["pass1_loop_s"] = WALL.get("pass1_loop_s", 0.0) + __import__("time").perf_counter() - t_loop
     run.octav_rows = torch.cat(rows) if rows else torch.zeros(0, run.T, 3, device=run.device)
     with wall("results_to_host_s"):

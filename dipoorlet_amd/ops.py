@@ -454,6 +454,10 @@ class OctavPipeline:
             self.lanes = []
         self._plans = {}          # id(plan) -> this pipeline's rotation state for the plan
         self._touched = []
+        # record_events = True: per submit a (start, end) pair of timing events around the streaming kernel ON ITS LANE, kept in
+        # .events (what --timing_json reports as the statistics' GPU seconds: the caller's stream no longer carries the kernel)
+        self.record_events = False
+        self.events = []
         # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
         self.reset_stats()
 
@@ -606,11 +610,16 @@ class OctavPipeline:
         job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
                                         ps["use"][r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
                                         compaction_inline=0, rescue=cur, tail=tail)
+        if self.record_events:
+            began = torch.cuda.Event(enable_timing=True)
+            began.record(main)
         if not tail:
             _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
         _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
-        streamed = torch.cuda.Event()
+        streamed = torch.cuda.Event(enable_timing=self.record_events)
         streamed.record(main)
+        if self.record_events:
+            self.events.append((began, streamed))
         self.side.wait_event(streamed)
         # the rescue of the pairs a walk could not finish ('oneread': behind the walk of the multi-slice pairs), on the device: no
         # host round trip decides anything

@@ -4,6 +4,7 @@
 #         rocprofv3 run (never --pmc together with a trace domain)
 #   (ii)  the +-10 % contrast-jitter mse sweep   (scripts/mse_run.py resnet50, DPL_BENCH_JITTER=0.1)
 #   (iii) the ViT-B/16 mse sweep                 (scripts/mse_run.py vit)
+#   (iv)  the images-alike mse sweep with the streaming kernels NOT overlapped (DPL_OCTAV_LANES=1): the kernel's own duration
 # each of (ii), (iii): kernel stats + the two PMC passes -> traffic_<name>.json.  Usage: scripts/profile_gpu.sh <tag>
 set -u
 TAG=${1:-r04}
@@ -35,5 +36,8 @@ sweep() {   # name, workload, batches, env...
   rm -rf $OUT/s_$N $OUT/p_${N}_FETCH_SIZE $OUT/p_${N}_WRITE_SIZE $OUT/*.err
 }
 sweep jitter0.1 resnet50 64 DPL_BENCH_JITTER=0.1
+# the streaming kernel ALONE on the chip (DPL_OCTAV_LANES=1: every batch on the caller's stream, as in round 3): its own duration —
+# by default the kernels of consecutive batches overlap (two lane streams), their elapsed times then add up to more than the sweep
+sweep alike_lanes1 resnet50 64 DPL_OCTAV_LANES=1
 sweep vit vit 32 X=1
 head -12 $OUT/kernel_stats.md; cat $OUT/traffic.json | head -40; tail -c 1200 $OUT/bench_stats.json; tail -1 $OUT/run_jitter0.1.log $OUT/run_vit.log

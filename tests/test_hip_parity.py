@@ -577,16 +577,21 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
                 assert g[1] == x.min() and g[2] == x.max()
 
 
-@pytest.mark.parametrize("form,walk,sets", [("tail", "auto", 3), ("tail", "auto", 2), ("tail", "auto", 4), ("oneread", "group", 3),
-                                            ("oneread", "sorted", 3), ("oneread", "auto", 3), ("oneread", "auto", 2), ("oneread", "auto", 4)])
-def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, sets):
+@pytest.mark.parametrize("form,walk,sets,lanes", [("tail", "auto", 3, 2), ("tail", "auto", 2, 2), ("tail", "auto", 4, 2), ("tail", "auto", 3, 1),
+                                                  ("tail", "auto", 3, 3), ("tail", "auto", 2, 3), ("oneread", "group", 3, 2),
+                                                  ("oneread", "sorted", 3, 2), ("oneread", "auto", 3, 1), ("oneread", "auto", 2, 2),
+                                                  ("oneread", "auto", 4, 3)])
+def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, sets, lanes):
     """(form: the exact-tail form — the default — or the round-3 one-read form; walk: as above, auto = chosen by the listed share.
-    sets: how many batches the host runs ahead = sets of per-batch scratch, ops._PIPE_SETS.)  OctavPipeline (rescue / walk of
-    batch i on a side stream beside the streaming kernel of batch i + 1, rotating scratch) returns what the two-read form
-    returns batch by batch — including the first batches, which run without any history — and the oracle's scales."""
+    sets: how many batches the host runs ahead = sets of per-batch scratch, ops._PIPE_SETS.  lanes: the streams the streaming
+    kernels of consecutive batches rotate over — 2 by default: batch i + 1 starts while batch i drains; 1: the caller's stream.)
+    OctavPipeline (rescue / walk of batch i on a side stream beside the streaming kernel of batch i + 1, rotating scratch)
+    returns what the two-read form returns batch by batch — including the first batches, which run without any history — and
+    the oracle's scales."""
     from dipoorlet_amd import ops
     monkeypatch.setenv("DPL_OCTAV_FORM", form)
     monkeypatch.setenv("DPL_OCTAV_WALK", walk)
+    monkeypatch.setenv("DPL_OCTAV_LANES", str(lanes))
     monkeypatch.setattr(ops, "_PIPE_SETS", sets)
     rng = np.random.default_rng(41)
     B, sizes = 4, [401408, 30000, 802816, 777, 200704]

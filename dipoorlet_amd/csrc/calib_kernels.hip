@@ -252,7 +252,8 @@ __global__ void k_hist_prepare(const float* __restrict__ gmin, const float* __re
 
 // ================================================================ K4: percentile clip (basic_algorithm.py:40-53)
 // One wave per slot.  The cumulative sum is a SEQUENTIAL fp64 accumulation in bin order (the >=
-// threshold test is order sensitive), so lanes load 64 bins at a time and the wave walks them in order.
+// threshold test is order sensitive), so lanes load 64 bins at a time and the wave walks them in order
+// (2048 dependent fp64 additions: ~10 us per launch; through ds_bpermute shuffles and a branch per bin it was 190 us).
 __global__ __launch_bounds__(kWave) void k_hist_percentile(const uint64_t* __restrict__ hist,
                                                             const float* __restrict__ gmin_a,
                                                             const float* __restrict__ gmax_a, int bins,
@@ -268,18 +269,31 @@ __global__ __launch_bounds__(kWave) void k_hist_percentile(const uint64_t* __res
     const float gmin = gmin_a[slot], gmax = gmax_a[slot];
     double accum = 0.0;
     int found = -1;
+    // One chunk of 64 bins per round.  The next chunk's counts are requested BEFORE this chunk is walked (the load's latency
+    // sits beside the 64 additions); the lane index of the walk is wave-uniform (v_readlane, not a shuffle through LDS) and the
+    // chain of additions carries no branch: the bins that reach the threshold are collected in a mask, its lowest bit is the answer.
+    uint64_t raw_next = lane < bins ? h[lane] : 0ull;
     for (int base = 0; base < bins && found < 0; base += kWave) {
         const int b = base + lane;
         // hist.astype(float32) / hist.sum()  -> float64(float32(count)) / float64(total)
-        const double hv = (b < bins) ? (double)(float)(long long)h[b] / total : 0.0;
+        const double hv = (b < bins) ? (double)(float)(long long)raw_next / total : 0.0;
+        raw_next = (b + kWave < bins) ? h[b + kWave] : 0ull;
         const int lim = (bins - base) < kWave ? (bins - base) : kWave;
-        for (int j = 0; j < lim; ++j) {
-            accum += __shfl(hv, j, kWave);
-            if (accum >= threshold) {
-                found = base + j;
-                break;
+        const int h_lo = __double2loint(hv), h_hi = __double2hiint(hv);
+        uint64_t reached = 0;
+        if (lim == kWave) {
+#pragma unroll
+            for (int j = 0; j < kWave; ++j) {
+                accum += __hiloint2double(__builtin_amdgcn_readlane(h_hi, j), __builtin_amdgcn_readlane(h_lo, j));
+                reached |= (accum >= threshold) ? (1ull << j) : 0ull;
+            }
+        } else {
+            for (int j = 0; j < lim; ++j) {
+                accum += __hiloint2double(__builtin_amdgcn_readlane(h_hi, j), __builtin_amdgcn_readlane(h_lo, j));
+                reached |= (accum >= threshold) ? (1ull << j) : 0ull;
             }
         }
+        if (reached) found = base + __builtin_ctzll(reached);
     }
     if (lane == 0) {
         float lo = gmin, hi = gmax;

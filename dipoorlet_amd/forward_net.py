@@ -325,7 +325,9 @@ def forward_net_octav(onnx_graph, args, run=None):
     run = _run_of(onnx_graph, args, run)
     dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
     rows = []
-    pipe = ops.OctavPipeline(dynamic_sym, run.device)    # the walk of batch i runs beside the forward / streaming pass of batch i + 1
+    # (the rescue of batch i runs beside the forward of batch i + 1; the streaming kernel itself stays on this stream, between two
+    # forwards: lanes = 1 — overlapped with the next forward's convolutions it slows them by more than it takes, measured)
+    pipe = ops.OctavPipeline(dynamic_sym, run.device, lanes=1)
     # (timed: the streaming kernel of every batch — it also walks the pairs — by events on the pipeline's own stream that carries
     # it, beside the next batch's forward; the rescue of the few pairs it could not finish runs on the pipeline's side stream)
     pipe.record_events = bool(getattr(args, "timing_json", None))

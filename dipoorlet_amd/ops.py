@@ -440,7 +440,7 @@ class OctavPipeline:
     streaming kernel).  A tensor set the one-read forms cannot take (a pair above 64 slices) runs octav_batch on the caller's
     stream instead."""
 
-    def __init__(self, dynamic_sym, device=None):
+    def __init__(self, dynamic_sym, device=None, lanes=None):
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
@@ -448,8 +448,11 @@ class OctavPipeline:
         # caller's stream as of its submit), so that batch i + 1 starts while batch i drains: the last workgroups of a batch are
         # the pairs whose walks took longest (raised thresholds, long lists) and hold a few slots while the rest of the chip idles
         # — same-box A/B (scripts/mse_run.py): images alike +- 0, +- 10 % jitter - 3.5 %, feature maps at +- 30 % - 5.5 %,
-        # ViT-B/16 - 0.7 %; three streams: + 3 ... 6 % (three kernels share the slots).  DPL_OCTAV_LANES=1: the caller's stream.
-        self.lanes = [torch.cuda.Stream(self.device) for _ in range(int(os.environ.get("DPL_OCTAV_LANES", "2")))]
+        # ViT-B/16 - 0.7 %; three streams: + 3 ... 6 % (three kernels share the slots).  lanes = 1 (or DPL_OCTAV_LANES=1): the
+        # caller's stream — what a caller that runs a network forward between two submits wants (forward_net_octav: beside the
+        # next forward's convolutions the streaming kernel costs the forward 10 % and the loop 6 %, scripts/e2e_lanes_ab.sh).
+        n_lanes = int(os.environ.get("DPL_OCTAV_LANES", "0")) or (2 if lanes is None else int(lanes))
+        self.lanes = [torch.cuda.Stream(self.device) for _ in range(n_lanes)]
         if len(self.lanes) < 2:
             self.lanes = []
         self._plans = {}          # id(plan) -> this pipeline's rotation state for the plan

@@ -7,6 +7,7 @@ import numpy as np
 from dipoorlet_amd import models
 
 d, n = sys.argv[1], int(sys.argv[2])
+os.makedirs(d, exist_ok=True)
 g = models.resnet50()
 g.output_dir = d
 g.save_onnx_model("r50")

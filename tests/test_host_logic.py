@@ -272,3 +272,40 @@ def test_bench_dry_run_gloo(world):
     assert line["hist_checksum"] == line["hist_checksum_expected"] == 123 * 2048 * world * (world + 1) // 2
     assert line["range"] == [-float(world), float(world)]    # MIN / MAX over the ranks' ranges
     assert line["world_size_seen_by_backend"] == world and len(line["per_rank_ok"]) == world and all(line["per_rank_ok"])
+
+
+def test_dump_indent4_is_json_dump_byte_for_byte():
+    """utils.dump_indent4 — the writer of act_clip_val.json / weight_clip_val.json — yields exactly json.dumps(obj, indent=4)
+    (the reference's format, utils.py:313-323) for nested dicts / lists of numbers, non-finite values, escapes, empty containers."""
+    import io
+    import json
+    import random
+
+    import numpy as np
+
+    from dipoorlet_amd.utils import dump_indent4
+    leaves = [0.0, -0.0, 1, -7, 2 ** 70, True, False, None, float("nan"), float("inf"), float("-inf"), "a\"b\\c\né", "",
+              np.float64(1.5), 1e22, 1e-7, 123456789.123456789]
+
+    def rnd(depth=0):
+        r = random.random()
+        if depth > 3 or r < 0.3:
+            return random.choice(leaves + [random.uniform(-1e6, 1e6), random.gauss(0, 1) * 10 ** random.randint(-30, 30)])
+        if r < 0.55:
+            return [random.gauss(0, 1) for _ in range(random.randint(0, 6))]
+        if r < 0.8:
+            return [rnd(depth + 1) for _ in range(random.randint(0, 4))]
+        return {random.choice(["k", "conv.w", "x y", "é", ""]) + str(i): rnd(depth + 1) for i in range(random.randint(0, 4))}
+    random.seed(1)
+    for _ in range(3000):
+        o = rnd()
+        b = io.StringIO()
+        dump_indent4(o, b)
+        assert b.getvalue() == json.dumps(o, indent=4), o
+    clip = {f"w{i}": [np.random.default_rng(i).standard_normal(64).astype(np.float32).tolist(), (1.0, float(i))] for i in range(8)}
+    b = io.StringIO()
+    dump_indent4(clip, b)
+    assert b.getvalue() == json.dumps(clip, indent=4)
+    b = io.StringIO()
+    dump_indent4({1: [1.0]}, b)                      # (anything unusual: json.dump itself)
+    assert b.getvalue() == json.dumps({1: [1.0]}, indent=4)

@@ -797,12 +797,13 @@ def test_octav_tail_randomised_shapes_and_distributions(dev):
                 assert g[1] == x.min() and g[2] == x.max()
 
 
-def test_octav_tail_thresholds_follow_the_images(dev):
+def test_octav_tail_thresholds_follow_the_images(dev, monkeypatch):
     """What the exact-tail form lists and how often it has to be rescued, over a run of batches through the pipeline: images
     alike (thresholds from the earlier batches: ~1 % listed, next to no rescues), then images that differ in scale by +-30 %
     (a brighter image raises its threshold on the fly; a dimmer one may need the rescue) — results equal to the oracle's
     either way."""
     from dipoorlet_amd import ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", "tail")      # (the bounds below are this form's, whatever the environment selects)
     rng = np.random.default_rng(91)
     B, sizes = 4, [401408, 100352, 802816, 25088, 200704]
     plan = ops.TensorSetPlan(sizes, B, dev)
@@ -899,7 +900,7 @@ def test_octav_tail_soak_short():
     """scripts/tail_soak.py for a few seconds: random tensor sets (sizes 1 .. 1 044 480, 16 distribution kinds, per-image scales up
     to x 4, both dynamic_sym settings) through the pipeline in the exact-tail form — threshold history, raises on the fly, rescues,
     the compaction route — every pair against the two-read form, a sample against the numpy oracle.  (The long runs:
-    profiles/r04/tail_soak.txt — 1.5 M pairs, 0 mismatches.)"""
+    profiles/r04/tail_soak.txt — 4 M pairs, 0 mismatches.)"""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1962,7 +1962,6 @@ int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     const int64_t init_n = (j->n_pairs + 1 > vis_words ? j->n_pairs + 1 : vis_words);
     if (j->predict < 0 || j->predict > 2) return fail_msg("dpl_octav_oneread_prepare: predict must be 0, 1 or 2");
     if (j->tail) {   // exact-tail form: state + the tensors' threshold snapshot
-        if (j->n_multi != 0) return fail_msg("dpl_octav_oneread_prepare: the exact-tail form takes single-slice pairs only");
         const int64_t n = j->n_pairs + 1 > j->n_tensors ? j->n_pairs + 1 : j->n_tensors;
         hipLaunchKernelGGL(k_octav_tail_init, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)s, j->d_states, j->n_pairs, d_vis_w, d_vis_o,
                            j->d_pred, j->n_tensors, j->reset_epoch);
@@ -1988,12 +1987,24 @@ int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_stream");
     if (j->tail) {
-        if (j->n_multi != 0) return fail_msg("dpl_octav_oneread_stream: the exact-tail form takes single-slice pairs only");
-        hipLaunchKernelGGL(k_octav_tail, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kTailLdsB + DPL_TAIL_LDS_PAD), (hipStream_t)s, j->d_slices,
-                           j->d_seg_ptrs, j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs,
-                           TailArgs{j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords, j->d_pred, j->d_rescue_bm, j->d_missed,
-                                    reinterpret_cast<unsigned long long*>(j->d_resc), j->dynamic_sym, j->max_iters, g_exact_fail_every});
+        const TailArgs fa{j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords, j->d_pred, j->d_rescue_bm, j->d_missed,
+                          reinterpret_cast<unsigned long long*>(j->d_resc), j->dynamic_sym, j->max_iters, g_exact_fail_every};
+        const size_t lds = (size_t)(kLdsA + kTailLdsB + DPL_TAIL_LDS_PAD);
+        if (j->n_multi > 0) {   // the slices of the pairs above one slice (the first of d_slices: largest first) leave their rows ...
+            hipLaunchKernelGGL(k_octav_tail_slices, dim3((unsigned)j->n_slices), dim3(kThreads), lds, (hipStream_t)s, j->d_slices, j->d_seg_ptrs,
+                               j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs, j->d_pair_spans,
+                               reinterpret_cast<unsigned long long*>(j->d_lh), fa);
+            DPL_LAUNCH_CHECK("k_octav_tail_slices");
+        }
+        hipLaunchKernelGGL(k_octav_tail, dim3((unsigned)j->n_slices), dim3(kThreads), lds, (hipStream_t)s, j->d_slices,
+                           j->d_seg_ptrs, j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs, fa);
         DPL_LAUNCH_CHECK("k_octav_tail");
+        if (j->n_multi > 0) {   // ... which one workgroup per such pair adds up and walks (d_pair_order: these pairs come first)
+            hipLaunchKernelGGL(k_octav_tail_merge, dim3((unsigned)j->n_multi), dim3(kThreads), lds, (hipStream_t)s, j->d_slices, j->d_states,
+                               (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs, j->d_pair_spans,
+                               reinterpret_cast<const unsigned long long*>(j->d_lh), j->d_pair_order, j->d_pair_slice0, fa);
+            DPL_LAUNCH_CHECK("k_octav_tail_merge");
+        }
         return 0;
     }
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,

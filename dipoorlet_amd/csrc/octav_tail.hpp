@@ -286,13 +286,13 @@ template <int kVecT>
 __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t tensor, unsigned char* lds_raw, Shared& sh,
                                           dpl_octav_state* __restrict__ st, dpl_octav_state* __restrict__ ctl,
                                           const uint64_t* __restrict__ pair_base, const float* __restrict__ list0,
-                                          const TailArgs& fa, const uint32_t cnt) {
+                                          const TailArgs& fa, const uint32_t cnt, const unsigned long long n_merged = 0ull) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & (kWave - 1);
     const int w = tid / kWave;
     dpl_octav_state* me = st + pair;
-    const unsigned long long n_pair = (unsigned long long)cnt;
-    const bool small = cnt <= kSmallCap;
+    const unsigned long long n_pair = n_merged ? n_merged : (unsigned long long)cnt;   // (n_merged: a pair of several slices, k_octav_tail_merge)
+    const bool small = !n_merged && cnt <= kSmallCap;
 #ifdef DPL_RES_PROF
     unsigned long long prof_keep[3] = {0ull, 0ull, 0ull};
 #endif
@@ -795,6 +795,7 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     const uint32_t tid = threadIdx.x;
     DPL_PROF_T(kt0);
     const dpl_work_item it = slices[blockIdx.x];
+    if (it.reserved > 1u) return;          // a slice of a longer pair: k_octav_tail_slices / k_octav_tail_merge (uniform)
     const uint32_t pair = it.slot, cnt = it.count;
     const float* pg = segs[it.seg] + it.offset;
     const uint32_t tensor = pair % n_tensors;
@@ -830,6 +831,177 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     DPL_PROF_T(kt2);
     DPL_PROF_ADD(4, kt0, kt1);
     DPL_PROF_ADD(5, kt1, kt2);
+}
+
+// ---- pairs of more than one slice (> 1 044 480 elements: the packed histogram's 20-bit counts) -------------------------------
+// A slice is streamed like a pair of its own (k_octav_tail_slices: histogram in LDS, its own threshold, its values listed into
+// its part of the pair's list region) and leaves its packed histogram row (16 KiB per 4 MiB read), its list's length and final
+// threshold bin (word 0 of the row) and — by atomics on the pair's freshly initialised state — range, out-of-window sums and
+// NaN flag.  k_octav_tail_merge, one workgroup per such pair behind it: the rows added up in LDS (a bin that holds 2^20 values or
+// more does not fit the packed word: such a pair goes to the compaction route), the slices' lists moved together, then the
+// SAME walk (walk_tail) over the merged histogram and list.
+__global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail_slices(
+    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
+    uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0, dpl_octav_state* __restrict__ ctl,
+    const dpl_span* __restrict__ spans, unsigned long long* __restrict__ rows, const TailArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    const dpl_work_item it = slices[blockIdx.x];
+    if (it.reserved <= 1u) return;         // a whole pair: k_octav_tail (uniform)
+    const uint32_t pair = it.slot, cnt = it.count;
+    const float* pg = segs[it.seg] + it.offset;
+    const uint32_t tensor = pair % n_tensors;
+    const uint64_t within = it.offset - spans[pair].offset;    // the slice's first element inside its pair = its part of the list region
+    for (int b = tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
+    if (tid == 0) {
+        const uint32_t hist = fa.pred[(size_t)tensor * kPredRow];
+        sh.tail_j = (hist >= 1u && hist < (uint32_t)kLogNB) ? (uint32_t)kLogNB - hist : 1u;
+        sh.cursor = 0u;
+        sh.low_sum = 0.0;
+        sh.low_cnt = 0u;
+        sh.low_nan = 0u;
+    }
+    __syncthreads();
+    stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + within), sh, ctl, true);
+    __syncthreads();
+    unsigned long long* row = rows + (size_t)blockIdx.x * kLogNB;
+    for (int b = tid; b < kLogNB; b += kThreads)
+        row[b] = b == 0 ? ((unsigned long long)sh.tail_j << 32) | (unsigned long long)sh.cursor : l_packed[b];
+    if (tid == 0) {
+        dpl_octav_state* me = st + pair;
+        const float gmn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
+        const float gmx = fmaxf(fmaxf(sh.red_mx[0], sh.red_mx[1]), fmaxf(sh.red_mx[2], sh.red_mx[3]));
+        if (gmn <= gmx) {
+            atomicMin(&me->min_enc, enc_f32(gmn));
+            atomicMax(&me->max_enc, enc_f32(gmx));
+        }
+        if (sh.low_cnt) {
+            atomicAdd(&me->sum, sh.low_sum);
+            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)sh.low_cnt);
+        }
+        if (sh.low_nan) atomicOr(&me->nan_seen, 1u);
+    }
+}
+
+__global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail_merge(
+    const dpl_work_item* __restrict__ slices, dpl_octav_state* __restrict__ st, uint32_t n_tensors,
+    const uint64_t* __restrict__ pair_base, float* __restrict__ list0, dpl_octav_state* __restrict__ ctl,
+    const dpl_span* __restrict__ spans, const unsigned long long* __restrict__ rows, const uint32_t* __restrict__ pair_order,
+    const uint32_t* __restrict__ pair_slice0, const TailArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
+    __shared__ Shared sh;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t pair = pair_order[blockIdx.x];           // largest first: the pairs of more than one slice come first
+    const uint32_t sl0 = pair_slice0[2 * pair], sl1 = pair_slice0[2 * pair + 1];
+    const uint32_t tensor = pair % n_tensors;
+    const unsigned long long n_pair = spans[pair].count;
+    // ---- the rows added up (a thread: bins tid, tid + 256, ...), the counts watched
+    constexpr int kPer = kLogNB / kThreads;
+    unsigned long long acc[kPer];
+    uint32_t over = 0u, nsum = 0u;
+    double dsum = 0.0;          // (the window's total from the slices' own words: what s_0 is made of should the merged words not hold)
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) acc[q] = 0ull;
+    for (uint32_t sl = sl0; sl < sl1; ++sl) {
+        const unsigned long long* row = rows + (size_t)sl * kLogNB;
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int b = (int)tid + q * kThreads;
+            const unsigned long long x = b == 0 ? 0ull : row[b];
+            acc[q] += x;
+            over |= (uint32_t)(acc[q] >> 63);       // (the count field is bits 43 .. 62: bit 63 set = 2^20 values or more in one bin)
+            const uint32_t cx = (uint32_t)(x >> kPackShift);
+            nsum += cx;
+            dsum += bin_sum(x & kPackMask, cx, b);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) l_packed[(int)tid + q * kThreads] = acc[q];
+    for (int b = kLogNB + (int)tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
+    // ---- the slices' lists: lengths, thresholds, where each goes
+    if (tid == 0) {
+        uint32_t off = 0u, jmax = 1u;
+        for (uint32_t sl = sl0; sl < sl1; ++sl) {
+            const unsigned long long w0 = rows[(size_t)sl * kLogNB];
+            sh.seg_off[sl - sl0] = off;
+            sh.seg_len[sl - sl0] = (uint32_t)w0;
+            off += (uint32_t)w0;
+            jmax = max(jmax, (uint32_t)(w0 >> 32));
+        }
+        const dpl_octav_state* me = st + pair;
+        sh.cursor = off;
+        sh.tail_j = jmax;
+        sh.low_sum = me->sum;
+        sh.low_cnt = (uint32_t)me->cnt_gt;
+        sh.low_nan = me->nan_seen;
+        const bool any = me->min_enc <= me->max_enc;
+        sh.red_mn[0] = any ? dec_f32(me->min_enc) : INFINITY;
+        sh.red_mx[0] = any ? dec_f32(me->max_enc) : -INFINITY;
+        for (int q = 1; q < kWaves; ++q) sh.red_mn[q] = INFINITY, sh.red_mx[q] = -INFINITY;
+        sh.bad = 0u;
+    }
+    if (__any(over != 0u) && (tid & (kWave - 1)) == 0) atomicOr(&sh.bad, 1u);
+    __syncthreads();
+    if (__any(over != 0u) && (tid & (kWave - 1)) == 0) atomicOr(&sh.bad, 1u);   // (sh.bad was cleared by thread 0 above: set again behind the barrier)
+    __syncthreads();
+    float* lp = list0 + pair_base[pair];
+    // moved together towards the front, slice by slice, tile by tile: a tile is read whole before any of it is written (the
+    // destination never lies behind the source, and never reaches a later tile's source)
+    for (uint32_t sl = sl0 + 1; sl < sl1; ++sl) {
+        const uint32_t len = sh.seg_len[sl - sl0], off = sh.seg_off[sl - sl0];
+        const float* src = lp + (slices[sl].offset - spans[pair].offset);
+        float* dst = lp + off;
+        for (uint32_t i0 = 0; i0 < len; i0 += kThreads) {       // (uniform)
+            const uint32_t i = i0 + tid;
+            const float x = i < len ? __builtin_nontemporal_load(src + i) : 0.0f;
+            __syncthreads();
+            if (i < len) dst[i] = x;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (no line of the region read above may answer the walk's loads from this CU's L1)
+    __syncthreads();
+    if (sh.bad) {   // a bin of 2^20 values or more: the compaction route (the state as walk_tail leaves it for that route)
+        const double wd = wave_sum(dsum);
+        const uint32_t wn = wave_sum(nsum);
+        if ((tid & (kWave - 1)) == 0) {
+            sh.red_d[tid / kWave] = wd;
+            sh.red_a[tid / kWave] = wn;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            dpl_octav_state* me = st + pair;
+            dpl_octav_state z = *me;
+            const float gmn = sh.red_mn[0], gmx = sh.red_mx[0];
+            const bool nanseen = z.nan_seen != 0u;
+            double tot = sh.low_sum;
+            unsigned long long nz = sh.low_cnt;
+            for (int q = 0; q < kWaves; ++q) tot += sh.red_d[q], nz += sh.red_a[q];
+            // forward_net.py:324 — sum(|x|) / count(|x| > 0)
+            const float s0 = nanseen ? __uint_as_float(0x7FC00000u) : __fdiv_rn((float)tot, (float)(long long)nz);
+            z.sum = 0.0;
+            z.cnt_gt = 0ull;
+            z.cnt_le = 0ull;
+            z.unsigned_div = (fa.dynamic_sym && fabsf(gmn) < 1e-6f && !nanseen) ? 4.0f : 1.0f;
+            z.n_elems = n_pair;
+            z.len[0] = 0u;
+            z.len[1] = 0u;
+            z.cur = 2u;
+            z.reserved = 0u;
+            z.s = s0;
+            z.iters = 0u;
+            z.done = (s0 != s0 || fa.max_iters <= 0) ? 1u : 0u;     // (NaN is a fixed point: finished)
+            z.mode = z.done ? 2u : 1u;
+            *me = z;
+            if (!z.done) atomicAdd(reinterpret_cast<unsigned long long*>(&ctl->cnt_le), 1ull);
+            (void)gmx;
+        }
+        return;
+    }
+    walk_tail<kTailVec>(pair, tensor, lds_raw, sh, st, ctl, pair_base, list0, fa, (uint32_t)0u, n_pair);
 }
 
 // State + threshold snapshot of a batch: pred[t][0] = what the tensor's pairs asked for in the current and the previous epoch.

@@ -308,9 +308,10 @@ def _default_form():
 
 
 def _tail_ok(res):
-    """The exact-tail form takes tensor sets whose pairs are all one slice (<= dpl_octav_slice_cap() elements per image and
-    tensor: every pair of the ResNet-50 and ViT-B/16 sets); others run the round-3 one-read form."""
-    return res is not None and res["n_multi"] == 0
+    """The exact-tail form takes every tensor set the one-read scratch exists for (pairs of up to 64 slices; a pair above one
+    slice — dpl_octav_slice_cap() elements per image and tensor — is streamed slice by slice and walked by a merge kernel).
+    DPL_OCTAV_TAIL_MULTI=0: such sets run the round-3 one-read form, as before."""
+    return res is not None and (res["n_multi"] == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0")
 
 
 def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):

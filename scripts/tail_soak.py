@@ -1,4 +1,4 @@
-"""GPU soak of the exact-tail OCTAV form: random tensor sets (sizes 1 .. 1 044 480 incl. odd ones, 16 distribution kinds incl.
+"""GPU soak of the exact-tail OCTAV form: random tensor sets (sizes 1 .. 3 500 000 incl. odd ones and pairs above one slice, 16 distribution kinds incl.
 saturating / discrete / constant / heavy-tailed / per-channel-scaled, per-image scale jitter up to x 4, both dynamic_sym
 settings) through ops.OctavPipeline over runs of batches (threshold history, raises on the fly, rescues, the compaction route) —
 every pair against the two-read form on the GPU (which walks the reference's whole iterate sequence), a sample of pairs against
@@ -54,7 +54,8 @@ def main():
     while time.time() < t_end:
         T = int(rng.integers(3, 9))
         B = int(rng.integers(1, 5))
-        sizes = [int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 60000), rng.integers(60000, 1044481)])) for _ in range(T)]
+        sizes = [int(rng.choice([rng.integers(1, 3000), rng.integers(3000, 60000), rng.integers(60000, 1044481), rng.integers(60000, 1044481),
+                                 rng.integers(1044481, 3500000)])) for _ in range(T)]     # (one in five: a pair above one slice)
         kinds = [int(rng.integers(0, 16)) for _ in range(T)]
         dyn = bool(rng.random() < 0.3)
         plan = ops.TensorSetPlan(sizes, B, dev)

@@ -896,6 +896,72 @@ def test_fake_quant_set_launch_matches_per_tensor_launches(dev):
         assert np.array_equal(again[t].cpu().numpy(), want[t]), t
 
 
+@pytest.mark.parametrize("fail_every", [0, 2])
+def test_octav_tail_pairs_above_one_slice(dev, monkeypatch, fail_every):
+    """The exact-tail form on pairs of MORE than one slice (> 1 044 480 elements per image and tensor: k_octav_tail_slices +
+    k_octav_tail_merge) next to ordinary ones: every route — accepted walks, the rescue (forced by the C ABI's test hook for every
+    second pair), a bin of 2^20 values or more (a constant tensor: the merged packed words do not hold it, compaction route),
+    values >= 2^14, NaN, an all-zero tensor, dynamic_sym — through the pipeline over batches that differ in scale, against the
+    two-read form and the numpy oracle; DPL_OCTAV_TAIL_MULTI=0 (the round-3 form serves such a set) gives the same."""
+    from dipoorlet_amd import _hip, ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
+    rng = np.random.default_rng(31)
+    g = torch.Generator(device=dev)
+    g.manual_seed(31)
+    B = 2
+    sizes = [1200007, 777, 3000000, 150528, 2097152, 1044481, 2500000, 1100003, 1300000]
+    kinds = ["normal", "relu", "uniform", "normal", "const", "heavy", "huge", "nan", "zero"]
+
+    def draw(kind, n, scale):
+        z = torch.randn(B, n, generator=g, device=dev)
+        if kind == "relu":
+            z = z.clamp_(min=0)
+        elif kind == "uniform":
+            z = torch.rand(B, n, generator=g, device=dev) * 2 - 1
+        elif kind == "const":
+            z = torch.full((B, n), 0.37, device=dev)
+        elif kind == "heavy":
+            z = z * torch.exp(torch.randn(B, n, generator=g, device=dev))
+        elif kind == "huge":
+            z = z * 9000.0                      # values >= 2^14
+        elif kind == "nan":
+            z[0, n // 2] = float("nan")         # image 0 only
+        elif kind == "zero":
+            z = torch.zeros(B, n, device=dev)
+        return (z * scale).contiguous()
+    batches = [[draw(k, n, 1.0 + 0.25 * it + 0.1 * t) for t, (k, n) in enumerate(zip(kinds, sizes))] for it in range(4)]
+    for dyn in (False, True):
+        want = [ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), x, dyn, form="bracket").cpu().numpy() for x in batches]
+        old = _hip.lib().dpl_test_hook_exact_fail_every(fail_every)
+        try:
+            plan = ops.TensorSetPlan(sizes, B, dev)
+            assert plan.octav_oneread_scratch()["n_multi"] == 7 * B
+            pipe = ops.OctavPipeline(dyn, dev)
+            outs = [pipe.submit(plan, x) for x in batches]
+            pipe.sync()
+            torch.cuda.synchronize()
+            single = ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), batches[1], dyn).cpu().numpy()    # (cold, one stream)
+        finally:
+            _hip.lib().dpl_test_hook_exact_fail_every(old)
+        assert pipe.compaction_pairs >= 2 * B * len(batches)        # the constant tensor and the one beyond 2^14, every batch
+        if fail_every:
+            assert pipe.fallback_pairs >= len(batches) * plan.n_pairs // 4
+        for k, (o, w) in enumerate(zip(outs + [single], want + [want[1]])):
+            got = o.cpu().numpy() if hasattr(o, "cpu") else o
+            assert np.array_equal(got[..., 1:], w[..., 1:], equal_nan=True), k
+            assert _close(got[..., 0], w[..., 0]), (k, got[..., 0], w[..., 0])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            got = outs[-1].cpu().numpy()
+            for t in (0, 2, 4, 5, 6, 7):
+                for b in range(B):
+                    x = batches[-1][t][b].cpu().numpy()
+                    assert _close(got[b, t, 0], O.octav_scale(x, 4 if (dyn and abs(float(np.nanmin(x))) < 1e-6 and not np.isnan(x).any()) else 1)), (t, b)
+    monkeypatch.setenv("DPL_OCTAV_TAIL_MULTI", "0")
+    r3 = ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), batches[0], True).cpu().numpy()      # (dyn = True: the loop's last `want`)
+    assert _close(r3[..., 0], want[0][..., 0]) and np.array_equal(r3[..., 1:], want[0][..., 1:], equal_nan=True)
+
+
 def test_octav_tail_soak_short():
     """scripts/tail_soak.py for a few seconds: random tensor sets (sizes 1 .. 1 044 480, 16 distribution kinds, per-image scales up
     to x 4, both dynamic_sym settings) through the pipeline in the exact-tail form — threshold history, raises on the fly, rescues,

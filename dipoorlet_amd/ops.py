@@ -586,10 +586,11 @@ class OctavPipeline:
             return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form in ("oneread", "tail") else form)
         tail = 1 if (form == "tail" and _tail_ok(res)) else 0
         if form == "tail" and not tail and not getattr(plan, "_octav_told", False):
-            plan._octav_told = True     # (once per plan: such a set runs at about 0.85 of the exact-tail form's rate)
+            plan._octav_told = True     # (once per plan; DPL_OCTAV_TAIL_MULTI=0: such a set runs at about 0.7 of the exact-tail form's rate)
             import logging
             logging.getLogger("dipoorlet").info(
-                "OCTAV: a tensor of more than 1044480 elements per image in this set: the one-read form of round 3 serves it")
+                "OCTAV: a tensor of more than 1044480 elements per image in this set and DPL_OCTAV_TAIL_MULTI=0: the one-read "
+                "form of round 3 serves it")
         main = torch.cuda.current_stream(plan.device)
         ps = self._state(plan, res)
         sets = ps["sets"]

@@ -230,12 +230,15 @@ typedef struct dpl_octav_oneread_job {
     float probe_z;                   /* width of the sample's brackets in standard deviations; 0: the default (3, then adapted per tensor to the misses it produces) */
     int32_t fuse;                    /* 1: k_octav_oneread walks every single-slice pair itself (histogram still in LDS, list in L2);
                                         dpl_octav_oneread_finish then walks the multi-slice pairs only.  0: every pair is walked by finish */
-    int32_t tail;                    /* 1: the EXACT-TAIL form (csrc/octav_tail.hpp; single-slice pairs only): k_octav_tail lists only |x| at or above a
+    int32_t tail;                    /* 1: the EXACT-TAIL form (csrc/octav_tail.hpp): k_octav_tail lists only |x| at or above a
                                         threshold bin (per tensor: the lowest bin its pairs asked for in the last two epochs, word 0 of the tensor's
                                         d_vis / d_pred rows; raised on the fly by a wave that lists more than its budget), takes the early iterates as
                                         LOWER BOUNDS from the exact histogram, the late ones exactly from the list, and accepts only a walk that ended
-                                        on >= 2 exact evaluations (anything else: the rescue, as above).  d_pred_pair / d_use_probe / d_tstat / d_lh /
-                                        d_dir are not touched; dpl_octav_oneread_probe is a no-op */
+                                        on >= 2 exact evaluations (anything else: the rescue, as above).  A pair of more than one slice (n_multi > 0): its
+                                        slices are streamed like pairs (k_octav_tail_slices: a packed histogram row per slice in d_lh, its values in its part
+                                        of the pair's d_list0 region), then one workgroup per such pair adds the rows up, moves the lists together and
+                                        walks (k_octav_tail_merge; a bin of 2^20 values or more: compaction route).  d_pred_pair / d_use_probe / d_tstat /
+                                        d_dir are not touched (d_lh only with n_multi > 0); dpl_octav_oneread_probe is a no-op */
     int32_t compaction_inline;       /* 1: dpl_octav_oneread_finish ends with dpl_octav_oneread_compaction; 0: the caller reads d_states[n_pairs].cnt_le
                                         when the batch is done and calls it only when that is non-zero */
 } dpl_octav_oneread_job;

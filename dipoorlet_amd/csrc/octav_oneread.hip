@@ -1990,14 +1990,10 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
         const TailArgs fa{j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords, j->d_pred, j->d_rescue_bm, j->d_missed,
                           reinterpret_cast<unsigned long long*>(j->d_resc), j->dynamic_sym, j->max_iters, g_exact_fail_every};
         const size_t lds = (size_t)(kLdsA + kTailLdsB + DPL_TAIL_LDS_PAD);
-        if (j->n_multi > 0) {   // the slices of the pairs above one slice (the first of d_slices: largest first) leave their rows ...
-            hipLaunchKernelGGL(k_octav_tail_slices, dim3((unsigned)j->n_slices), dim3(kThreads), lds, (hipStream_t)s, j->d_slices, j->d_seg_ptrs,
-                               j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs, j->d_pair_spans,
-                               reinterpret_cast<unsigned long long*>(j->d_lh), fa);
-            DPL_LAUNCH_CHECK("k_octav_tail_slices");
-        }
+        // (a slice of a pair above one slice — the first items of d_slices, largest first — leaves its row in d_lh ...)
         hipLaunchKernelGGL(k_octav_tail, dim3((unsigned)j->n_slices), dim3(kThreads), lds, (hipStream_t)s, j->d_slices,
-                           j->d_seg_ptrs, j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs, fa);
+                           j->d_seg_ptrs, j->d_states, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_states + j->n_pairs,
+                           j->d_pair_spans, reinterpret_cast<unsigned long long*>(j->d_lh), fa);
         DPL_LAUNCH_CHECK("k_octav_tail");
         if (j->n_multi > 0) {   // ... which one workgroup per such pair adds up and walks (d_pair_order: these pairs come first)
             hipLaunchKernelGGL(k_octav_tail_merge, dim3((unsigned)j->n_multi), dim3(kThreads), lds, (hipStream_t)s, j->d_slices, j->d_states,

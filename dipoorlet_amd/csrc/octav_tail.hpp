@@ -788,18 +788,20 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
 __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
     uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0, dpl_octav_state* __restrict__ ctl,
-    const TailArgs fa) {
+    const dpl_span* __restrict__ spans, unsigned long long* __restrict__ rows, const TailArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
     __shared__ Shared sh;
     const uint32_t tid = threadIdx.x;
     DPL_PROF_T(kt0);
     const dpl_work_item it = slices[blockIdx.x];
-    if (it.reserved > 1u) return;          // a slice of a longer pair: k_octav_tail_slices / k_octav_tail_merge (uniform)
+    const bool part = it.reserved > 1u;    // a slice of a pair of several (uniform): streamed like a pair, its row left for k_octav_tail_merge
     const uint32_t pair = it.slot, cnt = it.count;
     const float* pg = segs[it.seg] + it.offset;
     const uint32_t tensor = pair % n_tensors;
-    const bool small = cnt <= kSmallCap;   // lists its whole window: every step exact
+    const bool small = !part && cnt <= kSmallCap;   // lists its whole window: every step exact
+    // (a slice lists into its part of the pair's list region: from its first element's place inside the pair)
+    const uint64_t list_at = pair_base[pair] + (part ? it.offset - spans[pair].offset : 0ull);
     for (int b = tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
     if (tid == 0) {
         const uint32_t hist = small ? 0u : fa.pred[(size_t)tensor * kPredRow];   // kLogNB - bin; 0: none (a cold start lists from bin 1 and raises)
@@ -810,9 +812,31 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
         sh.low_nan = 0u;
     }
     __syncthreads();
-    stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair]), sh, ctl, !small);
+    stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + list_at), sh, ctl, !small);
     __syncthreads();   // every LDS histogram add has landed; the per-wave ranges and the out-of-window sums are in sh
     DPL_PROF_T(kt1);
+    if (part) {
+        // the packed histogram row (16 KiB per 4 MiB read), the list's length and final threshold bin in its word 0; range,
+        // out-of-window sums and NaN flag by atomics on the pair's freshly initialised state
+        unsigned long long* row = rows + (size_t)blockIdx.x * kLogNB;
+        for (int b = tid; b < kLogNB; b += kThreads)
+            row[b] = b == 0 ? ((unsigned long long)sh.tail_j << 32) | (unsigned long long)sh.cursor : l_packed[b];
+        if (tid == 0) {
+            dpl_octav_state* me = st + pair;
+            const float gmn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
+            const float gmx = fmaxf(fmaxf(sh.red_mx[0], sh.red_mx[1]), fmaxf(sh.red_mx[2], sh.red_mx[3]));
+            if (gmn <= gmx) {
+                atomicMin(&me->min_enc, enc_f32(gmn));
+                atomicMax(&me->max_enc, enc_f32(gmx));
+            }
+            if (sh.low_cnt) {
+                atomicAdd(&me->sum, sh.low_sum);
+                atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)sh.low_cnt);
+            }
+            if (sh.low_nan) atomicOr(&me->nan_seen, 1u);
+        }
+        return;
+    }
 #if defined(DPL_TAIL_ABL_NOWALK)
     if (tid == 0) {
         st[pair].done = 1u;
@@ -834,57 +858,12 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
 }
 
 // ---- pairs of more than one slice (> 1 044 480 elements: the packed histogram's 20-bit counts) -------------------------------
-// A slice is streamed like a pair of its own (k_octav_tail_slices: histogram in LDS, its own threshold, its values listed into
-// its part of the pair's list region) and leaves its packed histogram row (16 KiB per 4 MiB read), its list's length and final
+// A slice is streamed like a pair of its own (k_octav_tail above, `part`: histogram in LDS, its own threshold, its values listed
+// into its part of the pair's list region) and leaves its packed histogram row (16 KiB per 4 MiB read), its list's length and final
 // threshold bin (word 0 of the row) and — by atomics on the pair's freshly initialised state — range, out-of-window sums and
 // NaN flag.  k_octav_tail_merge, one workgroup per such pair behind it: the rows added up in LDS (a bin that holds 2^20 values or
 // more does not fit the packed word: such a pair goes to the compaction route), the slices' lists moved together, then the
 // SAME walk (walk_tail) over the merged histogram and list.
-__global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail_slices(
-    const dpl_work_item* __restrict__ slices, const float* const* __restrict__ segs, dpl_octav_state* __restrict__ st,
-    uint32_t n_tensors, const uint64_t* __restrict__ pair_base, float* __restrict__ list0, dpl_octav_state* __restrict__ ctl,
-    const dpl_span* __restrict__ spans, unsigned long long* __restrict__ rows, const TailArgs fa) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    unsigned long long* l_packed = reinterpret_cast<unsigned long long*>(lds_raw);
-    __shared__ Shared sh;
-    const uint32_t tid = threadIdx.x;
-    const dpl_work_item it = slices[blockIdx.x];
-    if (it.reserved <= 1u) return;         // a whole pair: k_octav_tail (uniform)
-    const uint32_t pair = it.slot, cnt = it.count;
-    const float* pg = segs[it.seg] + it.offset;
-    const uint32_t tensor = pair % n_tensors;
-    const uint64_t within = it.offset - spans[pair].offset;    // the slice's first element inside its pair = its part of the list region
-    for (int b = tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
-    if (tid == 0) {
-        const uint32_t hist = fa.pred[(size_t)tensor * kPredRow];
-        sh.tail_j = (hist >= 1u && hist < (uint32_t)kLogNB) ? (uint32_t)kLogNB - hist : 1u;
-        sh.cursor = 0u;
-        sh.low_sum = 0.0;
-        sh.low_cnt = 0u;
-        sh.low_nan = 0u;
-    }
-    __syncthreads();
-    stream_tail(pg, cnt, reinterpret_cast<uint32_t*>(list0 + pair_base[pair] + within), sh, ctl, true);
-    __syncthreads();
-    unsigned long long* row = rows + (size_t)blockIdx.x * kLogNB;
-    for (int b = tid; b < kLogNB; b += kThreads)
-        row[b] = b == 0 ? ((unsigned long long)sh.tail_j << 32) | (unsigned long long)sh.cursor : l_packed[b];
-    if (tid == 0) {
-        dpl_octav_state* me = st + pair;
-        const float gmn = fminf(fminf(sh.red_mn[0], sh.red_mn[1]), fminf(sh.red_mn[2], sh.red_mn[3]));
-        const float gmx = fmaxf(fmaxf(sh.red_mx[0], sh.red_mx[1]), fmaxf(sh.red_mx[2], sh.red_mx[3]));
-        if (gmn <= gmx) {
-            atomicMin(&me->min_enc, enc_f32(gmn));
-            atomicMax(&me->max_enc, enc_f32(gmx));
-        }
-        if (sh.low_cnt) {
-            atomicAdd(&me->sum, sh.low_sum);
-            atomicAdd(reinterpret_cast<unsigned long long*>(&me->cnt_gt), (unsigned long long)sh.low_cnt);
-        }
-        if (sh.low_nan) atomicOr(&me->nan_seen, 1u);
-    }
-}
-
 __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail_merge(
     const dpl_work_item* __restrict__ slices, dpl_octav_state* __restrict__ st, uint32_t n_tensors,
     const uint64_t* __restrict__ pair_base, float* __restrict__ list0, dpl_octav_state* __restrict__ ctl,

@@ -235,7 +235,7 @@ typedef struct dpl_octav_oneread_job {
                                         d_vis / d_pred rows; raised on the fly by a wave that lists more than its budget), takes the early iterates as
                                         LOWER BOUNDS from the exact histogram, the late ones exactly from the list, and accepts only a walk that ended
                                         on >= 2 exact evaluations (anything else: the rescue, as above).  A pair of more than one slice (n_multi > 0): its
-                                        slices are streamed like pairs (k_octav_tail_slices: a packed histogram row per slice in d_lh, its values in its part
+                                        slices are streamed like pairs (by k_octav_tail itself: a packed histogram row per slice in d_lh, its values in its part
                                         of the pair's d_list0 region), then one workgroup per such pair adds the rows up, moves the lists together and
                                         walks (k_octav_tail_merge; a bin of 2^20 values or more: compaction route).  d_pred_pair / d_use_probe / d_tstat /
                                         d_dir are not touched (d_lh only with n_multi > 0); dpl_octav_oneread_probe is a no-op */

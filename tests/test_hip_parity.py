@@ -898,8 +898,8 @@ def test_fake_quant_set_launch_matches_per_tensor_launches(dev):
 
 @pytest.mark.parametrize("fail_every", [0, 2])
 def test_octav_tail_pairs_above_one_slice(dev, monkeypatch, fail_every):
-    """The exact-tail form on pairs of MORE than one slice (> 1 044 480 elements per image and tensor: k_octav_tail_slices +
-    k_octav_tail_merge) next to ordinary ones: every route — accepted walks, the rescue (forced by the C ABI's test hook for every
+    """The exact-tail form on pairs of MORE than one slice (> 1 044 480 elements per image and tensor: k_octav_tail's slice
+    path + k_octav_tail_merge) next to ordinary ones: every route — accepted walks, the rescue (forced by the C ABI's test hook for every
     second pair), a bin of 2^20 values or more (a constant tensor: the merged packed words do not hold it, compaction route),
     values >= 2^14, NaN, an all-zero tensor, dynamic_sym — through the pipeline over batches that differ in scale, against the
     two-read form and the numpy oracle; DPL_OCTAV_TAIL_MULTI=0 (the round-3 form serves such a set) gives the same."""

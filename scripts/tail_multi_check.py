@@ -1,5 +1,5 @@
 import os, sys, warnings
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dipoorlet_amd import ops
 from oracle import np_oracle as O

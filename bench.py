@@ -56,6 +56,8 @@ def parse():
     p.add_argument("--e2e-images", type=int, default=1024, help="N of the end-to-end CLI object (real .onnx + .bin files, fresh process; 0 skips it)")
     p.add_argument("--real-images", type=int, default=2048, help="N of the mse objects over executor-produced ResNet-50 activations (0 skips them)")
     p.add_argument("--vit-images", type=int, default=256, help="N of the ViT-B/16 mse object (0 skips it)")
+    p.add_argument("--big-images", type=int, default=256, help="N of the mse object over ResNet-50's shapes at 448 x 448 input: tensors above "
+                   "one OCTAV slice, batches of 8 (0 skips it)")
     p.add_argument("--fq-reps", type=int, default=3, help="timed passes of the fake-quant object (0 skips it)")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher / rendezvous / collective plumbing only, on CPU tensors (no kernels, no GPU): what the "
@@ -278,7 +280,7 @@ def main():
     # what earlier sweeps learned (octav_reset) inside the timed region, so the first batches run without a prediction as they
     # do in a fresh process.  The pool holds more distinct batches than the prediction remembers (2 epochs of
     # DPL_ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
-    mse, mse_jitter, vit_mse, mse_real = None, {}, None, {}
+    mse, mse_jitter, vit_mse, mse_real, mse_big = None, {}, None, {}, None
     if a.mse_steps > 0:
         import ctypes
         form = ops._default_form()
@@ -415,6 +417,17 @@ def main():
                      for _ in range(min_pool)]
             vit_mse = run_mse(vpool, 1, 0.0, plan=vplan, n_images=a.vit_images, net="ViT-B/16")
             del vpool, vsess
+            torch.cuda.empty_cache()
+
+        # Tensors above one OCTAV slice (1 044 480 elements per image and tensor: the packed histogram's 20-bit counts): ResNet-50's
+        # shapes at 448 x 448 input — every tensor four times its size, 216 of a batch's 984 pairs of 2 .. 4 slices — in batches of 8:
+        # streamed slice by slice, walked by the merge kernel
+        if a.big_images > 0:
+            bspec = [(n, 4 * e, k) for n, e, k in spec]
+            bplan = ops.TensorSetPlan([e for _, e, _ in bspec], 8, dev)
+            bpool = [synth_activations(bspec, 8, dev, seed=4321 + 1000 * rank + j) for j in range(min_pool)]
+            mse_big = run_mse(bpool, 1, 0.0, plan=bplan, n_images=a.big_images, net="ResNet-50 at 448 x 448 (tensors above one slice)")
+            del bpool
             torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ the fake-quant forward (quantize.py:197-239)
@@ -602,7 +615,7 @@ def main():
         "hist": {"images_per_s": hist_rate, "ms_per_step": dt_hist / a.steps * 1e3, "roofline": hist_roof,
                  "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9, "hist_checksum": hist_checksum,
                  "hist_checksum_expected": E * N_HIST * world, "clip_checksum": clip_checksum, "collectives_ms_per_sweep": coll_ms},
-        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse,
+        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "mse_448": mse_big,
         "mse_feature_maps": mse_real or None, "e2e": e2e,
     }
     # The record's line: BASELINE.json's metric on its headline configuration, every headline scalar inside `roofline` / `config`
@@ -613,6 +626,7 @@ def main():
     roof["mse_jitter"] = {k: brief(v) for k, v in mse_jitter.items()} or None    # ... with per-image contrast jitter
     roof["mse_feature_maps"] = {k: brief(v) for k, v in mse_real.items()} or None   # ... executor-produced ResNet-50 activations
     roof["mse_vit"] = brief(vit_mse)                                             # configs[4]'s workload on one GPU
+    roof["mse_448"] = brief(mse_big)                                             # tensors above one OCTAV slice (ResNet-50 at 448 x 448)
     if fake_quant:
         # per mode: [frac of one launch per tensor over the set, ... over the tensors of >= 50 MB, ... of the set in ONE launch]
         roof["fake_quant"] = {m: [round(fake_quant[m]["frac"], 4), round(fake_quant[m]["tensors_of_50MB_and_more"]["frac"], 4),
@@ -655,7 +669,7 @@ def main():
         line = json.dumps(out)
         # (the driver keeps the last 2 000 characters of stdout as `tail`: should the line ever outgrow that, the side objects go
         # first — they are all in the details line above —, never the contract's fields)
-        for k in ("fake_quant", "e2e", "mse_feature_maps", "mse_jitter", "mse_vit"):
+        for k in ("mse_448", "fake_quant", "e2e", "mse_feature_maps", "mse_jitter", "mse_vit"):
             if len(line) < 1990:
                 break
             out["roofline"].pop(k, None)

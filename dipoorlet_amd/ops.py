@@ -193,13 +193,15 @@ class TensorSetPlan:
         """Device table of base pointers for this launch (cached per pointer tuple)."""
         if len(tensors) != self.T:
             raise _hip.DipoorletHipError(f"expected {self.T} tensors, got {len(tensors)}")
-        for t, (x, e) in enumerate(zip(tensors, self.elems)):
-            _require_cuda(x, f"tensor {t}")
-            if x.numel() != e * self.batch:
-                raise _hip.DipoorletHipError(f"tensor {t}: {x.numel()} elements, plan expects {e * self.batch}")
         key = tuple(x.data_ptr() for x in tensors)
         tab = self._seg_cache.get(key)
         if tab is None:
+            # (checked when a set of pointers is first seen: a resident set comes back every sweep — 557 tensors of a ViT-B/16 set
+            # are 0.1 ms of checks per launch, which is what the host has to spare per batch)
+            for t, (x, e) in enumerate(zip(tensors, self.elems)):
+                _require_cuda(x, f"tensor {t}")
+                if x.numel() != e * self.batch:
+                    raise _hip.DipoorletHipError(f"tensor {t}: {x.numel()} elements, plan expects {e * self.batch}")
             if len(self._seg_cache) >= _SEG_CACHE_MAX:
                 self._seg_cache.clear()
             host = torch.tensor(key, dtype=torch.int64).pin_memory()

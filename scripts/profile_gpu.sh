@@ -14,7 +14,7 @@ rm -rf $OUT; mkdir -p $OUT
 # counters for this library's kernels only (collecting them for every torch kernel made a torch.rand launch of the jittered set crash
 # inside the profiler)
 KERNELS="k_octav|k_abs_hist|k_minmax|k_hist|k_fake_quant"
-BENCH="python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --mse-jitter"
+BENCH="python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --big-images 0 --mse-jitter"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH "" > $OUT/bench_stats.json 2> $OUT/stats.err
 python3 scripts/summarize_prof.py stats $OUT/stats $OUT/kernel_stats.md > /dev/null
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null

@@ -10,7 +10,7 @@ rm -f /tmp/sq_rows.jsonl
 IFS=';' read -ra GROUPS_ <<< "${SQ_GROUPS:-SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS;SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS;SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY}"
 for GROUP in "${GROUPS_[@]}"; do
   rm -rf /tmp/sq_run
-  rocprofv3 --pmc $GROUP --kernel-include-regex "k_octav|k_abs_hist|k_minmax|k_fake_quant" --output-format csv -d /tmp/sq_run -o b -- python3 bench.py --cpu-seconds 0 --steps 6 --warmup 2 --e2e-images 0 --vit-images 0 --real-images 0 --mse-jitter "" --mse-steps 1 "$@" > /dev/null 2> /tmp/sq_err.txt || tail -3 /tmp/sq_err.txt
+  rocprofv3 --pmc $GROUP --kernel-include-regex "k_octav|k_abs_hist|k_minmax|k_fake_quant" --output-format csv -d /tmp/sq_run -o b -- python3 bench.py --cpu-seconds 0 --steps 6 --warmup 2 --e2e-images 0 --vit-images 0 --real-images 0 --big-images 0 --mse-jitter "" --mse-steps 1 "$@" > /dev/null 2> /tmp/sq_err.txt || tail -3 /tmp/sq_err.txt
   python3 - <<'PY'
 import csv, glob, json, re
 from collections import defaultdict

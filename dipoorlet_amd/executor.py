@@ -22,6 +22,7 @@ torch.backends.cudnn.allow_tf32 = False
 torch.backends.cuda.matmul.allow_tf32 = False
 
 from .forward_net import ActivationSession
+from .forward_net import wall as _wall
 from .utils import logger
 
 _OPS = {}
@@ -300,9 +301,12 @@ def _slice(s, node, x, starts=None, ends=None, axes=None, steps=None):
     steps = _ints(steps) if steps is not None else [1] * len(starts)
     idx = [slice(None)] * x.dim()
     for st, en, ax, sp in zip(starts, ends, axes, steps):
-        if sp < 0:
-            raise NotImplementedError("Slice with negative step")
         n = x.shape[ax]
+        if sp < 0:      # (the exporter reverses the pads vector of F.pad this way) start in [0, n-1], end in [-1, n-1]
+            st = max(0, min(n - 1, st + n if st < 0 else st))
+            en = max(-1, min(n - 1, en + n if en < 0 else en))
+            x = torch.index_select(x, ax, torch.arange(st, en, sp, device=x.device))
+            continue
         st = max(0, min(n, st + n if st < 0 else st))
         en = max(0, min(n, en + n if en < 0 else en))
         idx[ax] = slice(st, en, sp)
@@ -406,7 +410,7 @@ def _cos(s, node, shape):
 @op("Expand")
 def _expand(s, node, x, shape):
     shp = _ints(shape)
-    return x.expand(torch.broadcast_shapes(tuple(x.shape), tuple(shp)))
+    return x.expand(tuple(int(d) for d in np.broadcast_shapes(tuple(x.shape), tuple(shp))))
 
 
 @op("Where")
@@ -458,10 +462,8 @@ class GraphSession(ActivationSession):
         self.device = torch.device(device)
         self.batch = 1
         self.consts = {}
-        for name, arr in graph.initializer.items():
-            a = np.array(arr, order="C")  # (np.ascontiguousarray would turn a 0-d scalar into shape (1,))
-            t = torch.from_numpy(a.astype(np.float32)) if a.dtype == np.float16 else torch.from_numpy(a)
-            self.consts[name] = _host_ints(t.to(self.device), t)
+        with _wall("session_consts_s"):
+            self._upload_consts()
         missing = sorted({n.op_type for n in graph.graph.node if n.op_type not in _OPS})
         if missing:
             raise NotImplementedError(f"executor: unsupported ONNX ops {missing}")
@@ -477,35 +479,58 @@ class GraphSession(ActivationSession):
                 self._folded.add(node.name)
         self._infer()
 
-    def _infer_meta(self):
-        """The shape pass WITHOUT running anything: floating-point tensors on torch's 'meta' device (shapes only), integer
-        constants — the shape arithmetic of exported graphs — on the host.  A graph whose shapes depend on values this pass does
-        not have (or an op without a meta kernel) raises; the caller then runs the real batch-1 forward."""
-        real_consts, real_device = self.consts, self.device
-        try:
-            self.device = torch.device("cpu")
-            self.consts = {k: (torch.empty_like(v, device="meta") if v.is_floating_point() else v.cpu()) for k, v in real_consts.items()}
-            feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32, device="meta")
-                     for n in self.input_names}
-            return self._forward(feeds, 1)
-        finally:
-            self.consts, self.device = real_consts, real_device
+    def _upload_consts(self):
+        """Every initializer to the device ONCE: the fp32 ones (weights, biases: 102 MB for ResNet-50) are packed into one
+        pinned host buffer and leave in a single asynchronous transfer (161 pageable copies, each a host round trip, took
+        a third of a second together with the ranges' second upload); a constant is a view of that one device buffer
+        (256-byte aligned).  Integer constants — shapes, indices — keep their host values (_host_ints)."""
+        flat, other = [], []
+        for name, arr in self.graph.initializer.items():
+            a = np.asarray(arr)
+            if a.dtype in (np.float32, np.float16) and a.ndim > 0 and a.size > 0:
+                flat.append((name, a))
+            else:
+                other.append((name, a))
+        if flat and self.device.type == "cuda":
+            offs, total = [], 0
+            for _, a in flat:
+                offs.append(total)
+                total += (a.size + 63) // 64 * 64
+            host = torch.empty(total, dtype=torch.float32, pin_memory=True)
+            hv = host.numpy()
+            for (_, a), o in zip(flat, offs):
+                hv[o:o + a.size] = a.reshape(-1)            # (fp16 initializers widen here)
+            dev = host.to(self.device, non_blocking=True)
+            self._consts_host = host                       # pinned source: alive until the copy has run
+            for (name, a), o in zip(flat, offs):
+                v = dev[o:o + a.size].view(a.shape)
+                self.consts[name] = _host_ints(v, [float(x) for x in a.reshape(-1)]) if a.size <= 16 else v
+        else:
+            other = flat + other
+        for name, a in other:
+            a = np.array(a, order="C")  # (np.ascontiguousarray would turn a 0-d scalar into shape (1,))
+            t = torch.from_numpy(a.astype(np.float32)) if a.dtype == np.float16 else torch.from_numpy(a)
+            self.consts[name] = _host_ints(t.to(self.device), t)
 
     def _infer(self):
-        """Every tensor's per-image shape (replaces onnx shape inference): one batch-1 forward on zeros (0.3 s of a fresh
-        process on the device: MIOpen loads / chooses kernels for batch 1).  DPL_INFER_META=1: a pass over meta tensors instead —
-        no kernels, but the first meta call imports torch's reference decompositions (0.5 s measured: slower in a fresh
-        process; worth it where torch._refs is loaded anyway)."""
+        """Every tensor's per-image shape (replaces onnx shape inference): on the host, shape_infer's rule per op — no device
+        work (a batch-1 forward on zeros cost a fresh process 0.3 s: the libraries load and choose kernels for a batch size
+        the run never uses).  A graph with an op that has no rule runs that batch-1 forward instead (DPL_INFER_DEVICE=1
+        forces it)."""
         env = None
-        if os.environ.get("DPL_INFER_META", "0") == "1":
+        if os.environ.get("DPL_INFER_DEVICE", "0") != "1":
+            from . import shape_infer
             try:
-                env = self._infer_meta()
-            except Exception:   # noqa: BLE001
+                with _wall("session_infer_host_s"):
+                    env = shape_infer.infer(self.graph, self._folded, self.input_names, 1)
+            except shape_infer.Unsupported as e:
+                logger.info("executor: shapes from a batch-1 forward on the device (%s)", e)
                 env = None
         if env is None:
-            feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
-                                    device=self.device) for n in self.input_names}
-            env = self._forward(feeds, 1)
+            with _wall("session_infer_device_s"):
+                feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
+                                        device=self.device) for n in self.input_names}
+                env = self._forward(feeds, 1)
         names, elems = [], []
         self.shape1 = {}
         for n in self.input_names:
@@ -582,6 +607,8 @@ class GraphSession(ActivationSession):
         if self._batched_ok is None and os.environ.get("DPL_EXECUTOR_PER_IMAGE"):   # (testing aid: the fallback mode)
             self._batched_ok = False
         if self._batched_ok is None:
+            import time
+            t_check = time.perf_counter()
             g = torch.Generator(device="cpu").manual_seed(20260)
             lead = self._lead()
             feeds = {n: torch.randn([2 * lead] + [max(1, int(d)) for d in self.graph.get_tensor_shape(n)[1:]], generator=g)
@@ -610,6 +637,8 @@ class GraphSession(ActivationSession):
                 logger.warning("executor: batched execution of this graph failed (%s): running one image at a time", e)
                 ok = False
             self._batched_ok = ok
+            from .forward_net import WALL
+            WALL["batched_check_s"] = WALL.get("batched_check_s", 0.0) + time.perf_counter() - t_check
         return self._batched_ok
 
     def _run_any(self, inputs, names):

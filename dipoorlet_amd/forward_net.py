@@ -99,28 +99,33 @@ class CalibrationRun:
     last = None    # the most recent run of this process WHEN --timing_json asks for it (its timing() is what gets reported;
                    # __main__ clears it once written: a run pins its session, accumulators and every plan's scratch)
 
-    def __init__(self, onnx_graph, args):
+    def __init__(self, onnx_graph, args, session=None):
         if getattr(args, "timing_json", None):
             CalibrationRun.last = self
         self.graph = onnx_graph
         self.args = args
-        with wall("session_build_s"):      # weights to the device, node schedule
-            self.session = onnx_graph.make_session(args)
+        self.batch = int(getattr(args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
+        self.st, self.ed = shard_range(args.data_num, args.rank, args.world_size)
+        self.ingest_s = 0.0
+        # the .bin files of the first batches are read (pinned staging) WHILE the session is built: the reader needs the graph's
+        # declared input shapes only
+        self._reader = self._start_reader(torch.cuda.is_available())
+        if session is None:
+            with wall("session_build_s"):      # weights to the device (one transfer), node schedule, shapes (host rules)
+                session = onnx_graph.make_session(args)
+        self.session = session
         self.names = list(self.session.tensor_names)
         self.elems = [int(e) for e in self.session.elems_per_image]
         self.T = len(self.names)
         self.device = torch.device("cuda", torch.cuda.current_device())
-        self.batch = int(getattr(args, "calib_batch", DEFAULT_BATCH) or DEFAULT_BATCH)
-        self.st, self.ed = shard_range(args.data_num, args.rank, args.world_size)
         self._plans = {}
         budget_gb = float(getattr(args, "resident_gb", 160.0))
         self._budget = int(budget_gb * 2**30)
         self._resident = []  # tensor sets kept in HBM between pass 1 and pass 2
         self._resident_ok = True
         self._resident_bytes = 0
-        # where a run's time goes (--timing_json): host seconds reading .bin files, GPU milliseconds (HIP events on the launch
-        # stream) of the network forward and of the statistics kernels
-        self.ingest_s = 0.0
+        # where a run's time goes (--timing_json): host seconds reading .bin files (ingest_s), GPU milliseconds (HIP events on
+        # the launch stream) of the network forward and of the statistics kernels
         self._events = {"forward": [], "statistics": []}
 
     def timed(self, phase):
@@ -166,38 +171,69 @@ class CalibrationRun:
             yield i, j
             i = j
 
-    def _input_batches(self):
-        """(b, {input: device tensor}) per batch; the .bin files of the NEXT batch are read into pinned memory by
-        a helper thread while the GPU works on the current one (file I/O releases the GIL)."""
+    def _start_reader(self, pinned):
+        """A helper thread reads the shard's .bin files batch by batch into (pinned) staging memory, at most two batches ahead
+        (file I/O releases the GIL).  Returns (queue, thread, n_batches) or None for an empty shard."""
         import queue
         import threading
         shapes = {n: self.graph.get_tensor_shape(n) for n in self.graph.network_inputs}
         bounds = list(self.batches())
         if not bounds:
-            return
+            return None
         q = queue.Queue(maxsize=2)
+        stop = threading.Event()
+
+        def put(item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def reader():
             try:
                 import time
                 for i, j in bounds:
                     t0 = time.perf_counter()
-                    staged = stage_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j,
-                                               self.device.type == "cuda")
+                    staged = stage_input_batch(self.args.input_dir, self.graph.network_inputs, shapes, i, j, pinned)
                     self.ingest_s += time.perf_counter() - t0
-                    q.put((j - i, staged))
+                    if not put((j - i, staged)):
+                        return
             except BaseException as e:  # surfaced in the consumer
-                q.put(e)
+                put(e)
 
         t = threading.Thread(target=reader, daemon=True)
         t.start()
-        for _ in bounds:
-            item = q.get()
-            if isinstance(item, BaseException):
-                raise item
-            b, staged = item
-            yield b, {n: h.to(self.device, non_blocking=True).reshape(full) for n, (h, full) in staged.items()}
-        t.join()
+        return q, t, len(bounds), stop
+
+    def close(self):
+        """Stops a reader nobody will consume (a run that is dropped before its first sweep)."""
+        if self._reader is not None:
+            self._reader[3].set()
+            self._reader = None
+
+    def _input_batches(self):
+        """(b, {input: device tensor}) per batch; the .bin files of the NEXT batches are read into pinned memory by
+        a helper thread while the GPU works on the current one.  The first sweep's reader has been running since the run
+        was constructed."""
+        reader, self._reader = self._reader, None
+        if reader is None:
+            reader = self._start_reader(self.device.type == "cuda")
+            if reader is None:
+                return
+        q, t, n, stop = reader
+        try:
+            for _ in range(n):
+                item = q.get()
+                if isinstance(item, BaseException):
+                    raise item
+                b, staged = item
+                yield b, {name: h.to(self.device, non_blocking=True).reshape(full) for name, (h, full) in staged.items()}
+            t.join()
+        finally:
+            stop.set()
 
     def forward(self, keep=False):
         """Yields (b, tensors) per batch.  With keep=True the tensor sets stay resident in HBM (up to
@@ -208,6 +244,7 @@ class CalibrationRun:
             if keep and self._resident_ok:
                 nbytes = sum(t.numel() * 4 for t in tensors)
                 if self._resident_bytes + nbytes <= self._budget:
+                    tensors = self.plan(b).bind(tensors)      # (validated once; pass 2 launches over the held set)
                     self._resident.append((b, tensors))
                     self._resident_bytes += nbytes
                 else:

@@ -189,19 +189,40 @@ class TensorSetPlan:
         for pipe in list(getattr(self, "_octav_pipes", ())):
             pipe._forget(self)
 
-    def seg_table(self, tensors):
-        """Device table of base pointers for this launch (cached per pointer tuple)."""
+    def _validate(self, tensors):
         if len(tensors) != self.T:
             raise _hip.DipoorletHipError(f"expected {self.T} tensors, got {len(tensors)}")
+        for t, (x, e) in enumerate(zip(tensors, self.elems)):
+            _require_cuda(x, f"tensor {t}")
+            if x.numel() != e * self.batch:
+                raise _hip.DipoorletHipError(f"tensor {t}: {x.numel()} elements, plan expects {e * self.batch}")
+
+    def bind(self, tensors):
+        """A tensor set a caller keeps RESIDENT and launches over again and again (pass 2 of `-A hist`, bench.py's pools):
+        validated once, then held — the BoundSet owns references to the tensors, so their memory cannot be handed to another
+        tensor while it lives, and a launch over it costs no per-tensor checks (557 tensors of a ViT-B/16 set: 0.1 - 0.2 ms of
+        host time per launch otherwise, more than the host has to spare per batch)."""
+        if isinstance(tensors, BoundSet):
+            if tensors.plan is not self:
+                raise _hip.DipoorletHipError("this tensor set is bound to another plan")
+            return tensors
+        tensors = list(tensors)
+        self._validate(tensors)
+        host = torch.tensor([x.data_ptr() for x in tensors], dtype=torch.int64).pin_memory()
+        return BoundSet(self, tensors, host.to(self.device, non_blocking=True), host)
+
+    def seg_table(self, tensors):
+        """Device table of base pointers for this launch.  A list of tensors is checked on EVERY call (device, dtype, contiguity,
+        element count: the allocator hands a freed set's addresses to other tensors, so a pointer seen before proves nothing);
+        the table itself is cached per pointer tuple.  A BoundSet (bind()) was checked when it was bound."""
+        if isinstance(tensors, BoundSet):
+            if tensors.plan is not self:
+                raise _hip.DipoorletHipError("this tensor set is bound to another plan")
+            return tensors.table
+        self._validate(tensors)
         key = tuple(x.data_ptr() for x in tensors)
         tab = self._seg_cache.get(key)
         if tab is None:
-            # (checked when a set of pointers is first seen: a resident set comes back every sweep — 557 tensors of a ViT-B/16 set
-            # are 0.1 ms of checks per launch, which is what the host has to spare per batch)
-            for t, (x, e) in enumerate(zip(tensors, self.elems)):
-                _require_cuda(x, f"tensor {t}")
-                if x.numel() != e * self.batch:
-                    raise _hip.DipoorletHipError(f"tensor {t}: {x.numel()} elements, plan expects {e * self.batch}")
             if len(self._seg_cache) >= _SEG_CACHE_MAX:
                 self._seg_cache.clear()
             host = torch.tensor(key, dtype=torch.int64).pin_memory()
@@ -209,6 +230,24 @@ class TensorSetPlan:
             self._seg_cache[key] = (tab, host)  # keep the pinned source alive until the copy has run
             return tab
         return tab[0]
+
+
+class BoundSet:
+    """A validated, resident tensor set of one plan (TensorSetPlan.bind): the tensors, kept alive, and their device pointer
+    table.  Accepted wherever a list of the set's tensors is."""
+    __slots__ = ("plan", "tensors", "table", "_host")
+
+    def __init__(self, plan, tensors, table, host):
+        self.plan, self.tensors, self.table, self._host = plan, tensors, table, host
+
+    def __len__(self):
+        return len(self.tensors)
+
+    def __iter__(self):
+        return iter(self.tensors)
+
+    def __getitem__(self, i):
+        return self.tensors[i]
 
 
 class CalibAccumulators:
@@ -610,7 +649,7 @@ class OctavPipeline:
         out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
         if main is not caller:
             main.wait_stream(caller)            # the batch's activations and its pointer table are the caller's stream's work
-        cur["refs"] = (list(tensors), tab, out)
+        cur["refs"] = (tensors if isinstance(tensors, BoundSet) else list(tensors), tab, out)
         cur["k"] = k
         cur["tail"] = tail
         cur["states"] = ps["states"][r]
@@ -685,12 +724,19 @@ def abs_hist(x, bins, gmin, gmax):
     return acc.hist[0], acc
 
 
-def rowwise_minmax(w2d):
-    """Per-row (min, max) of a [rows, cols] fp32 device matrix (basic_algorithm.py:88-90)."""
+def rowwise_minmax(w2d, out=None):
+    """Per-row (min, max) of a [rows, cols] fp32 device matrix (basic_algorithm.py:88-90); out = (lo, hi): where to write them."""
     _require_cuda(w2d, "w2d")
     rows, cols = w2d.shape
-    lo = torch.empty(rows, dtype=torch.float32, device=w2d.device)
-    hi = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    if out is None:
+        lo = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+        hi = torch.empty(rows, dtype=torch.float32, device=w2d.device)
+    else:       # (a graph's initializers: slices of one result buffer, read back in one transfer)
+        lo, hi = out
+        _require_cuda(lo, "out[0]")
+        _require_cuda(hi, "out[1]")
+        if lo.numel() != rows or hi.numel() != rows:
+            raise _hip.DipoorletHipError(f"rowwise_minmax: out holds {lo.numel()} / {hi.numel()} values for {rows} rows")
     _hip.check(_hip.lib().dpl_rowwise_minmax(_ptr(w2d), rows, cols, _ptr(lo), _ptr(hi), _stream()),
                "dpl_rowwise_minmax")
     return lo, hi

@@ -38,9 +38,10 @@ def _as_clip_dict(names, lo, hi):
 
 
 @tensor_cali_dispatcher.register("minmax")
-def find_clip_val_minmax(onnx_graph, args, **kwargs):
-    """basic_algorithm.py:13-22 — [min over images, max over images] per tensor."""
-    run = CalibrationRun(onnx_graph, args)
+def find_clip_val_minmax(onnx_graph, args, run=None, **kwargs):
+    """basic_algorithm.py:13-22 — [min over images, max over images] per tensor.
+    run: a CalibrationRun over (onnx_graph, args) to sweep with (tensor_calibration builds one); default: a new one."""
+    run = run or CalibrationRun(onnx_graph, args)
     forward_get_minmax(onnx_graph, args, run=run)
     gmin, gmax = run.acc.gmin, run.acc.gmax
     if _merged(args):
@@ -49,7 +50,7 @@ def find_clip_val_minmax(onnx_graph, args, **kwargs):
 
 
 @tensor_cali_dispatcher.register("hist")
-def find_clip_val_hist(onnx_graph, args, store_stats=None, **kwargs):
+def find_clip_val_hist(onnx_graph, args, store_stats=None, run=None, **kwargs):
     """basic_algorithm.py:25-54 — percentile (cumulative mass >= args.threshold) of the |x| histogram.
 
     store_stats = {'minmax': {name: {'min': [...], 'max': [...]}}, 'hist': {name: int64[bins]}} skips the
@@ -65,7 +66,7 @@ def find_clip_val_hist(onnx_graph, args, store_stats=None, **kwargs):
         acc.hist_prepare()
         acc.hist.copy_(torch.from_numpy(np.stack([np.asarray(store_stats["hist"][n], np.int64) for n in names])))
     else:
-        run = CalibrationRun(onnx_graph, args)
+        run = run or CalibrationRun(onnx_graph, args)
         forward_get_minmax(onnx_graph, args, run=run, keep_resident=True)   # pass 1
         gmin, gmax = run.acc.gmin.clone(), run.acc.gmax.clone()
         if _merged(args):
@@ -79,11 +80,11 @@ def find_clip_val_hist(onnx_graph, args, store_stats=None, **kwargs):
 
 
 @tensor_cali_dispatcher.register("mse")
-def find_clip_val_octav(onnx_graph, args, **kwargs):
+def find_clip_val_octav(onnx_graph, args, run=None, **kwargs):
     """basic_algorithm.py:57-69 — OCTAV scale per image, then [max(min_all, -mean s), min(max_all, mean s)].
     The mean is taken with numpy in fp32 over the per-image list exactly as the reference does, so it is
     reproduced bit for bit given the per-image scales (python max/min: a NaN mean falls back to the range)."""
-    run = CalibrationRun(onnx_graph, args)
+    run = run or CalibrationRun(onnx_graph, args)
     forward_net_octav(onnx_graph, args, run=run)
     rows = run.octav_rows
     if _merged(args):
@@ -99,10 +100,13 @@ def find_clip_val_octav(onnx_graph, args, **kwargs):
     return clip_val
 
 
-def find_clip_val_minmax_weight(onnx_graph, args):
+def find_clip_val_minmax_weight(onnx_graph, args, session=None):
     """basic_algorithm.py:72-91 — per output channel [min, max] of every initializer input (node.input[1:])
     of Conv / Gemm / ConvTranspose / PRelu / BatchNormalization; ConvTranspose weights are viewed
-    [1,0,2,3]-transposed; 0-d initializers are skipped.  Row reductions run in k_rowwise_minmax."""
+    [1,0,2,3]-transposed; 0-d initializers are skipped.  Row reductions run in k_rowwise_minmax.
+
+    session: an executor session of THIS graph — its initializers are on the device already (one transfer at session
+    build) and are reduced where they lie; without one every initializer is uploaded here."""
     weight_tensor, need_transpose = {}, []
     for node in onnx_graph.graph.node:
         if node.op_type in LAYER_HAS_WEIGHT:
@@ -111,23 +115,30 @@ def find_clip_val_minmax_weight(onnx_graph, args):
             if node.op_type == "ConvTranspose":
                 need_transpose.append(node.input[1])
     dev = torch.device("cuda", torch.cuda.current_device())
-    pending = []     # (name, rows, lo, hi) on the device: ONE transfer back for the whole graph (a round trip per initializer
-                     # — 161 of them for ResNet-50 — was a tenth of a second of a run)
-    for name, tensor in weight_tensor.items():
-        tensor = np.asarray(tensor)
-        if tensor.ndim < 1:
-            continue
-        if name in need_transpose:
-            tensor = tensor.transpose([1, 0, 2, 3])
-        c = tensor.shape[0]
-        w2 = torch.from_numpy(np.ascontiguousarray(tensor.reshape(c, -1), dtype=np.float32)).to(dev, non_blocking=True)
-        lo, hi = ops.rowwise_minmax(w2)
-        pending.append((name, c, lo, hi))
-    out = {}
-    if pending:
-        flat = torch.cat([torch.stack([lo, hi]).reshape(-1) for _, _, lo, hi in pending]).cpu().numpy()
-        off = 0
-        for name, c, _, _ in pending:
-            out[name] = [flat[off:off + c].copy(), flat[off + c:off + 2 * c].copy()]
-            off += 2 * c
+    resident = getattr(session, "consts", None) or {}
+    todo = [(name, np.asarray(t)) for name, t in weight_tensor.items() if np.asarray(t).ndim >= 1]
+    if not todo:
+        return {}
+    # every row's (min, max) into ONE device buffer, read back in one transfer (a round trip per initializer — 161 of them for
+    # ResNet-50 — was a tenth of a second of a run)
+    rows = [t.shape[1] if name in need_transpose else t.shape[0] for name, t in todo]
+    res = torch.empty(2, sum(rows), dtype=torch.float32, device=dev)
+    off = 0
+    for (name, tensor), c in zip(todo, rows):
+        w = resident.get(name)
+        if w is not None and w.is_cuda and w.dtype == torch.float32 and tuple(w.shape) == tuple(tensor.shape):
+            if name in need_transpose:
+                w = w.permute(1, 0, 2, 3)
+            w2 = w.reshape(c, -1).contiguous()
+        else:
+            if name in need_transpose:
+                tensor = tensor.transpose([1, 0, 2, 3])
+            w2 = torch.from_numpy(np.ascontiguousarray(tensor.reshape(c, -1), dtype=np.float32)).to(dev, non_blocking=True)
+        ops.rowwise_minmax(w2, out=(res[0, off:off + c], res[1, off:off + c]))
+        off += c
+    flat = res.cpu().numpy()
+    out, off = {}, 0
+    for (name, _), c in zip(todo, rows):
+        out[name] = [flat[0, off:off + c].copy(), flat[1, off:off + c].copy()]
+        off += c
     return out

@@ -53,8 +53,9 @@ class SmallMLP(torch.nn.Module):
         return torch.softmax(self.l2(y), -1)
 
 
-@pytest.mark.parametrize("mk,shape", [(SmallCNN, (1, 3, 16, 16)), (SmallMLP, (1, 5, 16))])
+@pytest.mark.parametrize("mk,shape", [("SmallCNN", (1, 3, 16, 16)), ("SmallMLP", (1, 5, 16)), ("ShapeZoo", (1, 3, 17, 19))])
 def test_reader_and_executor_on_torch_exported_onnx(tmp_path, mk, shape):
+    mk = globals()[mk]
     torch.manual_seed(0)
     model = mk().eval()
     for p in model.parameters():
@@ -79,7 +80,10 @@ def test_reader_and_executor_on_torch_exported_onnx(tmp_path, mk, shape):
         assert gb[n].shape[0] == 3 and gb[n].numel() == 3 * e and gb[n].is_contiguous()
     # every node output is exposed, network inputs first (forward_net.py:193-198, 220-235)
     outs = [o for n in g.graph.node for o in n.output]
-    assert s.tensor_names == ["input"] + outs
+    if mk is ShapeZoo:      # (its integer tensors — the exported shape arithmetic — are not calibration tensors)
+        assert s.tensor_names == [n for n in ["input"] + outs if n in set(s.tensor_names)] and len(s.tensor_names) > 20
+    else:
+        assert s.tensor_names == ["input"] + outs
 
 
 def test_writer_roundtrip_and_reference_graph_surface(tmp_path):
@@ -213,3 +217,101 @@ def test_batched_execution_is_verified_against_per_image():
     ok = GraphSession(models.resnet18(), device="cpu")
     ok.run({n: torch.randn(2, *ok.graph.get_tensor_shape(n)[1:]) for n in ok.input_names})
     assert ok._batched_ok is True
+
+
+def _shape_sets(g, monkeypatch):
+    """(names, elems, per-image shapes) from the host rules and from the real batch-1 forward."""
+    from dipoorlet_amd.forward_net import WALL
+    monkeypatch.setenv("DPL_INFER_DEVICE", "0")
+    WALL.pop("session_infer_host_s", None)
+    a = GraphSession(g, device="cpu")
+    assert "session_infer_host_s" in WALL and "session_infer_device_s" not in WALL   # no silent fall-back to the forward
+    monkeypatch.setenv("DPL_INFER_DEVICE", "1")
+    b = GraphSession(g, device="cpu")
+    WALL.pop("session_infer_device_s", None)
+    return (a.tensor_names, a.elems_per_image, a.shape1), (b.tensor_names, b.elems_per_image, b.shape1)
+
+
+class ShapeZoo(torch.nn.Module):
+    """Ops whose output shape takes arithmetic: strided / dilated / grouped / transposed convolutions, pools in ceil mode,
+    pads, slices, concat, upsampling, squeeze / unsqueeze, reductions, a view computed from x.shape (Shape -> Gather ->
+    Concat -> Reshape in the exported graph), matmul broadcasting."""
+
+    def __init__(self):
+        super().__init__()
+        self.c1 = torch.nn.Conv2d(3, 8, 5, stride=2, padding=1, dilation=2)
+        self.ct = torch.nn.ConvTranspose2d(8, 6, 3, stride=2, padding=1, output_padding=1)
+        self.c3 = torch.nn.Conv2d(6, 6, 3, padding=1, groups=3)
+        self.p = torch.nn.PReLU(6)
+        self.fc = torch.nn.Linear(14, 7)
+
+    def forward(self, x):
+        y = self.c1(x)                                                    # [1, 8, 6, 7] from 17 x 19
+        y = torch.nn.functional.max_pool2d(y, 3, 2, 1, ceil_mode=True)
+        y = self.p(self.c3(self.ct(y)))
+        y = torch.nn.functional.pad(y, (1, 2, 0, 1))
+        y = torch.nn.functional.avg_pool2d(y, 2, 2, ceil_mode=True, count_include_pad=True)
+        a, b = y[:, :4], y[:, 2:, 1:]
+        z = torch.cat([a[:, :, 1:, 1:], b[:, :, :, 1:]], 1)
+        z = torch.nn.functional.interpolate(z, scale_factor=2.0, mode="nearest")
+        z = z.reshape(z.shape[0], z.shape[1], -1)                          # Shape -> Gather -> ... -> Reshape
+        w = z.mean(-1, keepdim=True).squeeze(-1).unsqueeze(1)              # [1, 1, 8]
+        m = torch.matmul(z.transpose(1, 2)[:, :14], z[:, :, :14])          # [1, 14, 14]
+        return self.fc(m).sum(1) + w.amax(-1)
+
+
+def test_host_shape_inference_matches_the_forward(tmp_path, monkeypatch):
+    """executor.GraphSession takes every tensor's per-image shape from shape_infer's host rules, not from a batch-1
+    forward (forward_net.py:193-202 needs none: ORT infers).  Every rule is held to the shapes the real forward produces."""
+    for g in (models.resnet18(), models.resnet50(), models.vit(depth=2, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10),
+              models.resnet18(image=97)):
+        host, real = _shape_sets(g, monkeypatch)
+        assert host == real
+    torch.manual_seed(0)
+    for mk, shape in ((SmallCNN, (1, 3, 16, 16)), (SmallMLP, (1, 5, 16)), (ShapeZoo, (1, 3, 17, 19))):
+        path = str(tmp_path / f"{mk.__name__}.onnx")
+        _torch_export(mk().eval(), torch.randn(*shape), path)
+        g = ONNXGraph.load(path)
+        host, real = _shape_sets(g, monkeypatch)
+        assert host == real, mk.__name__
+        assert len(host[0]) > 5
+    # hand-built: Split, Slice with steps, Gather by a vector, Where / Equal / Expand / ConstantOfShape / Cast, asymmetric pool pads
+    from dipoorlet_amd.onnx_io import Node
+    g = ONNXGraph()
+    i64 = lambda *v: np.array(v, np.int64)    # noqa: E731
+    g.graph.node = [
+        Node("Split", ["x", "sizes"], ["s0", "s1"], name="split", attrs={"axis": 1}),
+        Node("Slice", ["s1", "st", "en", "ax", "sp"], ["sl"], name="slice"),
+        Node("Gather", ["sl", "gi"], ["ga"], name="gather", attrs={"axis": 2}),
+        Node("MaxPool", ["s0"], ["mp"], name="mp", attrs={"kernel_shape": [2, 2], "strides": [2, 2], "pads": [0, 1, 1, 0]}),
+        Node("Shape", ["mp"], ["mps"], name="shape"),
+        Node("ConstantOfShape", ["mps"], ["zeros"], name="cos", attrs={"value": np.zeros(1, np.float32)}),
+        Node("Equal", ["mp", "zeros"], ["eq"], name="eq"),
+        Node("Where", ["eq", "one", "mp"], ["wh"], name="where"),
+        Node("Cast", ["eq"], ["eqf"], name="cast", attrs={"to": 1}),
+        Node("Expand", ["k", "mps"], ["ex"], name="expand"),
+        Node("Add", ["wh", "ex"], ["y"], name="add"),
+        Node("ReduceMax", ["y"], ["rm"], name="rmax", attrs={"axes": [2, 3], "keepdims": 0}),
+        Node("GlobalMaxPool", ["ga"], ["gm"], name="gmp"),
+    ]
+    g.initializer = {"sizes": i64(2, 3), "st": i64(1, 0), "en": i64(100, -1), "ax": i64(2, 3), "sp": i64(2, 1), "gi": i64(0, 2, 1, 0),
+                     "one": np.array(1.0, np.float32), "k": np.full((1, 1, 1), 0.5, np.float32)}
+    g.network_inputs, g.network_outputs = ["x"], ["rm", "gm"]
+    g.input = ["x"] + list(g.initializer)
+    g.tensor_name_shape_map = {"x": [1, 5, 9, 8]}
+    g.topologize_graph()
+    g.set_index()
+    host, real = _shape_sets(g, monkeypatch)
+    assert host == real
+    assert dict(zip(host[0], host[1]))["ga"] == 3 * 4 * 7       # (the int / bool tensors are not calibration tensors)
+    assert "eq" not in host[0] and "mps" not in host[0] and "eqf" in host[0]
+
+
+def test_host_shape_inference_falls_back_when_a_rule_is_missing(monkeypatch):
+    from dipoorlet_amd import shape_infer
+    from dipoorlet_amd.forward_net import WALL
+    monkeypatch.delitem(shape_infer._RULES, "MaxPool")
+    monkeypatch.setenv("DPL_INFER_DEVICE", "0")
+    WALL.pop("session_infer_device_s", None)
+    s = GraphSession(models.resnet18(), device="cpu")
+    assert "session_infer_device_s" in WALL and (len(s.tensor_names), sum(s.elems_per_image)) == (50, 5897704)

@@ -102,8 +102,14 @@ def _main(argv=None):
         dist_helper.init_default()
     t_dist = time.time()
     rank, world = dist.get_rank(), dist.get_world_size()
-    if __import__("torch").cuda.is_available():      # the HIP context (first touch of the device), timed on its own
-        __import__("torch").cuda.synchronize()
+    import torch
+    warm = None
+    if torch.cuda.is_available():
+        # the HIP context and the libraries' first calls: on a helper thread from here on, beside the model load and the
+        # session build (executor.warm_libraries; its own clock reports the context's seconds)
+        from . import executor
+        executor.warm_libraries(torch.device("cuda", rank % max(1, torch.cuda.device_count())))
+        warm = executor._WARM
     t_ctx = time.time()
     if args.output_dir is None:
         args.output_dir = os.path.join(os.path.abspath(os.path.dirname(args.model)), "results")
@@ -121,11 +127,20 @@ def _main(argv=None):
         if n_folded and rank == 0:
             logger.info("Folded {} BatchNormalization nodes into their producers.".format(n_folded))
     args.rank, args.world_size = rank, world
-    args.local_rank = rank % max(1, __import__("torch").cuda.device_count())
+    args.local_rank = rank % max(1, torch.cuda.device_count())
     if rank == 0:
         logger.info("Do tensor calibration...")
     t_cal = time.time()
-    act_clip_val, weight_clip_val = tensor_calibration(onnx_graph, args)
+    prof_path = os.environ.get("DPL_PROFILE_HOST")     # (a tuning aid: cProfile of this rank's calibration phase, top entries to that file)
+    if prof_path:
+        import cProfile
+        import pstats
+        prof = cProfile.Profile()
+        act_clip_val, weight_clip_val = prof.runcall(tensor_calibration, onnx_graph, args)
+        with open(prof_path, "w") as f:
+            pstats.Stats(prof, stream=f).sort_stats("cumtime").print_stats(60)
+    else:
+        act_clip_val, weight_clip_val = tensor_calibration(onnx_graph, args)
     if args.timing_json and rank == 0:
         import json
         from .forward_net import CalibrationRun
@@ -139,7 +154,8 @@ def _main(argv=None):
                            "process_group_backend": dist.get_backend(),
                            # first touch of the HIP runtime + the context (seconds longer right after a process that held
                            # most of the HBM has exited: the driver is still releasing it)
-                           "hip_context_s": dist_helper.TIMES.get("device", 0.0) + (t_ctx - t_dist),
+                           "hip_context_s": dist_helper.TIMES.get("device", 0.0) + (t_ctx - t_dist) + ((warm or {}).get("context_s") or 0.0),
+                           "library_warm_thread_s": (warm or {}).get("total_s"),
                            "until_calibration_starts_s": t_cal - t_enter})
         with open(args.timing_json, "w") as f:
             json.dump(tm, f)

@@ -27,6 +27,60 @@ from .utils import logger
 
 _OPS = {}
 
+_WARM = {"thread": None}
+
+
+def warm_libraries(device=None):
+    """Starts (once per process) a helper thread that makes the FIRST calls of the libraries a forward uses — hipBLASLt's
+    first GEMM alone costs a fresh process 0.17 - 0.22 s (its kernel library for gfx950 is loaded then), the first launch of
+    each family of torch's own kernels 10 - 25 ms (code objects are loaded lazily) — on tiny tensors and a stream of its own,
+    while the main thread reads the model, packs the initializers and starts the .bin reader (torch ops release the GIL).
+    A session's first forward waits for it (wait_warm).  Measured on MI355X, ResNet-50: first forward of a fresh process
+    248 ms -> 52 - 92 ms (scripts/startup_probe.py)."""
+    if _WARM["thread"] is not None or not torch.cuda.is_available():
+        return
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def warm():
+        import time
+        t0 = time.perf_counter()
+        try:
+            torch.cuda.set_device(dev)
+            torch.zeros(1, device=dev)
+            torch.cuda.synchronize(dev)
+            _WARM["context_s"] = time.perf_counter() - t0       # (the HIP context, if this thread is the first to touch the device)
+            with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream(dev)):
+                a = torch.zeros(8, 64, device=dev)
+                torch.addmm(torch.zeros(64, device=dev), a, torch.zeros(64, 64, device=dev))
+                torch.matmul(torch.zeros(2, 4, 8, 8, device=dev), torch.zeros(2, 4, 8, 8, device=dev))
+                x = torch.zeros(2, 8, 16, 16, device=dev)
+                y = F.conv2d(x, torch.zeros(8, 8, 3, 3, device=dev), torch.zeros(8, device=dev), 1, 1)
+                y = F.max_pool2d(torch.relu(y), 3, 2, 1)
+                y = y + y
+                y.mean((2, 3), keepdim=True)
+                y.abs().amax()
+                y.transpose(0, 1).contiguous()
+                torch.softmax(y, -1)
+                torch.erf(y) * y
+                F.layer_norm(y, y.shape[-1:])
+                torch.cat([y, y], 1)
+                torch.cuda.current_stream(dev).synchronize()
+        except Exception:   # noqa: BLE001  (best effort: whatever did not get warm is paid by the first forward, as before)
+            pass
+        _WARM["total_s"] = time.perf_counter() - t0
+
+    import threading
+    _WARM["thread"] = threading.Thread(target=warm, daemon=True, name="dpl-warm")
+    _WARM["thread"].start()
+
+
+def wait_warm():
+    t = _WARM["thread"]
+    if t is not None and t is not True:
+        with _wall("warm_wait_s"):
+            t.join()
+        _WARM["thread"] = True
+
 
 def op(*names):
     def deco(fn):
@@ -462,6 +516,8 @@ class GraphSession(ActivationSession):
         self.device = torch.device(device)
         self.batch = 1
         self.consts = {}
+        if self.device.type == "cuda":
+            warm_libraries(self.device)     # (no-op when the CLI has started it already)
         with _wall("session_consts_s"):
             self._upload_consts()
         missing = sorted({n.op_type for n in graph.graph.node if n.op_type not in _OPS})
@@ -585,6 +641,7 @@ class GraphSession(ActivationSession):
 
     @torch.no_grad()
     def _run_env(self, inputs, batch):
+        wait_warm()
         return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
 
     def _collect(self, env, names, batch):

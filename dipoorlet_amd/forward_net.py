@@ -150,6 +150,7 @@ class CalibrationRun:
         for k, evs in self._events.items():
             out[k + "_gpu_s"] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
         fw = [a.elapsed_time(b) * 1e-3 for a, b in self._events["forward"]]
+        out["forward_batches_ms"] = [round(1e3 * x, 2) for x in fw]
         if len(fw) > 2:   # the first batch carries the one-time costs (MIOpen kernel loading / algorithm choice)
             out["forward_first_batch_gpu_s"] = fw[0]
             out["forward_steady_images_per_s"] = self.batch * (len(fw) - 1) / max(sum(fw[1:]), 1e-9)

@@ -18,7 +18,7 @@ from . import dist_helper
 from .deploy import to_deploy
 from .graph import ONNXGraph
 from .tensor_cali import tensor_calibration
-from .utils import load_clip_val, logger, reduce_clip_val, save_clip_val, setup_logger
+from .utils import MARKS, load_clip_val, logger, mark, reduce_clip_val, save_clip_val, setup_logger
 
 
 def build_parser():
@@ -89,6 +89,7 @@ def _process_age_s():
 
 def _main(argv=None):
     t_enter = time.time()
+    mark("main:enter")
     age_at_enter = _process_age_s()       # interpreter + imports (torch, the package) up to here
     args = build_parser().parse_args(argv)
     if args.quant_format == "QOP":
@@ -101,6 +102,7 @@ def _main(argv=None):
     else:
         dist_helper.init_default()
     t_dist = time.time()
+    mark("main:group_and_device")
     rank, world = dist.get_rank(), dist.get_world_size()
     import torch
     warm = None
@@ -131,6 +133,7 @@ def _main(argv=None):
     if rank == 0:
         logger.info("Do tensor calibration...")
     t_cal = time.time()
+    mark("main:calibration_starts")
     prof_path = os.environ.get("DPL_PROFILE_HOST")     # (a tuning aid: cProfile of this rank's calibration phase, top entries to that file)
     if prof_path:
         import cProfile
@@ -144,7 +147,10 @@ def _main(argv=None):
     if args.timing_json and rank == 0:
         import json
         from .forward_net import CalibrationRun
+        mark("main:calibration_done")
         tm = CalibrationRun.last.timing() if CalibrationRun.last is not None else {}
+        # seconds after main() was entered at which each point of a fresh process was first passed (warm:* = the helper thread)
+        tm["timeline_s"] = {k: round(v - t_enter, 4) for k, v in sorted(MARKS.items(), key=lambda kv: kv[1])}
         tm.update(tensor_calibration_wall_s=time.time() - t_cal, load_model_wall_s=t_cal - start, act_quant=args.act_quant,
                   calib_batch=args.calib_batch, world_size=world,
                   # the fixed costs of a fresh process, itemised: interpreter + imports, process group, HIP context (the
@@ -155,7 +161,7 @@ def _main(argv=None):
                            # first touch of the HIP runtime + the context (seconds longer right after a process that held
                            # most of the HBM has exited: the driver is still releasing it)
                            "hip_context_s": dist_helper.TIMES.get("device", 0.0) + (t_ctx - t_dist) + ((warm or {}).get("context_s") or 0.0),
-                           "library_warm_thread_s": (warm or {}).get("total_s"),
+                           "library_warm_threads_s": {k: round(v, 4) for k, v in (warm or {}).items() if k in ("kernels_s", "blas_s")},
                            "until_calibration_starts_s": t_cal - t_enter})
         with open(args.timing_json, "w") as f:
             json.dump(tm, f)

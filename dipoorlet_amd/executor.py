@@ -23,63 +23,75 @@ torch.backends.cuda.matmul.allow_tf32 = False
 
 from .forward_net import ActivationSession
 from .forward_net import wall as _wall
-from .utils import logger
+from .utils import logger, mark
 
 _OPS = {}
 
-_WARM = {"thread": None}
+_WARM = {}     # "kernels" / "blas": the helper threads (True once joined); "context_s", "kernels_s", "blas_s": their own clocks
 
 
 def warm_libraries(device=None):
-    """Starts (once per process) a helper thread that makes the FIRST calls of the libraries a forward uses — hipBLASLt's
-    first GEMM alone costs a fresh process 0.17 - 0.22 s (its kernel library for gfx950 is loaded then), the first launch of
-    each family of torch's own kernels 10 - 25 ms (code objects are loaded lazily) — on tiny tensors and a stream of its own,
-    while the main thread reads the model, packs the initializers and starts the .bin reader (torch ops release the GIL).
-    A session's first forward waits for it (wait_warm).  Measured on MI355X, ResNet-50: first forward of a fresh process
-    248 ms -> 52 - 92 ms (scripts/startup_probe.py)."""
-    if _WARM["thread"] is not None or not torch.cuda.is_available():
+    """Starts (once per process) two helper threads that make the FIRST calls of the libraries a forward uses, on tiny tensors
+    and streams of their own, while the main thread reads the model, packs the initializers and starts the .bin reader (torch
+    ops release the GIL; measured on MI355X, scripts/warm_probe.py: made one after the other the first calls take 0.39 s after
+    hipInit, from two threads 0.26 s):
+      'blas'     the first GEMM — hipBLASLt (rocBLAS alike) loads its kernel library for gfx950 then: 0.17 - 0.2 s.  Only an op that
+                 multiplies matrices waits for it (wait_warm('blas') in MatMul / Gemm): ResNet-50's one Gemm is its last node, the
+                 first batch's convolutions are issued while this thread is still loading
+      'kernels'  the first launch of each family of torch's own kernels (code objects are loaded lazily: 10 - 25 ms each) and
+                 MIOpen's first convolution; a session's first forward waits for it (wait_warm('kernels'))
+    A fresh ResNet-50 process: first forward 248 ms -> 52 - 92 ms (scripts/startup_probe.py)."""
+    if "kernels" in _WARM or not torch.cuda.is_available():
         return
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
-    def warm():
+    def run(name, body):
         import time
         t0 = time.perf_counter()
+        mark(f"warm:{name}:start")
         try:
             torch.cuda.set_device(dev)
-            torch.zeros(1, device=dev)
-            torch.cuda.synchronize(dev)
-            _WARM["context_s"] = time.perf_counter() - t0       # (the HIP context, if this thread is the first to touch the device)
             with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream(dev)):
-                a = torch.zeros(8, 64, device=dev)
-                torch.addmm(torch.zeros(64, device=dev), a, torch.zeros(64, 64, device=dev))
-                torch.matmul(torch.zeros(2, 4, 8, 8, device=dev), torch.zeros(2, 4, 8, 8, device=dev))
-                x = torch.zeros(2, 8, 16, 16, device=dev)
-                y = F.conv2d(x, torch.zeros(8, 8, 3, 3, device=dev), torch.zeros(8, device=dev), 1, 1)
-                y = F.max_pool2d(torch.relu(y), 3, 2, 1)
-                y = y + y
-                y.mean((2, 3), keepdim=True)
-                y.abs().amax()
-                y.transpose(0, 1).contiguous()
-                torch.softmax(y, -1)
-                torch.erf(y) * y
-                F.layer_norm(y, y.shape[-1:])
-                torch.cat([y, y], 1)
+                body(t0)
                 torch.cuda.current_stream(dev).synchronize()
         except Exception:   # noqa: BLE001  (best effort: whatever did not get warm is paid by the first forward, as before)
             pass
-        _WARM["total_s"] = time.perf_counter() - t0
+        _WARM[name + "_s"] = time.perf_counter() - t0
+        mark(f"warm:{name}:end")
+
+    def blas(t0):
+        a = torch.zeros(8, 64, device=dev)
+        torch.addmm(torch.zeros(64, device=dev), a, torch.zeros(64, 64, device=dev))
+        torch.matmul(torch.zeros(2, 4, 8, 8, device=dev), torch.zeros(2, 4, 8, 8, device=dev))
+
+    def kernels(t0):
+        import time
+        x = torch.zeros(2, 8, 16, 16, device=dev)
+        torch.cuda.current_stream(dev).synchronize()
+        _WARM["context_s"] = time.perf_counter() - t0       # (the HIP context and the first code object, if this thread gets there first)
+        y = F.conv2d(x, torch.zeros(8, 8, 3, 3, device=dev), torch.zeros(8, device=dev), 1, 1)
+        y = F.max_pool2d(torch.relu(y), 3, 2, 1)
+        y = y + y
+        y.mean((2, 3), keepdim=True)
+        y.abs().amax()
+        y.transpose(0, 1).contiguous()
+        torch.softmax(y, -1)
+        torch.erf(y) * y
+        F.layer_norm(y, y.shape[-1:])
+        torch.cat([y, y], 1)
 
     import threading
-    _WARM["thread"] = threading.Thread(target=warm, daemon=True, name="dpl-warm")
-    _WARM["thread"].start()
+    for name, body in (("blas", blas), ("kernels", kernels)):
+        _WARM[name] = threading.Thread(target=run, args=(name, body), daemon=True, name="dpl-warm-" + name)
+        _WARM[name].start()
 
 
-def wait_warm():
-    t = _WARM["thread"]
+def wait_warm(name):
+    t = _WARM.get(name)
     if t is not None and t is not True:
-        with _wall("warm_wait_s"):
+        with _wall(f"warm_wait_{name}_s"):
             t.join()
-        _WARM["thread"] = True
+        _WARM[name] = True
 
 
 def op(*names):
@@ -282,11 +294,15 @@ def _gmp(s, node, x):
 
 @op("MatMul")
 def _matmul(s, node, a, b):
+    if a.is_cuda:
+        wait_warm("blas")
     return torch.matmul(a, b)
 
 
 @op("Gemm")
 def _gemm(s, node, a, b, c=None):
+    if a.is_cuda:
+        wait_warm("blas")
     if node.attrs.get("transA", 0):
         a = a.t()
     if node.attrs.get("transB", 0):
@@ -520,6 +536,7 @@ class GraphSession(ActivationSession):
             warm_libraries(self.device)     # (no-op when the CLI has started it already)
         with _wall("session_consts_s"):
             self._upload_consts()
+        mark("session:consts_issued")
         missing = sorted({n.op_type for n in graph.graph.node if n.op_type not in _OPS})
         if missing:
             raise NotImplementedError(f"executor: unsupported ONNX ops {missing}")
@@ -587,6 +604,13 @@ class GraphSession(ActivationSession):
                 feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
                                         device=self.device) for n in self.input_names}
                 env = self._forward(feeds, 1)
+        if self._batched_ok is None and os.environ.get("DPL_EXECUTOR_VERIFY_BATCHING", "0") != "1":
+            from . import shape_infer
+            try:    # batching proven per-sample node by node: no batch-2 against batch-1 forwards at the first batched run
+                if shape_infer.batch_transparent(self.graph, self._folded, self.input_names, env):
+                    self._batched_ok = True
+            except Exception:   # noqa: BLE001  (no proof: the session verifies dynamically)
+                pass
         names, elems = [], []
         self.shape1 = {}
         for n in self.input_names:
@@ -641,7 +665,9 @@ class GraphSession(ActivationSession):
 
     @torch.no_grad()
     def _run_env(self, inputs, batch):
-        wait_warm()
+        mark("first_forward:reached")
+        wait_warm("kernels")
+        mark("first_forward:start")
         return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
 
     def _collect(self, env, names, batch):

@@ -21,7 +21,7 @@ import torch
 from . import ops
 from .dist_helper import shard_range
 from .platform_settings import platform_setting_table
-from .utils import logger
+from .utils import logger, mark
 
 DEFAULT_BATCH = 32   # images per forward (the batch bench.py measures the statistics kernels at)
 
@@ -110,9 +110,11 @@ class CalibrationRun:
         # the .bin files of the first batches are read (pinned staging) WHILE the session is built: the reader needs the graph's
         # declared input shapes only
         self._reader = self._start_reader(torch.cuda.is_available())
+        mark("run:reader_started")
         if session is None:
             with wall("session_build_s"):      # weights to the device (one transfer), node schedule, shapes (host rules)
                 session = onnx_graph.make_session(args)
+        mark("run:session_built")
         self.session = session
         self.names = list(self.session.tensor_names)
         self.elems = [int(e) for e in self.session.elems_per_image]
@@ -242,6 +244,7 @@ class CalibrationRun:
         for b, inputs in self._input_batches():
             with self.timed("forward"):
                 tensors = self.session.run(inputs)
+            mark("first_forward:issued")
             if keep and self._resident_ok:
                 nbytes = sum(t.numel() * 4 for t in tensors)
                 if self._resident_bytes + nbytes <= self._budget:

@@ -416,3 +416,137 @@ def infer(graph, folded, input_names, batch=1):
         else:
             env[node.output[0]] = out
     return env
+
+
+# ------------------------------------------------------------------------------------------ is batching provably safe?
+_PER_SAMPLE_UNARY = {"Relu", "LeakyRelu", "Sigmoid", "Tanh", "HardSigmoid", "HardSwish", "Clip", "Gelu", "Erf", "Sqrt", "Exp", "Log",
+                     "Abs", "Neg", "Reciprocal", "Floor", "Ceil", "Identity", "Dropout", "Cast"}
+_PER_SAMPLE_NCHW = {"Conv", "ConvTranspose", "MaxPool", "AveragePool", "GlobalAveragePool", "GlobalMaxPool", "BatchNormalization",
+                    "InstanceNormalization"}
+_BINARY = {"Add", "Sub", "Mul", "Div", "Pow", "Eltwise", "PRelu"}
+
+
+def batch_transparent(graph, folded, input_names, env):
+    """True when every node of `graph` provably maps image b of its inputs to image b of its outputs, the images stacked on ONE
+    known axis of every tensor (axis 0 of the network inputs; a Transpose / Gather may move it) — so that B images through a
+    graph exported for one are B single runs, and the session need not verify that with a batch-2 forward against two batch-1
+    forwards (executor.GraphSession.batched_ok: three more forwards at batch sizes the run never uses, 0.14 s of a fresh
+    ResNet-50 process).  Conservative: anything that merges, splits or indexes the batch axis (a Reshape beyond a leading
+    0 / 1, Gather / Slice / Concat / a reduction on it, an op not listed) answers False and the session verifies dynamically,
+    as before.  env: shape_infer.infer's result at batch 1 (ranks and constant values are read from it)."""
+    from . import executor as ex
+    batch_axis = {}                                     # tensor name -> the axis its images are stacked on
+    for n in input_names:
+        shp = graph.get_tensor_shape(n)
+        if not shp or max(1, int(shp[0])) != 1:
+            return False
+        batch_axis[n] = 0
+    const = set(graph.initializer)
+
+    def rank(name):
+        return len(env[name].shape)
+
+    def ax(a, nd):
+        return a + nd if a < 0 else a
+
+    def values(name):
+        v = env.get(name)
+        return ex._ints(v) if _real(v) else None
+
+    for node in graph.graph.node:
+        if node.name in folded:
+            const.add(node.output[0])
+            continue
+        ins = [i for i in node.input if i != ""]
+        if any(i not in batch_axis and i not in const for i in ins):
+            return False
+        if all(i in const for i in ins):
+            const.update(o for o in node.output if o)
+            continue
+        op, x = node.op_type, ins[0]
+        rest_const = x in batch_axis and all(i in const for i in ins[1:])
+        nd = rank(x)
+        k = batch_axis.get(x)
+        out = None                                       # the outputs' batch axis once the node is proven per-sample
+        if op in _PER_SAMPLE_UNARY:
+            out = k if rest_const else None
+        elif op in _PER_SAMPLE_NCHW:
+            out = 0 if rest_const and k == 0 else None
+        elif op == "FakeQuant":
+            q = graph._qdq.get(node.name)
+            if rest_const and q is not None and not (q.per_channel and ax(int(q.axis), nd) == k):
+                out = k
+        elif op in _BINARY:
+            a, b = ins
+            if a in batch_axis and b in batch_axis:
+                out = batch_axis[a] if (rank(a) == rank(b) and batch_axis[a] == batch_axis[b]) else None
+            else:
+                t, c = (a, b) if a in batch_axis else (b, a)
+                cs, rt, kt = env[c].shape, rank(t), batch_axis[t]
+                grow = max(0, len(cs) - rt)             # right-aligned broadcasting: the result has max(rank) axes
+                pos = kt + grow - (max(len(cs), rt) - len(cs))
+                if pos < 0 or cs[pos] == 1:
+                    out = kt + grow
+        elif op == "Flatten":
+            out = 0 if rest_const and k == 0 and ax(int(node.attrs.get("axis", 1)), nd) >= 1 else None
+        elif op == "Gemm":
+            out = 0 if rest_const and k == 0 and not node.attrs.get("transA", 0) and nd == 2 else None
+        elif op == "MatMul":
+            a, b = ins
+            if a in batch_axis and b in batch_axis:
+                if rank(a) == rank(b) >= 3 and batch_axis[a] == batch_axis[b] < rank(a) - 2:
+                    out = batch_axis[a]
+            elif a in batch_axis and nd >= 2 and rank(b) == 2 and k <= nd - 2:
+                out = k
+        elif op == "Softmax":
+            out = k if rest_const and ax(int(node.attrs.get("axis", -1)), nd) != k else None
+        elif op == "LayerNormalization":
+            out = k if rest_const and k < ax(int(node.attrs.get("axis", -1)), nd) else None
+        elif op in ("ReduceMean", "ReduceSum", "ReduceMax", "ReduceMin", "Squeeze"):
+            axes = node.attrs.get("axes") if len(ins) < 2 else values(ins[1])
+            if rest_const and axes is not None:
+                axes = [ax(int(a), nd) for a in axes]
+                if k not in axes:
+                    gone = op == "Squeeze" or not node.attrs.get("keepdims", 1)
+                    out = k - (sum(1 for a in axes if a < k) if gone else 0)
+        elif op == "Unsqueeze":
+            axes = node.attrs.get("axes") if len(ins) < 2 else values(ins[1])
+            if rest_const and axes is not None:
+                new = sorted(ax(int(a), nd + len(axes)) for a in axes)
+                old = [i for i in range(nd + len(axes)) if i not in new]
+                out = old[k]
+        elif op == "Concat":
+            ca = ax(int(node.attrs["axis"]), nd)
+            ks = {batch_axis[i] for i in ins if i in batch_axis}
+            cs_ok = all(i in batch_axis or (len(env[i].shape) == nd and env[i].shape[0] == 1) for i in ins)
+            if len(ks) == 1 and cs_ok and ca not in ks and all(rank(i) == nd for i in ins):
+                kk = next(iter(ks))
+                if kk == 0 or all(i in batch_axis for i in ins):    # (the executor expands constants along axis 0 only)
+                    out = kk
+        elif op == "Transpose":
+            perm = node.attrs.get("perm") or list(reversed(range(nd)))
+            out = list(perm).index(k) if rest_const else None
+        elif op == "Reshape":
+            shp = values(ins[1]) if len(ins) > 1 else None
+            if rest_const and k == 0 and shp and shp[0] in (0, 1) and env[x].shape[0] == 1 and shp.count(-1) <= 1:
+                out = 0
+        elif op == "Split":
+            out = k if rest_const and ax(int(node.attrs.get("axis", 0)), nd) != k else None
+        elif op == "Gather":
+            ga = ax(int(node.attrs.get("axis", 0)), nd)
+            if rest_const and ga != k:
+                out = k + (len(env[ins[1]].shape) - 1 if ga < k else 0)
+        elif op == "Slice":
+            axes = node.attrs.get("axes") if len(ins) < 4 else values(ins[3])
+            if rest_const and axes is not None and all(ax(int(a), nd) != k for a in axes):
+                out = k
+        elif op == "Pad":
+            pads = node.attrs.get("pads") if len(ins) < 2 else values(ins[1])
+            if rest_const and pads is not None and len(pads) == 2 * nd and pads[k] == 0 and pads[nd + k] == 0:
+                out = k
+        if out is None:
+            return False
+        for o in node.output:
+            if o:
+                batch_axis[o] = out
+    return True

@@ -15,6 +15,13 @@ from .platform_settings import platform_setting_table
 
 logger = logging.getLogger("dipoorlet")
 
+MARKS = {}     # name -> time.time() of the first pass through mark(name): a fresh process' timeline (--timing_json)
+
+
+def mark(name):
+    import time
+    MARKS.setdefault(name, time.time())
+
 
 class _Dispatcher:
     """`d = dispatch_functool(default)`; `@d.register(key)`; `d(key, *args, **kw)` calls the function

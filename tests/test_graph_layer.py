@@ -315,3 +315,51 @@ def test_host_shape_inference_falls_back_when_a_rule_is_missing(monkeypatch):
     WALL.pop("session_infer_device_s", None)
     s = GraphSession(models.resnet18(), device="cpu")
     assert "session_infer_device_s" in WALL and (len(s.tensor_names), sum(s.elems_per_image)) == (50, 5897704)
+
+
+def test_static_batching_proof_never_contradicts_the_dynamic_check(tmp_path, monkeypatch):
+    """shape_infer.batch_transparent lets a session skip the batch-2-against-batch-1 verification.  Whenever it says 'proven',
+    the verification — forced here — must agree; the graph that scrambles a batch must not be proven."""
+    graphs = [("r18", models.resnet18()), ("vit", models.vit(depth=2, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10))]
+    torch.manual_seed(0)
+    for mk, shape in ((SmallCNN, (1, 3, 16, 16)), (SmallMLP, (1, 5, 16)), (ShapeZoo, (1, 3, 17, 19))):
+        path = str(tmp_path / f"{mk.__name__}.onnx")
+        _torch_export(mk().eval(), torch.randn(*shape), path)
+        graphs.append((mk.__name__, ONNXGraph.load(path)))
+    proven = {}
+    for name, g in graphs:
+        monkeypatch.setenv("DPL_EXECUTOR_VERIFY_BATCHING", "0")
+        proven[name] = GraphSession(g, device="cpu")._batched_ok
+        monkeypatch.setenv("DPL_EXECUTOR_VERIFY_BATCHING", "1")
+        s = GraphSession(g, device="cpu")
+        assert s._batched_ok is None
+        assert s.batched_ok() or not proven[name], name
+    assert proven["r18"] is True and proven["vit"] is True and proven["SmallCNN"] is True
+    # the scrambling Reshape of test_batched_execution_is_verified_against_per_image: no proof
+    from dipoorlet_amd.onnx_io import Node
+    monkeypatch.setenv("DPL_EXECUTOR_VERIFY_BATCHING", "0")
+    g = ONNXGraph()
+    g.graph.node = [Node("Relu", ["x"], ["r"], name="relu"), Node("Reshape", ["r", "shp"], ["y"], name="reshape")]
+    g.initializer = {"shp": np.array([4, -1], np.int64)}
+    g.network_inputs, g.network_outputs = ["x"], ["y"]
+    g.input = ["x", "shp"]
+    g.tensor_name_shape_map = {"x": [1, 4, 6]}
+    g.topologize_graph()
+    g.set_index()
+    assert GraphSession(g, device="cpu")._batched_ok is None
+    # ... nor an axis-0 Concat of the input with itself, a Transpose that is followed by an NCHW op, a reduction over the batch
+    for nodes, init in (([Node("Concat", ["x", "x"], ["y"], name="c", attrs={"axis": 0})], {}),
+                        ([Node("Transpose", ["x"], ["t"], name="t", attrs={"perm": [1, 0, 2]}),
+                          Node("GlobalAveragePool", ["t"], ["y"], name="gap")], {}),
+                        ([Node("ReduceMean", ["x"], ["y"], name="rm", attrs={"axes": [0], "keepdims": 1})], {}),
+                        ([Node("Add", ["x", "k"], ["y"], name="add")], {"k": np.ones((2, 4, 6), np.float32)})):
+        g = ONNXGraph()
+        g.graph.node, g.initializer = nodes, dict(init)
+        g.network_inputs, g.network_outputs = ["x"], ["y"]
+        g.input = ["x"] + list(init)
+        g.tensor_name_shape_map = {"x": [1, 4, 6]}
+        g.topologize_graph()
+        g.set_index()
+        from dipoorlet_amd import shape_infer
+        env = shape_infer.infer(g, set(), ["x"], 1)
+        assert shape_infer.batch_transparent(g, set(), ["x"], env) is False, nodes[0].op_type

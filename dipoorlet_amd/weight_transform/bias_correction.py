@@ -16,6 +16,7 @@ The fake-quant structure does not depend on bias values, so the quantised graph 
 """
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from .. import ops
 from ..executor import _OPS, GraphSession
@@ -27,26 +28,39 @@ from ..utils import logger
 BIAS_CORRECTION_NODE_TYPE = ["Conv", "Gemm"]
 
 
-def _channel_mean_diff(fp_chunks, q_chunks, is_conv):
+def _channel_mean_diff(fp_chunks, q_chunks, is_conv, world_size=1, n_ch=None):
     """bias_correction.py:10-13 — mean(fp - q) over every axis but the channel one (axis 1 of a Conv output
-    [n, C, spatial...]; the last axis of a Gemm output [n, C]): one fused kernel per chunk pair, fp64 sums."""
+    [n, C, spatial...]; the last axis of a Gemm output [n, C]): one fused kernel per chunk pair, fp64 sums.
+    world_size > 1: the chunks are this rank's shard of the images; the per-channel fp64 sums and the count are added up over
+    the ranks (ONE all-reduce of [C + 1] doubles per node), so every rank returns the mean over the whole set."""
     acc, cnt = None, 0
     dev = torch.device("cuda", torch.cuda.current_device())
+    if n_ch is not None:        # (a rank whose shard is empty still joins the all-reduce)
+        acc = torch.zeros(int(n_ch), dtype=torch.float64, device=dev)
     for a, b in zip(fp_chunks, q_chunks):
         a, b = a.to(dev, non_blocking=True), b.to(dev, non_blocking=True)   # (no-ops unless the frontier is kept on the host)
         if not is_conv:
             a, b = a.reshape(-1, a.shape[-1]), b.reshape(-1, b.shape[-1])
         acc = ops.channel_diff_sum(a.contiguous(), b.contiguous(), acc)
         cnt += a.numel() // a.shape[1]
+    if world_size > 1:
+        packed = torch.cat([acc, torch.tensor([float(cnt)], dtype=torch.float64, device=acc.device)])
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+        return (packed[:-1] / packed[-1]).float()
     return (acc / cnt).float()
 
 
-def update_conv_node_bias(graph_bc, node, fp_activations, q_activations):
+def update_conv_node_bias(graph_bc, node, fp_activations, q_activations, world_size=1):
     """bias_correction.py:9-31 on device tensors: bias += mean(fp - q) over every axis but the channel one (Conv output
     chunks [n, C, H, W], Gemm output chunks [n, C]); a node without a bias input gets `<node>_bias`.  Returns the
-    per-channel difference (fp32 device tensor) that was added.  `*_activations`: lists of per-chunk device tensors."""
-    diff = _channel_mean_diff(fp_activations, q_activations, node.op_type == "Conv")
+    per-channel difference (fp32 device tensor) that was added.  `*_activations`: lists of per-chunk device tensors
+    (world_size > 1: of this rank's shard; the mean is over all ranks' images)."""
     bc_node = next(n for n in graph_bc.graph.node if n.name == node.name)
+    n_ch = None
+    if world_size > 1:          # the channel count from the weights: [C_out, ...] (Conv; Gemm with transB), [K, C_out] (Gemm)
+        w = graph_bc.get_initializer(bc_node.input[1])
+        n_ch = w.shape[0] if (node.op_type == "Conv" or bc_node.attrs.get("transB", 0)) else w.shape[1]
+    diff = _channel_mean_diff(fp_activations, q_activations, node.op_type == "Conv", world_size, n_ch)
     if len(bc_node.input) > 2:
         bname = bc_node.input[2]
         new_bias = graph_bc.get_initializer(bname).astype(np.float32) + diff.cpu().numpy()
@@ -57,6 +71,12 @@ def update_conv_node_bias(graph_bc, node, fp_activations, q_activations):
         graph_bc.input.append(bname)
     graph_bc.set_initializer(bname, new_bias.astype(np.float32))
     return diff
+
+
+def bc_shard(data_num, rank, world_size):
+    """Images [st, ed) of rank `rank` for the sharded --bc walk: a balanced split that covers ALL data_num images (the reference
+    corrects with every image, forward_net.py:50-52; the calibration sweeps' floor split would drop data_num % world_size)."""
+    return rank * data_num // world_size, (rank + 1) * data_num // world_size
 
 
 def _frontier_peak_elems(graph, session):
@@ -150,8 +170,16 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
     s_fp = GraphSession(graph, device=dev)
     s_q = GraphSession(graph_q, device=dev)
     chunk = int(getattr(args, "calib_batch", 16) or 16)
-    N = args.data_num  # rank 0 walks ALL images, like the reference (forward_net.py:50-52)
-    bounds = [(i, min(i + chunk, N)) for i in range(0, N, chunk)]
+    # The reference lets rank 0 walk ALL images while the others wait (weight_trans_base.py:21-29, forward_net.py:50-52).  The
+    # correction is a per-channel SUM over images, so with several ranks each walks its shard of the images node-major as
+    # before and the sums are all-reduced per Conv / Gemm node (RCCL): every rank holds the same corrected biases, and its
+    # frontier is 1 / world of the set.  args.merge == 'reference' keeps the reference's schedule.
+    world = int(getattr(args, "world_size", 1) or 1)
+    sharded = world > 1 and getattr(args, "merge", "allreduce") != "reference" and dist.is_available() and dist.is_initialized()
+    st, ed = bc_shard(args.data_num, int(getattr(args, "rank", 0)), world) if sharded else (0, args.data_num)
+    world = world if sharded else 1
+    N = ed - st
+    bounds = [(i, min(i + chunk, ed)) for i in range(st, ed, chunk)]
     sizes = [j - i for i, j in bounds]
     shapes = {n: graph.get_tensor_shape(n) for n in graph.network_inputs}
     # HBM budget: the two frontiers hold the WHOLE set's live activations.  Refuse up front with a plain message rather than
@@ -186,7 +214,7 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
         out = node.output[0]
         if node.op_type in BIAS_CORRECTION_NODE_TYPE:
             logger.info("Update bias for node: {}".format(node.name))
-            diff = update_conv_node_bias(graph_bc, node, keep_fp[out], qf.env[out])
+            diff = update_conv_node_bias(graph_bc, node, keep_fp[out], qf.env[out], world)
             shape = [1, -1] + [1] * (qf.env[out][0].dim() - 2)
             d_host = diff.reshape(shape).cpu() if on_host else None
             for t in qf.env[out]:  # the bias is additive in the output: fix the computed q output in place
@@ -196,7 +224,7 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
             if env_ref.ref[o] == 0:
                 env_ref.env.pop(o, None)
     graph_bc.update_model()
-    if getattr(args, "output_dir", None):
+    if getattr(args, "output_dir", None) and (not sharded or int(getattr(args, "rank", 0)) == 0):
         graph_bc.output_dir = args.output_dir
         graph_bc.save_onnx_model("update_bias_model")
     return graph_bc

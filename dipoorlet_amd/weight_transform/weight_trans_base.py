@@ -40,9 +40,13 @@ def weight_calibration(onnx_graph, act_clip_val, weight_clip_val, args):
     with the same model and ranges."""
     graph_after_wt = ONNXGraph()
     graph_after_wt.copy_from(onnx_graph)
-    if getattr(args, "bc", False):   # :21-29 — rank 0 corrects, everyone reloads, weight (bias) ranges refreshed
+    if getattr(args, "bc", False):   # :21-29 — the reference: rank 0 corrects, everyone reloads, weight (bias) ranges refreshed
+        # here every rank corrects over its shard of the images and the per-channel sums are all-reduced (bias_correction);
+        # --merge reference: rank 0 alone, over all images.  Rank 0 writes the model, everyone reloads it, as before.
+        sharded = dist.get_world_size() > 1 and getattr(args, "merge", "allreduce") != "reference"
         if dist.get_rank() == 0:
             logger.info("Weight transform: bias correction...")
+        if sharded or dist.get_rank() == 0:
             bias_correction(graph_after_wt, act_clip_val, weight_clip_val, args)
         dist.barrier()
         graph_after_wt = _reload("update_bias_model", args)

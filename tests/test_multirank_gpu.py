@@ -80,3 +80,51 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["config"]["hist_checksum_ok"] is True and len(line["config"]["per_rank_images_per_s"]) == 2
     assert line["config"]["collectives_ms_per_sweep"] > 0
     assert line["roofline"]["mse"]["ok"] is True and line["value"] > 0
+
+
+def _bc_worker(rank, world, port, model, calib, out_dir, n):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      DPL_DIST_BACKEND="gloo")
+    from dipoorlet_amd.__main__ import main
+    rc = main(["-M", model, "-I", calib, "-N", str(n), "-A", "minmax", "-D", "trt", "-O", out_dir, "--calib_batch", "4",
+               "--bc", "--skip_profiling"])
+    assert rc == 0
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [8, 7])
+def test_bias_correction_sharded_over_two_ranks_equals_one_rank(tmp_path, n):
+    """`--bc` with the images sharded over two ranks (each walks its shard node-major, the per-channel fp64 sums are
+    all-reduced per Conv / Gemm node; weight_transform/bias_correction.py) writes the biases the one-rank run writes
+    (the reference's schedule: rank 0 over all images, weight_trans_base.py:21-29).  N = 7: the balanced split 3 + 4
+    covers every image — the calibration sweeps' floor split would drop one."""
+    from dipoorlet_amd import models
+    from dipoorlet_amd.graph import ONNXGraph
+    g = models.resnet18(seed=11, image=64)
+    g.output_dir = str(tmp_path)
+    model = g.save_onnx_model("model")
+    os.makedirs(tmp_path / "calib" / "input")
+    rng = np.random.default_rng(5)
+    for i in range(n):
+        rng.standard_normal(3 * 64 * 64).astype(np.float32).tofile(tmp_path / "calib" / "input" / f"{i}.bin")
+    port = 29300 + os.getpid() % 200
+    mp.spawn(_bc_worker, args=(1, port, model, str(tmp_path / "calib"), str(tmp_path / "w1"), n), nprocs=1, join=True)
+    mp.spawn(_bc_worker, args=(2, port + 1, model, str(tmp_path / "calib"), str(tmp_path / "w2"), n), nprocs=2, join=True)
+    g1 = ONNXGraph.load(str(tmp_path / "w1" / "update_bias_model.onnx"))
+    g2 = ONNXGraph.load(str(tmp_path / "w2" / "update_bias_model.onnx"))
+    checked, moved = 0, 0.0
+    for node in g.graph.node:
+        if node.op_type in ("Conv", "Gemm"):
+            b0 = g.get_initializer(node.input[2]).astype(np.float64)
+            b1 = g1.get_initializer(node.input[2]).astype(np.float64)
+            b2 = g2.get_initializer(node.input[2]).astype(np.float64)
+            moved = max(moved, float(np.abs(b1 - b0).max()))
+            # n = 8: both runs execute the same batches of 4 (same library kernels), only the order of the fp64 sums differs.
+            # n = 7: batches of 4 + 3 against 3 and 4: other convolution kernels, last-bit noise upstream, now and then a
+            # flipped quantisation step downstream
+            tol = 1e-6 if n == 8 else 6e-4
+            assert np.allclose(b1, b2, rtol=0, atol=tol), (node.name, float(np.abs(b1 - b2).max()))
+            checked += 1
+    assert checked >= 10 and moved > 1e-4       # (the correction did something)
+    with open(tmp_path / "w2" / "weight_clip_val.json") as f1, open(tmp_path / "w1" / "weight_clip_val.json") as f2:
+        assert set(json.load(f1)) == set(json.load(f2))

@@ -90,6 +90,8 @@ def _process_age_s():
 def _main(argv=None):
     t_enter = time.time()
     mark("main:enter")
+    if os.environ.get("DPL_SWITCH_INTERVAL"):      # (a tuning aid: the interpreter's thread switch interval, seconds)
+        sys.setswitchinterval(float(os.environ["DPL_SWITCH_INTERVAL"]))
     age_at_enter = _process_age_s()       # interpreter + imports (torch, the package) up to here
     args = build_parser().parse_args(argv)
     if args.quant_format == "QOP":

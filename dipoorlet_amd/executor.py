@@ -634,6 +634,44 @@ class GraphSession(ActivationSession):
     def match_batch(self, a, b):
         return a, b
 
+    def prewarm_convs(self, batch, threads=3):
+        """The first call of every DISTINCT convolution configuration of this graph at `batch` images, on zeros, from `threads`
+        helper threads (streams of their own; the graph's last layers first, the forward starts at the other end).  MIOpen
+        resolves a configuration's solver and loads its code object on first use — 2.7 ms per configuration, 63 ms for
+        ResNet-50's 23 from one thread, 18 ms from three, and the main thread's own first forward then finds them loaded
+        (scripts/miopen_probe.py).  Returns at once; nothing waits for the threads."""
+        if self.device.type != "cuda" or batch < 1 or os.environ.get("DPL_PREWARM_CONVS", "1") == "0":
+            return
+        seen, todo = set(), []
+        for node in self.graph.graph.node:
+            if node.op_type != "Conv" or node.name in self._folded:
+                continue
+            shp, w = self.shape1.get(node.input[0]), self.consts.get(node.input[1])
+            if shp is None or w is None or len(shp) != w.dim() or shp[0] != 1:
+                continue
+            key = (tuple(shp), tuple(w.shape), tuple(node.attrs.get("strides", ())), tuple(node.attrs.get("pads", ())),
+                   tuple(node.attrs.get("dilations", ())), int(node.attrs.get("group", 1)), node.attrs.get("auto_pad", ""), len(node.input))
+            if key not in seen:
+                seen.add(key)
+                todo.append((node, (batch,) + tuple(shp[1:])))
+        todo.reverse()
+
+        def work(part):
+            try:
+                torch.cuda.set_device(self.device)
+                with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream(self.device)):
+                    for node, shape in part:
+                        args = [self.consts[i] for i in node.input[1:] if i != ""]
+                        _OPS["Conv"](self, node, torch.zeros(shape, device=self.device), *args)
+                    torch.cuda.current_stream(self.device).synchronize()
+            except Exception:   # noqa: BLE001  (best effort)
+                pass
+            mark("warm:convs:end")
+
+        import threading
+        for k in range(max(1, min(threads, len(todo)))):
+            threading.Thread(target=work, args=(todo[k::threads],), daemon=True, name=f"dpl-warm-conv{k}").start()
+
     def set_const(self, name, tensor):
         """Replace an initializer on the device (a weight updated by a weight transform) and refresh the folded
         fake-quantised copy that depends on it."""
@@ -665,9 +703,7 @@ class GraphSession(ActivationSession):
 
     @torch.no_grad()
     def _run_env(self, inputs, batch):
-        mark("first_forward:reached")
-        wait_warm("kernels")
-        mark("first_forward:start")
+        mark("first_forward:start")     # (no wait for the helper threads: first calls are serialised by the libraries' own locks)
         return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
 
     def _collect(self, env, names, batch):

@@ -116,6 +116,8 @@ class CalibrationRun:
                 session = onnx_graph.make_session(args)
         mark("run:session_built")
         self.session = session
+        if self.ed > self.st and hasattr(session, "prewarm_convs"):
+            session.prewarm_convs(min(self.batch, self.ed - self.st))     # (helper threads; returns at once)
         self.names = list(self.session.tensor_names)
         self.elems = [int(e) for e in self.session.elems_per_image]
         self.T = len(self.names)
@@ -153,6 +155,11 @@ class CalibrationRun:
             out[k + "_gpu_s"] = sum(a.elapsed_time(b) for a, b in evs) * 1e-3
         fw = [a.elapsed_time(b) * 1e-3 for a, b in self._events["forward"]]
         out["forward_batches_ms"] = [round(1e3 * x, 2) for x in fw]
+        ms = torch.cuda.memory_stats(self.device)
+        free_b, total_b = torch.cuda.mem_get_info(self.device)
+        out["allocator"] = {"device_allocs": ms.get("num_device_alloc"), "device_frees": ms.get("num_device_free"),
+                            "alloc_retries": ms.get("num_alloc_retries"), "reserved_peak_gb": round(ms.get("reserved_bytes.all.peak", 0) / 1e9, 2),
+                            "device_free_gb": round(free_b / 1e9, 1), "device_total_gb": round(total_b / 1e9, 1)}
         if len(fw) > 2:   # the first batch carries the one-time costs (MIOpen kernel loading / algorithm choice)
             out["forward_first_batch_gpu_s"] = fw[0]
             out["forward_steady_images_per_s"] = self.batch * (len(fw) - 1) / max(sum(fw[1:]), 1e-9)

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_BINS = 16384
 
 
@@ -61,14 +61,22 @@ class OctavOnereadJob(C.Structure):
                 ("d_items", C.c_void_p), ("n_items", C.c_int64), ("d_block_begin", C.c_void_p), ("n_blocks", C.c_int64),
                 ("d_seg_ptrs", C.c_void_p), ("d_states", C.c_void_p), ("d_lh", C.c_void_p), ("d_pred", C.c_void_p),
                 ("d_pred_pair", C.c_void_p), ("d_use_probe", C.c_void_p),
-                ("d_list0", C.c_void_p), ("d_list1", C.c_void_p), ("d_dir", C.c_void_p), ("d_rescue_bm", C.c_void_p),
+                ("d_list0", C.c_void_p), ("d_list1", C.c_void_p), ("d_pair_base_full", C.c_void_p), ("d_clist0", C.c_void_p),
+                ("d_clist1", C.c_void_p), ("d_dir", C.c_void_p), ("d_rescue_bm", C.c_void_p),
                 ("d_missed", C.c_void_p), ("d_resc", C.c_void_p), ("d_vis", C.c_void_p), ("d_tstat", C.c_void_p), ("write_epoch", C.c_int32),
                 ("reset_epoch", C.c_int32), ("sorted", C.c_int32), ("dynamic_sym", C.c_int32), ("max_iters", C.c_int32),
                 ("predict", C.c_int32), ("probe_z", C.c_float), ("fuse", C.c_int32), ("tail", C.c_int32),
                 ("compaction_inline", C.c_int32)]
 
 
-assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 272 and C.sizeof(FakeQuantParams) == 40
+class OctavWorkspaceSizes(C.Structure):
+    """dpl_octav_workspace_sizes: bytes of every part of the exact-tail form's workspace (dpl_octav_plan_sizes)."""
+    _fields_ = [("tables_bytes", C.c_uint64), ("history_bytes", C.c_uint64), ("state_bytes", C.c_uint64), ("rescue_bytes", C.c_uint64),
+                ("list_bytes", C.c_uint64), ("fallback_bytes", C.c_uint64), ("result_bytes", C.c_uint64),
+                ("n_pairs", C.c_int64), ("n_slices", C.c_int64), ("n_multi", C.c_int64), ("n_small", C.c_int64)]
+
+
+assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 296 and C.sizeof(FakeQuantParams) == 40
 assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 80
 
 _P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
@@ -103,6 +111,12 @@ SIGNATURES = {
     "dpl_octav_oneread_finish": (C.c_int, [_P, _P]),
     "dpl_octav_oneread_compaction": (C.c_int, [_P, _P]),
     "dpl_octav_run_oneread": (C.c_int, [_P, _P]),
+    "dpl_octav_list_cap": (C.c_uint32, [_U64]),
+    "dpl_octav_plan_create": (_P, [_P, _I64, _I64, _I64]),
+    "dpl_octav_plan_destroy": (None, [_P]),
+    "dpl_octav_plan_sizes": (C.c_int, [_P, _P]),
+    "dpl_octav_plan_upload": (C.c_int, [_P, _P, _P]),
+    "dpl_octav_plan_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_test_hook_rescue_fail_every": (C.c_int, [C.c_int]),
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),

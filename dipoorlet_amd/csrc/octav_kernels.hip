@@ -759,8 +759,10 @@ static_assert((kLogKey0 & 31u) == 0u, "the window must start on a bitmap word");
 
 // One span of one pair: the values of the marked bins (bm: the bitmap over the whole key space, in LDS) -> per-lane queues
 // -> the pair's list (cursor: me->len[0], a returning global atomic per wave flush).
+// cap: values the destination region holds — a flush that would pass it is dropped while the cursor keeps counting, so a
+// length above the region's capacity tells the reader that the list is incomplete (the rescue walk then refuses the pair).
 __device__ __forceinline__ void gather_span(const float* __restrict__ p, uint32_t count, const uint32_t* bm, uint32_t* q,
-                                            dpl_octav_state* me, uint32_t* __restrict__ dst) {
+                                            dpl_octav_state* me, uint32_t* __restrict__ dst, uint32_t cap = 0xFFFFFFFFu) {
     const uint32_t lane = threadIdx.x & (kWave - 1);
     uint32_t cnt = 0;
     auto flush = [&]() {
@@ -773,8 +775,10 @@ __device__ __forceinline__ void gather_span(const float* __restrict__ p, uint32_
         const uint32_t total = __shfl(inc, kWave - 1, kWave);
         uint32_t base = 0;
         if (lane == kWave - 1) base = atomicAdd(&me->len[0], total);
-        base = __shfl(base, kWave - 1, kWave) + inc - cnt;
-        for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j * kWave];
+        const uint32_t first = __shfl(base, kWave - 1, kWave);
+        base = first + inc - cnt;
+        if (first + total <= cap)
+            for (uint32_t j = 0; j < cnt; ++j) dst[base + j] = q[j * kWave];
         cnt = 0;
     };
     for_each_tile<kBlock>(p, count, [&](const f4 (&v)[4], uint32_t, bool) {
@@ -883,7 +887,8 @@ __global__ __launch_bounds__(kBlock) void k_octav_rescue_gather(const uint32_t* 
         const dpl_span sp = pair_spans[pair];
         const uint64_t off = (uint64_t)c * kRescueUnit;
         const uint32_t cnt = (uint32_t)min((uint64_t)kRescueUnit, sp.count - off);
-        gather_span(segs[sp.seg] + sp.offset + off, cnt, bm, q, me, reinterpret_cast<uint32_t*>(list1 + pair_base[pair]));
+        gather_span(segs[sp.seg] + sp.offset + off, cnt, bm, q, me, reinterpret_cast<uint32_t*>(list1 + pair_base[pair]),
+                    (uint32_t)(pair_base[pair + 1] - pair_base[pair]));
     }
 }
 

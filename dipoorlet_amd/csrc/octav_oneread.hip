@@ -71,6 +71,7 @@ constexpr int kWaves = kThreads / kWave;
 constexpr int kVec = DPL_RES_VEC;                               // 16-byte vectors per thread the walk keeps a list in
 constexpr int kOver = 4;                                         // rows of a list beyond the resident ones streamed per step of an iteration
 constexpr uint32_t kSmallCap = 20480;                           // pairs this small gather their whole window (no prediction)
+static_assert(kSmallCap == kListWhole, "a small pair's list region must hold the whole pair (list_cap_of)");
 #ifndef DPL_SLICE_CAP
 #define DPL_SLICE_CAP 1044480
 #endif
@@ -90,6 +91,7 @@ constexpr int kQueueTop = DPL_QUEUE_TOP;                        // ... and, at a
 #endif
 constexpr int kAppendLag = DPL_APPEND_LAG;                      // vectors between a vector's adds and the look at their returns
 constexpr uint32_t kMaxCluster = 64;
+constexpr int64_t kPlanEpoch = 8;   // batches per threshold-history epoch (dpl_octav_plan_bind; the Python pipeline's _ONEREAD_EPOCH)
 #ifndef DPL_RESCUE_GRID
 #define DPL_RESCUE_GRID 512
 #endif
@@ -176,6 +178,7 @@ struct Shared {
     uint32_t cheapw[kLogWords], thinw[kLogWords];   // walk: bins holding next to nothing / the sparse tail (bitmaps)
     uint32_t would_list;          // walk: values the tensor's prediction from earlier batches would have listed of this pair
     uint32_t cursor;              // streaming kernel: entries of the slice's list region handed out so far
+    uint32_t list_cap, region_cap;   // exact-tail form: values this workgroup's list part / the pair's whole list region holds
     uint32_t tail_j;              // exact-tail form (octav_tail.hpp): the bin at and above which values are listed (only ever raised)
     uint32_t jwant;               // ... and the bin this pair asks the tensor's next batches to list from
     // ... wave 0 walks alone; what it hands to the others (and to the pair's state) at the joints of the walk
@@ -628,7 +631,8 @@ __device__ __forceinline__ void walk_pair(
         sh.s0 = me->s;
         sh.ud = me->unsigned_div;
         sh.n_elems = me->n_elems;
-        sh.route = 2u;
+        // (more gathered than the pair's region of the rescue list holds: the list is incomplete — the compaction route)
+        sh.route = me->len[0] > (uint32_t)(pair_base[pair + 1] - pair_base[pair]) ? 1u : 2u;
     } else if (tid == 0) {
         const double sum_out = fused ? sh.f_sum : me->sum;
         const unsigned long long nz_out = fused ? (unsigned long long)sh.f_nz : me->cnt_gt;
@@ -1870,6 +1874,7 @@ int dpl_res_prof_read(unsigned long long* host_out, int reset) {   // tuning bui
 #endif
 
 uint32_t dpl_octav_slice_cap(void) { return kCap; }
+uint32_t dpl_octav_list_cap(uint64_t n_elements) { return list_cap_of(n_elements); }
 uint32_t dpl_octav_sort_chunk(void) { return kChunk; }
 uint32_t dpl_octav_dir_row(void) { return (uint32_t)kDirRow; }
 uint32_t dpl_octav_small_pair(void) { return kSmallCap; }
@@ -1939,10 +1944,15 @@ static int check_job(const char* who, const dpl_octav_oneread_job* j) {
         snprintf(g_err, sizeof(g_err), "%s: bad tensor count / epoch", who);
         return -1;
     }
-    if (!j->d_slices || !j->d_pair_slice0 || !j->d_slice_chunk0 || !j->d_pair_spans || !j->d_pair_base || !j->d_pair_order ||
-        !j->d_seg_ptrs || !j->d_states || !j->d_lh || !j->d_pred || !j->d_list0 || !j->d_list1 || !j->d_dir || !j->d_rescue_bm ||
-        !j->d_missed || !j->d_vis || !j->d_pred_pair || !j->d_use_probe || !j->d_tstat || !j->d_resc) {
+    if (!j->d_slices || !j->d_pair_slice0 || !j->d_pair_spans || !j->d_pair_base || !j->d_pair_order || !j->d_seg_ptrs ||
+        !j->d_states || !j->d_pred || !j->d_list0 || !j->d_list1 || !j->d_rescue_bm || !j->d_missed || !j->d_vis || !j->d_resc ||
+        (j->n_multi > 0 && !j->d_lh)) {
         snprintf(g_err, sizeof(g_err), "%s: null buffer in the job", who);
+        return -1;
+    }
+    // (the round-3 form's own: prediction rows per pair, the choice per tensor, the selection statistics, the sorted runs)
+    if (!j->tail && (!j->d_lh || !j->d_slice_chunk0 || !j->d_dir || !j->d_pred_pair || !j->d_use_probe || !j->d_tstat)) {
+        snprintf(g_err, sizeof(g_err), "%s: null buffer in the job (round-3 form)", who);
         return -1;
     }
     if (j->n_small < 0 || j->n_small > j->n_pairs || j->n_multi < 0 || j->n_multi > j->n_pairs) {
@@ -2086,9 +2096,215 @@ int dpl_octav_oneread_compaction(const dpl_octav_oneread_job* j, dpl_stream_t s)
     if (j->max_iters <= 0) return 0;
     if (int e = check_blocks("dpl_octav_oneread_compaction", j->n_items, j->d_block_begin, j->n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
+    // its own whole-pair list regions (d_pair_base_full) in its own two lists: the one-read forms' lists hold list_cap_of(n)
+    // values per pair, and the streaming kernel of a later batch may be writing d_list0 by now
+    if (!j->d_pair_base_full || !j->d_clist0 || !j->d_clist1)
+        return fail_msg("dpl_octav_oneread_compaction: the compaction route's lists (d_pair_base_full, d_clist0, d_clist1) are missing");
     return dpl_octav_fallback_route(j->d_items, j->n_items, j->d_block_begin, j->n_blocks, j->d_seg_ptrs, j->d_states, j->n_pairs,
-                                    j->d_pair_spans, j->d_pair_base, j->d_pair_order, j->d_list0, j->d_list1, j->dynamic_sym,
+                                    j->d_pair_spans, j->d_pair_base_full, j->d_pair_order, j->d_clist0, j->d_clist1, j->dynamic_sym,
                                     j->max_iters, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The exact-tail form as a SELF-SUFFICIENT ABI (forward_net.py:315-340 is the call site it serves): a HOST plan over the pairs of
+// one tensor-set geometry knows every buffer's size, uploads the static tables and fills the job.  A caller allocates what
+// dpl_octav_plan_sizes reports, nothing else.
+struct dpl_octav_plan {
+    int64_t n_pairs = 0, n_tensors = 0, n_slices = 0, n_multi = 0, n_small = 0, n_items = 0, n_blocks = 0, n_multi_slices = 0;
+    uint64_t list_elems = 0, full_elems = 0;
+    // host copies of the tables, in the order they sit in the device block (offsets below, bytes)
+    dpl_work_item* slices = nullptr;
+    uint32_t* pair_slice0 = nullptr;
+    dpl_span* spans = nullptr;
+    uint64_t* pair_base = nullptr;       // [n_pairs + 1]: capped regions
+    uint64_t* pair_base_full = nullptr;  // [n_pairs + 1]: whole-pair regions (the compaction route's lists)
+    uint32_t* pair_order = nullptr;
+    dpl_work_item* items = nullptr;
+    uint32_t* block_begin = nullptr;
+    uint64_t off_slices = 0, off_ps0 = 0, off_spans = 0, off_base = 0, off_basef = 0, off_order = 0, off_items = 0, off_bb = 0, tables = 0;
+};
+static uint64_t up256(uint64_t x) { return (x + 255ull) & ~255ull; }
+
+dpl_octav_plan* dpl_octav_plan_create(const dpl_span* spans, int64_t n_spans, int64_t n_tensors, int64_t n_blocks) {
+    if (!spans || n_spans < 1 || n_tensors < 1 || n_blocks < 1) {
+        fail_msg("dpl_octav_plan_create: bad arguments");
+        return nullptr;
+    }
+    for (int64_t i = 0; i < n_spans; ++i)
+        if (spans[i].slot != (uint32_t)i) {
+            fail_msg("dpl_octav_plan_create: spans must carry slots 0 .. n_spans-1 in order (slot = image * n_tensors + tensor)");
+            return nullptr;
+        }
+    dpl_octav_plan* p = new dpl_octav_plan();
+    p->n_pairs = n_spans;
+    p->n_tensors = n_tensors;
+    p->n_blocks = n_blocks;
+    const int64_t ns = dpl_build_octav_slices(spans, n_spans, nullptr, 0, nullptr);
+    if (ns < 0) {   // (-3: a pair above 64 slices: dpl_octav_run_bracket serves such a set)
+        delete p;
+        return nullptr;
+    }
+    p->n_slices = ns;
+    p->slices = (dpl_work_item*)calloc((size_t)(ns > 0 ? ns : 1), sizeof(dpl_work_item));
+    p->pair_slice0 = (uint32_t*)calloc((size_t)(2 * n_spans), sizeof(uint32_t));
+    p->spans = (dpl_span*)malloc(sizeof(dpl_span) * (size_t)n_spans);
+    p->pair_base = (uint64_t*)calloc((size_t)(n_spans + 1), sizeof(uint64_t));
+    p->pair_base_full = (uint64_t*)calloc((size_t)(n_spans + 1), sizeof(uint64_t));
+    p->pair_order = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)n_spans);
+    memcpy(p->spans, spans, sizeof(dpl_span) * (size_t)n_spans);
+    dpl_build_octav_slices(spans, n_spans, p->slices, ns, p->pair_slice0);
+    // list regions, in pair order: a single-slice pair list_cap_of(n) values, a pair of c slices c parts of list_cap_of(slice)
+    for (int64_t i = 0; i < n_spans; ++i) {
+        const uint64_t n = spans[i].count, c = n == 0 ? 0 : (n + kCap - 1) / kCap;
+        uint64_t region = 0;
+        if (c == 1) region = list_cap_of(n);
+        else if (c > 1) region = c * (uint64_t)list_cap_of((((n + c - 1) / c) + 3) & ~3ull);
+        p->pair_base[i + 1] = p->pair_base[i] + region;
+        p->pair_base_full[i + 1] = p->pair_base_full[i] + ((n + 31ull) & ~31ull);
+        if (c > 1) p->n_multi += 1, p->n_multi_slices += (int64_t)c;
+        if (n <= kSmallCap) p->n_small += 1;
+    }
+    p->list_elems = p->pair_base[n_spans];
+    p->full_elems = p->pair_base_full[n_spans];
+    // pair order: largest first (stable) — the multi-slice pairs are its first n_multi entries, the small pairs its last n_small
+    for (int64_t i = 0; i < n_spans; ++i) p->pair_order[i] = (uint32_t)i;
+    struct Cmp {
+        static int f(const void* a, const void* b, void* ctx) {
+            const dpl_span* sp = (const dpl_span*)ctx;
+            const uint32_t ia = *(const uint32_t*)a, ib = *(const uint32_t*)b;
+            if (sp[ia].count != sp[ib].count) return sp[ia].count > sp[ib].count ? -1 : 1;
+            return ia < ib ? -1 : (ia > ib ? 1 : 0);
+        }
+    };
+    qsort_r(p->pair_order, (size_t)n_spans, sizeof(uint32_t), Cmp::f, (void*)spans);
+    // the balanced partition of the same pairs (the compaction route's kernels)
+    const int64_t ni = dpl_build_balanced_items(spans, n_spans, n_blocks, nullptr, 0, nullptr);
+    if (ni < 0) {
+        dpl_octav_plan_destroy(p);
+        return nullptr;
+    }
+    p->n_items = ni;
+    p->items = (dpl_work_item*)calloc((size_t)(ni > 0 ? ni : 1), sizeof(dpl_work_item));
+    p->block_begin = (uint32_t*)calloc((size_t)(n_blocks + 1), sizeof(uint32_t));
+    dpl_build_balanced_items(spans, n_spans, n_blocks, p->items, ni, p->block_begin);
+    uint64_t o = 0;
+    p->off_slices = o, o += up256(sizeof(dpl_work_item) * (uint64_t)(ns > 0 ? ns : 1));
+    p->off_ps0 = o, o += up256(sizeof(uint32_t) * 2ull * (uint64_t)n_spans);
+    p->off_spans = o, o += up256(sizeof(dpl_span) * (uint64_t)n_spans);
+    p->off_base = o, o += up256(sizeof(uint64_t) * (uint64_t)(n_spans + 1));
+    p->off_basef = o, o += up256(sizeof(uint64_t) * (uint64_t)(n_spans + 1));
+    p->off_order = o, o += up256(sizeof(uint32_t) * (uint64_t)n_spans);
+    p->off_items = o, o += up256(sizeof(dpl_work_item) * (uint64_t)(ni > 0 ? ni : 1));
+    p->off_bb = o, o += up256(sizeof(uint32_t) * (uint64_t)(n_blocks + 1));
+    p->tables = o;
+    return p;
+}
+
+void dpl_octav_plan_destroy(dpl_octav_plan* p) {
+    if (!p) return;
+    free(p->slices);
+    free(p->pair_slice0);
+    free(p->spans);
+    free(p->pair_base);
+    free(p->pair_base_full);
+    free(p->pair_order);
+    free(p->items);
+    free(p->block_begin);
+    delete p;
+}
+
+// the layout of the per-batch blocks (bytes from their base)
+static uint64_t state_pred_off(const dpl_octav_plan* p) { return up256(sizeof(dpl_octav_state) * (uint64_t)(p->n_pairs + 1)); }
+static uint64_t rescue_missed_off(const dpl_octav_plan* p) { return up256(sizeof(uint32_t) * (uint64_t)kLogWords * (uint64_t)p->n_pairs); }
+static uint64_t rescue_resc_off(const dpl_octav_plan* p) { return rescue_missed_off(p) + up256(sizeof(uint32_t) * 3ull * (uint64_t)p->n_pairs); }
+static uint64_t rescue_lh_off(const dpl_octav_plan* p) { return rescue_resc_off(p) + up256(8ull * (uint64_t)kRescRow * (uint64_t)p->n_pairs); }
+
+int dpl_octav_plan_sizes(const dpl_octav_plan* p, dpl_octav_workspace_sizes* out) {
+    if (!p || !out) return fail_msg("dpl_octav_plan_sizes: null argument");
+    out->tables_bytes = p->tables;
+    out->history_bytes = sizeof(uint32_t) * 2ull * (uint64_t)p->n_tensors * (uint64_t)kLogWords;
+    out->state_bytes = state_pred_off(p) + up256(sizeof(uint32_t) * (uint64_t)kPredRow * (uint64_t)p->n_tensors);
+    out->rescue_bytes = rescue_lh_off(p) + 8ull * (uint64_t)kLogNB * (uint64_t)p->n_multi_slices;
+    out->list_bytes = 4ull * (p->list_elems > 0 ? p->list_elems : 32ull);
+    out->fallback_bytes = 2ull * 4ull * (p->full_elems > 0 ? p->full_elems : 32ull);
+    out->result_bytes = sizeof(float) * 3ull * (uint64_t)p->n_pairs;
+    out->n_pairs = p->n_pairs;
+    out->n_slices = p->n_slices;
+    out->n_multi = p->n_multi;
+    out->n_small = p->n_small;
+    return 0;
+}
+
+int dpl_octav_plan_upload(const dpl_octav_plan* p, void* d_tables, dpl_stream_t s) {
+    if (!p || !d_tables) return fail_msg("dpl_octav_plan_upload: null argument");
+    char* d = (char*)d_tables;
+    hipStream_t st = (hipStream_t)s;
+    const struct { uint64_t off; const void* src; uint64_t bytes; } parts[] = {
+        {p->off_slices, p->slices, sizeof(dpl_work_item) * (uint64_t)p->n_slices},
+        {p->off_ps0, p->pair_slice0, sizeof(uint32_t) * 2ull * (uint64_t)p->n_pairs},
+        {p->off_spans, p->spans, sizeof(dpl_span) * (uint64_t)p->n_pairs},
+        {p->off_base, p->pair_base, sizeof(uint64_t) * (uint64_t)(p->n_pairs + 1)},
+        {p->off_basef, p->pair_base_full, sizeof(uint64_t) * (uint64_t)(p->n_pairs + 1)},
+        {p->off_order, p->pair_order, sizeof(uint32_t) * (uint64_t)p->n_pairs},
+        {p->off_items, p->items, sizeof(dpl_work_item) * (uint64_t)p->n_items},
+        {p->off_bb, p->block_begin, sizeof(uint32_t) * (uint64_t)(p->n_blocks + 1)},
+    };
+    for (const auto& q : parts) {
+        if (q.bytes == 0) continue;
+        const hipError_t e = hipMemcpyAsync(d + q.off, q.src, q.bytes, hipMemcpyHostToDevice, st);   // (the plan owns the sources)
+        if (e != hipSuccess) return fail("dpl_octav_plan_upload", e);
+    }
+    return 0;
+}
+
+int dpl_octav_plan_bind(const dpl_octav_plan* p, void* d_tables, void* d_history, void* d_state, void* d_rescue, void* d_list0,
+                        void* d_list1, void* d_fallback, const float* const* d_seg_ptrs, int64_t call_index, int dynamic_sym,
+                        int max_iters, dpl_octav_oneread_job* j) {
+    if (!p || !j || !d_tables || !d_history || !d_state || !d_rescue || !d_list0 || !d_list1)
+        return fail_msg("dpl_octav_plan_bind: null argument");
+    if (call_index < 0) return fail_msg("dpl_octav_plan_bind: negative call index");
+    memset(j, 0, sizeof(*j));
+    char* t = (char*)d_tables;
+    j->d_slices = (const dpl_work_item*)(t + p->off_slices);
+    j->n_slices = p->n_slices;
+    j->d_pair_slice0 = (const uint32_t*)(t + p->off_ps0);
+    j->d_pair_spans = (const dpl_span*)(t + p->off_spans);
+    j->d_pair_base = (const uint64_t*)(t + p->off_base);
+    j->d_pair_base_full = (const uint64_t*)(t + p->off_basef);
+    j->d_pair_order = (const uint32_t*)(t + p->off_order);
+    j->n_pairs = p->n_pairs;
+    j->n_tensors = p->n_tensors;
+    j->n_small = p->n_small;
+    j->n_multi = p->n_multi;
+    j->d_items = (const dpl_work_item*)(t + p->off_items);
+    j->n_items = p->n_items;
+    j->d_block_begin = (const uint32_t*)(t + p->off_bb);
+    j->n_blocks = p->n_blocks;
+    j->d_seg_ptrs = d_seg_ptrs;
+    j->d_states = (dpl_octav_state*)d_state;
+    j->d_pred = (uint32_t*)((char*)d_state + state_pred_off(p));
+    char* r = (char*)d_rescue;
+    j->d_rescue_bm = (uint32_t*)r;
+    j->d_missed = (uint32_t*)(r + rescue_missed_off(p));
+    j->d_resc = (uint64_t*)(r + rescue_resc_off(p));
+    j->d_lh = (uint64_t*)(r + rescue_lh_off(p));
+    j->d_list0 = (float*)d_list0;
+    j->d_list1 = (float*)d_list1;
+    if (d_fallback) {
+        j->d_clist0 = (float*)d_fallback;
+        j->d_clist1 = (float*)d_fallback + (p->full_elems > 0 ? p->full_elems : 32ull);
+    }
+    j->d_vis = (uint32_t*)d_history;
+    // two alternating epoch accumulators of kTailEpoch batches each: batch k adds to accumulator (k / epoch) % 2, cleared by the
+    // first batch of an epoch (dpl_octav_oneread_prepare)
+    j->write_epoch = (int32_t)((call_index / kPlanEpoch) % 2);
+    j->reset_epoch = (call_index % kPlanEpoch) == 0 ? 1 : 0;
+    j->dynamic_sym = dynamic_sym;
+    j->max_iters = max_iters;
+    j->tail = 1;
+    j->fuse = 1;
+    j->compaction_inline = d_fallback ? 1 : 0;
+    return 0;
 }
 
 int dpl_octav_run_oneread(const dpl_octav_oneread_job* j, dpl_stream_t s) {

@@ -101,13 +101,17 @@ const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
     uint32_t backoff = 512u;     // a raise that could not move the threshold (an atom at the top: saturating activations) doubles it
     uint32_t raises = 0u;
     int jm1 = (int)__builtin_amdgcn_readfirstlane((int)sh.tail_j) - 1;   // listed: bin key t = bin - 1 >= jm1
+    // what the list region holds (list_cap_of): a flush that would pass it is dropped, the cursor still counts it — a list
+    // longer than its region says "not all listed" and the pair's walk is refused (walk_tail, k_octav_tail_merge)
+    const uint32_t cap = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.list_cap);
     auto flush = [&]() {
         typedef __attribute__((address_space(1))) uint32_t* gptr_u32;
         gptr_u32 gdst = (gptr_u32)dst;
         uint32_t base = 0u;
         if (lane == 0) base = __hip_atomic_fetch_add((lptr_u32)&sh.cursor, tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        for (uint32_t i = lane; i < tail; i += kWave) gdst[base + i] = wq[i] & 0x7FFFFFFFu;
+        if (base + tail <= cap)
+            for (uint32_t i = lane; i < tail; i += kWave) gdst[base + i] = wq[i] & 0x7FFFFFFFu;
         tail = 0u;
     };
     // The threshold of a wave that lists too much: the bin above which 1 / 2^kTailTauShift of what the workgroup has seen so
@@ -303,7 +307,10 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
     // the list: this workgroup's own global stores (one CU, one L1), requested before anything else
     const float* lp = list0 + pair_base[pair];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const uint32_t L = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cursor);
+    const uint32_t L_listed = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cursor);
+    // more listed than the region holds: part of the list was dropped (stream_tail's flush) — nothing of it is read, the walk refused
+    const bool over = L_listed > (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.list_cap);
+    const uint32_t L = over ? 0u : L_listed;
     const uint32_t n_rows = (L + 1023u) >> 10;
     const bool fits = L <= kFitCap;
     // ONE register array, two layouts: the workgroup's rows of 1024 values (a list that does not fit a wave), or — in its first
@@ -491,6 +498,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
         if (route == 2u) {
             const int J = (int)__builtin_amdgcn_readfirstlane((int)sh.tail_j);
             if (fa.fail_every > 0 && pair % (uint32_t)fa.fail_every == 0u) bad = 1u;   // test hook: the rescue path
+            if (over) bad = 1u;
             // ---- bounded steps: lower bounds of F from the suffix totals; past the list's first bin while more values lie above
             // the iterate than a wave holds
             jb = log_bin(s);
@@ -718,7 +726,13 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
         suffix_in_place(n_ge, s_ge, sh);
         if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
         __syncthreads();
-        if (tid == 0) sh.route = bracket_marks(n_ge, s_ge, sh.pub, s0, ud, n_pair).route;
+        if (tid == 0) {
+            BracketResult br = bracket_marks(n_ge, s_ge, sh.pub, s0, ud, n_pair);
+            // the rescue gathers the bracket's bins into the pair's region of the rescue list: what cannot fit goes straight
+            // to the compaction route
+            if (br.route == 2u && n_ge[br.jmin] - n_ge[br.jmax + 1] > sh.region_cap) br.route = 1u;
+            sh.route = br.route;
+        }
         __syncthreads();
         rescued = sh.route == 2u;
         if (rescued) {
@@ -770,7 +784,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
             z.done = 1u;
         }
         *me = z;
-        atomicAdd(&ctl->sum, (double)L);   // the batch's listed values (statistics)
+        atomicAdd(&ctl->sum, (double)L_listed);   // the batch's listed values (statistics)
         // history: the bin this pair asked for (whatever became of its walk)
         if (!small && route != 0u) atomicMax(fa.vis_w + (size_t)tensor * kLogWords, (uint32_t)kLogNB - sh.jwant);
     }
@@ -780,7 +794,7 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
     DPL_PROF_ADD(3, wt4, wt5);
     if (tid == 0) {
         g_prof_iters_add(blockIdx.x, evals);
-        DPL_PROF_L(L);
+        DPL_PROF_L(L_listed);
     }
 }
 
@@ -800,10 +814,22 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail(
     const float* pg = segs[it.seg] + it.offset;
     const uint32_t tensor = pair % n_tensors;
     const bool small = !part && cnt <= kSmallCap;   // lists its whole window: every step exact
-    // (a slice lists into its part of the pair's list region: from its first element's place inside the pair)
-    const uint64_t list_at = pair_base[pair] + (part ? it.offset - spans[pair].offset : 0ull);
+    // The pair's list region: pair_base[pair] .. pair_base[pair + 1] (list_cap_of(elements) values; a pair of c slices: c equal
+    // parts, slice j lists into part j).
+    const uint64_t region0 = pair_base[pair];
+    const uint32_t region = (uint32_t)(pair_base[pair + 1] - region0);
+    uint32_t cap = region;
+    uint64_t list_at = region0;
+    if (part) {
+        const unsigned long long n = spans[pair].count, c = it.reserved;
+        const unsigned long long per = (((n + c - 1ull) / c) + 3ull) & ~3ull;     // (dpl_build_octav_slices' cut)
+        cap = (uint32_t)((region / (uint32_t)c) & ~31u);
+        list_at = region0 + ((it.offset - spans[pair].offset) / per) * (unsigned long long)cap;
+    }
     for (int b = tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
     if (tid == 0) {
+        sh.list_cap = cap;
+        sh.region_cap = region;
         const uint32_t hist = small ? 0u : fa.pred[(size_t)tensor * kPredRow];   // kLogNB - bin; 0: none (a cold start lists from bin 1 and raises)
         sh.tail_j = (hist >= 1u && hist < (uint32_t)kLogNB) ? (uint32_t)kLogNB - hist : 1u;
         sh.cursor = 0u;
@@ -901,15 +927,21 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail_merge(
     for (int q = 0; q < kPer; ++q) l_packed[(int)tid + q * kThreads] = acc[q];
     for (int b = kLogNB + (int)tid; b < kLogNB + kWave; b += kThreads) l_packed[b] = 0ull;
     // ---- the slices' lists: lengths, thresholds, where each goes
+    const uint32_t region = (uint32_t)(pair_base[pair + 1] - pair_base[pair]);
+    const uint32_t part_cap = (region / (sl1 - sl0)) & ~31u;          // (as k_octav_tail cut the region)
     if (tid == 0) {
-        uint32_t off = 0u, jmax = 1u;
+        uint32_t off = 0u, jmax = 1u, dropped = 0u;
         for (uint32_t sl = sl0; sl < sl1; ++sl) {
             const unsigned long long w0 = rows[(size_t)sl * kLogNB];
+            const uint32_t len = (uint32_t)w0;
+            dropped |= len > part_cap ? 1u : 0u;      // a slice that listed more than its part holds: nothing of it was kept
             sh.seg_off[sl - sl0] = off;
-            sh.seg_len[sl - sl0] = (uint32_t)w0;
-            off += (uint32_t)w0;
+            sh.seg_len[sl - sl0] = len > part_cap ? 0u : len;
+            off += len > part_cap ? 0u : len;
             jmax = max(jmax, (uint32_t)(w0 >> 32));
         }
+        sh.list_cap = region;
+        sh.region_cap = region;
         const dpl_octav_state* me = st + pair;
         sh.cursor = off;
         sh.tail_j = jmax;
@@ -920,18 +952,17 @@ __global__ __launch_bounds__(kThreads, DPL_TAIL_OCC) void k_octav_tail_merge(
         sh.red_mn[0] = any ? dec_f32(me->min_enc) : INFINITY;
         sh.red_mx[0] = any ? dec_f32(me->max_enc) : -INFINITY;
         for (int q = 1; q < kWaves; ++q) sh.red_mn[q] = INFINITY, sh.red_mx[q] = -INFINITY;
-        sh.bad = 0u;
+        sh.bad = dropped;        // (an incomplete list: the compaction route, like a bin of 2^20 values)
     }
-    if (__any(over != 0u) && (tid & (kWave - 1)) == 0) atomicOr(&sh.bad, 1u);
     __syncthreads();
-    if (__any(over != 0u) && (tid & (kWave - 1)) == 0) atomicOr(&sh.bad, 1u);   // (sh.bad was cleared by thread 0 above: set again behind the barrier)
+    if (__any(over != 0u) && (tid & (kWave - 1)) == 0) atomicOr(&sh.bad, 1u);   // (behind the barrier: thread 0 has set sh.bad above)
     __syncthreads();
     float* lp = list0 + pair_base[pair];
     // moved together towards the front, slice by slice, tile by tile: a tile is read whole before any of it is written (the
     // destination never lies behind the source, and never reaches a later tile's source)
     for (uint32_t sl = sl0 + 1; sl < sl1; ++sl) {
         const uint32_t len = sh.seg_len[sl - sl0], off = sh.seg_off[sl - sl0];
-        const float* src = lp + (slices[sl].offset - spans[pair].offset);
+        const float* src = lp + (size_t)(sl - sl0) * part_cap;
         float* dst = lp + off;
         for (uint32_t i0 = 0; i0 < len; i0 += kThreads) {       // (uniform)
             const uint32_t i = i0 + tid;

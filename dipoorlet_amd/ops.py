@@ -115,8 +115,8 @@ class TensorSetPlan:
             # written, and no other workgroup of the launch may have pulled a line of it into the CU's L1 beforehand — which a
             # neighbouring pair's last, straddling line would)
             sizes = [((e + 31) // 32) * 32 for _ in range(self.batch) for e in self.elems]
-            base = np.zeros(len(sizes), np.int64)
-            base[1:] = np.cumsum(sizes)[:-1]
+            base = np.zeros(len(sizes) + 1, np.int64)       # (n + 1 entries: a region's size is the difference of two)
+            base[1:] = np.cumsum(sizes)
             tot = int(sum(sizes))
             arr, ns = _hip._span_array(self._spans(True))
             order = np.argsort(-np.array(sizes, np.int64), kind="stable").astype(np.int32)  # largest pairs first
@@ -176,6 +176,19 @@ class TensorSetPlan:
                     resc=torch.empty(self.n_pairs, 3072, dtype=torch.int64, device=self.device))
         return self._octav_one or None
 
+    def octav_tail(self):
+        """The exact-tail form's HOST plan (dpl_octav_plan_*: every buffer size comes from the C ABI), its static tables on the
+        device and the threshold history of this tensor set — or None when a pair needs more than 64 slices."""
+        if getattr(self, "_octav_tail", None) is None:
+            arr, ns = _hip._span_array(self._spans(True))
+            L = _hip.lib()
+            handle = L.dpl_octav_plan_create(C.addressof(arr), ns, self.T, max(1, min(_blocks_for("octav"), (self.total + 4095) // 4096)))
+            if not handle:
+                self._octav_tail = False
+            else:
+                self._octav_tail = OctavTailPlan(self, handle)
+        return self._octav_tail or None
+
     def octav_reset(self):
         """Cold start of the one-read OCTAV forms: what the plan learned from earlier batches (bins visited / thresholds asked
         for, choice of walk) is forgotten — the state of a plan that has never run.  Call between independent calibration runs
@@ -186,6 +199,11 @@ class TensorSetPlan:
             one["pred"].zero_()
             one["tstat"].zero_()
             one["calls"] = 0
+        tp = getattr(self, "_octav_tail", None)
+        if tp:
+            tp.history.zero_()
+            tp.calls = 0
+        self.__dict__.pop("_octav_sorted", None)
         for pipe in list(getattr(self, "_octav_pipes", ())):
             pipe._forget(self)
 
@@ -230,6 +248,53 @@ class TensorSetPlan:
             self._seg_cache[key] = (tab, host)  # keep the pinned source alive until the copy has run
             return tab
         return tab[0]
+
+
+class OctavTailPlan:
+    """dpl_octav_plan of one TensorSetPlan: sizes, tables, history, and the buffers of the single-stream use (octav_batch)."""
+
+    def __init__(self, plan, handle):
+        self.plan, self.handle = plan, handle
+        L = _hip.lib()
+        self.sizes = _hip.OctavWorkspaceSizes()
+        _hip.check(L.dpl_octav_plan_sizes(handle, C.byref(self.sizes)), "dpl_octav_plan_sizes")
+        dev = plan.device
+        self.tables = torch.empty(int(self.sizes.tables_bytes), dtype=torch.uint8, device=dev)
+        _hip.check(L.dpl_octav_plan_upload(handle, _ptr(self.tables), _stream()), "dpl_octav_plan_upload")
+        torch.cuda.current_stream(dev).synchronize()      # (the plan's host tables are pageable: the copies have run when this returns)
+        self.history = torch.zeros(int(self.sizes.history_bytes), dtype=torch.uint8, device=dev)
+        self.calls = 0          # batches run on this history through octav_batch (pipelines count their own)
+        self.n_multi = int(self.sizes.n_multi)
+        self._single = None     # (state, rescue, list0, list1) of octav_batch
+        self.fallback = None    # the compaction route's lists: allocated when a batch first reports unfinished pairs
+
+    def __del__(self):
+        try:
+            _hip.lib().dpl_octav_plan_destroy(self.handle)
+        except Exception:   # noqa: BLE001  (interpreter shutdown)
+            pass
+
+    def new(self, what):
+        """A device buffer of the workspace part `what` ('state', 'rescue', 'list', 'fallback', 'result')."""
+        n = int(getattr(self.sizes, what + "_bytes"))
+        return torch.empty(max(n, 256), dtype=torch.uint8, device=self.plan.device)
+
+    def need_fallback(self):
+        if self.fallback is None:
+            self.fallback = self.new("fallback")
+        return self.fallback
+
+    def bind(self, state, rescue, list0, list1, tab, call_index, dyn, fallback=None):
+        j = _hip.OctavOnereadJob()
+        _hip.check(_hip.lib().dpl_octav_plan_bind(self.handle, _ptr(self.tables), _ptr(self.history), _ptr(state), _ptr(rescue),
+                                                  _ptr(list0), _ptr(list1), _ptr(fallback) if fallback is not None else None,
+                                                  _ptr(tab), int(call_index), dyn, _OCTAV_MAX_ITERS, C.byref(j)), "dpl_octav_plan_bind")
+        return j
+
+    def single(self):
+        if self._single is None:
+            self._single = (self.new("state"), self.new("rescue"), self.new("list"), self.new("list"))
+        return self._single
 
 
 class BoundSet:
@@ -373,10 +438,14 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     if form is None:
         form = ("compact" if compact else "full") if compact is not None else _default_form()
     mode = _OCTAV_MODE[form]
+    if form == "tail":
+        tp = plan.octav_tail()
+        if tp is not None and (tp.n_multi == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0"):
+            return _octav_batch_tail(plan, tp, tensors, dynamic_sym)
     res = plan.octav_oneread_scratch() if mode == 3 else None
     if mode == 3 and res is None:
         mode = 2
-    tail = 1 if (form == "tail" and _tail_ok(res)) else 0
+    tail = 0
     w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
     nbytes = (n_pairs + 1) * C.sizeof(_hip.OctavState)  # + control block
@@ -416,6 +485,29 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     return out
 
 
+def _octav_batch_tail(plan, tp, tensors, dynamic_sym):
+    """One batch of the exact-tail form on the caller's stream.  The compaction route (flat distributions, values beyond 2^14,
+    lists beyond their regions: rare) needs two whole-batch lists, which are allocated the first time a batch asks for them —
+    so this reads the batch's control block back (the one host synchronisation of this call; OctavPipeline defers it)."""
+    L = _hip.lib()
+    tab = plan.seg_table(tensors)
+    state, rescue, l0, l1 = tp.single()
+    k = tp.calls
+    tp.calls = k + 1
+    job = tp.bind(state, rescue, l0, l1, tab, k, 1 if dynamic_sym else 0, tp.fallback)
+    job.compaction_inline = 0
+    for fn in ("dpl_octav_oneread_prepare", "dpl_octav_oneread_stream", "dpl_octav_oneread_finish"):
+        _hip.check(getattr(L, fn)(C.byref(job), _stream()), fn)
+    csz = C.sizeof(_hip.OctavState)
+    ctl = _hip.OctavState.from_buffer_copy(state[plan.n_pairs * csz:(plan.n_pairs + 1) * csz].cpu().numpy().tobytes())
+    if ctl.cnt_le:
+        job = tp.bind(state, rescue, l0, l1, tab, k, 1 if dynamic_sym else 0, tp.need_fallback())
+        _hip.check(L.dpl_octav_oneread_compaction(C.byref(job), _stream()), "dpl_octav_oneread_compaction")
+    out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
+    _hip.check(L.dpl_octav_finalize(_ptr(state), plan.n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
+    return out
+
+
 _PREDICT = {"learned": 0, "probe": 1, "auto": 2}
 
 
@@ -437,6 +529,7 @@ def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, wri
     j.predict = _PREDICT[os.environ.get("DPL_OCTAV_PREDICT", "auto")]
     j.probe_z = float(os.environ.get("DPL_PROBE_Z", "0"))
     j.d_list0, j.d_list1, j.d_dir = l0.data_ptr(), l1.data_ptr(), res["dir"].data_ptr()
+    j.d_pair_base_full, j.d_clist0, j.d_clist1 = base.data_ptr(), l0.data_ptr(), l1.data_ptr()   # (this form's regions are whole pairs)
     rescue = rescue or res            # (the pipeline's batches in flight have their own rescue buffers)
     j.d_rescue_bm, j.d_missed, j.d_resc = rescue["rescue_bm"].data_ptr(), rescue["missed"].data_ptr(), rescue["resc"].data_ptr()
     j.d_vis, j.n_multi = res["vis"].data_ptr(), res["n_multi"]
@@ -511,6 +604,41 @@ class OctavPipeline:
         self.probe_tensors = self.tiles_reread = self.raises = 0
         self.list_share = self.max_share = 0.0    # listed values / elements (running mean / maximum over the settled batches)
 
+    def _state_tail(self, plan, tp):
+        """This pipeline's rotation on `plan` in the exact-tail form; every buffer's size is the C plan's (dpl_octav_plan_sizes):
+        2 S state blocks (call k uses k % 2S; the block for call k + S is initialised at the end of call k's side-stream work,
+        the one of call k must survive until the host has read k's control block, S submits later), S rescue blocks, one list
+        per stream that carries streaming kernels, one rescue list (one side stream).  Nothing is shared with another
+        pipeline on the same plan but what the plan has learned (the history's atomic maxima)."""
+        ps = self._plans.get(id(plan))
+        if ps is None:
+            S = _PIPE_SETS
+            csz = C.sizeof(_hip.OctavState)
+            off = plan.n_pairs * csz
+            states = [tp.new("state") for _ in range(2 * S)]
+            ps = dict(plan=plan, tp=tp, calls=0, states=states, failed=[x[off:off + csz] for x in states],
+                      list0=[tp.new("list") for _ in range(max(1, len(self.lanes)))], list1=tp.new("list"), fallback=None, sets=[])
+            for _ in range(S):
+                ps["sets"].append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(), rescue=tp.new("rescue"),
+                                       done=None, refs=None, pending=False, k=-1, prepared=None))
+            self._plans[id(plan)] = ps
+            if getattr(plan, "_octav_pipes", None) is None:
+                import weakref
+                plan._octav_pipes = weakref.WeakSet()
+            plan._octav_pipes.add(self)
+        return ps
+
+    def scratch_bytes(self, plan):
+        """Device bytes of this pipeline's OCTAV scratch on `plan` (exact-tail form): tables, history, state / rescue blocks,
+        lists, and the compaction route's lists if a batch has asked for them."""
+        ps = self._plans.get(id(plan))
+        if ps is None or ps.get("tp") is None:
+            return None
+        tp = ps["tp"]
+        n = tp.tables.numel() + tp.history.numel() + sum(x.numel() for x in ps["states"]) + sum(x.numel() for x in ps["list0"])
+        n += ps["list1"].numel() + sum(st["rescue"].numel() for st in ps["sets"])
+        return n + (ps["fallback"].numel() if ps["fallback"] is not None else 0)
+
     def _state(self, plan, res):
         ps = self._plans.get(id(plan))
         if ps is None:
@@ -564,6 +692,12 @@ class OctavPipeline:
 
     def _prepare(self, plan, res, ps, st, k, stream, tail):
         """State array + threshold / prediction snapshot (in set `st`) for this pipeline's call number k on the plan."""
+        if ps.get("tp") is not None:
+            r = k % (2 * _PIPE_SETS)
+            job = ps["tp"].bind(ps["states"][r], st["rescue"], ps["list0"][0], ps["list1"], ps["list1"], k, self.dyn)   # (prepare reads no tensors)
+            _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
+            st["prepared"] = k
+            return
         ep, first = divmod(k, _ONEREAD_EPOCH)
         r = k % (2 * _PIPE_SETS)
         job = _oneread_job(plan, res, ps["pred"][r], ps["states"][r], st["lh"], ps["pred"][r],
@@ -614,26 +748,30 @@ class OctavPipeline:
             self.fallback_batches += 1
         if ctl.cnt_le:
             # what neither the walk nor the rescue could finish (a bracket that cannot be formed: flat distributions, values
-            # beyond 2^14): the compaction route, launched only now that the count is known — the set's batch is S submits
-            # old, its tensors are still referenced — and its results written over the batch's output rows
-            _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(st["job"]), C.c_void_p(self.side.cuda_stream)),
+            # beyond 2^14, a list beyond its region): the compaction route, launched only now that the count is known — the set's
+            # batch is S submits old, its tensors are still referenced — and its results written over the batch's output rows
+            job = st["job"]
+            if ps.get("tp") is not None:      # its two whole-batch lists exist from the first batch on that needs them
+                if ps["fallback"] is None:
+                    ps["fallback"] = ps["tp"].new("fallback")
+                job = ps["tp"].bind(st["states"], st["rescue"], ps["list0"][0], ps["list1"], st["refs"][1], st["k"], self.dyn, ps["fallback"])
+            _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(job), C.c_void_p(self.side.cuda_stream)),
                        "dpl_octav_oneread_compaction")
             self._finish(plan, res, ps, st)
 
     def submit(self, plan, tensors):
         form = _default_form()
-        res = plan.octav_oneread_scratch() if form in ("oneread", "tail") else None
-        if res is None:
-            return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form in ("oneread", "tail") else form)
-        tail = 1 if (form == "tail" and _tail_ok(res)) else 0
-        if form == "tail" and not tail and not getattr(plan, "_octav_told", False):
-            plan._octav_told = True     # (once per plan; DPL_OCTAV_TAIL_MULTI=0: such a set runs at about 0.7 of the exact-tail form's rate)
-            import logging
-            logging.getLogger("dipoorlet").info(
-                "OCTAV: a tensor of more than 1044480 elements per image in this set and DPL_OCTAV_TAIL_MULTI=0: the one-read "
-                "form of round 3 serves it")
+        tp = plan.octav_tail() if form == "tail" else None
+        if tp is not None and tp.n_multi and os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") == "0":
+            tp = None                   # (A/B: a set with a pair above one slice on the round-3 form)
+        res = None
+        if tp is None:
+            res = plan.octav_oneread_scratch() if form in ("oneread", "tail") else None
+            if res is None:
+                return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form in ("oneread", "tail") else form)
+        tail = 1 if tp is not None else 0
         main = torch.cuda.current_stream(plan.device)
-        ps = self._state(plan, res)
+        ps = self._state_tail(plan, tp) if tp is not None else self._state(plan, res)
         sets = ps["sets"]
         k = ps["calls"]
         ps["calls"] = k + 1
@@ -653,14 +791,17 @@ class OctavPipeline:
         cur["k"] = k
         cur["tail"] = tail
         cur["states"] = ps["states"][r]
-        cur["pred"] = ps["pred"][r]
         cur["sorted"] = 0 if tail else _walk_sorted(plan)
         L = _hip.lib()
         if cur.get("prepared") != k:
             self._prepare(plan, res, ps, cur, k, main.cuda_stream, tail)
-        job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
-                                        ps["use"][r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
-                                        compaction_inline=0, rescue=cur, tail=tail)
+        if tail:
+            job = cur["job"] = tp.bind(cur["states"], cur["rescue"], ps["list0"][k % len(ps["list0"])], ps["list1"], tab, k, self.dyn)
+        else:
+            cur["pred"] = ps["pred"][r]
+            job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
+                                            ps["use"][r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
+                                            compaction_inline=0, rescue=cur, tail=0)
         if self.record_events:
             began = torch.cuda.Event(enable_timing=True)
             began.record(main)

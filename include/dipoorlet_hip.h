@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 16
+#define DPL_ABI_VERSION 17
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -196,9 +196,12 @@ typedef struct dpl_octav_oneread_job {
     const uint32_t* d_pair_slice0;   /* [n_pairs, 2] */
     const uint32_t* d_slice_chunk0;  /* [n_slices]: first directory row of a slice = running sum of ceil(slice count / dpl_octav_sort_chunk()) */
     const dpl_span* d_pair_spans;    /* [n_pairs]: where each pair's data lives */
-    const uint64_t* d_pair_base;     /* [n_pairs]: element offset of the pair's region in the lists (a region holds the pair's element count);
-                                        job.fuse: multiples of 32 elements (a region must not share a 128-byte line with its neighbour: the
-                                        streaming workgroup reads back the list it has just written) */
+    const uint64_t* d_pair_base;     /* [n_pairs + 1]: element offset of the pair's region in d_list0 / d_list1; a region holds
+                                        d_pair_base[p + 1] - d_pair_base[p] values, a multiple of 32 (a region must not share a 128-byte line
+                                        with its neighbour: the streaming workgroup reads back the list it has just written).  job.tail: a
+                                        region is dpl_octav_list_cap(elements) values (a pair of c slices: c x dpl_octav_list_cap(slice));
+                                        what a pair lists or its rescue gathers beyond that is dropped and the pair finishes on the
+                                        compaction route.  The round-3 form: the pair's element count, rounded up to 32 */
     const uint32_t* d_pair_order;    /* [n_pairs]: pair indices, largest first; its last n_small entries gather their whole window */
     int64_t n_pairs, n_tensors, n_small;
     int64_t n_multi;                 /* pairs of more than one slice (the first n_multi entries of d_pair_order) */
@@ -213,8 +216,11 @@ typedef struct dpl_octav_oneread_job {
     uint32_t* d_pred;                /* [n_tensors, 128]: the prediction from earlier batches (snapshot of d_vis) */
     uint32_t* d_pred_pair;           /* [n_pairs, 128]: the row each pair's slices gather by (dpl_octav_oneread_probe writes it) */
     uint32_t* d_use_probe;           /* [n_tensors]: this batch's choice per tensor (dpl_octav_oneread_prepare writes it) */
-    float* d_list0;                  /* gathered values, region per pair */
-    float* d_list1;                  /* rescue / compaction lists, same layout */
+    float* d_list0;                  /* listed values, region per pair: written by dpl_octav_oneread_stream, dead once it has run */
+    float* d_list1;                  /* the rescue's gathered values, same layout (dpl_octav_oneread_finish) */
+    const uint64_t* d_pair_base_full;/* [n_pairs + 1]: whole-pair regions (element count rounded up to 32) ... */
+    float* d_clist0;                 /* ... in the compaction route's two lists (dpl_octav_oneread_compaction): only needed once a batch */
+    float* d_clist1;                 /*     reports unfinished pairs (d_states[n_pairs].cnt_le != 0), or up front with compaction_inline */
     uint16_t* d_dir;                 /* [n_chunks, dpl_octav_dir_row()]: per sorted run the position of each rank's first value */
     uint32_t* d_rescue_bm;           /* [n_pairs, 64]: exact bracket of a rescued pair */
     uint32_t* d_missed;              /* [n_pairs, 3]: (pair, first unit, units) of the rescued pairs */
@@ -243,6 +249,7 @@ typedef struct dpl_octav_oneread_job {
                                         when the batch is done and calls it only when that is non-zero */
 } dpl_octav_oneread_job;
 uint32_t dpl_octav_slice_cap(void);
+uint32_t dpl_octav_list_cap(uint64_t n_elements); /* values the list region of a single-slice pair / of one slice of n elements holds */
 uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run */
 uint32_t dpl_octav_dir_row(void);    /* uint16 entries of a run's directory row */
 uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements gather their whole window */
@@ -253,6 +260,41 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_finish(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_compaction(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_run_oneread(const dpl_octav_oneread_job* job, dpl_stream_t s);
+
+/* The exact-tail form WITHOUT knowing any buffer's size (what forward_net.py:315-340 needs from a binding): a HOST plan over the
+ * (image, tensor) pairs of one tensor-set geometry reports the bytes of every part of the workspace, uploads its static tables
+ * into caller memory and fills the job.  Minimal use, one batch at a time on one stream:
+ *     p = dpl_octav_plan_create(spans, B * T, T, 1024);  dpl_octav_plan_sizes(p, &z);
+ *     [hipMalloc z.tables_bytes, z.history_bytes (memset 0), z.state_bytes, z.rescue_bytes, 2 x z.list_bytes, z.fallback_bytes, z.result_bytes]
+ *     dpl_octav_plan_upload(p, d_tables, s);
+ *     per batch k: dpl_octav_plan_bind(p, d_tables, d_history, d_state, d_rescue, d_list0, d_list1, d_fallback, d_seg_ptrs, k, dyn, 20, &job);
+ *                  dpl_octav_run_oneread(&job, s);  dpl_octav_finalize(job.d_states, job.n_pairs, d_result, s);
+ * spans: one per pair, slot = image * n_tensors + tensor = its index.  NULL (dpl_last_error) when a pair needs more than 64
+ * slices (dpl_octav_run_bracket serves such a set).  n_blocks: workgroups of the compaction route's partition (1024).
+ * A pipeline that keeps several batches in flight gives each its own d_state / d_rescue, one d_list0 per stream that carries
+ * dpl_octav_oneread_stream, one d_list1 per stream that carries dpl_octav_oneread_finish, and may pass d_fallback = NULL:
+ * job.compaction_inline is then 0 and the caller binds a fallback block (z.fallback_bytes) only when it reads a non-zero
+ * d_states[n_pairs].cnt_le, then calls dpl_octav_oneread_compaction + dpl_octav_finalize for that batch. */
+typedef struct dpl_octav_plan dpl_octav_plan;
+typedef struct dpl_octav_workspace_sizes {
+    uint64_t tables_bytes;   /* the static decomposition (dpl_octav_plan_upload fills it) */
+    uint64_t history_bytes;  /* what the tensors' pairs asked for in earlier batches: zero it once per calibration run, share it between the run's batches */
+    uint64_t state_bytes;    /* per batch in flight: pair states + control block, the tensors' threshold snapshot */
+    uint64_t rescue_bytes;   /* per batch in flight: brackets, work list and suffix totals of rescued pairs, histogram rows of multi-slice pairs */
+    uint64_t list_bytes;     /* ONE list buffer; a job takes two (d_list0, d_list1) */
+    uint64_t fallback_bytes; /* the compaction route's two whole-pair lists */
+    uint64_t result_bytes;   /* fp32 [n_pairs, 3] of dpl_octav_finalize */
+    int64_t n_pairs, n_slices, n_multi, n_small;
+} dpl_octav_workspace_sizes;
+dpl_octav_plan* dpl_octav_plan_create(const dpl_span* spans, int64_t n_spans, int64_t n_tensors, int64_t n_blocks);
+void dpl_octav_plan_destroy(dpl_octav_plan* plan);
+int dpl_octav_plan_sizes(const dpl_octav_plan* plan, dpl_octav_workspace_sizes* out);
+int dpl_octav_plan_upload(const dpl_octav_plan* plan, void* d_tables, dpl_stream_t s);
+/* call_index: batches bound before this one on the same d_history in this calibration run (0 for the first: the history's
+ * two epoch accumulators alternate every 8 batches).  d_fallback may be NULL (see above). */
+int dpl_octav_plan_bind(const dpl_octav_plan* plan, void* d_tables, void* d_history, void* d_state, void* d_rescue, void* d_list0,
+                        void* d_list1, void* d_fallback, const float* const* d_seg_ptrs, int64_t call_index, int dynamic_sym,
+                        int max_iters, dpl_octav_oneread_job* job);
 /* TEST HOOKS (0 = off; return the previous setting): _exact_ makes the exact walk of dpl_octav_run_bracket and the first walk
  * of the one-read form reject every `every`-th pair, so that the restart paths — taken in production only when an iterate
  * leaves the gathered bins — can be exercised; _rescue_ does the same to the one-read form's rescue walk (-> compaction route). */

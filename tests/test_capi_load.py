@@ -172,3 +172,108 @@ def test_integration_md_job_struct_matches_the_binding():
     kinds = {"P": C.c_void_p, "I64": C.c_int64, "I32": C.c_int32, "F32": C.c_float}
     assert [(n, kinds[k]) for n, k in listed] == [(f[0], f[1]) for f in _hip.OctavOnereadJob._fields_]
     assert "sizeof(Job) == %d" % C.sizeof(_hip.OctavOnereadJob) in text
+
+
+def test_octav_plan_host_side(tmp_path):
+    """dpl_octav_plan_* (HOST): sizes follow from the spans alone — list regions of dpl_octav_list_cap(n) values, whole-pair
+    regions only in the compaction route's lists, histogram rows only for the slices of multi-slice pairs — and the ctypes
+    mirror of dpl_octav_workspace_sizes has the C compiler's layout."""
+    import shutil
+    import subprocess
+    L = _hip.lib()
+    cap = L.dpl_octav_slice_cap()
+    assert L.dpl_octav_list_cap(1000) == 1024 and L.dpl_octav_list_cap(20480) == 20480 and L.dpl_octav_list_cap(20481) == 17024 and L.dpl_octav_list_cap(802816) == 25088 + 16384
+    assert all(L.dpl_octav_list_cap(n) % 32 == 0 and L.dpl_octav_list_cap(n) <= (n + 31) // 32 * 32 for n in (1, 31, 33, 4097, 10**6))
+    T, B = 3, 2
+    elems = [1000, 802816, 2 * cap + 4096]                    # a small pair, a single-slice pair, a pair of three slices
+    arr, ns = _hip._span_array([(t, b * e, e, b * T + t) for b in range(B) for t, e in enumerate(elems)])
+    plan = L.dpl_octav_plan_create(C.addressof(arr), ns, T, 64)
+    assert plan
+    z = _hip.OctavWorkspaceSizes()
+    assert L.dpl_octav_plan_sizes(plan, C.byref(z)) == 0
+    per3 = (((elems[2] + 2) // 3) + 3) & ~3
+    want_list = B * (L.dpl_octav_list_cap(1000) + L.dpl_octav_list_cap(802816) + 3 * L.dpl_octav_list_cap(per3))
+    assert z.list_bytes == 4 * want_list
+    assert z.fallback_bytes == 2 * 4 * B * sum((e + 31) // 32 * 32 for e in elems)
+    assert (z.n_pairs, z.n_slices, z.n_multi, z.n_small) == (B * T, B * 5, B, B)
+    assert z.history_bytes == 4 * 2 * T * 64 and z.result_bytes == 4 * 3 * B * T
+    assert z.rescue_bytes >= 8 * 2048 * (B * 3) + 8 * 3072 * B * T and z.rescue_bytes < 8 * 2048 * (B * 3) + 8 * 3072 * B * T + 4096 + 4 * 67 * B * T
+    # a job bound to fake addresses: the tables' pointers fall inside the tables block, the lists where they were put
+    job = _hip.OctavOnereadJob()
+    base = 1 << 40
+    st = L.dpl_octav_plan_bind(plan, base, base + (1 << 30), base + (2 << 30), base + (3 << 30), base + (4 << 30), base + (5 << 30), None,
+                               base + (6 << 30), 9, 1, 20, C.byref(job))
+    assert st == 0 and job.tail == 1 and job.compaction_inline == 0 and job.d_clist0 is None
+    assert (job.write_epoch, job.reset_epoch, job.dynamic_sym, job.max_iters) == (1, 0, 1, 20)
+    for f in ("d_slices", "d_pair_slice0", "d_pair_spans", "d_pair_base", "d_pair_base_full", "d_pair_order", "d_items", "d_block_begin"):
+        assert base <= getattr(job, f) < base + z.tables_bytes, f
+    assert job.d_vis == base + (1 << 30) and job.d_states == base + (2 << 30) and job.d_rescue_bm == base + (3 << 30)
+    assert job.d_list0 == base + (4 << 30) and job.d_list1 == base + (5 << 30) and job.d_seg_ptrs == base + (6 << 30)
+    assert L.dpl_octav_plan_bind(plan, base, base, base, base, base, base, base + (7 << 30), base, 16, 0, 20, C.byref(job)) == 0
+    assert job.compaction_inline == 1 and job.d_clist1 - job.d_clist0 == z.fallback_bytes // 2 and (job.write_epoch, job.reset_epoch) == (0, 1)
+    L.dpl_octav_plan_destroy(plan)
+    # more than 64 slices: no plan (the two-read form serves such a set)
+    big, _ = _hip._span_array([(0, 0, 65 * cap, 0)])
+    assert not L.dpl_octav_plan_create(C.addressof(big), 1, 1, 64)
+    assert b"slices" in L.dpl_last_error()
+    if shutil.which("gcc") is None:
+        return
+    fields = [f[0] for f in _hip.OctavWorkspaceSizes._fields_]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "dipoorlet_hip.h"\nint main(void) {\n'
+                   + "".join(f'  printf("{f} %zu\\n", offsetof(dpl_octav_workspace_sizes, {f}));\n' for f in fields)
+                   + '  printf("sizeof %zu\\n", sizeof(dpl_octav_workspace_sizes));\n  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for f in fields:
+        assert int(out[f]) == getattr(_hip.OctavWorkspaceSizes, f).offset, f
+    assert int(out["sizeof"]) == C.sizeof(_hip.OctavWorkspaceSizes)
+
+
+def _integration_md_example():
+    """The python block of INTEGRATION.md §B that binds `-A mse` by hand (ctypes + torch for device memory, nothing of this
+    package), as a namespace."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    i = text.index("import ctypes, torch\nP, I64, I32, F32, U64")
+    code = text[i:text.index("```", i)]
+    assert len([ln for ln in code[code.index("def octav_rows"):].splitlines() if ln.strip() and not ln.strip().startswith("#")]) <= 60
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    return ns
+
+
+def test_integration_md_octav_example_compiles():
+    ns = _integration_md_example()
+    assert C.sizeof(ns["Job"]) == C.sizeof(_hip.OctavOnereadJob) and C.sizeof(ns["Sizes"]) == C.sizeof(_hip.OctavWorkspaceSizes)
+    assert [f[0] for f in ns["Sizes"]._fields_] == [f[0] for f in _hip.OctavWorkspaceSizes._fields_]
+
+
+@pytest.mark.gpu
+def test_integration_md_octav_example_runs(golden_dir):
+    """A maintainer's binding of `-A mse` — INTEGRATION.md §B's block, verbatim: dpl_octav_plan_* size and lay out the
+    workspace, dpl_octav_run_oneread + dpl_octav_finalize run the batch — against the reference's own values
+    (tests/golden/kernel_level.*: forward_net.py:315-330 under the Appendix-A stubs), trt and ti (dynamic_sym)."""
+    import json
+
+    import numpy as np
+    import torch
+
+    from _cases import make_tensor
+    ns = _integration_md_example()
+    with open(os.path.join(golden_dir, "kernel_level.json")) as f:
+        meta = json.load(f)
+    g = np.load(os.path.join(golden_dir, "kernel_level.npz"))
+    cases = meta["cases"]
+    for dyn, deploy in ((0, "trt"), (1, "ti")):
+        # one batch of two images over all the cases' tensors: image 0 = the golden tensor, image 1 = the same values reversed
+        xs = [make_tensor(c["kind"], c["n"], c["seed"]) for c in cases]
+        tensors = [torch.from_numpy(np.stack([x, x[::-1].copy()])).to("cuda") for x in xs]
+        rows = ns["octav_rows"](_hip.LIB_PATH, tensors, dyn).cpu().numpy()
+        for t, c in enumerate(cases):
+            want = g[f"{c['key']}/octav_{deploy}"]
+            for b in range(2):
+                got = rows[b, t]
+                assert abs(got[0] - want[0]) <= 1e-5 * max(1.0, abs(want[0])) or (np.isnan(got[0]) and np.isnan(want[0])), (c["key"], deploy, b, got, want)
+                assert np.array_equal(got[1:], want[1:], equal_nan=True), (c["key"], deploy, b, got, want)

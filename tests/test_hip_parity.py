@@ -860,6 +860,95 @@ def test_two_pipelines_share_a_plan(dev, monkeypatch, form):
             assert _close(got[..., 0], want[k][..., 0]), k
 
 
+@pytest.mark.parametrize("hook", ["exact", "rescue"])
+def test_two_pipelines_rescue_at_once(dev, monkeypatch, hook):
+    """Two pipelines on ONE plan whose walks are refused for every second pair (the C ABI's test hooks) rescue the same pair
+    indices of different batches at the same time, each on its own side stream: every pipeline owns its rescue list, rescue rows
+    and — `rescue`: the rescue walk is refused too — the compaction route's lists (a plan-level rescue list let one
+    pipeline's gather overwrite the other's)."""
+    from dipoorlet_amd import _hip, ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
+    rng = np.random.default_rng(78)
+    B, sizes = 2, [200704, 30000, 802816, 401408]
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    batches = [[torch.from_numpy((rng.standard_normal((B, n)) * (1 + t + 0.5 * k)).astype(np.float32)).to(dev) for t, n in enumerate(sizes)]
+               for k in range(8)]
+    want = [ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), x, False, form="bracket").cpu().numpy() for x in batches]
+    L = _hip.lib()
+    old = (L.dpl_test_hook_exact_fail_every(2), L.dpl_test_hook_rescue_fail_every(2 if hook == "rescue" else 0))
+    try:
+        p1, p2 = ops.OctavPipeline(False, dev), ops.OctavPipeline(False, dev)
+        r1, r2 = [], []
+        for k, x in enumerate(batches):
+            r1.append(p1.submit(plan, x))
+            r2.append(p2.submit(plan, batches[len(batches) - 1 - k]))
+        p1.sync()
+        p2.sync()
+        torch.cuda.synchronize()
+    finally:
+        L.dpl_test_hook_exact_fail_every(old[0])
+        L.dpl_test_hook_rescue_fail_every(old[1])
+    assert p1.fallback_pairs >= len(batches) * plan.n_pairs // 4 and p2.fallback_pairs >= len(batches) * plan.n_pairs // 4
+    if hook == "rescue":
+        assert p1.compaction_pairs > 0 and p2.compaction_pairs > 0
+    for k in range(len(batches)):
+        for got in (r1[k].cpu().numpy(), r2[len(batches) - 1 - k].cpu().numpy()):
+            assert np.array_equal(got[..., 1:], want[k][..., 1:]), k
+            assert _close(got[..., 0], want[k][..., 0]), k
+
+
+def test_octav_tail_lists_beyond_their_regions(dev, monkeypatch):
+    """The exact-tail form's list regions hold dpl_octav_list_cap(n) values per pair (n / 32 + 16384), not the pair: what a pair
+    lists — or its rescue gathers — beyond that is dropped and the pair finishes on the compaction route, whose whole-batch
+    lists the pipeline allocates only when a batch first asks for them.  Saturating activations (a third of the values AT the
+    maximum: every one of them is above any threshold), a constant tensor, a two-level one and a dense small pair next to
+    ordinary tensors; the scratch of the pipeline stays below half the batch's activations until then."""
+    from dipoorlet_amd import _hip, ops
+    monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    B = 4
+    sizes = [802816, 401408, 20480, 602112, 300000, 150528]
+    kinds = ["normal", "saturated", "dense_small", "const", "two_level", "relu"]
+
+    def draw(kind, n, scale):
+        z = torch.randn(B, n, generator=g, device=dev) * scale
+        if kind == "saturated":
+            z = z.clamp_(-0.4 * scale, 0.4 * scale)            # ~ 2/3 of a normal's mass sits on the two rails
+        elif kind == "dense_small":
+            z = z.abs_() + 0.5                                 # no zeros: the small pair lists all 20 480 values
+        elif kind == "const":
+            z = torch.full((B, n), 1.25 * scale, device=dev)
+        elif kind == "two_level":
+            z = torch.where(z > 0, torch.full_like(z, 2.0 * scale), torch.full_like(z, 0.125))
+        elif kind == "relu":
+            z = z.clamp_(min=0)
+        return z.contiguous()
+    batches = [[draw(k, n, 1.0 + 0.3 * it) for k, n in zip(kinds, sizes)] for it in range(6)]
+    want = [ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), x, False, form="bracket").cpu().numpy() for x in batches]
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    pipe = ops.OctavPipeline(False, dev)
+    outs = [pipe.submit(plan, batches[0])]
+    before = pipe.scratch_bytes(plan)
+    assert before < 0.5 * 4 * B * sum(sizes)
+    assert _hip.lib().dpl_octav_list_cap(401408) < 401408 // 8      # (the saturated pair's ~270 k rail values cannot fit)
+    outs += [pipe.submit(plan, x) for x in batches[1:]]
+    pipe.sync()
+    torch.cuda.synchronize()
+    assert pipe.compaction_pairs >= 3 * B * len(batches)            # saturated, const, two_level: every image of every batch
+    assert pipe.scratch_bytes(plan) >= before + 2 * 4 * B * sum(sizes)     # ... and the compaction route's lists exist now
+    for k, (o, w) in enumerate(zip(outs, want)):
+        got = o.cpu().numpy()
+        assert np.array_equal(got[..., 1:], w[..., 1:]), k
+        assert _close(got[..., 0], w[..., 0]), (k, got[..., 0], w[..., 0])
+    single = ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), batches[2], False).cpu().numpy()      # one stream, cold
+    assert np.array_equal(single[..., 1:], want[2][..., 1:]) and _close(single[..., 0], want[2][..., 0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in (1, 2, 3, 4):
+            assert _close(single[0, t, 0], O.octav_scale(batches[2][t][0].cpu().numpy(), 1)), t
+
+
 def test_fake_quant_set_launch_matches_per_tensor_launches(dev):
     """dpl_fake_quant_items — a whole tensor set fake-quantised in ONE launch — against one dpl_fake_quant launch per tensor and
     the oracle (ONNX opset-13 Q -> DQ, quantize.py:197-239), bit for bit: per-tensor and per-channel rows mixed, channel rows
@@ -935,7 +1024,7 @@ def test_octav_tail_pairs_above_one_slice(dev, monkeypatch, fail_every):
         old = _hip.lib().dpl_test_hook_exact_fail_every(fail_every)
         try:
             plan = ops.TensorSetPlan(sizes, B, dev)
-            assert plan.octav_oneread_scratch()["n_multi"] == 7 * B
+            assert plan.octav_tail().n_multi == 7 * B
             pipe = ops.OctavPipeline(dyn, dev)
             outs = [pipe.submit(plan, x) for x in batches]
             pipe.sync()

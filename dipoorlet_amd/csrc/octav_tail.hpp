@@ -727,12 +727,23 @@ __device__ __forceinline__ void walk_tail(const uint32_t pair, const uint32_t te
         if (tid < (uint32_t)kLogWords) sh.pub[tid] = 0u;
         __syncthreads();
         if (tid == 0) {
-            BracketResult br = bracket_marks(n_ge, s_ge, sh.pub, s0, ud, n_pair);
-            // the rescue gathers the bracket's bins into the pair's region of the rescue list: what cannot fit goes straight
-            // to the compaction route
-            if (br.route == 2u && n_ge[br.jmin] - n_ge[br.jmax + 1] > sh.region_cap) br.route = 1u;
-            sh.route = br.route;
+            sh.route = bracket_marks(n_ge, s_ge, sh.pub, s0, ud, n_pair).route;
+            sh.would_list = 0u;
         }
+        __syncthreads();
+        // the rescue gathers the values of the bracket's (marked) bins into the pair's region of the rescue list: a bracket that
+        // holds more than the region does goes straight to the compaction route
+        if (sh.route == 2u) {
+            uint32_t held = 0u;
+#pragma unroll
+            for (int q = 0; q < kPerT; ++q) {
+                const int b = hi - q;
+                if (b >= 1 && b < kLogNB - 1 && ((sh.pub[b >> 5] >> (b & 31)) & 1u)) held += n_ge[b] - n_ge[b + 1];
+            }
+            if (held) atomicAdd(&sh.would_list, held);
+        }
+        __syncthreads();
+        if (tid == 0 && sh.route == 2u && sh.would_list > sh.region_cap) sh.route = 1u;
         __syncthreads();
         rescued = sh.route == 2u;
         if (rescued) {

@@ -441,7 +441,7 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     if form == "tail":
         tp = plan.octav_tail()
         if tp is not None and (tp.n_multi == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0"):
-            return _octav_batch_tail(plan, tp, tensors, dynamic_sym)
+            return _octav_batch_tail(plan, tp, tensors, dynamic_sym, states)
     res = plan.octav_oneread_scratch() if mode == 3 else None
     if mode == 3 and res is None:
         mode = 2
@@ -485,7 +485,7 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     return out
 
 
-def _octav_batch_tail(plan, tp, tensors, dynamic_sym):
+def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
     """One batch of the exact-tail form on the caller's stream.  The compaction route (flat distributions, values beyond 2^14,
     lists beyond their regions: rare) needs two whole-batch lists, which are allocated the first time a batch asks for them —
     so this reads the batch's control block back (the one host synchronisation of this call; OctavPipeline defers it)."""
@@ -505,6 +505,10 @@ def _octav_batch_tail(plan, tp, tensors, dynamic_sym):
         _hip.check(L.dpl_octav_oneread_compaction(C.byref(job), _stream()), "dpl_octav_oneread_compaction")
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(state), plan.n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
+    if states_out is not None:      # (the caller's view of the pairs' states and the control block, as the other forms leave them)
+        n = (plan.n_pairs + 1) * csz
+        if states_out.numel() >= n:
+            states_out[:n].copy_(state[:n])
     return out
 
 

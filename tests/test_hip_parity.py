@@ -935,7 +935,9 @@ def test_octav_tail_lists_beyond_their_regions(dev, monkeypatch):
     outs += [pipe.submit(plan, x) for x in batches[1:]]
     pipe.sync()
     torch.cuda.synchronize()
-    assert pipe.compaction_pairs >= 3 * B * len(batches)            # saturated, const, two_level: every image of every batch
+    # the constant tensor in every image of every batch; the saturated / two-level ones whenever their rail is not a bin edge (an
+    # iterate just below a power of two sits in the EMPTY bin under the rail's: the rescue then needs no values at all)
+    assert pipe.compaction_pairs >= 2 * B * len(batches)
     assert pipe.scratch_bytes(plan) >= before + 2 * 4 * B * sum(sizes)     # ... and the compaction route's lists exist now
     for k, (o, w) in enumerate(zip(outs, want)):
         got = o.cpu().numpy()

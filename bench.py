@@ -154,6 +154,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if not a.dry_run:
+            if backend == "nccl" and torch.cuda.device_count() < world:
+                sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                         "(RCCL refuses two ranks on one device; DPL_DIST_BACKEND=gloo runs them on one GPU for plumbing tests)")
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend)
     if a.dry_run:
@@ -195,8 +198,9 @@ def main():
     B = BATCH
     # DPL_BENCH_JITTER (a tuning aid, not the headline workload): per-image contrast jitter of the synthetic activations
     jitter = float(os.environ.get("DPL_BENCH_JITTER", "0"))
-    pool = [synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j, image_jitter=jitter) for j in range(max(1, a.pool))]
     plan = ops.TensorSetPlan(elems, B, dev)
+    # (resident sets are validated and pinned once, TensorSetPlan.bind: a launch over them costs no per-tensor checks)
+    pool = [plan.bind(synth_activations(spec, B, dev, seed=1234 + 1000 * rank + j, image_jitter=jitter)) for j in range(max(1, a.pool))]
     n_pool = len(pool)
 
     def fence():
@@ -280,12 +284,13 @@ def main():
     # what earlier sweeps learned (octav_reset) inside the timed region, so the first batches run without a prediction as they
     # do in a fresh process.  The pool holds more distinct batches than the prediction remembers (2 epochs of
     # DPL_ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
-    mse, mse_jitter, vit_mse, mse_real, mse_big = None, {}, None, {}, None
+    mse, mse_jitter, vit_mse, mse_real, mse_big, mse_lanes1 = None, {}, None, {}, None, None
     if a.mse_steps > 0:
         import ctypes
         form = ops._default_form()
         pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form in ("oneread", "tail")
         pipe = ops.OctavPipeline(False, dev) if pipeline else None
+        pipe1 = ops.OctavPipeline(False, dev, lanes=1) if pipeline else None    # the schedule forward_net_octav runs (below)
         min_pool = 2 * ops._ONEREAD_EPOCH + 1
         # DPL_BENCH_FAIL_EVERY=n (a tuning aid, not the headline workload): the C ABI's test hook makes every n-th pair's walk
         # report a missed prediction, to price the device-side rescue of such pairs
@@ -293,8 +298,9 @@ def main():
         if inject > 0:
             _hip.lib().dpl_test_hook_exact_fail_every(inject)
 
-        def run_mse(mpool, steps, jit, plan=plan, n_images=N_MSE, net="ResNet-50"):
-            mse_ev = []
+        def run_mse(mpool, steps, jit, plan=plan, n_images=N_MSE, net="ResNet-50", pipe=pipe):
+            mse_ev, mse_coll = [], []
+            mpool = [plan.bind(x) for x in mpool]
             B, T, E = plan.batch, plan.T, sum(plan.elems)        # (the ViT object runs its own plan through the same code)
             n_mse_batches = n_images // B
             rows = torch.empty(n_images, T, 3, dtype=torch.float32, device=dev)
@@ -305,7 +311,10 @@ def main():
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
                 plan.octav_reset()         # a cold run: nothing learned from the previous sweep
-                if pipe is not None:       # the product's schedule (forward_net.forward_net_octav): walk(i) beside stream(i + 1)
+                # pipe: two lane streams — the streaming kernel of batch i + 1 starts while batch i drains (the statistics
+                # kernels alone on the chip: this object); pipe1: lanes = 1, one stream — what forward_net.forward_net_octav runs
+                # between two network forwards (`mse_lanes1`); either way the rescue of batch i runs beside batch i + 1
+                if pipe is not None:
                     outs = [pipe.submit(plan, mpool[b % len(mpool)]) for b in range(n_mse_batches)]
                     pipe.sync()
                     torch.cat(outs, out=rows)
@@ -315,7 +324,13 @@ def main():
                 if timed:
                     e1.record()
                     mse_ev.append((e0, e1))
+                if use_dist and timed:
+                    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    c0.record()
                 allr = gather_rows(rows, world) if use_dist else rows          # the algorithm's exchange: per-image rows
+                if use_dist and timed:
+                    c1.record()
+                    mse_coll.append((c0, c1))
                 s_mean = allr[:, :, 0].mean(0)                                 # basic_algorithm.py:57-69 on the device
                 lo = torch.maximum(allr[:, :, 1].amin(0), -s_mean)
                 hi = torch.minimum(allr[:, :, 2].amax(0), s_mean)
@@ -358,7 +373,14 @@ def main():
                                 "achieved": mse_ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": mse_ach / HBM_PEAK_GBPS,
                                 "traffic": None, "bytes_per_launch": mse_bytes, "avg_batch_ms": mse_ms},
                    "clip_checksum": float(mclip.double().abs().sum().item()),
-                   "sample_ok": bool(ok), "sample_worst_rel_err": worst}
+                   "sample_ok": bool(ok), "sample_worst_rel_err": worst,
+                   # the all_gather of the [n, T, 3] rows (RCCL), milliseconds per sweep
+                   "collectives_ms_per_sweep": round(sum(s.elapsed_time(e) for s, e in mse_coll) / max(1, len(mse_coll)), 4) if mse_coll else None}
+            if pipe is not None and pipe.scratch_bytes(plan) is not None:
+                # every device byte the form holds besides the activations: tables, threshold history, state / rescue blocks,
+                # lists (and the compaction route's lists, had a batch asked for them)
+                obj["scratch_bytes"] = int(pipe.scratch_bytes(plan))
+                obj["scratch_over_batch_activations"] = round(pipe.scratch_bytes(plan) / (4.0 * E * B), 4)
             if inject > 0:
                 obj["injected_miss_every"] = inject
             if pipe is not None:   # prediction misses (pairs finished by a re-read of the pair), timed sweeps only
@@ -377,6 +399,7 @@ def main():
         if len(pool) < min_pool and rank == 0:
             print(f"bench.py: --pool {len(pool)} < {min_pool}: batches repeat inside the prediction's memory", file=sys.stderr)
         mse = run_mse(pool, a.mse_steps, jitter)
+        mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
         # the same sweep over images that differ in contrast (one sweep each): what a prediction from other images costs
         for jit in ([float(x) for x in a.mse_jitter.split(",") if x] if jitter == 0.0 else []):
             jp = [synth_activations(spec, B, dev, seed=99 + 1000 * rank + j, image_jitter=jit) for j in range(len(pool))]
@@ -480,7 +503,7 @@ def main():
                         "tensors_of_50MB_and_more": {"launches": len(big), "ms": ms_big, "achieved": gbps_big,
                                                      "frac": gbps_big / HBM_PEAK_GBPS}}
         # ... and the whole set in ONE launch (dpl_fake_quant_items: what a caller that holds every tensor of a forward uses)
-        ys = [torch.empty_like(x) for x in xs]
+        ys = plan.bind([torch.empty_like(x) for x in xs])
         fq["set_launch"] = {}
         for mode in ("per_tensor", "per_channel"):
             prm = [((q[0], q[1], 1, -128, 127) if mode == "per_tensor" else (q[2], q[3], h * w, -128, 127))
@@ -497,6 +520,52 @@ def main():
             gbps = 8 * E * B / (ms * 1e-3) / 1e9
             fq["set_launch"][mode] = {"ms_per_batch": ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS, "launches": 1}
         del ys
+        # ... and where the PRODUCT runs it: the activation Q/DQ nodes of a fake-quantised ResNet-50 forward (quantize.quant_graph
+        # for -D trt, executor.GraphSession; the weights' Q/DQ are folded at session build), one launch per node between the
+        # network's own kernels, at the CLI's default batch: bytes of all Q/DQ nodes of one forward / their summed GPU time
+        # (HIP events around each node on the launch stream while the stream is kept busy: kernel durations, not launch gaps)
+        try:
+            import types as _types
+            from dipoorlet_amd import executor as _ex, models as _models
+            from dipoorlet_amd.forward_net import DEFAULT_BATCH as _PB
+            from dipoorlet_amd.quantize import quant_graph as _quant_graph
+            from dipoorlet_amd.tensor_cali import find_clip_val_minmax_weight as _wranges
+            gfp = _models.resnet50()
+            sfp = gfp.make_session()
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(99)
+            xin = torch.randn(_PB, 3, 224, 224, generator=gen, device=dev)
+            clipv = {n: [float(t.amin()), float(t.amax())] for n, t in zip(sfp.tensor_names, sfp.run({"input": xin}))}
+            clipv.update(_wranges(gfp, None, session=sfp))
+            del sfp
+            gq, _ = _quant_graph(gfp, clipv, _types.SimpleNamespace(deploy="trt", skip_layers=[]))
+            sq = gq.make_session()
+            evs, orig = [], _ex._OPS["FakeQuant"]
+
+            def timed_fq(sess, node, x):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                y = orig(sess, node, x)
+                e1.record()
+                evs.append((e0, e1, x.numel()))
+                return y
+            sq.run({"input": xin})
+            sq.run({"input": xin})
+            _ex._OPS["FakeQuant"] = timed_fq
+            try:
+                for _ in range(a.fq_reps):
+                    sq.run({"input": xin})
+                torch.cuda.synchronize()
+            finally:
+                _ex._OPS["FakeQuant"] = orig
+            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / a.fq_reps
+            nbytes = 8 * sum(n for _, _, n in evs) / a.fq_reps
+            fq["product_forward"] = {"batch": _PB, "nodes": len(evs) // a.fq_reps, "bytes": nbytes, "ms": ms,
+                                     "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+            del sq, gq, gfp, xin
+            torch.cuda.empty_cache()
+        except Exception as e:   # noqa: BLE001  (a side object: the line goes out without it)
+            fq["product_forward"] = {"error": repr(e)[:300]}
         fake_quant = {"workload": f"ResNet-50 activation set, one batch of {B} images, fused QuantizeLinear -> DequantizeLinear, int8 grid",
                       "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS, "bytes_per_batch": 8 * E * B, **fq}
         del ybuf, xs, qp, xv, yv
@@ -510,56 +579,66 @@ def main():
     cpu_sample = [t.cpu() for t in pool[0]] if (rank == 0 and world == 1 and a.cpu_seconds > 0) else None
     if a.e2e_images > 0 and rank == 0 and world == 1:
         pool = None            # the child keeps its own 109 GB of activations resident between its two passes
+        pipe = pipe1 = None
+        plan = None
         torch.cuda.empty_cache()
         import shutil
         import tempfile
         import numpy as np
         from dipoorlet_amd import models
         d = tempfile.mkdtemp(prefix="dpl_e2e_")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+        env["MASTER_PORT"] = str(29600 + os.getpid() % 300)
+
+        def write_images(sub, n):
+            os.makedirs(os.path.join(d, sub, "input"), exist_ok=True)
+            rs = np.random.default_rng(0)
+            base = rs.standard_normal((64, 3 * 224 * 224)).astype(np.float32)
+            have = len(os.listdir(os.path.join(d, sub, "input")))
+            for i in range(have, n):       # distinct images from 64 base draws (scaled): file I/O is what matters here
+                (base[i % 64] * np.float32(1.0 + 0.01 * (i // 64))).tofile(os.path.join(d, sub, "input", f"{i}.bin"))
+
+        def cli(model, sub, n, algo, tag, extra=()):
+            """One fresh CLI process (python -m dipoorlet_amd ...): {command, process wall, calibration images/s, the child's split}."""
+            tj = os.path.join(d, f"timing_{tag}.json")
+            cmd = [sys.executable, "-m", "dipoorlet_amd", "-M", os.path.join(d, model), "-I", os.path.join(d, sub), "-N", str(n), "-A", algo,
+                   "-D", "trt", "-O", os.path.join(d, "out_" + tag), "--skip_profiling", "--timing_json", tj, *extra]
+            time.sleep(2.0)        # (the driver is still releasing the previous process' HBM: a fresh process right behind one that
+            torch.cuda.empty_cache()   # held 100 GB pays seconds for its first allocations — not what a user's run sees)
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+            wall = time.perf_counter() - t0
+            if r.returncode != 0 or not os.path.exists(tj):
+                return {"error": (r.stderr or r.stdout)[-600:], "returncode": r.returncode}
+            with open(tj) as f:
+                tm = json.load(f)
+            with open(os.path.join(d, "out_" + tag, "act_clip_val.json")) as f:
+                n_clips = len(json.load(f))
+            tm.pop("forward_batches_ms", None)
+            return {"command": "python -m dipoorlet_amd -M %s -I %s -N %d -A %s -D trt --skip_profiling %s" % (model, sub, n, algo, " ".join(extra)),
+                    "process_wall_s": wall, "images_per_s_process": n / wall,
+                    "images_per_s_calibration": n / tm["tensor_calibration_wall_s"], "tensors": n_clips, "split": tm}
         try:
             g = models.resnet50()
             g.output_dir = d
             g.save_onnx_model("r50")
-            os.makedirs(os.path.join(d, "calib", "input"))
-            rs = np.random.default_rng(0)
-            base = rs.standard_normal((64, 3 * 224 * 224)).astype(np.float32)
-            for i in range(a.e2e_images):      # distinct images from 64 base draws (scaled): file I/O is what matters here
-                (base[i % 64] * np.float32(1.0 + 0.01 * (i // 64))).tofile(os.path.join(d, "calib", "input", f"{i}.bin"))
-            del g, base
-            tj = os.path.join(d, "timing.json")
-            cmd = [sys.executable, "-m", "dipoorlet_amd", "-M", os.path.join(d, "r50.onnx"), "-I", os.path.join(d, "calib"),
-                   "-N", str(a.e2e_images), "-A", "hist", "-D", "trt", "-O", os.path.join(d, "out"), "--calib_batch", "32",
-                   "--skip_profiling", "--timing_json", tj]
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-            env["MASTER_PORT"] = str(29600 + os.getpid() % 300)
-            torch.cuda.empty_cache()
-            t0 = time.perf_counter()
-            r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-            wall = time.perf_counter() - t0
-            if r.returncode == 0 and os.path.exists(tj):
-                with open(tj) as f:
-                    tm = json.load(f)
-                with open(os.path.join(d, "out", "act_clip_val.json")) as f:
-                    n_clips = len(json.load(f))
-                e2e = {"command": "python -m dipoorlet_amd -M r50.onnx -I calib -N %d -A hist -D trt --calib_batch 32 --skip_profiling" % a.e2e_images,
-                       "process_wall_s": wall, "images_per_s_process": a.e2e_images / wall,
-                       "images_per_s_calibration": a.e2e_images / tm["tensor_calibration_wall_s"], "tensors": n_clips, "split": tm}
-                # the same files through `-A mse` (BASELINE configs[2]'s algorithm; a second fresh process, warm file cache)
-                tj2 = os.path.join(d, "timing_mse.json")
-                cmd2 = [c if c != "hist" else "mse" for c in cmd[:-1]] + [tj2]
-                cmd2[cmd2.index(os.path.join(d, "out"))] = os.path.join(d, "out_mse")
-                t0 = time.perf_counter()
-                r2 = subprocess.run(cmd2, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-                wall2 = time.perf_counter() - t0
-                if r2.returncode == 0 and os.path.exists(tj2):
-                    with open(tj2) as f:
-                        tm2 = json.load(f)
-                    e2e["mse"] = {"process_wall_s": wall2, "images_per_s_calibration": a.e2e_images / tm2["tensor_calibration_wall_s"],
-                                  "split": tm2}
-                else:
-                    e2e["mse"] = {"error": (r2.stderr or r2.stdout)[-600:], "returncode": r2.returncode}
-            else:
-                e2e = {"error": (r.stderr or r.stdout)[-600:], "returncode": r.returncode}
+            del g
+            write_images("calib", a.e2e_images)
+            cli("r50.onnx", "calib", min(64, a.e2e_images), "minmax", "warm")   # (untimed: the box's page cache sees the libraries and the files)
+            e2e = cli("r50.onnx", "calib", a.e2e_images, "hist", "hist")
+            if "error" not in e2e:
+                # the same files through `-A mse` (BASELINE configs[2]'s algorithm), then configs[2]'s own N = 4096
+                e2e["mse"] = cli("r50.onnx", "calib", a.e2e_images, "mse", "mse")
+                if a.e2e_images >= 1024:
+                    write_images("calib", N_MSE)
+                    e2e["mse_4096"] = cli("r50.onnx", "calib", N_MSE, "mse", "mse4096")
+                # configs[4]'s network on one GPU: ViT-B/16 (557 exposed tensors, 133 M elements per image), -A mse, N = 256
+                if a.vit_images > 0:
+                    g = models.vit_b16(seed=5, attn_gain=10.0)
+                    g.output_dir = d
+                    g.save_onnx_model("vit")
+                    del g
+                    e2e["vit_mse"] = cli("vit.onnx", "calib", min(a.vit_images, 256), "mse", "vit", ("--calib_batch", "16"))
         finally:
             shutil.rmtree(d, ignore_errors=True)
 
@@ -569,7 +648,7 @@ def main():
     # HBM bytes per launch by the PMC counters (scripts/profile_gpu.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     # this very script).  Quoted only when the record was measured on the kernel sources this run uses (sha over csrc/), else null.
     def traffic_record():
-        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r04", "traffic.json"))
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r05", "traffic.json"))
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             from summarize_prof import source_sha
@@ -582,6 +661,9 @@ def main():
         return None
     tk = traffic_record()
     traffic = tk["k_abs_hist"]["hbm_bytes_per_launch"] if tk and "k_abs_hist" in tk else None
+    # (`traffic` is NOT counted in this run: it is the PMC record of scripts/profile_gpu.sh over this script, replayed when its
+    # source hash matches the kernels this run uses — the line names the file)
+    traffic_from = os.path.relpath(os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r05", "traffic.json")), ROOT) if tk else None
 
     def mse_batch_traffic():
         """HBM bytes of ONE mse batch: every k_octav_* kernel of the profiled run, per launch of the streaming kernel."""
@@ -594,6 +676,8 @@ def main():
         return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / ks[main]["launches"]
     if mse is not None:
         mse["roofline"]["traffic"] = mse_batch_traffic()
+    if mse_lanes1 is not None:
+        mse_lanes1["roofline"]["kernel"] = "OCTAV batch on ONE stream (OctavPipeline(lanes=1): forward_net.forward_net_octav's schedule; the rescue beside the next batch)"
     images = N_HIST * world * a.steps
     hist_rate = images / dt_hist
     headline_mse = a.algo == "mse" and mse is not None
@@ -608,14 +692,17 @@ def main():
             b["traffic_ratio"] = round(r["traffic"] / r["bytes_per_launch"], 4)
         if p:
             b.update(listed=round(p["listed_share_of_elements"], 4), rescued=round(p["pairs_missed"] / max(1, p["batches"]), 1))
+        if o.get("scratch_over_batch_activations") is not None:
+            b["scratch"] = o["scratch_over_batch_activations"]
         return b
     hist_roof = {"bound": "hbm", "kernel": "k_abs_hist", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "bytes_per_launch": kernel_bytes, "avg_kernel_ms": hist_kern_ms}
+                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_from": traffic_from, "bytes_per_launch": kernel_bytes,
+                 "avg_kernel_ms": hist_kern_ms}
     full = {
         "hist": {"images_per_s": hist_rate, "ms_per_step": dt_hist / a.steps * 1e3, "roofline": hist_roof,
                  "algorithmic_GBps_job": 8 * E * images / dt_hist / 1e9, "hist_checksum": hist_checksum,
                  "hist_checksum_expected": E * N_HIST * world, "clip_checksum": clip_checksum, "collectives_ms_per_sweep": coll_ms},
-        "mse": mse, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "mse_448": mse_big,
+        "mse": mse, "mse_lanes1": mse_lanes1, "mse_jitter": mse_jitter or None, "fake_quant": fake_quant, "vit_mse": vit_mse, "mse_448": mse_big,
         "mse_feature_maps": mse_real or None, "e2e": e2e,
     }
     # The record's line: BASELINE.json's metric on its headline configuration, every headline scalar inside `roofline` / `config`
@@ -623,6 +710,7 @@ def main():
     # is the `details` line printed BEFORE it.
     roof = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (mse["roofline"] if headline_mse else hist_roof).items()}
     roof["mse"] = brief(mse)                                                     # BASELINE configs[2]: -A mse, N = 4096, images alike
+    roof["mse_lanes1"] = brief(mse_lanes1)                                       # ... on one stream, as forward_net_octav schedules it
     roof["mse_jitter"] = {k: brief(v) for k, v in mse_jitter.items()} or None    # ... with per-image contrast jitter
     roof["mse_feature_maps"] = {k: brief(v) for k, v in mse_real.items()} or None   # ... executor-produced ResNet-50 activations
     roof["mse_vit"] = brief(vit_mse)                                             # configs[4]'s workload on one GPU
@@ -631,12 +719,20 @@ def main():
         # per mode: [frac of one launch per tensor over the set, ... over the tensors of >= 50 MB, ... of the set in ONE launch]
         roof["fake_quant"] = {m: [round(fake_quant[m]["frac"], 4), round(fake_quant[m]["tensors_of_50MB_and_more"]["frac"], 4),
                                   round(fake_quant["set_launch"][m]["frac"], 4)] for m in ("per_tensor", "per_channel")}
+        # the 4th: the Q/DQ nodes of a fake-quantised ResNet-50 forward through the product's executor (per tensor, -D trt)
+        if "frac" in fake_quant.get("product_forward", {}):
+            roof["fake_quant"]["product_forward"] = round(fake_quant["product_forward"]["frac"], 4)
     if e2e and "error" not in e2e:
-        # images/s of calibration (fresh CLI process over .bin files) | of the network forward in steady state
-        roof["e2e"] = {"hist": [round(e2e["images_per_s_calibration"]), round(e2e["split"].get("forward_steady_images_per_s", 0.0))]}
-        if "mse" in e2e and "error" not in e2e["mse"]:
-            roof["e2e"]["mse"] = [round(e2e["mse"]["images_per_s_calibration"]), round(e2e["mse"]["split"].get("forward_steady_images_per_s", 0.0))]
-            roof["e2e"]["mse_statistics_gpu_s"] = round(e2e["mse"]["split"].get("statistics_gpu_s", 0.0), 4)
+        # per run: [images/s of calibration (fresh CLI process over .bin files), images/s of the network forward in steady state]
+        def pair(o):
+            return [round(o["images_per_s_calibration"]), round(o["split"].get("forward_steady_images_per_s", 0.0))]
+        roof["e2e"] = {"hist": pair(e2e)}
+        for k in ("mse", "mse_4096", "vit_mse"):
+            if k in e2e and "error" not in e2e[k]:
+                roof["e2e"][k] = pair(e2e[k])
+        sp = e2e["split"]
+        # the headline run's wall against its GPU work: tensor_calibration_wall_s - (forward_gpu_s + statistics_gpu_s)
+        roof["e2e"]["hist_host_s"] = round(sp["tensor_calibration_wall_s"] - sp["forward_gpu_s"] - sp["statistics_gpu_s"], 3)
     out = {
         # BASELINE.json's metric; images/s is `value`, the achieved HBM GB/s of the dominant kernel is `roofline.achieved`
         "metric": "calibration images/sec (whole node) + achieved HBM GB/s, ResNet-50 ONNX N=%d, -A %s"
@@ -669,7 +765,7 @@ def main():
         line = json.dumps(out)
         # (the driver keeps the last 2 000 characters of stdout as `tail`: should the line ever outgrow that, the side objects go
         # first — they are all in the details line above —, never the contract's fields)
-        for k in ("mse_448", "fake_quant", "e2e", "mse_feature_maps", "mse_jitter", "mse_vit"):
+        for k in ("mse_448", "mse_feature_maps", "mse_jitter", "fake_quant", "mse_vit", "mse_lanes1", "e2e"):
             if len(line) < 1990:
                 break
             out["roofline"].pop(k, None)

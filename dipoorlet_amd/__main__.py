@@ -43,7 +43,7 @@ def build_parser():
     p.add_argument("--model_type", choices=["unet"], default=None)
     p.add_argument("--quant_format", default="QDQ", type=str, choices=["QOP", "QDQ"])
     # MI355X-side knobs
-    p.add_argument("--calib_batch", type=int, default=32, help="calibration images per forward (32: the batch the statistics kernels are benchmarked at)")
+    p.add_argument("--calib_batch", type=int, default=64, help="calibration images per forward")
     p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
     p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
     p.add_argument("--skip_profiling", default=False, action="store_true")

@@ -545,12 +545,44 @@ class GraphSession(ActivationSession):
         # fake-quantised WEIGHTS are constants: quantise them once here instead of on every forward
         self._folded = set()
         self._batched_ok = None   # decided by batched_ok() at the first batched run
-        for node in graph.graph.node:
-            if node.op_type == "FakeQuant" and node.input[0] in self.consts:
-                w = self.consts[node.input[0]]
-                self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, w) if w.is_cuda else w
-                self._folded.add(node.name)
+        fold = [n for n in graph.graph.node if n.op_type == "FakeQuant" and n.input[0] in self.consts]
+        for node in fold:
+            self._folded.add(node.name)
+        self._fold_weights(fold)
         self._infer()
+
+    def _fold_weights(self, nodes):
+        """Fake-quantised WEIGHTS are constants: quantised once, here, instead of on every forward — every weight of the graph
+        in ONE launch (dpl_fake_quant_items over the set of weight tensors, per-channel rows along each weight's own axis: 54
+        tensors for ResNet-50) rather than one launch and two parameter uploads per weight (quantize.py:197-239 builds a Q/DQ
+        pair per weight; ONNXRuntime runs each on every inference)."""
+        if not nodes:
+            return
+        ws = [self.consts[n.input[0]] for n in nodes]
+        if self.device.type != "cuda" or not all(w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.numel() > 0 for w in ws):
+            for n, w in zip(nodes, ws):
+                self.consts[n.output[0]] = _OPS["FakeQuant"](self, n, w) if w.is_cuda else w
+            return
+        from . import ops
+        plan = ops.TensorSetPlan([w.numel() for w in ws], 1, self.device)
+        # all scales / zero points of the set in two transfers
+        qs = [self.graph._qdq[n.name] for n in nodes]
+        sizes = [q.scale.size for q in qs]
+        scale = torch.from_numpy(np.concatenate([q.scale for q in qs]).astype(np.float32)).to(self.device)
+        zp = torch.from_numpy(np.concatenate([np.broadcast_to(q.zero_point_as_stored(), q.scale.shape) for q in qs]).astype(np.int32)).to(self.device)
+        params, off = [], 0
+        for q, w, k in zip(qs, ws, sizes):
+            lo, hi = q.saturation()
+            inner = 1
+            if k > 1:       # channel c of element i = (i / inner) % n_channels: inner = the elements behind the channel axis
+                if w.shape[q.axis] != k:
+                    raise ValueError(f"fake-quant of {q.tensor_name}: {k} channel scales for axis {q.axis} of {tuple(w.shape)}")
+                inner = int(np.prod(w.shape[q.axis + 1:])) if q.axis + 1 < w.dim() else 1
+            params.append((scale[off:off + k], zp[off:off + k], inner, lo, hi))
+            off += k
+        outs = ops.FakeQuantSet(plan, params)([w.reshape(1, -1) for w in ws])
+        for n, w, y in zip(nodes, ws, outs):
+            self.consts[n.output[0]] = y.view(w.shape)
 
     def _upload_consts(self):
         """Every initializer to the device ONCE: the fp32 ones (weights, biases: 102 MB for ResNet-50) are packed into one

@@ -156,6 +156,48 @@ def test_config2_resnet50_mse_n256_plus_ragged(r50_pool):
             assert _close(allr[256 + k, t, 0], s), (t, k)
 
 
+def test_config2_resnet50_mse_full_n4096_through_the_pipeline(r50_pool):
+    """BASELINE configs[2] at its own N: 4 096 images = 128 batches of 32 through ops.OctavPipeline (exact-tail form, two lane
+    streams, the threshold history of a whole run: sixteen epochs), as bench.py's `mse` object runs them.  Every pair's
+    min / max against torch's own reductions, 208 sampled pairs' scales against the numpy oracle (forward_net.py:315-330), the
+    clip of basic_algorithm.py:64-68 on top; the pipeline's scratch stays below half a batch's activations."""
+    from dipoorlet_amd import ops
+    dev, spec, pool = r50_pool
+    elems = [e for _, e, _ in spec]
+    T, B, n_batches = len(elems), 32, 128
+    plan = ops.TensorSetPlan(elems, B, dev)
+    bound = [plan.bind(p) for p in pool]
+    pipe = ops.OctavPipeline(False, dev)
+    outs = [pipe.submit(plan, bound[b % 3]) for b in range(n_batches)]
+    pipe.sync()
+    rows = torch.cat(outs)
+    assert rows.shape == (4096, T, 3) and bool(torch.isfinite(rows).all())
+    assert pipe.scratch_bytes(plan) < 0.5 * 4 * B * sum(elems) and pipe.compaction_pairs == 0
+    mins = [torch.stack([p[t].min(1).values for t in range(T)], 1) for p in pool]      # [B, T] per pool batch
+    maxs = [torch.stack([p[t].max(1).values for t in range(T)], 1) for p in pool]
+    r4 = rows.view(n_batches, B, T, 3)
+    for b in range(n_batches):
+        assert torch.equal(r4[b, :, :, 1], mins[b % 3]) and torch.equal(r4[b, :, :, 2], maxs[b % 3]), b
+    # the same images again give the same scale up to the stop rule firing one step apart (1e-6 absolute)
+    first = r4[0:3, :, :, 0]
+    for b in range(3, n_batches):
+        assert float((r4[b, :, :, 0] - first[b % 3]).abs().max()) <= 2e-6, b
+    rng = np.random.default_rng(17)
+    want_cache = {}
+    got = rows.cpu().numpy()
+    for _ in range(208):
+        b, k, t = int(rng.integers(0, n_batches)), int(rng.integers(0, B)), int(rng.integers(0, T))
+        key = (b % 3, k, t)
+        if key not in want_cache:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                want_cache[key] = O.octav_scale(pool[b % 3][t][k].cpu().numpy(), 1)
+        assert _close(got[b * B + k, t, 0], want_cache[key]), (b, k, t)
+    s_mean = rows[:, :, 0].mean(0)
+    clip = torch.stack([torch.maximum(rows[:, :, 1].amin(0), -s_mean), torch.minimum(rows[:, :, 2].amax(0), s_mean)], 1)
+    assert bool(torch.isfinite(clip).all()) and bool((clip[:, 0] <= clip[:, 1]).all())
+
+
 def test_config4_vit_b16_real_shapes_hist_and_mse():
     """BASELINE configs[4]'s workload on one GPU at its real shapes: ViT-B/16 (dim 768, depth 12, 197 tokens) run by the
     repo's own graph executor with every node output exposed — 557 calibration tensors per image, among them LayerNorm

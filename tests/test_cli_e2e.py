@@ -313,3 +313,43 @@ def test_activation_cache_by_name(workdir, activations):
     assert cache["conv1.weight"].shape == (64, 3, 7, 7)
     cache.reset()
     assert not cache.activation_cache
+
+
+@pytest.mark.parametrize("deploy", ["trt", "snpe", "ti"])
+def test_session_folds_all_weight_fake_quants_in_one_launch(workdir, deploy):
+    """A quant_graph session quantises every weight once at build time, all of them in ONE dpl_fake_quant_items launch
+    (executor.GraphSession._fold_weights): bit-identical to one QDQNode.apply per weight (per-channel rows on the weight's own
+    axis for trt, per-tensor asymmetric grids for snpe, power-of-two scales for ti) and to the oracle's Q -> DQ."""
+    import types
+
+    from dipoorlet_amd import dist_helper
+    from dipoorlet_amd.graph import ONNXGraph
+    from dipoorlet_amd.quantize import quant_graph
+    from dipoorlet_amd.tensor_cali import tensor_calibration
+    from dipoorlet_amd.utils import load_clip_val, save_clip_val
+    dist_helper.init_default()
+    g = ONNXGraph.load(str(workdir / "model.onnx"))
+    out = workdir / f"fold_{deploy}"
+    os.makedirs(out, exist_ok=True)
+    args = types.SimpleNamespace(input_dir=str(workdir / "calib"), data_num=N, rank=0, local_rank=0, world_size=1,
+                                 bins=2048, threshold=0.99999, deploy=deploy, act_quant="minmax", calib_batch=BATCH,
+                                 output_dir=str(out), skip_layers=[], savefp=False)
+    a, w = tensor_calibration(g, args)
+    save_clip_val(a, w, args)
+    a, w = load_clip_val(args)
+    clip = dict(a)
+    clip.update(w)
+    gq, _ = quant_graph(g, clip, args)
+    sq = gq.make_session()
+    n = 0
+    for node in gq.graph.node:
+        if node.name not in sq._folded:
+            continue
+        q = gq._qdq[node.name]
+        x = sq.consts[node.input[0]]
+        one = q.apply(x.contiguous())
+        assert torch.equal(sq.consts[node.output[0]], one), node.name
+        want = O.fake_quant_qdq(x.cpu().numpy(), q.scale, q.zero_point_as_stored(), axis=q.axis if q.scale.size > 1 else None, signed=q.symmetric)
+        assert np.array_equal(one.cpu().numpy(), want), node.name
+        n += 1
+    assert n >= 20

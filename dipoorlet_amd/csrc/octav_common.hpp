@@ -49,12 +49,13 @@ constexpr uint32_t kRescueUnit = 16384;                     // elements of a pai
 
 // Capacity (elements, a multiple of 32: whole 128-byte lines) of the LIST REGION of one slice of n elements in the one-read
 // forms' list buffers.  The exact-tail form lists ~0.5 - 1.5 % of a pair (a wave's budget: kTailAllow0 + what it has seen >> 6,
-// + 512 per raise) and the rescue gathers a bracket's bins (~2 %): a region holds n / 32 + 16384 values, never more than the
+// + 512 per raise) and the rescue gathers a bracket's bins (~2 %): a region holds n / 16 + 16384 values, never more than the
 // slice itself.  What does not fit — saturating activations with a tenth of their values at the maximum, constant tensors —
 // is not listed: the pair's walk is refused (its list length says so) and it finishes on the compaction route, whose
 // full-size lists the caller provides only when a batch reports such pairs.  Round 4 gave every pair a region of its own
-// size in every list: 4 x the batch's activations in scratch.
-constexpr uint32_t kListCapShift = 5, kListCapConst = 16384;
+// size in every list: 4 x the batch's activations in scratch.  (n / 32 + 16384 was too tight for the rescue: the bracket of a
+// cold 802 816-element pair holds 5 - 6 % of it, and 14 pairs of every cold ResNet-50 sweep ended on the compaction route.)
+constexpr uint32_t kListCapShift = 4, kListCapConst = 16384;
 constexpr uint32_t kListWhole = 20480;   // a pair this small lists its whole window (octav_oneread.hip: kSmallCap): its region holds all of it
 __host__ __device__ inline uint32_t list_cap_of(unsigned long long n) {
     const unsigned long long whole = (n + 31ull) & ~31ull, part = ((n >> kListCapShift) + kListCapConst + 31ull) & ~31ull;

@@ -182,7 +182,7 @@ def test_octav_plan_host_side(tmp_path):
     import subprocess
     L = _hip.lib()
     cap = L.dpl_octav_slice_cap()
-    assert L.dpl_octav_list_cap(1000) == 1024 and L.dpl_octav_list_cap(20480) == 20480 and L.dpl_octav_list_cap(20481) == 17024 and L.dpl_octav_list_cap(802816) == 25088 + 16384
+    assert L.dpl_octav_list_cap(1000) == 1024 and L.dpl_octav_list_cap(20480) == 20480 and L.dpl_octav_list_cap(20481) == 17664 and L.dpl_octav_list_cap(802816) == 50176 + 16384
     assert all(L.dpl_octav_list_cap(n) % 32 == 0 and L.dpl_octav_list_cap(n) <= (n + 31) // 32 * 32 for n in (1, 31, 33, 4097, 10**6))
     T, B = 3, 2
     elems = [1000, 802816, 2 * cap + 4096]                    # a small pair, a single-slice pair, a pair of three slices

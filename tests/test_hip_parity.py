@@ -898,7 +898,7 @@ def test_two_pipelines_rescue_at_once(dev, monkeypatch, hook):
 
 
 def test_octav_tail_lists_beyond_their_regions(dev, monkeypatch):
-    """The exact-tail form's list regions hold dpl_octav_list_cap(n) values per pair (n / 32 + 16384), not the pair: what a pair
+    """The exact-tail form's list regions hold dpl_octav_list_cap(n) values per pair (n / 16 + 16384), not the pair: what a pair
     lists — or its rescue gathers — beyond that is dropped and the pair finishes on the compaction route, whose whole-batch
     lists the pipeline allocates only when a batch first asks for them.  Saturating activations (a third of the values AT the
     maximum: every one of them is above any threshold), a constant tensor, a two-level one and a dense small pair next to
@@ -931,7 +931,7 @@ def test_octav_tail_lists_beyond_their_regions(dev, monkeypatch):
     outs = [pipe.submit(plan, batches[0])]
     before = pipe.scratch_bytes(plan)
     assert before < 0.5 * 4 * B * sum(sizes)
-    assert _hip.lib().dpl_octav_list_cap(401408) < 401408 // 8      # (the saturated pair's ~270 k rail values cannot fit)
+    assert _hip.lib().dpl_octav_list_cap(401408) < 401408 // 4      # (the saturated pair's ~270 k rail values cannot fit)
     outs += [pipe.submit(plan, x) for x in batches[1:]]
     pipe.sync()
     torch.cuda.synchronize()

@@ -116,6 +116,7 @@ SIGNATURES = {
     "dpl_octav_plan_destroy": (None, [_P]),
     "dpl_octav_plan_sizes": (C.c_int, [_P, _P]),
     "dpl_octav_plan_upload": (C.c_int, [_P, _P, _P]),
+    "dpl_octav_fallback_layout": (_I64, [_P, _I64, _P]),
     "dpl_octav_plan_bind": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_test_hook_exact_fail_every": (C.c_int, [C.c_int]),
     "dpl_test_hook_rescue_fail_every": (C.c_int, [C.c_int]),

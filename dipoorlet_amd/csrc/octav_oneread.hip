@@ -2307,6 +2307,21 @@ int dpl_octav_plan_bind(const dpl_octav_plan* p, void* d_tables, void* d_history
     return 0;
 }
 
+// HOST: where the compaction route's lists hold the pairs that are still unfinished after dpl_octav_oneread_finish — whole-pair
+// regions for those pairs (mode 1, not done), empty ones for every other pair: a caller that reads the states back when the
+// control block reports such pairs allocates two lists of the returned size instead of two whole-batch ones (14 pairs of a cold
+// ResNet-50 batch of 3 936: 40 MB instead of 6.8 GB).
+int64_t dpl_octav_fallback_layout(const dpl_octav_state* h_states, int64_t n_pairs, uint64_t* h_base_out) {
+    if (!h_states || !h_base_out || n_pairs < 0) return fail_msg("dpl_octav_fallback_layout: bad arguments");
+    uint64_t at = 0;
+    for (int64_t i = 0; i < n_pairs; ++i) {
+        h_base_out[i] = at;
+        if (h_states[i].mode == 1u && !h_states[i].done) at += (h_states[i].n_elems + 31ull) & ~31ull;
+    }
+    h_base_out[n_pairs] = at;
+    return (int64_t)at;
+}
+
 int dpl_octav_run_oneread(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     if (int e = dpl_octav_oneread_prepare(j, s)) return e;
     if (int e = dpl_octav_oneread_probe(j, s)) return e;

@@ -279,10 +279,32 @@ class OctavTailPlan:
         n = int(getattr(self.sizes, what + "_bytes"))
         return torch.empty(max(n, 256), dtype=torch.uint8, device=self.plan.device)
 
-    def need_fallback(self):
-        if self.fallback is None:
-            self.fallback = self.new("fallback")
-        return self.fallback
+    def compaction(self, job, states, stream, arena=None):
+        """The compaction route for the pairs of `job`'s batch that neither their walk nor the rescue finished (its control block
+        said so): the states are read back (a host synchronisation on `stream`: rare — flat distributions, values beyond 2^14,
+        lists beyond their regions, a dozen pairs of a cold first batch), dpl_octav_fallback_layout gives regions to just those
+        pairs, and the route's two lists are that small (arena: a buffer to reuse; returned, grown if need be)."""
+        L = _hip.lib()
+        n = self.plan.n_pairs
+        with torch.cuda.stream(stream):
+            host = states[:(n + 1) * C.sizeof(_hip.OctavState)].cpu()
+        base = np.zeros(n + 1, np.uint64)
+        total = int(L.dpl_octav_fallback_layout(host.data_ptr(), n, base.ctypes.data))
+        if total < 0:
+            _hip.check(total, "dpl_octav_fallback_layout")
+        if total == 0:
+            return arena
+        with torch.cuda.stream(stream):
+            need = 2 * 4 * total + 8 * (n + 1)
+            if arena is None or arena.numel() < need:
+                arena = torch.empty(need + need // 2, dtype=torch.uint8, device=self.plan.device)
+            tab = arena[2 * 4 * total:2 * 4 * total + 8 * (n + 1)]
+            tab.copy_(torch.from_numpy(base.view(np.uint8)))       # (a blocking copy of 8 (n + 1) bytes)
+        job.d_pair_base_full = tab.data_ptr()
+        job.d_clist0 = arena.data_ptr()
+        job.d_clist1 = arena.data_ptr() + 4 * total
+        _hip.check(L.dpl_octav_oneread_compaction(C.byref(job), C.c_void_p(stream.cuda_stream)), "dpl_octav_oneread_compaction")
+        return arena
 
     def bind(self, state, rescue, list0, list1, tab, call_index, dyn, fallback=None):
         j = _hip.OctavOnereadJob()
@@ -494,15 +516,14 @@ def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
     state, rescue, l0, l1 = tp.single()
     k = tp.calls
     tp.calls = k + 1
-    job = tp.bind(state, rescue, l0, l1, tab, k, 1 if dynamic_sym else 0, tp.fallback)
+    job = tp.bind(state, rescue, l0, l1, tab, k, 1 if dynamic_sym else 0)
     job.compaction_inline = 0
     for fn in ("dpl_octav_oneread_prepare", "dpl_octav_oneread_stream", "dpl_octav_oneread_finish"):
         _hip.check(getattr(L, fn)(C.byref(job), _stream()), fn)
     csz = C.sizeof(_hip.OctavState)
     ctl = _hip.OctavState.from_buffer_copy(state[plan.n_pairs * csz:(plan.n_pairs + 1) * csz].cpu().numpy().tobytes())
     if ctl.cnt_le:
-        job = tp.bind(state, rescue, l0, l1, tab, k, 1 if dynamic_sym else 0, tp.need_fallback())
-        _hip.check(L.dpl_octav_oneread_compaction(C.byref(job), _stream()), "dpl_octav_oneread_compaction")
+        tp.fallback = tp.compaction(job, state, torch.cuda.current_stream(plan.device), tp.fallback)
     out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
     _hip.check(L.dpl_octav_finalize(_ptr(state), plan.n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
     if states_out is not None:      # (the caller's view of the pairs' states and the control block, as the other forms leave them)
@@ -754,13 +775,11 @@ class OctavPipeline:
             # what neither the walk nor the rescue could finish (a bracket that cannot be formed: flat distributions, values
             # beyond 2^14, a list beyond its region): the compaction route, launched only now that the count is known — the set's
             # batch is S submits old, its tensors are still referenced — and its results written over the batch's output rows
-            job = st["job"]
-            if ps.get("tp") is not None:      # its two whole-batch lists exist from the first batch on that needs them
-                if ps["fallback"] is None:
-                    ps["fallback"] = ps["tp"].new("fallback")
-                job = ps["tp"].bind(st["states"], st["rescue"], ps["list0"][0], ps["list1"], st["refs"][1], st["k"], self.dyn, ps["fallback"])
-            _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(job), C.c_void_p(self.side.cuda_stream)),
-                       "dpl_octav_oneread_compaction")
+            if ps.get("tp") is not None:      # its two lists: regions for just the pairs that need them (the states are read back)
+                ps["fallback"] = ps["tp"].compaction(st["job"], st["states"], self.side, ps["fallback"])
+            else:
+                _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(st["job"]), C.c_void_p(self.side.cuda_stream)),
+                           "dpl_octav_oneread_compaction")
             self._finish(plan, res, ps, st)
 
     def submit(self, plan, tensors):

@@ -292,6 +292,13 @@ int dpl_octav_plan_sizes(const dpl_octav_plan* plan, dpl_octav_workspace_sizes* 
 int dpl_octav_plan_upload(const dpl_octav_plan* plan, void* d_tables, dpl_stream_t s);
 /* call_index: batches bound before this one on the same d_history in this calibration run (0 for the first: the history's
  * two epoch accumulators alternate every 8 batches).  d_fallback may be NULL (see above). */
+/* HOST: the compaction route's lists for just the pairs that need them.  h_states: a host copy of job.d_states (n_pairs + 1
+ * entries) taken after dpl_octav_oneread_finish has run and the control block reported unfinished pairs (cnt_le != 0);
+ * h_base_out [n_pairs + 1] receives whole-pair regions for those pairs (mode 1, not done), empty regions for the rest.  Returns
+ * the elements ONE list takes: upload the table, allocate two lists of that many floats, point job.d_pair_base_full /
+ * d_clist0 / d_clist1 at them and call dpl_octav_oneread_compaction (+ dpl_octav_finalize) — instead of binding the
+ * whole-batch block of fallback_bytes. */
+int64_t dpl_octav_fallback_layout(const dpl_octav_state* h_states, int64_t n_pairs, uint64_t* h_base_out);
 int dpl_octav_plan_bind(const dpl_octav_plan* plan, void* d_tables, void* d_history, void* d_state, void* d_rescue, void* d_list0,
                         void* d_list1, void* d_fallback, const float* const* d_seg_ptrs, int64_t call_index, int dynamic_sym,
                         int max_iters, dpl_octav_oneread_job* job);

@@ -231,6 +231,21 @@ def test_octav_plan_host_side(tmp_path):
     assert int(out["sizeof"]) == C.sizeof(_hip.OctavWorkspaceSizes)
 
 
+def test_octav_fallback_layout_host():
+    """dpl_octav_fallback_layout: whole-pair regions (rounded up to 32 values) for the pairs a batch left on the compaction route
+    (mode 1, not done), nothing for the others."""
+    import numpy as np
+    L = _hip.lib()
+    n = 6
+    st = (_hip.OctavState * (n + 1))()
+    for i, (mode, done, elems) in enumerate([(2, 1, 1000), (1, 0, 1000), (3, 0, 50), (1, 1, 77), (1, 0, 33), (0, 0, 9)]):
+        st[i].mode, st[i].done, st[i].n_elems = mode, done, elems
+    base = np.full(n + 1, 99, np.uint64)
+    assert L.dpl_octav_fallback_layout(C.addressof(st), n, base.ctypes.data) == 1024 + 64
+    assert base.tolist() == [0, 0, 1024, 1024, 1024, 1088, 1088]
+    assert L.dpl_octav_fallback_layout(None, n, base.ctypes.data) < 0
+
+
 def _integration_md_example():
     """The python block of INTEGRATION.md §B that binds `-A mse` by hand (ctypes + torch for device memory, nothing of this
     package), as a namespace."""

@@ -82,24 +82,32 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["roofline"]["mse"]["ok"] is True and line["value"] > 0
 
 
-def _bc_worker(rank, world, port, model, calib, out_dir, n):
+def _bc_worker(rank, world, port, model, calib, out_dir, n, clips_from=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       DPL_DIST_BACKEND="gloo")
-    from dipoorlet_amd.__main__ import main
-    rc = main(["-M", model, "-I", calib, "-N", str(n), "-A", "minmax", "-D", "trt", "-O", out_dir, "--calib_batch", "4",
-               "--bc", "--skip_profiling"])
-    assert rc == 0
+    if clips_from is None:          # the whole CLI
+        from dipoorlet_amd.__main__ import main
+        rc = main(["-M", model, "-I", calib, "-N", str(n), "-A", "minmax", "-D", "trt", "-O", out_dir, "--calib_batch", "4",
+                   "--bc", "--skip_profiling"])
+        assert rc == 0
+    else:                           # bias_correction alone, on the clip ranges another run wrote
+        from dipoorlet_amd import dist_helper
+        from dipoorlet_amd.graph import ONNXGraph
+        from dipoorlet_amd.utils import load_clip_val
+        from dipoorlet_amd.weight_transform.bias_correction import bias_correction
+        dist_helper.init_default()
+        os.makedirs(out_dir, exist_ok=True)
+        args = types.SimpleNamespace(input_dir=calib, data_num=n, rank=rank, local_rank=0, world_size=world, deploy="trt",
+                                     calib_batch=4, output_dir=clips_from, skip_layers=[], merge="allreduce")
+        a, w = load_clip_val(args)
+        args.output_dir = out_dir
+        bias_correction(ONNXGraph.load(model), a, w, args)
+        torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [8, 7])
-def test_bias_correction_sharded_over_two_ranks_equals_one_rank(tmp_path, n):
-    """`--bc` with the images sharded over two ranks (each walks its shard node-major, the per-channel fp64 sums are
-    all-reduced per Conv / Gemm node; weight_transform/bias_correction.py) writes the biases the one-rank run writes
-    (the reference's schedule: rank 0 over all images, weight_trans_base.py:21-29).  N = 7: the balanced split 3 + 4
-    covers every image — the calibration sweeps' floor split would drop one."""
+def _bc_setup(tmp_path, n):
     from dipoorlet_amd import models
-    from dipoorlet_amd.graph import ONNXGraph
     g = models.resnet18(seed=11, image=64)
     g.output_dir = str(tmp_path)
     model = g.save_onnx_model("model")
@@ -107,9 +115,11 @@ def test_bias_correction_sharded_over_two_ranks_equals_one_rank(tmp_path, n):
     rng = np.random.default_rng(5)
     for i in range(n):
         rng.standard_normal(3 * 64 * 64).astype(np.float32).tofile(tmp_path / "calib" / "input" / f"{i}.bin")
-    port = 29300 + os.getpid() % 200
-    mp.spawn(_bc_worker, args=(1, port, model, str(tmp_path / "calib"), str(tmp_path / "w1"), n), nprocs=1, join=True)
-    mp.spawn(_bc_worker, args=(2, port + 1, model, str(tmp_path / "calib"), str(tmp_path / "w2"), n), nprocs=2, join=True)
+    return g, model
+
+
+def _bc_compare(g, tmp_path, tol):
+    from dipoorlet_amd.graph import ONNXGraph
     g1 = ONNXGraph.load(str(tmp_path / "w1" / "update_bias_model.onnx"))
     g2 = ONNXGraph.load(str(tmp_path / "w2" / "update_bias_model.onnx"))
     checked, moved = 0, 0.0
@@ -119,12 +129,33 @@ def test_bias_correction_sharded_over_two_ranks_equals_one_rank(tmp_path, n):
             b1 = g1.get_initializer(node.input[2]).astype(np.float64)
             b2 = g2.get_initializer(node.input[2]).astype(np.float64)
             moved = max(moved, float(np.abs(b1 - b0).max()))
-            # n = 8: both runs execute the same batches of 4 (same library kernels), only the order of the fp64 sums differs.
-            # n = 7: batches of 4 + 3 against 3 and 4: other convolution kernels, last-bit noise upstream, now and then a
-            # flipped quantisation step downstream
-            tol = 1e-5 if n == 8 else 6e-4      # (n = 8 measured: 1.6e-6 on the last layer's bias — a quantisation step upstream)
             assert np.allclose(b1, b2, rtol=0, atol=tol), (node.name, float(np.abs(b1 - b2).max()))
             checked += 1
     assert checked >= 10 and moved > 1e-4       # (the correction did something)
+
+
+def test_bias_correction_sharded_over_two_ranks_equals_one_rank(tmp_path):
+    """`--bc` with the images sharded over two ranks (each walks its shard node-major, the per-channel fp64 sums are
+    all-reduced per Conv / Gemm node; weight_transform/bias_correction.py) writes the biases the one-rank run writes
+    (the reference's schedule: rank 0 over all images, weight_trans_base.py:21-29).  The whole CLI, N = 8: both runs execute
+    the same batches of 4 (same library kernels); only the order of the fp64 sums differs (measured: 1.6e-6 on the last
+    layer's bias — a quantisation step upstream)."""
+    g, model = _bc_setup(tmp_path, 8)
+    port = 29300 + os.getpid() % 200
+    mp.spawn(_bc_worker, args=(1, port, model, str(tmp_path / "calib"), str(tmp_path / "w1"), 8), nprocs=1, join=True)
+    mp.spawn(_bc_worker, args=(2, port + 1, model, str(tmp_path / "calib"), str(tmp_path / "w2"), 8), nprocs=2, join=True)
+    _bc_compare(g, tmp_path, 1e-5)
     with open(tmp_path / "w2" / "weight_clip_val.json") as f1, open(tmp_path / "w1" / "weight_clip_val.json") as f2:
         assert set(json.load(f1)) == set(json.load(f2))
+
+
+def test_bias_correction_balanced_split_covers_every_image(tmp_path):
+    """N = 7 over two ranks: bias_correction's own split is balanced (3 + 4 images) and covers every image, where the
+    calibration sweeps' floor split (forward_net.py:207-209) would drop the seventh — the reference corrects with all N
+    (forward_net.py:50-52).  bias_correction alone, both runs on the clip ranges the one-rank CLI run wrote; batches of 4 + 3
+    against 3 and 4: other convolution kernels, last-bit noise upstream, now and then a flipped quantisation step."""
+    g, model = _bc_setup(tmp_path, 7)
+    port = 29500 + os.getpid() % 200
+    mp.spawn(_bc_worker, args=(1, port, model, str(tmp_path / "calib"), str(tmp_path / "w1"), 7), nprocs=1, join=True)
+    mp.spawn(_bc_worker, args=(2, port + 1, model, str(tmp_path / "calib"), str(tmp_path / "w2"), 7, str(tmp_path / "w1")), nprocs=2, join=True)
+    _bc_compare(g, tmp_path, 6e-4)

@@ -100,6 +100,7 @@ SIGNATURES = {
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
+    "dpl_octav_has_oneread": (C.c_int, []),
     "dpl_octav_slice_cap": (C.c_uint32, []),
     "dpl_octav_sort_chunk": (C.c_uint32, []),
     "dpl_octav_dir_row": (C.c_uint32, []),

@@ -288,6 +288,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t v) {
 // here (not handed in): ds_ instructions with constant offsets, nothing reloaded.
 typedef __attribute__((address_space(3))) unsigned long long* lptr_u64;
 typedef __attribute__((address_space(3))) uint32_t* lptr_u32;
+#ifdef DPL_WITH_ONEREAD   // the round-3 form's streaming pass
 __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__ pg, uint32_t cnt, uint32_t* __restrict__ dst,
                                                        Shared& sh, dpl_octav_state* __restrict__ ctl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -444,6 +445,7 @@ __device__ __attribute__((noinline)) void stream_slice(const float* __restrict__
     }
 }
 
+#endif   // DPL_WITH_ONEREAD
 // wave64 sum by DPP (row-local butterflies, then the two row broadcasts): ~6 VALU instead of six dependent ds_bpermute round
 // trips; the total arrives in lane 63 and is broadcast from there
 __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
@@ -924,6 +926,7 @@ __device__ __forceinline__ void walk_pair(
 #include "octav_tail.hpp"
 #endif
 
+#ifdef DPL_WITH_ONEREAD   // the round-3 form's streaming kernel and first walk
 // K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is
 // then free to interleave workgroups of the previous batch's walk kernel (second stream) with these.
 // A slice that is a WHOLE pair (all but the largest tensors) is walked right here (fuse != 0): its histogram is still in LDS
@@ -1040,6 +1043,7 @@ __global__ __launch_bounds__(kThreads, kVecT > 16 ? 2 : DPL_WALK_OCC) void k_oct
               pair_base, list0, slices, dynamic_sym, max_iters, fail_every, phase, rescue_bm, missed, nullptr, pred_t, tstat, resc, 0u);
 }
 
+#endif   // DPL_WITH_ONEREAD
 // The rescue walk (phase 2): a small persistent grid over the list of rescued pairs — usually empty, and a launch that has
 // nothing to do should not have thousands of workgroups to schedule between those of the next batch's streaming kernel.
 __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
@@ -1059,6 +1063,7 @@ __global__ __launch_bounds__(kThreads, DPL_WALK_OCC) void k_octav_walk_rescue(
 }
 
 
+#ifdef DPL_WITH_ONEREAD   // the round-3 form's sorted-run walk, state initialisation and sample-based prediction
 // ---------------------------------------------------------------------------------------------------------------------
 // Sorted runs.  k_octav_sort: one workgroup per slice; the slice's list (as gathered: arrival order) is sorted IN PLACE,
 // kChunk values at a time, by the rank of the values' bins — a counting sort staged in LDS: the rank's counter hands out
@@ -1847,6 +1852,7 @@ __global__ __launch_bounds__(kThreads, 6) void k_octav_probe(
     }
 }
 
+#endif   // DPL_WITH_ONEREAD
 }  // namespace
 
 extern int g_exact_fail_every, g_rescue_fail_every;   // octav_kernels.hip (dpl_test_hook_exact_fail_every / _rescue_fail_every)
@@ -1937,6 +1943,23 @@ int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_
     return n_total;
 }
 
+// The round-3 form (job.tail == 0: prediction of the bins all iterates visit, k_octav_oneread / k_octav_probe / k_octav_walk /
+// k_octav_sort / k_octav_walk_sorted) is compiled only with -DDPL_WITH_ONEREAD (DPL_WITH_ONEREAD=1 python -m
+// dipoorlet_amd.csrc.build): the exact-tail form superseded it in round 4; it is kept for A/B runs.
+int dpl_octav_has_oneread(void) {
+#ifdef DPL_WITH_ONEREAD
+    return 1;
+#else
+    return 0;
+#endif
+}
+#ifndef DPL_WITH_ONEREAD
+static int no_round3(const char* who) {
+    snprintf(g_err, sizeof(g_err), "%s: job.tail == 0, but this library was built without the round-3 one-read form (-DDPL_WITH_ONEREAD)", who);
+    return -5;
+}
+#endif
+
 static int check_job(const char* who, const dpl_octav_oneread_job* j) {
     if (!j) return fail_msg("dpl_octav_oneread: null job");
     if (j->n_pairs <= 0 || j->n_slices <= 0) return 1;   // nothing to do
@@ -1978,20 +2001,29 @@ int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* j, dpl_stream_t s) {
         DPL_LAUNCH_CHECK("k_octav_tail_init");
         return 0;
     }
+#ifdef DPL_WITH_ONEREAD
     hipLaunchKernelGGL(k_octav_oneread_init, dim3(grid_for(init_n, 256)), dim3(256), 0, (hipStream_t)s, j->d_states, j->n_pairs, d_vis_w,
                        d_vis_o, j->d_pred, vis_words, j->reset_epoch, j->d_tstat, j->d_use_probe, j->predict);
     DPL_LAUNCH_CHECK("k_octav_oneread_init");
     return 0;
+#else
+    (void)init_n;
+    return no_round3("dpl_octav_oneread_prepare");
+#endif
 }
 
 int dpl_octav_oneread_probe(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     DPL_JOB_CHECK("dpl_octav_oneread_probe");
     if (j->tail) return 0;   // the exact-tail form needs no prediction row
+#ifndef DPL_WITH_ONEREAD
+    return no_round3("dpl_octav_oneread_probe");
+#else
     hipLaunchKernelGGL(k_octav_probe, dim3((unsigned)j->n_pairs), dim3(kThreads), 0, (hipStream_t)s, j->d_pair_spans, j->d_seg_ptrs,
                        j->d_pred, j->d_use_probe, j->d_pred_pair, (uint32_t)j->n_tensors, j->dynamic_sym, j->max_iters,
                        j->probe_z > 0.0f ? j->probe_z : kProbeZ, j->d_pair_order, j->probe_z > 0.0f ? nullptr : j->d_tstat);
     DPL_LAUNCH_CHECK("k_octav_probe");
     return 0;
+#endif
 }
 
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
@@ -2013,6 +2045,9 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
         }
         return 0;
     }
+#ifndef DPL_WITH_ONEREAD
+    return no_round3("dpl_octav_oneread_stream");
+#else
     hipLaunchKernelGGL(k_octav_oneread, dim3((unsigned)j->n_slices), dim3(kThreads), (size_t)(kLdsA + kLdsB), (hipStream_t)s,
                        j->d_slices, j->d_seg_ptrs, j->d_states, reinterpret_cast<unsigned long long*>(j->d_lh), PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                        (uint32_t)j->n_tensors, j->d_pair_base, j->d_pair_slice0, j->d_list0, j->d_states + j->n_pairs,
@@ -2021,6 +2056,7 @@ int dpl_octav_oneread_stream(const dpl_octav_oneread_job* j, dpl_stream_t s) {
                                  j->fuse});
     DPL_LAUNCH_CHECK("k_octav_oneread");
     return 0;
+#endif
 }
 
 // Everything behind the streaming kernel, in stream order, nothing decided on the host:
@@ -2034,6 +2070,7 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
     uint32_t* d_vis_w = j->d_vis + (int64_t)j->write_epoch * j->n_tensors * kLogWords;
     const unsigned long long* lh = reinterpret_cast<const unsigned long long*>(j->d_lh);
     dpl_octav_state* ctl = j->d_states + j->n_pairs;
+#ifdef DPL_WITH_ONEREAD
     auto walk = [&](unsigned grid, const uint32_t* order, int phase) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_octav_walk<kVec>), dim3(grid), dim3(kThreads), 0, st, j->d_states, ctl, order, lh, j->d_pair_slice0, PredRows{j->d_pred, j->d_pred_pair, j->d_use_probe},
                            d_vis_w, (uint32_t)j->n_tensors, j->d_pair_base, j->d_list0, j->d_slices, j->dynamic_sym, j->max_iters,
@@ -2076,6 +2113,10 @@ int dpl_octav_oneread_finish(const dpl_octav_oneread_job* j, dpl_stream_t s) {
             DPL_LAUNCH_CHECK("k_octav_walk(only_missed)");
         }
     }
+#else
+    if (!j->tail) return no_round3("dpl_octav_oneread_finish");
+    (void)d_vis_w;      // (exact-tail form: every pair was walked by its streaming workgroup; what is left is the rescue below)
+#endif
     if (j->max_iters <= 0) return 0;
     if (int e = dpl_octav_rescue_gather_launch(j->d_missed, j->d_states, j->n_pairs, j->d_pair_spans, j->d_seg_ptrs, j->d_rescue_bm,
                                                j->d_pair_base, j->d_list1, st))

@@ -435,6 +435,17 @@ def _default_form():
     return os.environ.get("DPL_OCTAV_FORM", "tail")
 
 
+def _has_oneread():
+    """The round-3 one-read form ('oneread': k_octav_oneread and its walks) is compiled only into DPL_WITH_ONEREAD=1 builds."""
+    return bool(_hip.lib().dpl_octav_has_oneread())
+
+
+def _need_oneread():
+    if not _has_oneread():
+        raise _hip.DipoorletHipError("the round-3 one-read OCTAV form is not in this build of libdipoorlet_hip.so "
+                                     "(DPL_WITH_ONEREAD=1 python -m dipoorlet_amd.csrc.build --force); the default form is 'tail'")
+
+
 def _tail_ok(res):
     """The exact-tail form takes every tensor set the one-read scratch exists for (pairs of up to 64 slices; a pair above one
     slice — dpl_octav_slice_cap() elements per image and tensor — is streamed slice by slice and walked by a merge kernel).
@@ -462,8 +473,13 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     mode = _OCTAV_MODE[form]
     if form == "tail":
         tp = plan.octav_tail()
-        if tp is not None and (tp.n_multi == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0"):
+        # (DPL_OCTAV_TAIL_MULTI=0, A/B in a DPL_WITH_ONEREAD build: a set with a pair above one slice on the round-3 form)
+        if tp is not None and (tp.n_multi == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0" or not _has_oneread()):
             return _octav_batch_tail(plan, tp, tensors, dynamic_sym, states)
+        if tp is None:
+            mode = 2            # a pair above 64 slices: the two-read form
+    if form == "oneread":
+        _need_oneread()
     res = plan.octav_oneread_scratch() if mode == 3 else None
     if mode == 3 and res is None:
         mode = 2
@@ -785,11 +801,13 @@ class OctavPipeline:
     def submit(self, plan, tensors):
         form = _default_form()
         tp = plan.octav_tail() if form == "tail" else None
-        if tp is not None and tp.n_multi and os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") == "0":
+        if tp is not None and tp.n_multi and os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") == "0" and _has_oneread():
             tp = None                   # (A/B: a set with a pair above one slice on the round-3 form)
+        if form == "oneread":
+            _need_oneread()
         res = None
         if tp is None:
-            res = plan.octav_oneread_scratch() if form in ("oneread", "tail") else None
+            res = plan.octav_oneread_scratch() if (form == "oneread" or (form == "tail" and _has_oneread())) else None
             if res is None:
                 return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form in ("oneread", "tail") else form)
         tail = 1 if tp is not None else 0

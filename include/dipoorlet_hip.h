@@ -248,6 +248,7 @@ typedef struct dpl_octav_oneread_job {
     int32_t compaction_inline;       /* 1: dpl_octav_oneread_finish ends with dpl_octav_oneread_compaction; 0: the caller reads d_states[n_pairs].cnt_le
                                         when the batch is done and calls it only when that is non-zero */
 } dpl_octav_oneread_job;
+int dpl_octav_has_oneread(void);      /* 1: built with -DDPL_WITH_ONEREAD — jobs with tail == 0 (the round-3 form) are served; else they return -5 */
 uint32_t dpl_octav_slice_cap(void);
 uint32_t dpl_octav_list_cap(uint64_t n_elements); /* values the list region of a single-slice pair / of one slice of n elements holds */
 uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run */

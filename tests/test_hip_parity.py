@@ -11,6 +11,8 @@ import warnings
 
 import numpy as np
 import pytest
+
+from conftest import ONEREAD, has_oneread
 import torch
 
 from _cases import MINI_NET, make_tensor, mini_net_activations
@@ -152,7 +154,7 @@ def _octav(ops, plan, tensors, dyn, form, states=None):
     return got
 
 
-@pytest.mark.parametrize("form", ["tail", "oneread", "bracket", "compact", "full"])
+@pytest.mark.parametrize("form", ["tail", ONEREAD, "bracket", "compact", "full"])
 def test_octav_golden(dev, kl, form):
     """All forms against the reference's own outputs: exact tail / bounded bulk (the default), and the four that walk the
     reference's iterate sequence (one-read, two-read bracket, tail compaction, full re-reads)."""
@@ -191,7 +193,7 @@ def test_octav_non_monotone_pairs_fall_back_to_full_passes(dev):
     a = ops.octav_batch(plan, tensors, False, form="compact").cpu().numpy()
     f = ops.octav_batch(plan, tensors, False, form="full").cpu().numpy()
     k = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
-    r = _octav(ops, plan, tensors, False, "oneread")
+    r = _octav(ops, plan, tensors, False, "oneread") if has_oneread() else k
     e = _octav(ops, plan, tensors, False, "tail")      # (refuses such pairs: the rescue / the compaction route finishes them)
     for t in range(len(sizes)):
         for b in range(B):
@@ -430,7 +432,7 @@ def test_empty_and_tiny_spans(dev):
                 assert _close(oc[b, t, 0], s), (t, b, oc[b, t], s)
 
 
-@pytest.mark.parametrize("form", ["tail", "oneread", "bracket"])
+@pytest.mark.parametrize("form", ["tail", ONEREAD, "bracket"])
 def test_octav_bracket_routes(dev, form):
     """The histogram forms on data that exercises each route: ordinary tensors (bracket), a flat distribution whose
     bracket explodes, values beyond the 2^14 window, a huge dynamic range, all in one batched launch."""
@@ -454,7 +456,7 @@ def test_octav_bracket_routes(dev, form):
             assert _close(got[b, t, 0], s), (t, b, got[b, t], s)
 
 
-@pytest.mark.parametrize("form", ["tail", "oneread", "bracket"])
+@pytest.mark.parametrize("form", ["tail", ONEREAD, "bracket"])
 def test_octav_exact_walk_restart_path(dev, form, monkeypatch):
     _restart_path(dev, form)
     if form == "oneread":      # ... and with the sorted-run walk, whose misses a second kernel takes care of
@@ -526,7 +528,7 @@ def test_channel_diff_sum(dev):
     np.testing.assert_allclose(ops.channel_diff_sum(a, b).cpu().numpy(), a.double().sum((0, 2)).cpu().numpy(), rtol=1e-12)
 
 
-@pytest.mark.parametrize("walk", ["group", "sorted"])
+@pytest.mark.parametrize("walk", ["group", "sorted"] if has_oneread() else ["group"])
 def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
     """(Both walks of the one-read form: whole lists scanned from registers by a workgroup per pair / one wave per pair over
     sorted runs.)  A seeded sweep over odd sizes (not multiples of 4, below / above the small-pair threshold, split over several
@@ -562,8 +564,9 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
         tensors.append(torch.from_numpy(data).to(dev))
     plan = ops.TensorSetPlan(elems, B, dev)
     for dyn in (False, True):
-        got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("oneread", "bracket", "compact", "full")}
-        assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)   # (both: exact integer sums)
+        got = {form: _octav(ops, plan, tensors, dyn, form) for form in (("oneread",) if has_oneread() else ()) + ("bracket", "compact", "full")}
+        if has_oneread():
+            assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)   # (both: exact integer sums)
         assert _same_steps(got["bracket"], got["compact"])
         assert _same_steps(got["bracket"], got["full"])
         for t, n in enumerate(sizes):
@@ -578,9 +581,9 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
 
 
 @pytest.mark.parametrize("form,walk,sets,lanes", [("tail", "auto", 3, 2), ("tail", "auto", 2, 2), ("tail", "auto", 4, 2), ("tail", "auto", 3, 1),
-                                                  ("tail", "auto", 3, 3), ("tail", "auto", 2, 3), ("oneread", "group", 3, 2),
+                                                  ("tail", "auto", 3, 3), ("tail", "auto", 2, 3)] + ([("oneread", "group", 3, 2),
                                                   ("oneread", "sorted", 3, 2), ("oneread", "auto", 3, 1), ("oneread", "auto", 2, 2),
-                                                  ("oneread", "auto", 4, 3)])
+                                                  ("oneread", "auto", 4, 3)] if has_oneread() else []))
 def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, sets, lanes):
     """(form: the exact-tail form — the default — or the round-3 one-read form; walk: as above, auto = chosen by the listed share.
     sets: how many batches the host runs ahead = sets of per-batch scratch, ops._PIPE_SETS.  lanes: the streams the streaming
@@ -632,6 +635,7 @@ def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, 
             assert _close(a[1, t, 0].item(), O.octav_scale(x[t][1].cpu().numpy(), 1))
 
 
+@pytest.mark.skipif(not has_oneread(), reason="built without -DDPL_WITH_ONEREAD")
 def test_octav_oneread_schedules_and_predictions_agree(dev, monkeypatch):
     """The one-read form's variants walk the same exact integer sums: the walk inside the streaming kernel (DPL_OCTAV_FUSE=1,
     the default) or in its own kernel (=0); the prediction from earlier batches, from a sample of the pair itself, or chosen
@@ -670,7 +674,7 @@ def test_octav_oneread_schedules_and_predictions_agree(dev, monkeypatch):
                 assert pipe.fallback_pairs > 0
 
 
-@pytest.mark.parametrize("predict", ["auto", "probe", "learned"])
+@pytest.mark.parametrize("predict", ["auto", "probe", "learned"] if has_oneread() else ["auto"])
 def test_octav_special_values(dev, monkeypatch, predict):
     """Values the histogram window (2^-18 .. 2^14) does not hold, and the ones IEEE sets apart: all zeros, signed zeros, NaN,
     +-inf, denormals, tiny normals below the window mixed into ordinary data, a pair that lies below the window entirely,
@@ -712,10 +716,10 @@ def test_octav_special_values(dev, monkeypatch, predict):
         for dyn in (False, True):
             want = np.array([[O.octav_scale(t[b].cpu().numpy(), O.octav_unsigned(t[b].cpu().numpy().min(), dyn)) for t in tensors]
                              for b in range(B)], np.float64)
-            for fuse in ("1", "0"):
+            for fuse in ("1", "0") if has_oneread() else ("1",):
                 monkeypatch.setenv("DPL_OCTAV_FUSE", fuse)
                 plan = ops.TensorSetPlan(sizes, B, dev)
-                got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("oneread", "bracket", "compact", "full")}
+                got = {form: _octav(ops, plan, tensors, dyn, form) for form in (("oneread",) if has_oneread() else ()) + ("bracket", "compact", "full")}
                 if fuse == "1":     # (the exact-tail form has no unfused variant)
                     got["tail"] = _octav(ops, ops.TensorSetPlan(sizes, B, dev), tensors, dyn, "tail")
                 for form, g in got.items():
@@ -725,8 +729,9 @@ def test_octav_special_values(dev, monkeypatch, predict):
                             x = tensors[t][b].cpu().numpy()
                             if not np.isnan(x).any():
                                 assert g[b, t, 1] == x.min() and g[b, t, 2] == x.max(), (form, t, b)
-                assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)
-                for pform in ("oneread", "tail") if fuse == "1" else ("oneread",):
+                if has_oneread():
+                    assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)
+                for pform in ((("oneread", "tail") if fuse == "1" else ("oneread",)) if has_oneread() else ("tail",)):
                     monkeypatch.setenv("DPL_OCTAV_FORM", pform)
                     pipe = ops.OctavPipeline(dyn, dev)
                     plan2 = ops.TensorSetPlan(sizes, B, dev)
@@ -833,7 +838,7 @@ def test_octav_tail_thresholds_follow_the_images(dev, monkeypatch):
                         assert got[b, t, 1] == x.min() and got[b, t, 2] == x.max()
 
 
-@pytest.mark.parametrize("form", ["tail", "oneread"])
+@pytest.mark.parametrize("form", ["tail", ONEREAD])
 def test_two_pipelines_share_a_plan(dev, monkeypatch, form):
     """An OctavPipeline owns its rotation state (scratch sets, state arrays, snapshots, call counter) per plan: two pipelines —
     calibration and profiling, or two threads — may run the same TensorSetPlan interleaved without corrupting each other

@@ -159,3 +159,37 @@ def test_bias_correction_balanced_split_covers_every_image(tmp_path):
     mp.spawn(_bc_worker, args=(1, port, model, str(tmp_path / "calib"), str(tmp_path / "w1"), 7), nprocs=1, join=True)
     mp.spawn(_bc_worker, args=(2, port + 1, model, str(tmp_path / "calib"), str(tmp_path / "w2"), 7, str(tmp_path / "w1")), nprocs=2, join=True)
     _bc_compare(g, tmp_path, 6e-4)
+
+
+def test_bench_four_ranks_on_one_gpu():
+    """`bench.py --gpus 4` for real on the box's one GPU (gloo; --pool 3 keeps four ranks' resident batches small): rank-indexed
+    seeds, the ranges / histogram all-reduces and the gather of the OCTAV rows at world size 4, four per-rank rates, the
+    collectives' milliseconds of both sweeps in rank 0's line — what the driver's N = 4 run does above the backend string."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DPL_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--mse-steps", "1",
+                        "--e2e-images", "0", "--vit-images", "0", "--real-images", "0", "--big-images", "0", "--fq-reps", "0",
+                        "--mse-jitter", "", "--pool", "3", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    line = json.loads(lines[-1])
+    details = json.loads(lines[-2])["details"]
+    assert line["n_gpus"] == 4 and line["config"]["world_size_seen_by_backend"] == 4 and len(line["config"]["per_rank_images_per_s"]) == 4
+    assert line["config"]["hist_checksum_ok"] is True and line["config"]["collectives_ms_per_sweep"] > 0
+    assert line["roofline"]["mse"]["ok"] is True and details["mse"]["collectives_ms_per_sweep"] > 0
+    assert details["hist"]["hist_checksum"] == 4 * 1024 * 26598376
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    """Over RCCL a rank needs a GPU of its own: bench.py says so instead of hanging in the communicator's set-up."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    n = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "DPL_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--mse-steps", "0",
+                        "--e2e-images", "0", "--fq-reps", "0", "--cpu-seconds", "0", "--pool", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "need" in (r.stderr + r.stdout)

@@ -7,7 +7,7 @@
 #   (iv)  the images-alike mse sweep with the streaming kernels NOT overlapped (DPL_OCTAV_LANES=1): the kernel's own duration
 # each of (ii), (iii): kernel stats + the two PMC passes -> traffic_<name>.json.  Usage: scripts/profile_gpu.sh <tag>
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT

@@ -460,9 +460,12 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
       'tail' (default)     ONE read, one launch: statistics, exact log-scale histogram and the values at or above a threshold
                            bin (~1 % of a pair); the early iterates are taken as lower bounds from the histogram, the late
                            ones exactly from the list; a walk that does not end on two exact evaluations is rescued by the
-                           exact two-read route (csrc/octav_tail.hpp).  Single-slice pairs only: other sets use 'oneread'
-      'oneread'            ONE read: the values of the bins ALL iterates are predicted to visit are listed, every iterate is
-                           evaluated exactly and verified (csrc/octav_oneread.hip); a set with a pair too large: 'bracket'
+                           exact two-read route (csrc/octav_tail.hpp).  Pairs of up to 64 slices (a pair above one slice —
+                           dpl_octav_slice_cap() elements — is streamed slice by slice and walked by a merge kernel); every
+                           buffer is sized by the C ABI (dpl_octav_plan_*, OctavTailPlan).  This call reads the batch's
+                           control block back (one host synchronisation); OctavPipeline defers that
+      'oneread'            (DPL_WITH_ONEREAD=1 builds only) ONE read: the values of the bins ALL iterates are predicted to visit
+                           are listed, every iterate is evaluated exactly and verified (csrc/octav_oneread.hip)
       'bracket'            two reads: statistics + exact log-scale histogram, bracket walk, gather of the marked
                            bins, exact per-pair iteration; pairs it cannot serve finish on the compaction route
       'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists

@@ -130,7 +130,8 @@ def cpu_baseline(algo, bins, tensors, budget_s):
     if c_rate >= np_rate:
         out.update(value=c_rate, cores=int(used),
                    sample=f"{done} images ({done // B} passes over {B} images' ResNet-50-shaped activations), -A {algo}, "
-                          f"C oracle with OpenMP over (image, tensor) arrays, {t_used:.1f} s; host has {os.cpu_count()} cores")
+                          f"C oracle with OpenMP over (image, tensor) arrays, {t_used:.1f} s; host has {os.cpu_count()} cores "
+                          f"(memory- / NUMA-bound: {threads} threads give {c_rate / max(np_rate, 1e-9):.1f} x one numpy thread)")
     else:
         out.update(value=np_rate, cores=1,
                    sample=f"{n_np} images of the same ResNet-50-shaped activations, -A {algo}, numpy oracle on one "
@@ -764,7 +765,8 @@ def main():
             cb = cpu_baseline(a.algo, a.bins, cpu_sample, a.cpu_seconds)
             full["cpu_baseline"] = dict(cb)
             out["cpu_baseline"] = {"value": round(cb["value"], 2), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                   "sample": cb["sample"].split(" (")[0] + f" of the same set, -A {a.algo}, C oracle + OpenMP",
+                                   "sample": cb["sample"].split(" (")[0] + f" of the same set, -A {a.algo}, C oracle + OpenMP (memory-bound: "
+                                             f"{cb['c_openmp_images_per_s'] / max(cb['numpy_single_thread_images_per_s'], 1e-9):.1f} x one numpy thread)",
                                    "numpy_1_thread": round(cb["numpy_single_thread_images_per_s"], 2)}
         else:
             out["cpu_baseline"] = None

@@ -920,11 +920,7 @@ __device__ __forceinline__ void walk_pair(
 #ifndef DPL_TAIL_LDS_PAD
 #define DPL_TAIL_LDS_PAD 0   // (occupancy experiments: extra dynamic LDS per workgroup)
 #endif
-#ifdef DPL_TAIL_AB   // (A/B aid, scripts/ab_run.sh: another version of the header, kept untracked in scripts/ab/)
-#include "../../scripts/ab/octav_tail_prev.hpp"
-#else
 #include "octav_tail.hpp"
-#endif
 
 #ifdef DPL_WITH_ONEREAD   // the round-3 form's streaming kernel and first walk
 // K1: one workgroup per slice (largest pairs first).  A plain grid rather than a persistent loop: the hardware scheduler is

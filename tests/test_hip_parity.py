@@ -1071,3 +1071,40 @@ def test_octav_tail_soak_short():
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "tail_soak.py"), "8", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     assert " 0 mismatches" in r.stdout
+
+
+def test_seg_table_checks_every_unbound_call(dev):
+    """TensorSetPlan.seg_table: PyTorch's caching allocator hands a freed set's addresses to the next tensors, so a pointer tuple
+    seen before proves nothing about the tensors behind it — an unbound tensor list is validated on EVERY launch
+    (element count, dtype, contiguity, device); a set that is launched over again and again is bound once (TensorSetPlan.bind)
+    and then held, which is what makes skipping the checks safe."""
+    from dipoorlet_amd import _hip, ops
+    sizes = [4096, 1000, 65536]
+    B = 4
+    plan = ops.TensorSetPlan(sizes, B, dev)
+    acc = ops.CalibAccumulators(len(sizes), dev)
+    xs = [torch.randn(B, n, device=dev) for n in sizes]
+    acc.minmax_accumulate(plan, xs)                      # (the pointer tuple is cached now)
+    ptrs = [x.data_ptr() for x in xs]
+    del xs
+    # the same addresses, fewer elements: tensors of half the batch in the blocks the allocator has just got back
+    ys = [torch.randn(B // 2, n, device=dev) for n in sizes]
+    if [y.data_ptr() for y in ys] != ptrs:               # (the allocator answered otherwise: views of one buffer give the same addresses)
+        big = [torch.randn(B, n, device=dev) for n in sizes]
+        acc.minmax_accumulate(plan, big)
+        ys = [x[:B // 2] for x in big]
+        assert [y.data_ptr() for y in ys] == [x.data_ptr() for x in big]
+    with pytest.raises(_hip.DipoorletHipError, match="elements"):
+        acc.minmax_accumulate(plan, ys)
+    with pytest.raises(_hip.DipoorletHipError, match="contiguous float32"):
+        acc.minmax_accumulate(plan, [torch.zeros(B, n, device=dev, dtype=torch.float16) for n in sizes])
+    with pytest.raises(_hip.DipoorletHipError):
+        plan.bind(ys)
+    good = [torch.randn(B, n, device=dev) for n in sizes]
+    bound = plan.bind(good)
+    del good                                             # the BoundSet holds the tensors: their memory cannot be handed out again
+    other = [torch.randn(B, n, device=dev) for n in sizes]
+    assert not set(x.data_ptr() for x in other) & set(x.data_ptr() for x in bound)
+    acc.minmax_accumulate(plan, bound)
+    with pytest.raises(_hip.DipoorletHipError, match="another plan"):
+        acc.minmax_accumulate(ops.TensorSetPlan(sizes, B, dev), bound)

@@ -671,7 +671,7 @@ class GraphSession(ActivationSession):
         helper threads (streams of their own; the graph's last layers first, the forward starts at the other end).  MIOpen
         resolves a configuration's solver and loads its code object on first use — 2.7 ms per configuration, 63 ms for
         ResNet-50's 23 from one thread, 18 ms from three, and the main thread's own first forward then finds them loaded
-        (scripts/miopen_probe.py).  Returns at once; nothing waits for the threads."""
+        (scripts/miopen_probe.py).  Returns at once; the session's first forward joins the threads."""
         if self.device.type != "cuda" or batch < 1 or os.environ.get("DPL_PREWARM_CONVS", "1") == "0":
             return
         seen, todo = set(), []
@@ -701,8 +701,10 @@ class GraphSession(ActivationSession):
             mark("warm:convs:end")
 
         import threading
-        for k in range(max(1, min(threads, len(todo)))):
-            threading.Thread(target=work, args=(todo[k::threads],), daemon=True, name=f"dpl-warm-conv{k}").start()
+        self._conv_threads = [threading.Thread(target=work, args=(todo[k::threads],), daemon=True, name=f"dpl-warm-conv{k}")
+                              for k in range(max(1, min(threads, len(todo))))]
+        for t in self._conv_threads:
+            t.start()
 
     def set_const(self, name, tensor):
         """Replace an initializer on the device (a weight updated by a weight transform) and refresh the folded
@@ -735,7 +737,15 @@ class GraphSession(ActivationSession):
 
     @torch.no_grad()
     def _run_env(self, inputs, batch):
-        mark("first_forward:start")     # (no wait for the helper threads: first calls are serialised by the libraries' own locks)
+        if getattr(self, "_conv_threads", None):
+            # the first forward WAITS for the convolution threads instead of racing them (two threads resolving the same
+            # configuration at the same time both pay for it): DPL_PREWARM_WAIT=0 races, for A/B
+            if os.environ.get("DPL_PREWARM_WAIT", "1") != "0":
+                with _wall("warm_wait_convs_s"):
+                    for t in self._conv_threads:
+                        t.join()
+            self._conv_threads = None
+        mark("first_forward:start")     # (the other helper threads are not waited for: first calls are serialised by the libraries' own locks)
         return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
 
     def _collect(self, env, names, batch):

@@ -260,8 +260,8 @@ class OctavTailPlan:
         _hip.check(L.dpl_octav_plan_sizes(handle, C.byref(self.sizes)), "dpl_octav_plan_sizes")
         dev = plan.device
         self.tables = torch.empty(int(self.sizes.tables_bytes), dtype=torch.uint8, device=dev)
+        # (no synchronisation: the copies' sources are the C plan's own host tables, which live as long as this object)
         _hip.check(L.dpl_octav_plan_upload(handle, _ptr(self.tables), _stream()), "dpl_octav_plan_upload")
-        torch.cuda.current_stream(dev).synchronize()      # (the plan's host tables are pageable: the copies have run when this returns)
         self.history = torch.zeros(int(self.sizes.history_bytes), dtype=torch.uint8, device=dev)
         self.calls = 0          # batches run on this history through octav_batch (pipelines count their own)
         self.n_multi = int(self.sizes.n_multi)
@@ -444,13 +444,6 @@ def _need_oneread():
     if not _has_oneread():
         raise _hip.DipoorletHipError("the round-3 one-read OCTAV form is not in this build of libdipoorlet_hip.so "
                                      "(DPL_WITH_ONEREAD=1 python -m dipoorlet_amd.csrc.build --force); the default form is 'tail'")
-
-
-def _tail_ok(res):
-    """The exact-tail form takes every tensor set the one-read scratch exists for (pairs of up to 64 slices; a pair above one
-    slice — dpl_octav_slice_cap() elements per image and tensor — is streamed slice by slice and walked by a merge kernel).
-    DPL_OCTAV_TAIL_MULTI=0: such sets run the round-3 one-read form, as before."""
-    return res is not None and (res["n_multi"] == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0")
 
 
 def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):

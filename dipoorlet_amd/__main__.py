@@ -63,6 +63,7 @@ def main(argv=None):
     try:
         return _main(argv)
     except SystemExit:
+        _join_helpers()
         raise
     except BaseException as e:   # noqa: BLE001
         import traceback
@@ -72,7 +73,16 @@ def main(argv=None):
         sys.stderr.flush()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             os._exit(1)   # no atexit / destructor may wait on a collective the peers will never join
+        _join_helpers()
         raise
+
+
+def _join_helpers():
+    """The warm-up threads (executor.warm_libraries, GraphSession.prewarm_convs) are done within tenths of a second; a run that
+    fails before its first forward must not exit underneath them."""
+    ex = sys.modules.get(__package__ + ".executor")
+    if ex is not None:
+        ex.join_helpers()
 
 
 def _process_age_s():
@@ -199,6 +209,7 @@ def _main(argv=None):
         logger.info("Total time cost: {} seconds.".format(int(time.time() - start)))
     dist.barrier()
     _ = tensor_range
+    _join_helpers()
     return 0
 
 

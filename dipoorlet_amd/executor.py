@@ -83,7 +83,20 @@ def warm_libraries(device=None):
     import threading
     for name, body in (("blas", blas), ("kernels", kernels)):
         _WARM[name] = threading.Thread(target=run, args=(name, body), daemon=True, name="dpl-warm-" + name)
+        _HELPERS.append(_WARM[name])
         _WARM[name].start()
+
+
+_HELPERS = []      # every helper thread this module has started (warm-up, convolution pre-warm)
+
+
+def join_helpers(timeout=10.0):
+    """Waits for the helper threads (they run for a few tenths of a second): a process that leaves while one of them is
+    inside a library's initialisation ends in that library's static destructors instead of with its exit code."""
+    for t in list(_HELPERS):
+        if t.is_alive():
+            t.join(timeout)
+    _HELPERS.clear()
 
 
 def wait_warm(name):
@@ -704,6 +717,7 @@ class GraphSession(ActivationSession):
         self._conv_threads = [threading.Thread(target=work, args=(todo[k::threads],), daemon=True, name=f"dpl-warm-conv{k}")
                               for k in range(max(1, min(threads, len(todo))))]
         for t in self._conv_threads:
+            _HELPERS.append(t)
             t.start()
 
     def set_const(self, name, tensor):

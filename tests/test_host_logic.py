@@ -309,3 +309,19 @@ def test_dump_indent4_is_json_dump_byte_for_byte():
     b = io.StringIO()
     dump_indent4({1: [1.0]}, b)                      # (anything unusual: json.dump itself)
     assert b.getvalue() == json.dumps({1: [1.0]}, indent=4)
+
+
+def test_bc_shard_is_a_balanced_partition_of_all_images():
+    """weight_transform.bias_correction.bc_shard: the sharded `--bc` walk covers EVERY image exactly once (the reference corrects
+    with all N, forward_net.py:50-52), shards differ by at most one image; the calibration sweeps' floor split
+    (dist_helper.shard_range, forward_net.py:207-209) drops N mod W."""
+    from dipoorlet_amd.dist_helper import shard_range
+    from dipoorlet_amd.weight_transform.bias_correction import bc_shard
+    for n in (0, 1, 7, 8, 33, 1024, 2047):
+        for w in (1, 2, 3, 8):
+            parts = [bc_shard(n, r, w) for r in range(w)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[r][1] == parts[r + 1][0] for r in range(w - 1))
+            sizes = [b - a for a, b in parts]
+            assert max(sizes) - min(sizes) <= 1
+            assert sum(b - a for a, b in (shard_range(n, r, w) for r in range(w))) == (n // w) * w

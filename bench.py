@@ -646,7 +646,7 @@ def main():
                     g.output_dir = d
                     g.save_onnx_model("vit")
                     del g
-                    e2e["vit_mse"] = cli("vit.onnx", "calib", min(a.vit_images, 256), "mse", "vit", ("--calib_batch", "16"))
+                    e2e["vit_mse"] = cli("vit.onnx", "calib", min(a.vit_images, 256), "mse", "vit")
         finally:
             shutil.rmtree(d, ignore_errors=True)
 

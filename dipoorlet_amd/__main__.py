@@ -43,7 +43,8 @@ def build_parser():
     p.add_argument("--model_type", choices=["unet"], default=None)
     p.add_argument("--quant_format", default="QDQ", type=str, choices=["QOP", "QDQ"])
     # MI355X-side knobs
-    p.add_argument("--calib_batch", type=int, default=64, help="calibration images per forward")
+    p.add_argument("--calib_batch", type=int, default=None,
+                   help="calibration images per forward (default: by the graph's size — about 8 GB of exposed activations per batch, at most 64)")
     p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
     p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
     p.add_argument("--skip_profiling", default=False, action="store_true")
@@ -164,7 +165,7 @@ def _main(argv=None):
         # seconds after main() was entered at which each point of a fresh process was first passed (warm:* = the helper thread)
         tm["timeline_s"] = {k: round(v - t_enter, 4) for k, v in sorted(MARKS.items(), key=lambda kv: kv[1])}
         tm.update(tensor_calibration_wall_s=time.time() - t_cal, load_model_wall_s=t_cal - start, act_quant=args.act_quant,
-                  calib_batch=args.calib_batch, world_size=world,
+                  calib_batch=getattr(CalibrationRun.last, "batch", args.calib_batch), world_size=world,
                   # the fixed costs of a fresh process, itemised: interpreter + imports, process group, HIP context (the
                   # first batch's MIOpen algorithm search is forward_first_batch_gpu_s above)
                   startup={"interpreter_and_imports_s": age_at_enter,

@@ -886,7 +886,12 @@ int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale
         return fail_msg("dpl_fake_quant: n_channels and inner must be in [1, 2^32)");
     // contiguous chunks of at least 16 KiB, a multiple of 1024 elements (so that every chunk starts on a 16-byte boundary of an
     // aligned tensor), at most 2^32 - 1024 elements, about 4096 workgroups for a large tensor
-    int64_t chunk = (n + 4095) / 4096;
+    static const int64_t target_blocks = [] {       // (DPL_FQ_BLOCKS: a tuning aid, scripts/fq_blocks_ab.py)
+        const char* e = getenv("DPL_FQ_BLOCKS");
+        const int64_t v = e ? atoll(e) : 0;
+        return v > 0 ? v : (int64_t)4096;
+    }();
+    int64_t chunk = (n + target_blocks - 1) / target_blocks;
     chunk = ((chunk < 4096 ? 4096 : chunk) + 1023) / 1024 * 1024;
     if (chunk > 0xFFFFFC00ll) chunk = 0xFFFFFC00ll;
     const int64_t blocks = (n + chunk - 1) / chunk;

@@ -884,15 +884,20 @@ int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale
     if (n <= 0) return 0;
     if (n_channels < 1 || inner < 1 || n_channels > 0xFFFFFFFFll || inner > 0xFFFFFFFFll)
         return fail_msg("dpl_fake_quant: n_channels and inner must be in [1, 2^32)");
-    // contiguous chunks of at least 16 KiB, a multiple of 1024 elements (so that every chunk starts on a 16-byte boundary of an
-    // aligned tensor), at most 2^32 - 1024 elements, about 4096 workgroups for a large tensor
-    static const int64_t target_blocks = [] {       // (DPL_FQ_BLOCKS: a tuning aid, scripts/fq_blocks_ab.py)
-        const char* e = getenv("DPL_FQ_BLOCKS");
+    // A contiguous chunk of 3072 elements (12 KiB read + 12 KiB written) per workgroup, whatever the tensor's size (a multiple of
+    // 1024 elements: every chunk starts on a 16-byte boundary of an aligned tensor).  Measured on the tensors a fake-quantised
+    // ResNet-50 forward at batch 64 runs this on (26 - 205 MB, distinct buffers in rotation, scripts/fq_blocks_ab.py), fraction of
+    // 8 TB/s by chunk: 1024: 0.61 / 0.52 (205 MB / 26 MB), 2048: 0.72 / 0.57, 3072: 0.76 / 0.56, 4096: 0.75 / 0.54, 8192: 0.78 /
+    // 0.54, 12288: 0.72 / 0.43 — and rounds 3 - 4's rule (n / 4096 elements, at least 4096: 50 KB chunks for a 205 MB tensor):
+    // 0.70 / 0.54.  The Q/DQ nodes of that forward: 0.61 -> 0.65 of the roofline (bench.py `fake_quant.product_forward`).
+    // DPL_FQ_CHUNK: a tuning aid.
+    static const int64_t chunk_elems = [] {
+        const char* e = getenv("DPL_FQ_CHUNK");
         const int64_t v = e ? atoll(e) : 0;
-        return v > 0 ? v : (int64_t)4096;
+        return v >= 1024 ? (v + 1023) / 1024 * 1024 : (int64_t)3072;
     }();
-    int64_t chunk = (n + target_blocks - 1) / target_blocks;
-    chunk = ((chunk < 4096 ? 4096 : chunk) + 1023) / 1024 * 1024;
+    int64_t chunk = chunk_elems;
+    if ((n + chunk - 1) / chunk > 0x40000000ll) chunk = ((n + 0x3FFFFFFFll) / 0x40000000ll + 1023) / 1024 * 1024;
     if (chunk > 0xFFFFFC00ll) chunk = 0xFFFFFC00ll;
     const int64_t blocks = (n + chunk - 1) / chunk;
     if (blocks > 0x7FFFFFFFll) return fail_msg("dpl_fake_quant: tensor too large");

@@ -1,4 +1,4 @@
-"""GPU: k_fake_quant's workgroup count (DPL_FQ_BLOCKS) on the tensors a fake-quantised ResNet-50 forward at batch 64 runs it on
+"""GPU: k_fake_quant's chunk per workgroup in elements (DPL_FQ_CHUNK) on the tensors a fake-quantised ResNet-50 forward at batch 64 runs it on
 — launches over DISTINCT buffers in rotation (more than the 256 MB Infinity Cache between two uses of one).
 python scripts/fq_blocks_ab.py   (spawns one child per setting)"""
 import os
@@ -33,16 +33,16 @@ def child():
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / (reps * k)
-        out.append(f"{8 * n / us / 1e6 / 8000:.3f}")
+        out.append(f"{8 * n / us / 1e3 / 8000:.3f}")
         del xs, y
-    print(os.environ.get("DPL_FQ_BLOCKS", "4096").rjust(6), " ".join(out), flush=True)
+    print(os.environ.get("DPL_FQ_CHUNK", "3072").rjust(6), " ".join(out), flush=True)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         child()
     else:
-        print("blocks  [64,256,56,56] [64,512,28,28] [64,1024,14,14] [64,2048,7,7] [64,64,56,56] [64,128,28,28]  (fraction of 8 TB/s, read + write)")
+        print("chunk   [64,256,56,56] [64,512,28,28] [64,1024,14,14] [64,2048,7,7] [64,64,56,56] [64,128,28,28]  (fraction of 8 TB/s, read + write)")
         for rep in range(2):
-            for b in ("1024", "2048", "4096", "8192", "16384", "32768"):
-                subprocess.run([sys.executable, os.path.abspath(__file__), "x"], env=dict(os.environ, DPL_FQ_BLOCKS=b))
+            for b in ("1024", "2048", "3072", "4096", "8192", "12288"):
+                subprocess.run([sys.executable, os.path.abspath(__file__), "x"], env=dict(os.environ, DPL_FQ_CHUNK=b))

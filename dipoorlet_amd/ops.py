@@ -260,8 +260,11 @@ class OctavTailPlan:
         _hip.check(L.dpl_octav_plan_sizes(handle, C.byref(self.sizes)), "dpl_octav_plan_sizes")
         dev = plan.device
         self.tables = torch.empty(int(self.sizes.tables_bytes), dtype=torch.uint8, device=dev)
-        # (no synchronisation: the copies' sources are the C plan's own host tables, which live as long as this object)
+        # (no synchronisation here: the copies' sources are the C plan's own host tables, which live as long as this object —
+        # __del__ waits for this event before it lets go of them)
         _hip.check(L.dpl_octav_plan_upload(handle, _ptr(self.tables), _stream()), "dpl_octav_plan_upload")
+        self._uploaded = torch.cuda.Event()
+        self._uploaded.record(torch.cuda.current_stream(dev))
         self.history = torch.zeros(int(self.sizes.history_bytes), dtype=torch.uint8, device=dev)
         self.calls = 0          # batches run on this history through octav_batch (pipelines count their own)
         self.n_multi = int(self.sizes.n_multi)
@@ -270,6 +273,7 @@ class OctavTailPlan:
 
     def __del__(self):
         try:
+            self._uploaded.synchronize()
             _hip.lib().dpl_octav_plan_destroy(self.handle)
         except Exception:   # noqa: BLE001  (interpreter shutdown)
             pass

@@ -284,12 +284,12 @@ def main():
     # A timed sweep is ONE COLD calibration run (forward_net.py:297-340: one independent pass over the shard): the plan forgets
     # what earlier sweeps learned (octav_reset) inside the timed region, so the first batches run without a prediction as they
     # do in a fresh process.  The pool holds more distinct batches than the prediction remembers (2 epochs of
-    # DPL_ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
+    # ops._ONEREAD_EPOCH batches), so no batch is ever predicted from itself.
     mse, mse_jitter, vit_mse, mse_real, mse_big, mse_lanes1 = None, {}, None, {}, None, None
     if a.mse_steps > 0:
         import ctypes
         form = ops._default_form()
-        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form in ("oneread", "tail")
+        pipeline = os.environ.get("DPL_OCTAV_PIPELINE", "1") != "0" and form == "tail"
         pipe = ops.OctavPipeline(False, dev) if pipeline else None
         pipe1 = ops.OctavPipeline(False, dev, lanes=1) if pipeline else None    # the schedule forward_net_octav runs (below)
         min_pool = 2 * ops._ONEREAD_EPOCH + 1
@@ -389,9 +389,7 @@ def main():
                                      "pairs_missed": pipe.fallback_pairs, "pairs_compaction": pipe.compaction_pairs,
                                      "pairs_per_batch": plan.n_pairs,
                                      "listed_share_of_elements": pipe.list_share, "listed_share_max": pipe.max_share,
-                                     "batches_walked_sorted": pipe.sorted_batches,
-                                     "source": os.environ.get("DPL_OCTAV_PREDICT", "auto") if form == "oneread" else "threshold history",
-                                     "tensors_predicted_from_own_sample": pipe.probe_tensors / max(1, pipe.batches * T),
+                                     "source": "threshold history",
                                      "thresholds_raised_per_batch": pipe.raises / max(1, pipe.batches),
                                      # 1024-element tiles holding a non-zero value outside the 2^-18 .. 2^14 window (summed apart)
                                      "tiles_with_values_outside_window_share": pipe.tiles_reread / max(1, pipe.batches * B * sum((e + 1023) // 1024 for e in plan.elems))}
@@ -678,7 +676,7 @@ def main():
         if not tk:
             return None
         ks = {k: v for k, v in tk.items() if k.startswith("k_octav_")}
-        main = "k_octav_tail" if "k_octav_tail" in ks else "k_octav_oneread"
+        main = "k_octav_tail"
         if main not in ks:
             return None
         return sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ks.values()) / ks[main]["launches"]

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_BINS = 16384
 
 
@@ -54,19 +54,16 @@ class FakeQuantParams(C.Structure):
 
 
 class OctavOnereadJob(C.Structure):
-    """dpl_octav_oneread_job (include/dipoorlet_hip.h): one batch of the one-read OCTAV form."""
-    _fields_ = [("d_slices", C.c_void_p), ("n_slices", C.c_int64), ("d_pair_slice0", C.c_void_p), ("d_slice_chunk0", C.c_void_p),
+    """dpl_octav_oneread_job (include/dipoorlet_hip.h): one batch of the exact-tail OCTAV form."""
+    _fields_ = [("d_slices", C.c_void_p), ("n_slices", C.c_int64), ("d_pair_slice0", C.c_void_p),
                 ("d_pair_spans", C.c_void_p), ("d_pair_base", C.c_void_p), ("d_pair_order", C.c_void_p),
                 ("n_pairs", C.c_int64), ("n_tensors", C.c_int64), ("n_small", C.c_int64), ("n_multi", C.c_int64),
                 ("d_items", C.c_void_p), ("n_items", C.c_int64), ("d_block_begin", C.c_void_p), ("n_blocks", C.c_int64),
                 ("d_seg_ptrs", C.c_void_p), ("d_states", C.c_void_p), ("d_lh", C.c_void_p), ("d_pred", C.c_void_p),
-                ("d_pred_pair", C.c_void_p), ("d_use_probe", C.c_void_p),
                 ("d_list0", C.c_void_p), ("d_list1", C.c_void_p), ("d_pair_base_full", C.c_void_p), ("d_clist0", C.c_void_p),
-                ("d_clist1", C.c_void_p), ("d_dir", C.c_void_p), ("d_rescue_bm", C.c_void_p),
-                ("d_missed", C.c_void_p), ("d_resc", C.c_void_p), ("d_vis", C.c_void_p), ("d_tstat", C.c_void_p), ("write_epoch", C.c_int32),
-                ("reset_epoch", C.c_int32), ("sorted", C.c_int32), ("dynamic_sym", C.c_int32), ("max_iters", C.c_int32),
-                ("predict", C.c_int32), ("probe_z", C.c_float), ("fuse", C.c_int32), ("tail", C.c_int32),
-                ("compaction_inline", C.c_int32)]
+                ("d_clist1", C.c_void_p), ("d_rescue_bm", C.c_void_p), ("d_missed", C.c_void_p), ("d_resc", C.c_void_p),
+                ("d_vis", C.c_void_p), ("write_epoch", C.c_int32), ("reset_epoch", C.c_int32), ("dynamic_sym", C.c_int32),
+                ("max_iters", C.c_int32), ("compaction_inline", C.c_int32), ("reserved", C.c_int32)]
 
 
 class OctavWorkspaceSizes(C.Structure):
@@ -76,7 +73,7 @@ class OctavWorkspaceSizes(C.Structure):
                 ("n_pairs", C.c_int64), ("n_slices", C.c_int64), ("n_multi", C.c_int64), ("n_small", C.c_int64)]
 
 
-assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 296 and C.sizeof(FakeQuantParams) == 40
+assert C.sizeof(RoundStepParams) == 64 and C.sizeof(OctavOnereadJob) == 240 and C.sizeof(FakeQuantParams) == 40
 assert C.sizeof(Span) == 24 and C.sizeof(WorkItem) == 24 and C.sizeof(HistRange) == 32 and C.sizeof(OctavState) == 80
 
 _P, _I64, _I32, _U64, _DBL = C.c_void_p, C.c_int64, C.c_int32, C.c_uint64, C.c_double
@@ -100,14 +97,10 @@ SIGNATURES = {
     "dpl_octav_run": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, C.c_int, C.c_int, _P]),
     "dpl_octav_run_bracket": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int,
                                         C.c_int, _P]),
-    "dpl_octav_has_oneread": (C.c_int, []),
     "dpl_octav_slice_cap": (C.c_uint32, []),
-    "dpl_octav_sort_chunk": (C.c_uint32, []),
-    "dpl_octav_dir_row": (C.c_uint32, []),
     "dpl_octav_small_pair": (C.c_uint32, []),
     "dpl_build_octav_slices": (_I64, [_P, _I64, _P, _I64, _P]),
     "dpl_octav_oneread_prepare": (C.c_int, [_P, _P]),
-    "dpl_octav_oneread_probe": (C.c_int, [_P, _P]),
     "dpl_octav_oneread_stream": (C.c_int, [_P, _P]),
     "dpl_octav_oneread_finish": (C.c_int, [_P, _P]),
     "dpl_octav_oneread_compaction": (C.c_int, [_P, _P]),

@@ -35,8 +35,6 @@ def build(force=False, verbose=False):
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-fno-fast-math", "-ffp-contract=off", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function", "-o", OUT] + SRC
     cmd += os.environ.get("DPL_HIPCC_EXTRA", "").split()  # tuning knobs (-DDPL_...=N), see scripts/variant_bench.sh
-    if os.environ.get("DPL_WITH_ONEREAD", "0") == "1":    # the round-3 one-read OCTAV form (A/B only; the default build leaves it out)
-        cmd.append("-DDPL_WITH_ONEREAD")
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -135,47 +135,6 @@ class TensorSetPlan:
                               torch.empty(n, 66, dtype=torch.int32, device=self.device))
         return self._octav_lh
 
-    def octav_oneread_scratch(self):
-        """Work decomposition, scratch and prediction state of the one-read OCTAV form, or None when a pair is too large
-        for it: dict(slices, n_slices, pair_slice0, lh, vis [2, T, 64], pred [T, 64], calls)."""
-        if getattr(self, "_octav_one", None) is None:
-            built = _hip.build_octav_slices(self._spans(True))
-            if built is None:
-                self._octav_one = False
-            else:
-                arr, n, ps = built
-                chunk, small = _hip.lib().dpl_octav_sort_chunk(), _hip.lib().dpl_octav_small_pair()
-                counts = np.frombuffer(arr, dtype=np.dtype([("offset", "<u8"), ("count", "<u4"), ("seg", "<u4"), ("slot", "<u4"),
-                                                            ("reserved", "<u4")]), count=n)["count"].astype(np.int64)
-                per_slice = (counts + chunk - 1) // chunk                       # sorted runs a slice's list can have
-                chunk0 = np.zeros(n, np.int64)
-                chunk0[1:] = np.cumsum(per_slice)[:-1]
-                self._octav_one = dict(
-                    # first directory row of each slice; the directory itself: one row per run (position of each rank's first value)
-                    slice_chunk0=torch.from_numpy(chunk0.astype(np.int32)).to(self.device),
-                    dir=torch.empty(int(per_slice.sum()) * _hip.lib().dpl_octav_dir_row(), dtype=torch.int16, device=self.device),
-                    # pairs that gather their whole window (the last entries of the largest-first pair order): no sort
-                    n_small=self.batch * sum(1 for e in self.elems if e <= small),
-                    # pairs of more than one slice (the first entries of the largest-first pair order): the others are walked
-                    # by their streaming workgroup
-                    n_multi=self.batch * sum(1 for e in self.elems if e > _hip.lib().dpl_octav_slice_cap()),
-                    slices=_upload_struct_array(arr, n, self.device), n_slices=n,
-                    pair_slice0=torch.frombuffer(bytearray(bytes(ps)), dtype=torch.int32).to(self.device),
-                    lh=torch.empty(n, 2048, dtype=torch.int64, device=self.device),    # one histogram row per slice
-                    # bins each tensor's walks stepped into: two alternating epoch accumulators + this batch's snapshot
-                    vis=torch.zeros(2, self.T, 64, dtype=torch.int32, device=self.device),
-                    pred=torch.zeros(self.T, 128, dtype=torch.int32, device=self.device), calls=0,
-                    # the row each pair gathers by (the tensor's row above, or the one from a sample of the pair itself), this
-                    # batch's choice per tensor, and what the choice is made from
-                    pred_pair=torch.zeros(self.n_pairs, 128, dtype=torch.int32, device=self.device),
-                    use_probe=torch.zeros(self.T, dtype=torch.int32, device=self.device),
-                    tstat=torch.zeros(self.T, 12, dtype=torch.float32, device=self.device),
-                    # rescue of the pairs a walk could not finish: their exact bracket, the work list of the re-read
-                    rescue_bm=torch.empty(self.n_pairs, 64, dtype=torch.int32, device=self.device),
-                    missed=torch.empty(self.n_pairs, 3, dtype=torch.int32, device=self.device),
-                    resc=torch.empty(self.n_pairs, 3072, dtype=torch.int64, device=self.device))
-        return self._octav_one or None
-
     def octav_tail(self):
         """The exact-tail form's HOST plan (dpl_octav_plan_*: every buffer size comes from the C ABI), its static tables on the
         device and the threshold history of this tensor set — or None when a pair needs more than 64 slices."""
@@ -190,20 +149,13 @@ class TensorSetPlan:
         return self._octav_tail or None
 
     def octav_reset(self):
-        """Cold start of the one-read OCTAV forms: what the plan learned from earlier batches (bins visited / thresholds asked
-        for, choice of walk) is forgotten — the state of a plan that has never run.  Call between independent calibration runs
-        that share a plan (after OctavPipeline.sync())."""
-        one = getattr(self, "_octav_one", None)
-        if one:
-            one["vis"].zero_()
-            one["pred"].zero_()
-            one["tstat"].zero_()
-            one["calls"] = 0
+        """Cold start of the exact-tail OCTAV form: what the plan learned from earlier batches (the thresholds its tensors' pairs
+        asked for) is forgotten — the state of a plan that has never run.  Call between independent calibration runs that share
+        a plan (after OctavPipeline.sync())."""
         tp = getattr(self, "_octav_tail", None)
         if tp:
             tp.history.zero_()
             tp.calls = 0
-        self.__dict__.pop("_octav_sorted", None)
         for pipe in list(getattr(self, "_octav_pipes", ())):
             pipe._forget(self)
 
@@ -423,31 +375,17 @@ class CalibAccumulators:
 _OCTAV_MAX_ITERS = 20  # forward_net.py:325
 
 
-_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "oneread": 3, "tail": 3}
-# batches per prediction epoch of the one-read forms: a batch lists by what the walks of the current and the previous epoch
-# asked for (8-16 batches of history)
-_ONEREAD_MAX_SHARE = float(os.environ.get("DPL_ONEREAD_MAX_SHARE", "0.30"))
-# (round 3: with the single-slice pairs walked by their streaming workgroups, only the multi-slice pairs' lists reach the walk
-# kernels, and k_octav_walk<32> holds 32 Ki values in registers: sorted runs pay beyond ~12 % listed; measured at 4.3 % on the
-# ViT-B/16 set 0.51 vs 0.49, at 5.8 % on the ResNet-50 set 0.51 vs 0.48)
-_ONEREAD_SORT_SHARE = float(os.environ.get("DPL_ONEREAD_SORT_SHARE", "0.12"))
-_ONEREAD_EPOCH = int(os.environ.get("DPL_ONEREAD_EPOCH", "8"))
+_OCTAV_MODE = {"full": 0, "compact": 1, "bracket": 2, "tail": 3}
+_ONEREAD_EPOCH = 8      # batches per threshold-history epoch (the C ABI's: dpl_octav_plan_bind); a batch lists by what the
+                        # pairs of the current and the previous epoch asked for (8 - 16 batches of history)
 
 
 def _default_form():
     """DPL_OCTAV_FORM, else 'tail' (round 4: exact tail / bounded bulk; csrc/octav_tail.hpp)."""
-    return os.environ.get("DPL_OCTAV_FORM", "tail")
-
-
-def _has_oneread():
-    """The round-3 one-read form ('oneread': k_octav_oneread and its walks) is compiled only into DPL_WITH_ONEREAD=1 builds."""
-    return bool(_hip.lib().dpl_octav_has_oneread())
-
-
-def _need_oneread():
-    if not _has_oneread():
-        raise _hip.DipoorletHipError("the round-3 one-read OCTAV form is not in this build of libdipoorlet_hip.so "
-                                     "(DPL_WITH_ONEREAD=1 python -m dipoorlet_amd.csrc.build --force); the default form is 'tail'")
+    form = os.environ.get("DPL_OCTAV_FORM", "tail")
+    if form not in _OCTAV_MODE:
+        raise _hip.DipoorletHipError(f"DPL_OCTAV_FORM={form}: the forms are {sorted(_OCTAV_MODE)} (round 5 removed 'oneread')")
+    return form
 
 
 def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None):
@@ -458,32 +396,23 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
                            bin (~1 % of a pair); the early iterates are taken as lower bounds from the histogram, the late
                            ones exactly from the list; a walk that does not end on two exact evaluations is rescued by the
                            exact two-read route (csrc/octav_tail.hpp).  Pairs of up to 64 slices (a pair above one slice —
-                           dpl_octav_slice_cap() elements — is streamed slice by slice and walked by a merge kernel); every
-                           buffer is sized by the C ABI (dpl_octav_plan_*, OctavTailPlan).  This call reads the batch's
-                           control block back (one host synchronisation); OctavPipeline defers that
-      'oneread'            (DPL_WITH_ONEREAD=1 builds only) ONE read: the values of the bins ALL iterates are predicted to visit
-                           are listed, every iterate is evaluated exactly and verified (csrc/octav_oneread.hip)
+                           dpl_octav_slice_cap() elements — is streamed slice by slice and walked by a merge kernel; a set with
+                           a larger pair runs 'bracket'); every buffer is sized by the C ABI (dpl_octav_plan_*, OctavTailPlan).
+                           This call reads the batch's control block back (one host synchronisation); OctavPipeline defers that
       'bracket'            two reads: statistics + exact log-scale histogram, bracket walk, gather of the marked
                            bins, exact per-pair iteration; pairs it cannot serve finish on the compaction route
       'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists
       'full'               every evaluation re-reads the full data (21 passes)
-    `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default."""
+    `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default.
+    states (optional): a uint8 device buffer of (B * T + 1) * 80 bytes that receives the pairs' states and the control block."""
     if form is None:
         form = ("compact" if compact else "full") if compact is not None else _default_form()
     mode = _OCTAV_MODE[form]
     if form == "tail":
         tp = plan.octav_tail()
-        # (DPL_OCTAV_TAIL_MULTI=0, A/B in a DPL_WITH_ONEREAD build: a set with a pair above one slice on the round-3 form)
-        if tp is not None and (tp.n_multi == 0 or os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") != "0" or not _has_oneread()):
+        if tp is not None:
             return _octav_batch_tail(plan, tp, tensors, dynamic_sym, states)
-        if tp is None:
-            mode = 2            # a pair above 64 slices: the two-read form
-    if form == "oneread":
-        _need_oneread()
-    res = plan.octav_oneread_scratch() if mode == 3 else None
-    if mode == 3 and res is None:
-        mode = 2
-    tail = 0
+        mode = 2            # a pair above 64 slices: the two-read form
     w = plan.work("octav", per_image=True)
     n_pairs = plan.n_pairs
     nbytes = (n_pairs + 1) * C.sizeof(_hip.OctavState)  # + control block
@@ -492,17 +421,6 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
     tab = plan.seg_table(tensors)
     L = _hip.lib()
     dyn = 1 if dynamic_sym else 0
-    if mode == 3:
-        spans, base, order, l0, l1 = plan.octav_scratch()
-        k = res["calls"]
-        res["calls"] = k + 1
-        epoch, first = divmod(k, _ONEREAD_EPOCH)
-        job = _oneread_job(plan, res, tab, states, res["lh"], res["pred"], res["pred_pair"], res["use_probe"], l0, epoch % 2,
-                           1 if first == 0 else 0, _walk_sorted(plan), dyn, tail=tail)
-        _hip.check(L.dpl_octav_run_oneread(C.byref(job), _stream()), "dpl_octav_run_oneread")
-        out = torch.empty(plan.batch, plan.T, 3, dtype=torch.float32, device=plan.device)
-        _hip.check(L.dpl_octav_finalize(_ptr(states), n_pairs, _ptr(out), _stream()), "dpl_octav_finalize")
-        return out
     _hip.check(L.dpl_octav_init(_ptr(states), n_pairs, mode, _stream()), "dpl_octav_init")
     if mode == 0:
         _hip.check(L.dpl_octav_run(*w.args(), _ptr(tab), _ptr(states), n_pairs, dyn, _OCTAV_MAX_ITERS, _stream()),
@@ -525,8 +443,8 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
 
 def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
     """One batch of the exact-tail form on the caller's stream.  The compaction route (flat distributions, values beyond 2^14,
-    lists beyond their regions: rare) needs two whole-batch lists, which are allocated the first time a batch asks for them —
-    so this reads the batch's control block back (the one host synchronisation of this call; OctavPipeline defers it)."""
+    lists beyond their regions: rare) needs lists for the pairs that take it, which exist from the first batch on that asks for
+    them — so this reads the batch's control block back (the one host synchronisation of this call; OctavPipeline defers it)."""
     L = _hip.lib()
     tab = plan.seg_table(tensors)
     state, rescue, l0, l1 = tp.single()
@@ -549,72 +467,29 @@ def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
     return out
 
 
-_PREDICT = {"learned": 0, "probe": 1, "auto": 2}
-
-
-def _oneread_job(plan, res, tab, states, lh, pred, pred_pair, use_probe, l0, write_epoch, reset_epoch, sorted_walk, dyn,
-                 compaction_inline=1, rescue=None, tail=0):
-    """The C ABI's dpl_octav_oneread_job for one batch of `plan` (all device pointers; the tensors stay alive in the caller)."""
-    spans, base, order, _, l1 = plan.octav_scratch()
-    w = plan.work("octav", per_image=True)
-    d_items, n_items, d_bb, n_blocks = w.args()
-    j = _hip.OctavOnereadJob()
-    j.d_slices, j.n_slices = res["slices"].data_ptr(), res["n_slices"]
-    j.d_pair_slice0, j.d_slice_chunk0 = res["pair_slice0"].data_ptr(), res["slice_chunk0"].data_ptr()
-    j.d_pair_spans, j.d_pair_base, j.d_pair_order = spans.data_ptr(), base.data_ptr(), order.data_ptr()
-    j.n_pairs, j.n_tensors, j.n_small = plan.n_pairs, plan.T, res["n_small"]
-    j.d_items, j.n_items, j.d_block_begin, j.n_blocks = d_items.value, n_items, d_bb.value, n_blocks
-    j.d_seg_ptrs, j.d_states, j.d_lh, j.d_pred = tab.data_ptr(), states.data_ptr(), lh.data_ptr(), pred.data_ptr()
-    j.d_pred_pair, j.d_use_probe, j.d_tstat = pred_pair.data_ptr(), use_probe.data_ptr(), res["tstat"].data_ptr()
-    # DPL_OCTAV_PREDICT = learned | probe | auto: where a pair's prediction comes from (auto: chosen per tensor on the device)
-    j.predict = _PREDICT[os.environ.get("DPL_OCTAV_PREDICT", "auto")]
-    j.probe_z = float(os.environ.get("DPL_PROBE_Z", "0"))
-    j.d_list0, j.d_list1, j.d_dir = l0.data_ptr(), l1.data_ptr(), res["dir"].data_ptr()
-    j.d_pair_base_full, j.d_clist0, j.d_clist1 = base.data_ptr(), l0.data_ptr(), l1.data_ptr()   # (this form's regions are whole pairs)
-    rescue = rescue or res            # (the pipeline's batches in flight have their own rescue buffers)
-    j.d_rescue_bm, j.d_missed, j.d_resc = rescue["rescue_bm"].data_ptr(), rescue["missed"].data_ptr(), rescue["resc"].data_ptr()
-    j.d_vis, j.n_multi = res["vis"].data_ptr(), res["n_multi"]
-    # DPL_OCTAV_FUSE=0: every pair walked by dpl_octav_oneread_finish (the pre-round-3 schedule; A/B and tests)
-    j.fuse = 0 if os.environ.get("DPL_OCTAV_FUSE", "1") == "0" else 1
-    j.tail = tail
-    j.write_epoch, j.reset_epoch, j.sorted, j.dynamic_sym, j.max_iters = write_epoch, reset_epoch, sorted_walk, dyn, _OCTAV_MAX_ITERS
-    j.compaction_inline = compaction_inline
-    return j
-
-
 _PIPE_SETS = max(2, int(os.environ.get("DPL_OCTAV_PIPE_SETS", "3")))   # batches the host may run ahead of the device (OctavPipeline)
 
 
-def _walk_sorted(plan):
-    """1: the plan's next 'oneread' batch walks sorted runs, 0: whole lists from registers (DPL_OCTAV_WALK = sorted | group
-    forces one; default: by the share of values the plan's last batches listed, see OctavPipeline._settle)."""
-    forced = os.environ.get("DPL_OCTAV_WALK", "auto")
-    if forced in ("sorted", "group"):
-        return 1 if forced == "sorted" else 0
-    return plan.__dict__.get("_octav_sorted", 0)
-
-
 class OctavPipeline:
-    """OCTAV over a RUN of batches in a one-read form ('tail', or 'oneread') on three HIP streams of its own.  Same kernels,
-    same results as octav_batch.
+    """OCTAV over a RUN of batches in the exact-tail form on streams of its own.  Same kernels, same results as octav_batch.
 
         pipe = OctavPipeline(dynamic_sym)
         rows = [pipe.submit(plan, tensors) for ...]     # [B, T, 3] each, NOT valid yet
         pipe.sync()                                     # rows are valid for work on the caller's stream
 
     Lane streams (two, in rotation, each behind the caller's stream as of the submit): the streaming kernel, which also walks
-    every single-slice pair ('oneread': + the pairs' own predictions where the tensor needs them, k_octav_probe) — batch i + 1
-    starts while batch i drains.  Side stream, behind the streaming kernel of batch i and beside that of batch i + 1: the rescue of the pairs a walk could not finish (on the device, no host round trip; 'oneread': + the walk of the
-    multi-slice pairs), the result rows, the state and the threshold / prediction snapshot for batch i + 3.
-    The pipeline OWNS its rotation state per plan (three sets of per-batch scratch, six state arrays and snapshots, the call
-    counter): two pipelines may run the same plan (they share only what the plan has learned: bits OR-ed / maxima taken into
-    plan-level accumulators).  The control block of a batch (listed values, rescued pairs, pairs left for the compaction route)
-    is copied to pinned memory and read when the set comes up for reuse three submits later (or in sync()): statistics, the
-    choice of walk for long lists, and — only when the count is non-zero — the launch of the compaction route for that batch.
-    The activations of a batch, its pointer table and its result stay referenced from the set until then; the host runs at
-    most three batches ahead (DPL_OCTAV_PIPE_SETS; with two the host waited for side-stream work that ends with the previous
-    streaming kernel).  A tensor set the one-read forms cannot take (a pair above 64 slices) runs octav_batch on the caller's
-    stream instead."""
+    every pair — batch i + 1 starts while batch i drains.  Side stream, behind the streaming kernel of batch i and beside that
+    of batch i + 1: the rescue of the pairs a walk could not finish (on the device, no host round trip), the result rows, the
+    state and the threshold snapshot for batch i + 3.
+    The pipeline OWNS its rotation per plan (every size is the C plan's, dpl_octav_plan_sizes: 2 S state blocks, S rescue blocks,
+    one list per lane stream, one rescue list, the compaction route's lists once a batch has asked for them; the call counter):
+    two pipelines may run the same plan (they share only what the plan has learned: maxima taken into its threshold history).
+    The control block of a batch (listed values, rescued pairs, pairs left for the compaction route) is copied to pinned memory
+    and read when the set comes up for reuse three submits later (or in sync()): statistics, and — only when the count is
+    non-zero — the compaction route for that batch.  The activations of a batch, its pointer table and its result stay
+    referenced from the set until then; the host runs at most three batches ahead (DPL_OCTAV_PIPE_SETS; with two the host waited
+    for side-stream work that ends with the previous streaming kernel).  A tensor set with a pair above 64 slices runs
+    octav_batch (the two-read form) on the caller's stream instead."""
 
     def __init__(self, dynamic_sym, device=None, lanes=None):
         self.dyn = 1 if dynamic_sym else 0
@@ -637,20 +512,20 @@ class OctavPipeline:
         # .events (what --timing_json reports as the statistics' GPU seconds: the caller's stream no longer carries the kernel)
         self.record_events = False
         self.events = []
-        # statistics: batches settled, batches / (image, tensor) pairs that needed the compaction route (a missed prediction)
+        # statistics: batches settled, batches / (image, tensor) pairs whose walk was refused (rescued or compaction route)
         self.reset_stats()
 
     def reset_stats(self):
-        self.batches = self.fallback_batches = self.fallback_pairs = self.sorted_batches = self.compaction_pairs = 0
-        self.probe_tensors = self.tiles_reread = self.raises = 0
+        self.batches = self.fallback_batches = self.fallback_pairs = self.compaction_pairs = 0
+        self.tiles_reread = self.raises = 0
         self.list_share = self.max_share = 0.0    # listed values / elements (running mean / maximum over the settled batches)
 
-    def _state_tail(self, plan, tp):
-        """This pipeline's rotation on `plan` in the exact-tail form; every buffer's size is the C plan's (dpl_octav_plan_sizes):
-        2 S state blocks (call k uses k % 2S; the block for call k + S is initialised at the end of call k's side-stream work,
-        the one of call k must survive until the host has read k's control block, S submits later), S rescue blocks, one list
-        per stream that carries streaming kernels, one rescue list (one side stream).  Nothing is shared with another
-        pipeline on the same plan but what the plan has learned (the history's atomic maxima)."""
+    def _state(self, plan, tp):
+        """This pipeline's rotation on `plan`; every buffer's size is the C plan's (dpl_octav_plan_sizes): 2 S state blocks (call k
+        uses k % 2S; the block for call k + S is initialised at the end of call k's side-stream work, the one of call k must
+        survive until the host has read k's control block, S submits later), S rescue blocks, one list per stream that carries
+        streaming kernels, one rescue list (one side stream).  Nothing is shared with another pipeline on the same plan but what
+        the plan has learned (the history's atomic maxima)."""
         ps = self._plans.get(id(plan))
         if ps is None:
             S = _PIPE_SETS
@@ -670,53 +545,15 @@ class OctavPipeline:
         return ps
 
     def scratch_bytes(self, plan):
-        """Device bytes of this pipeline's OCTAV scratch on `plan` (exact-tail form): tables, history, state / rescue blocks,
-        lists, and the compaction route's lists if a batch has asked for them."""
+        """Device bytes of this pipeline's OCTAV scratch on `plan`: tables, history, state / rescue blocks, lists, and the
+        compaction route's lists if a batch has asked for them."""
         ps = self._plans.get(id(plan))
-        if ps is None or ps.get("tp") is None:
+        if ps is None:
             return None
         tp = ps["tp"]
         n = tp.tables.numel() + tp.history.numel() + sum(x.numel() for x in ps["states"]) + sum(x.numel() for x in ps["list0"])
         n += ps["list1"].numel() + sum(st["rescue"].numel() for st in ps["sets"])
         return n + (ps["fallback"].numel() if ps["fallback"] is not None else 0)
-
-    def _state(self, plan, res):
-        ps = self._plans.get(id(plan))
-        if ps is None:
-            _, _, _, l0, _ = plan.octav_scratch()
-            nbytes = (plan.n_pairs + 1) * C.sizeof(_hip.OctavState)
-            off, csz = plan.n_pairs * C.sizeof(_hip.OctavState), C.sizeof(_hip.OctavState)    # the control block
-            # S sets of per-batch scratch (call k uses set k % S) and 2 S state arrays in rotation (call k uses k % 2S): the array
-            # for call k + S is initialised at the end of call k's side-stream work, while the one of call k must survive until
-            # the host has read k's count of unfinished pairs (S submits later).  S = 3: with two sets the host, which reads
-            # the statistics of call k - S before it enqueues call k, waited for the side-stream work of call k - 2 — work that
-            # runs BESIDE the streaming kernel of call k - 1 and is often not done before that kernel's last tenth: the next
-            # batch was then enqueued after the kernel had ended (measured: 32 us of idle caller's stream per batch)
-            S = _PIPE_SETS
-            first = not getattr(plan, "_octav_pipes", None)    # the first pipeline on a plan uses the plan's own scratch
-            states = [torch.empty(nbytes, dtype=torch.uint8, device=plan.device) for _ in range(2 * S)]
-            ps = dict(plan=plan, calls=0, states=states, failed=[x[off:off + csz] for x in states],
-                      # the snapshots rotate the same way: the one of call k is still read when the pairs call k missed are
-                      # taken care of (S submits later), after the snapshot of call k + S has been written
-                      pred=[torch.zeros_like(res["pred"]) for _ in range(2 * S)],
-                      use=[torch.zeros_like(res["use_probe"]) for _ in range(2 * S)], sets=[])
-            for j in range(S):
-                own = first and j == 0
-                ps["sets"].append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(),
-                                       use_host=torch.zeros(plan.T, dtype=torch.int32).pin_memory(),
-                                       lh=res["lh"] if own else torch.empty_like(res["lh"]),
-                                       l0=l0 if own else torch.empty_like(l0),
-                                       pred_pair=res["pred_pair"] if own else torch.zeros_like(res["pred_pair"]),
-                                       rescue_bm=res["rescue_bm"] if own else torch.empty_like(res["rescue_bm"]),
-                                       missed=res["missed"] if own else torch.empty_like(res["missed"]),
-                                       resc=res["resc"] if own else torch.empty_like(res["resc"]),
-                                       done=None, refs=None, pending=False, k=-1, prepared=None))
-            self._plans[id(plan)] = ps
-            if getattr(plan, "_octav_pipes", None) is None:
-                import weakref
-                plan._octav_pipes = weakref.WeakSet()
-            plan._octav_pipes.add(self)
-        return ps
 
     def _forget(self, plan):
         """plan.octav_reset(): this pipeline's rotation for the plan starts over (nothing may be in flight)."""
@@ -729,36 +566,27 @@ class OctavPipeline:
             st["prepared"] = None
             st["k"] = -1
         ps["calls"] = 0
-        ps.pop("sorted", None)
 
-    def _prepare(self, plan, res, ps, st, k, stream, tail):
-        """State array + threshold / prediction snapshot (in set `st`) for this pipeline's call number k on the plan."""
-        if ps.get("tp") is not None:
-            r = k % (2 * _PIPE_SETS)
-            job = ps["tp"].bind(ps["states"][r], st["rescue"], ps["list0"][0], ps["list1"], ps["list1"], k, self.dyn)   # (prepare reads no tensors)
-            _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
-            st["prepared"] = k
-            return
-        ep, first = divmod(k, _ONEREAD_EPOCH)
+    def _prepare(self, ps, st, k, stream):
+        """State block + threshold snapshot for this pipeline's call number k on the plan (set `st` lends its rescue block to the
+        job; prepare reads no tensors: the pointer table argument is a stand-in)."""
         r = k % (2 * _PIPE_SETS)
-        job = _oneread_job(plan, res, ps["pred"][r], ps["states"][r], st["lh"], ps["pred"][r],
-                           st["pred_pair"], ps["use"][r], st["l0"], ep % 2, 1 if first == 0 else 0, 0,
-                           self.dyn, rescue=st, tail=tail)    # (prepare reads neither tensors nor the walk choice)
+        job = ps["tp"].bind(ps["states"][r], st["rescue"], ps["list0"][0], ps["list1"], ps["list1"], k, self.dyn)
         _hip.check(_hip.lib().dpl_octav_oneread_prepare(C.byref(job), C.c_void_p(stream)), "dpl_octav_oneread_prepare")
         st["prepared"] = k
 
-    def _finish(self, plan, res, ps, st):
+    def _finish(self, plan, ps, st):
         """Side stream: results of the set's batch -> its output rows, the set made ready for its next use, completion event."""
         side = self.side.cuda_stream
         _hip.check(_hip.lib().dpl_octav_finalize(_ptr(st["states"]), plan.n_pairs, _ptr(st["refs"][2]), side), "dpl_octav_finalize")
-        self._prepare(plan, res, ps, st, st["k"] + _PIPE_SETS, side, st["tail"])    # off the caller's stream: the set's next use is S calls away
+        self._prepare(ps, st, st["k"] + _PIPE_SETS, side)    # off the caller's stream: the set's next use is S calls away
         st["done"] = torch.cuda.Event()
         st["done"].record(self.side)
 
-    def _settle(self, plan, res, ps, st):
+    def _settle(self, plan, ps, st):
         """HOST: read the statistics the set's last batch left in pinned memory (the walk finished long ago: the set comes up
-        for reuse S submits later) and choose the walk of the plan's next batches.  Nothing is launched here unless pairs are
-        left for the compaction route: the pairs a walk could not finish are rescued on the device, without the host (submit)."""
+        for reuse S submits later).  Nothing is launched here unless pairs are left for the compaction route: the pairs a walk
+        could not finish are rescued on the device, without the host (submit)."""
         if not st["pending"]:
             return
         st["pending"] = False
@@ -767,52 +595,30 @@ class OctavPipeline:
         # listed values; pairs rescued by a re-read of the pair + pairs that ended on the compaction route
         listed, failed = float(ctl.sum), int(ctl.len0) + int(ctl.cnt_le)
         self.compaction_pairs += int(ctl.cnt_le)
-        if st["tail"]:
-            self.raises += int(ctl.iters)                              # thresholds raised on the fly (waves that listed beyond their budget)
-        else:
-            self.probe_tensors += int(st["use_host"].sum().item())     # tensors whose pairs predicted from a sample of themselves
-        self.tiles_reread += int(ctl.reserved)                     # 1024-element tiles holding a non-zero value outside the window
+        self.raises += int(ctl.iters)              # thresholds raised on the fly (waves that listed beyond their budget)
+        self.tiles_reread += int(ctl.reserved)     # 1024-element tiles holding a non-zero value outside the window
         self.batches += 1
         share = listed / max(1, plan.batch * sum(plan.elems))
         self.list_share = share if self.batches == 1 else 0.9 * self.list_share + 0.1 * share
         self.max_share = max(self.max_share, share)
-        # 'oneread': which walk the plan's next batches get (hysteresis): lists scanned whole from registers while they are short,
-        # sorted runs beyond _ONEREAD_SORT_SHARE of the elements
-        if not st["tail"]:
-            if share > _ONEREAD_SORT_SHARE * 1.2:
-                plan._octav_sorted = 1
-            elif share < _ONEREAD_SORT_SHARE * 0.8:
-                plan._octav_sorted = 0
-        self.sorted_batches += st["sorted"]
         if failed:
             self.fallback_pairs += failed
             self.fallback_batches += 1
         if ctl.cnt_le:
             # what neither the walk nor the rescue could finish (a bracket that cannot be formed: flat distributions, values
             # beyond 2^14, a list beyond its region): the compaction route, launched only now that the count is known — the set's
-            # batch is S submits old, its tensors are still referenced — and its results written over the batch's output rows
-            if ps.get("tp") is not None:      # its two lists: regions for just the pairs that need them (the states are read back)
-                ps["fallback"] = ps["tp"].compaction(st["job"], st["states"], self.side, ps["fallback"])
-            else:
-                _hip.check(_hip.lib().dpl_octav_oneread_compaction(C.byref(st["job"]), C.c_void_p(self.side.cuda_stream)),
-                           "dpl_octav_oneread_compaction")
-            self._finish(plan, res, ps, st)
+            # batch is S submits old, its tensors are still referenced — on lists with regions for just the pairs that need them
+            # (the states are read back), its results written over the batch's output rows
+            ps["fallback"] = ps["tp"].compaction(st["job"], st["states"], self.side, ps["fallback"])
+            self._finish(plan, ps, st)
 
     def submit(self, plan, tensors):
         form = _default_form()
         tp = plan.octav_tail() if form == "tail" else None
-        if tp is not None and tp.n_multi and os.environ.get("DPL_OCTAV_TAIL_MULTI", "1") == "0" and _has_oneread():
-            tp = None                   # (A/B: a set with a pair above one slice on the round-3 form)
-        if form == "oneread":
-            _need_oneread()
-        res = None
-        if tp is None:
-            res = plan.octav_oneread_scratch() if (form == "oneread" or (form == "tail" and _has_oneread())) else None
-            if res is None:
-                return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form in ("oneread", "tail") else form)
-        tail = 1 if tp is not None else 0
+        if tp is None:      # another form was asked for, or a pair above 64 slices: one batch at a time on the caller's stream
+            return octav_batch(plan, tensors, bool(self.dyn), form="bracket" if form == "tail" else form)
         main = torch.cuda.current_stream(plan.device)
-        ps = self._state_tail(plan, tp) if tp is not None else self._state(plan, res)
+        ps = self._state(plan, tp)
         sets = ps["sets"]
         k = ps["calls"]
         ps["calls"] = k + 1
@@ -821,7 +627,7 @@ class OctavPipeline:
             main = self.lanes[k % len(self.lanes)]
         cur = sets[k % _PIPE_SETS]
         r = k % (2 * _PIPE_SETS)
-        self._settle(plan, res, ps, cur)
+        self._settle(plan, ps, cur)
         if cur["done"] is not None:
             main.wait_event(cur["done"])        # everything that last used this set has finished
         tab = plan.seg_table(tensors)
@@ -830,54 +636,41 @@ class OctavPipeline:
             main.wait_stream(caller)            # the batch's activations and its pointer table are the caller's stream's work
         cur["refs"] = (tensors if isinstance(tensors, BoundSet) else list(tensors), tab, out)
         cur["k"] = k
-        cur["tail"] = tail
         cur["states"] = ps["states"][r]
-        cur["sorted"] = 0 if tail else _walk_sorted(plan)
         L = _hip.lib()
         if cur.get("prepared") != k:
-            self._prepare(plan, res, ps, cur, k, main.cuda_stream, tail)
-        if tail:
-            job = cur["job"] = tp.bind(cur["states"], cur["rescue"], ps["list0"][k % len(ps["list0"])], ps["list1"], tab, k, self.dyn)
-        else:
-            cur["pred"] = ps["pred"][r]
-            job = cur["job"] = _oneread_job(plan, res, tab, cur["states"], cur["lh"], cur["pred"], cur["pred_pair"],
-                                            ps["use"][r], cur["l0"], (k // _ONEREAD_EPOCH) % 2, 0, cur["sorted"], self.dyn,
-                                            compaction_inline=0, rescue=cur, tail=0)
+            self._prepare(ps, cur, k, main.cuda_stream)
+        job = cur["job"] = tp.bind(cur["states"], cur["rescue"], ps["list0"][k % len(ps["list0"])], ps["list1"], tab, k, self.dyn)
         if self.record_events:
             began = torch.cuda.Event(enable_timing=True)
             began.record(main)
-        if not tail:
-            _hip.check(L.dpl_octav_oneread_probe(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_probe")
         _hip.check(L.dpl_octav_oneread_stream(C.byref(job), C.c_void_p(main.cuda_stream)), "dpl_octav_oneread_stream")
         streamed = torch.cuda.Event(enable_timing=self.record_events)
         streamed.record(main)
         if self.record_events:
             self.events.append((began, streamed))
         self.side.wait_event(streamed)
-        # the rescue of the pairs a walk could not finish ('oneread': behind the walk of the multi-slice pairs), on the device: no
-        # host round trip decides anything
+        # the rescue of the pairs a walk could not finish, on the device: no host round trip decides anything
         _hip.check(L.dpl_octav_oneread_finish(C.byref(job), C.c_void_p(self.side.cuda_stream)), "dpl_octav_oneread_finish")
         with torch.cuda.stream(self.side):
             cur["failed"].copy_(ps["failed"][r], non_blocking=True)    # (statistics only: _settle)
-            if not tail:
-                cur["use_host"].copy_(ps["use"][r], non_blocking=True)
-        self._finish(plan, res, ps, cur)
+        self._finish(plan, ps, cur)
         cur["pending"] = True
-        if all(p is not plan for p, _ in self._touched):
-            self._touched.append((plan, res))
+        if all(p is not plan for p in self._touched):
+            self._touched.append(plan)
         return out
 
     def sync(self):
         """Settle every outstanding batch (host waits for the walks), order the caller's stream after the side stream and
         let go of the batches' tensors."""
-        for plan, res in self._touched:
+        for plan in self._touched:
             ps = self._plans[id(plan)]
             for st in sorted(ps["sets"], key=lambda q: q["k"]):
-                self._settle(plan, res, ps, st)
+                self._settle(plan, ps, st)
         torch.cuda.current_stream(self.device).wait_stream(self.side)
         for lane in self.lanes:
             torch.cuda.current_stream(self.device).wait_stream(lane)
-        for plan, _ in self._touched:
+        for plan in self._touched:
             for st in self._plans[id(plan)]["sets"]:
                 st["refs"] = None
         self._touched = []

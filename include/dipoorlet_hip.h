@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 17
+#define DPL_ABI_VERSION 18
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -150,113 +150,84 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                           int64_t n_pairs, const dpl_span* d_pair_spans, const uint64_t* d_pair_base,
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
                           uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
-/* Same iterate sequence in ONE read of the data (csrc/octav_oneread.hip; replaces forward_net.py:323-330's 21 numpy passes):
- *   k_octav_oneread — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one pair): the slice's only HBM
- *     read yields the pair's statistics, the slice's exact log-scale histogram row and the values of the bins the exact
- *     iteration is PREDICTED to visit (appended to the pair's list);
- *   (job.fuse: a slice that is a whole pair is walked by its streaming workgroup right away — no histogram row, no second launch)
- *   k_octav_walk — one workgroup per pair: per-bin totals = the sum of the pair's slice rows, suffix totals, s_0, then the
- *     reference's iteration on (exact totals of the bins above) + (listed values of the iterate's bin), every iterate
- *     VERIFIED to lie in a gathered bin (for long lists: k_octav_sort + k_octav_walk_sorted, one wave per pair over runs
- *     sorted by bin rank; job.sorted != 0);
- *   the RESCUE of a pair whose iterate left the gathered bins, on the device and without the host: the walk forms the pair's
- *     exact bracket from its histogram and puts the pair on a work list (d_missed); k_octav_rescue_gather re-reads THOSE PAIRS
- *     ALONE (many workgroups per pair) for the bracket's bins and k_octav_walk (phase 2) walks them; what even that cannot
- *     finish (a bracket that cannot be formed: flat distributions, values >= 2^14) ends on the compaction route
- *     (dpl_octav_oneread_compaction).  The rescue kernels are launched behind every walk and return at once when the
- *     control block (d_states[n_pairs]) lists nothing.
- * The prediction (a row per pair: the bins to gather, at most 255 of them, + per bitmap word the number of gathered bins
- * below it: a gathered bin's RANK) comes from one of two sources, chosen per tensor and batch on the device (job.predict):
- *   - what the same tensor's walks stepped into in earlier batches (two alternating epoch accumulators in d_vis, snapshot
- *     d_pred taken by dpl_octav_oneread_prepare): the narrowest there is while the images are alike, useless when they differ;
- *   - a strided SAMPLE of the pair itself (dpl_octav_oneread_probe, k_octav_probe: 128 bytes of every 2 KiB — of every KiB where the tensor's samples stay wide — binned like the
- *     full pass, the iteration walked on the sample's histogram with the sampling variance of every iterate carried along;
- *     gathered: the bins within z standard deviations of each sampled iterate (z = 3, then adapted per tensor to the misses it
- *     produces) + the sparse tail): costs a read of 1/16 of
- *     the pair and about twice the gathered values, but does not depend on any other image.
- * Pairs of at most dpl_octav_small_pair() elements gather their whole window.
+/* The reference's result in ONE read of the data and one launch per batch — the EXACT-TAIL form (csrc/octav_tail.hpp, included by
+ * csrc/octav_oneread.hip; replaces forward_net.py:323-330's 21 numpy passes):
+ *   k_octav_tail — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one (image, tensor) pair; all but the largest
+ *     pairs are one slice): the slice's only HBM read yields min / max, an exact log-scale histogram of |x| in LDS (64 bins per
+ *     octave over 2^-18 .. 2^14: per bin a count and an integer mantissa sum) and the LIST of the values at or above a threshold
+ *     bin (per tensor: the lowest bin its pairs asked for in the last two epochs of batches — a pair asks for the bin above which
+ *     1/256 of it lies —, raised on the fly by a wave that lists more than its budget: ~0.5 - 1.5 % of a pair); then the same
+ *     workgroup WALKS the pair: the early iterates as LOWER BOUNDS from the histogram's suffix totals, the late ones exactly from the
+ *     list; accepted only if it ends on two exact evaluations;
+ *   k_octav_tail_merge — a pair of more than one slice: its slices are streamed like pairs (packed histogram row per slice in d_lh),
+ *     one workgroup adds the rows up, moves the lists together and runs the same walk;
+ *   the RESCUE of a refused pair, on the device and without the host: the walk forms the pair's exact bracket from its histogram
+ *     and puts the pair on a work list (d_missed); k_octav_rescue_gather re-reads THOSE PAIRS ALONE (many workgroups per pair) for
+ *     the bracket's bins, k_octav_walk_rescue walks every iterate of the reference's sequence, verified; what even that cannot
+ *     finish (a bracket that cannot be formed: flat distributions, values >= 2^14; a list beyond its region) ends on the
+ *     compaction route (dpl_octav_oneread_compaction).  The rescue kernels are launched behind every batch and return at once
+ *     when the control block (d_states[n_pairs]) lists nothing.
+ * (Rounds 2 - 3 listed the bins ALL iterates were predicted to visit and evaluated every iterate exactly — k_octav_oneread,
+ * k_octav_probe, k_octav_sort, k_octav_walk[_sorted]: superseded in round 4, removed in round 5.)
  *   dpl_build_octav_slices (HOST): cuts every span (= pair), largest first, into ceil(count / cap) equal slices (multiples
  *     of 4 elements); item.reserved = the pair's slice count; pair_slice0[2 slot], [2 slot + 1] = first / one-past-last
  *     slice of the pair in slot `slot` (spans carry slots 0 .. n_spans-1).  Returns the slice count (call with out = NULL
  *     to size), -3 when a pair needs more than 64 slices (use dpl_octav_run_bracket for such a set).
- * One HOST struct carries a batch's buffers (all pointers are device pointers):
- *   dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the prediction snapshot and the choice per tensor;
- *   dpl_octav_oneread_probe   = the pairs' prediction rows (needs the batch's tensors: d_seg_ptrs);
- *   dpl_octav_oneread_stream  = k_octav_oneread;
- *   dpl_octav_oneread_finish  = the walk and the rescue behind it (+ dpl_octav_oneread_compaction when job.compaction_inline);
+ * One HOST struct carries a batch's buffers (all pointers are device pointers; dpl_octav_plan_bind below fills it):
+ *   dpl_octav_oneread_prepare = state initialisation (no dpl_octav_init call) + the tensors' threshold snapshot;
+ *   dpl_octav_oneread_stream  = k_octav_tail (+ k_octav_tail_merge);
+ *   dpl_octav_oneread_finish  = the rescue (+ dpl_octav_oneread_compaction when job.compaction_inline);
  *   dpl_octav_run_oneread = all of them on one stream.
- * stream and finish may run on different streams (the walk of batch i beside the streaming kernel of batch i + 1) when the
- * caller orders finish(i) after stream(i) and gives concurrently live batches their own d_states / d_lh / d_pred / d_list0 /
- * d_rescue_bm / d_missed; d_vis is shared (bits are only ever OR-ed in), d_list1 may be shared by batches whose finish calls
- * are on one stream. */
+ * stream and finish may run on different streams (the rescue of batch i beside the streaming kernel of batch i + 1) when the
+ * caller orders finish(i) after stream(i) and gives concurrently live batches their own d_states / d_pred / d_lh / d_rescue_bm /
+ * d_missed / d_resc; d_vis is shared (maxima are only ever raised), d_list0 may be shared by batches whose stream calls are on
+ * one stream, d_list1 by batches whose finish calls are on one stream. */
 typedef struct dpl_octav_oneread_job {
     /* the tensor set's decomposition (static per plan) */
     const dpl_work_item* d_slices;   /* dpl_build_octav_slices */
     int64_t n_slices;
     const uint32_t* d_pair_slice0;   /* [n_pairs, 2] */
-    const uint32_t* d_slice_chunk0;  /* [n_slices]: first directory row of a slice = running sum of ceil(slice count / dpl_octav_sort_chunk()) */
     const dpl_span* d_pair_spans;    /* [n_pairs]: where each pair's data lives */
     const uint64_t* d_pair_base;     /* [n_pairs + 1]: element offset of the pair's region in d_list0 / d_list1; a region holds
-                                        d_pair_base[p + 1] - d_pair_base[p] values, a multiple of 32 (a region must not share a 128-byte line
-                                        with its neighbour: the streaming workgroup reads back the list it has just written).  job.tail: a
-                                        region is dpl_octav_list_cap(elements) values (a pair of c slices: c x dpl_octav_list_cap(slice));
-                                        what a pair lists or its rescue gathers beyond that is dropped and the pair finishes on the
-                                        compaction route.  The round-3 form: the pair's element count, rounded up to 32 */
-    const uint32_t* d_pair_order;    /* [n_pairs]: pair indices, largest first; its last n_small entries gather their whole window */
-    int64_t n_pairs, n_tensors, n_small;
-    int64_t n_multi;                 /* pairs of more than one slice (the first n_multi entries of d_pair_order) */
+                                        d_pair_base[p + 1] - d_pair_base[p] = dpl_octav_list_cap(elements) values (a pair of c slices:
+                                        c x dpl_octav_list_cap(slice)), a multiple of 32 (a region must not share a 128-byte line with its
+                                        neighbour: the streaming workgroup reads back the list it has just written); what a pair lists or
+                                        its rescue gathers beyond that is dropped and the pair finishes on the compaction route */
+    const uint32_t* d_pair_order;    /* [n_pairs]: pair indices, largest first (the pairs of more than one slice are its first n_multi entries) */
+    int64_t n_pairs, n_tensors, n_small;   /* n_small: pairs of at most dpl_octav_small_pair() elements (they list their whole window) */
+    int64_t n_multi;                 /* pairs of more than one slice */
     const dpl_work_item* d_items;    /* the balanced partition of the same pairs (compaction route), as for dpl_octav_run_compact */
     int64_t n_items;
     const uint32_t* d_block_begin;
     int64_t n_blocks;
     /* this batch */
     const float* const* d_seg_ptrs;
-    dpl_octav_state* d_states;       /* [n_pairs + 1]; the last one is the control block */
-    uint64_t* d_lh;                  /* [n_slices, 2048]: one histogram row per slice (plain stores, nothing to zero) */
-    uint32_t* d_pred;                /* [n_tensors, 128]: the prediction from earlier batches (snapshot of d_vis) */
-    uint32_t* d_pred_pair;           /* [n_pairs, 128]: the row each pair's slices gather by (dpl_octav_oneread_probe writes it) */
-    uint32_t* d_use_probe;           /* [n_tensors]: this batch's choice per tensor (dpl_octav_oneread_prepare writes it) */
+    dpl_octav_state* d_states;       /* [n_pairs + 1]; the last one is the control block: len[0] = pairs rescued, cnt_le = pairs left
+                                        for the compaction route, sum = values listed */
+    uint64_t* d_lh;                  /* [slices of multi-slice pairs, 2048]: a packed histogram row per such slice (may be NULL with n_multi == 0) */
+    uint32_t* d_pred;                /* [n_tensors, 128]: the threshold snapshot (word 0 of a tensor's row) */
     float* d_list0;                  /* listed values, region per pair: written by dpl_octav_oneread_stream, dead once it has run */
     float* d_list1;                  /* the rescue's gathered values, same layout (dpl_octav_oneread_finish) */
     const uint64_t* d_pair_base_full;/* [n_pairs + 1]: whole-pair regions (element count rounded up to 32) ... */
     float* d_clist0;                 /* ... in the compaction route's two lists (dpl_octav_oneread_compaction): only needed once a batch */
     float* d_clist1;                 /*     reports unfinished pairs (d_states[n_pairs].cnt_le != 0), or up front with compaction_inline */
-    uint16_t* d_dir;                 /* [n_chunks, dpl_octav_dir_row()]: per sorted run the position of each rank's first value */
     uint32_t* d_rescue_bm;           /* [n_pairs, 64]: exact bracket of a rescued pair */
     uint32_t* d_missed;              /* [n_pairs, 3]: (pair, first unit, units) of the rescued pairs */
     uint64_t* d_resc;                /* [n_pairs, 3072]: suffix totals of a rescued pair (2048 fp64 sums, 2048 u32 counts): what its second walk starts from */
     /* carried across batches */
-    uint32_t* d_vis;                 /* [2, n_tensors, 64] epoch accumulators; walks add to d_vis[write_epoch], cleared first when reset_epoch != 0 */
-    float* d_tstat;                  /* [n_tensors, 12]: what each tensor's prediction from earlier batches would have cost lately (zeroed by the caller once) */
+    uint32_t* d_vis;                 /* [2, n_tensors, 64] threshold history: two epoch accumulators (word 0 of a tensor's row: 2048 - the lowest
+                                        bin its pairs asked for); walks raise d_vis[write_epoch], cleared first when reset_epoch != 0 */
     int32_t write_epoch, reset_epoch;
-    int32_t sorted;                  /* 0: lists scanned whole from registers (short lists), 1: sorted runs */
     int32_t dynamic_sym, max_iters;
-    int32_t predict;                 /* 0: every tensor predicts from earlier batches, 1: every pair from a sample of itself, 2: chosen per
-                                        tensor and batch on the device (by what the first would have listed / missed in the last batches) */
-    float probe_z;                   /* width of the sample's brackets in standard deviations; 0: the default (3, then adapted per tensor to the misses it produces) */
-    int32_t fuse;                    /* 1: k_octav_oneread walks every single-slice pair itself (histogram still in LDS, list in L2);
-                                        dpl_octav_oneread_finish then walks the multi-slice pairs only.  0: every pair is walked by finish */
-    int32_t tail;                    /* 1: the EXACT-TAIL form (csrc/octav_tail.hpp): k_octav_tail lists only |x| at or above a
-                                        threshold bin (per tensor: the lowest bin its pairs asked for in the last two epochs, word 0 of the tensor's
-                                        d_vis / d_pred rows; raised on the fly by a wave that lists more than its budget), takes the early iterates as
-                                        LOWER BOUNDS from the exact histogram, the late ones exactly from the list, and accepts only a walk that ended
-                                        on >= 2 exact evaluations (anything else: the rescue, as above).  A pair of more than one slice (n_multi > 0): its
-                                        slices are streamed like pairs (by k_octav_tail itself: a packed histogram row per slice in d_lh, its values in its part
-                                        of the pair's d_list0 region), then one workgroup per such pair adds the rows up, moves the lists together and
-                                        walks (k_octav_tail_merge; a bin of 2^20 values or more: compaction route).  d_pred_pair / d_use_probe / d_tstat /
-                                        d_dir are not touched (d_lh only with n_multi > 0); dpl_octav_oneread_probe is a no-op */
     int32_t compaction_inline;       /* 1: dpl_octav_oneread_finish ends with dpl_octav_oneread_compaction; 0: the caller reads d_states[n_pairs].cnt_le
                                         when the batch is done and calls it only when that is non-zero */
+    int32_t reserved;
 } dpl_octav_oneread_job;
-int dpl_octav_has_oneread(void);      /* 1: built with -DDPL_WITH_ONEREAD — jobs with tail == 0 (the round-3 form) are served; else they return -5 */
 uint32_t dpl_octav_slice_cap(void);
 uint32_t dpl_octav_list_cap(uint64_t n_elements); /* values the list region of a single-slice pair / of one slice of n elements holds */
-uint32_t dpl_octav_sort_chunk(void); /* values of a sorted run */
-uint32_t dpl_octav_dir_row(void);    /* uint16 entries of a run's directory row */
-uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements gather their whole window */
+uint32_t dpl_octav_small_pair(void); /* pairs of at most this many elements list their whole window */
 int64_t dpl_build_octav_slices(const dpl_span* spans, int64_t n_spans, dpl_work_item* out, int64_t cap, uint32_t* pair_slice0);
 int dpl_octav_oneread_prepare(const dpl_octav_oneread_job* job, dpl_stream_t s);
-int dpl_octav_oneread_probe(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_stream(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_finish(const dpl_octav_oneread_job* job, dpl_stream_t s);
 int dpl_octav_oneread_compaction(const dpl_octav_oneread_job* job, dpl_stream_t s);
@@ -303,8 +274,8 @@ int64_t dpl_octav_fallback_layout(const dpl_octav_state* h_states, int64_t n_pai
 int dpl_octav_plan_bind(const dpl_octav_plan* plan, void* d_tables, void* d_history, void* d_state, void* d_rescue, void* d_list0,
                         void* d_list1, void* d_fallback, const float* const* d_seg_ptrs, int64_t call_index, int dynamic_sym,
                         int max_iters, dpl_octav_oneread_job* job);
-/* TEST HOOKS (0 = off; return the previous setting): _exact_ makes the exact walk of dpl_octav_run_bracket and the first walk
- * of the one-read form reject every `every`-th pair, so that the restart paths — taken in production only when an iterate
+/* TEST HOOKS (0 = off; return the previous setting): _exact_ makes the exact walk of dpl_octav_run_bracket and the walk
+ * of the exact-tail form reject every `every`-th pair, so that the restart paths — taken in production only when an iterate
  * leaves the gathered bins — can be exercised; _rescue_ does the same to the one-read form's rescue walk (-> compaction route). */
 int dpl_test_hook_exact_fail_every(int every);
 int dpl_test_hook_rescue_fail_every(int every);

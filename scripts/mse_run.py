@@ -54,8 +54,8 @@ def main():
         print(f"{which} (single stream): {ms:.3f} ms/batch")
         return
     print(f"{which}: {ms:.3f} ms/batch, {gb / ms * 1e3:.0f} GB/s credited = {gb / ms / 8:.3f} of 8 TB/s; misses/batch {pipe.fallback_pairs / pipe.batches:.1f} "
-          f"compaction {pipe.compaction_pairs} listed {pipe.list_share:.4f} sorted {pipe.sorted_batches}/{pipe.batches} "
-          f"own-sample {pipe.probe_tensors / (pipe.batches * len(elems)):.2f} raises/batch {pipe.raises / pipe.batches:.1f} tiles twice/batch {pipe.tiles_reread / pipe.batches:.0f}")
+          f"compaction {pipe.compaction_pairs} listed {pipe.list_share:.4f} "
+          f"raises/batch {pipe.raises / pipe.batches:.1f} tiles twice/batch {pipe.tiles_reread / pipe.batches:.0f}")
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         k = re.sub(r".*::(k_\w+).*", r"\1", r["Kernel_Name"])
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), k, r.get("Queue_Id", "?")))
 rows.sort()
-main = "k_octav_tail" if any(r[2] == "k_octav_tail" for r in rows) else "k_octav_oneread"
+main = "k_octav_tail"
 ones = [i for i, r in enumerate(rows) if r[2] == main]
 ones = ones[len(ones) // 2:]          # the second (warm) run
 gaps, between = [], defaultdict(list)

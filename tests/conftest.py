@@ -16,15 +16,3 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
-
-
-def has_oneread():
-    """Was the library built with -DDPL_WITH_ONEREAD (the round-3 one-read OCTAV form: superseded, kept for A/B builds)?"""
-    try:
-        from dipoorlet_amd import _hip
-        return bool(_hip.lib().dpl_octav_has_oneread())
-    except Exception:   # noqa: BLE001
-        return False
-
-
-ONEREAD = pytest.param("oneread", marks=pytest.mark.skipif(not has_oneread(), reason="built without -DDPL_WITH_ONEREAD"))

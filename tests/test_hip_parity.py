@@ -12,7 +12,6 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import ONEREAD, has_oneread
 import torch
 
 from _cases import MINI_NET, make_tensor, mini_net_activations
@@ -130,16 +129,9 @@ def _same_steps(a, b):
 
 
 def _octav(ops, plan, tensors, dyn, form, states=None):
-    """octav_batch; the one-read form is run three times on the same plan — the first call has no prediction (every
-    multi-slice pair finishes on the compaction route), the later ones gather the predicted bins and walk exact integer
-    sums: bit-identical among themselves (returned: the last), same steps as the first."""
+    """octav_batch; the exact-tail form is run three times on the same plan (cold, then with a threshold history): returned is
+    the second call's result, checked against the other two."""
     got = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
-    if form == "oneread":
-        first = got
-        got = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
-        again = ops.octav_batch(plan, tensors, dyn, states, form=form).cpu().numpy()
-        assert np.array_equal(got, again, equal_nan=True)
-        assert _same_steps(first, got)
     if form == "tail":
         # the exact-tail form: the first call of a plan has no threshold history (lists from the bottom of the window and raises
         # the threshold on the fly), the later ones start from what the earlier calls asked for.  Where the list starts decides
@@ -154,10 +146,10 @@ def _octav(ops, plan, tensors, dyn, form, states=None):
     return got
 
 
-@pytest.mark.parametrize("form", ["tail", ONEREAD, "bracket", "compact", "full"])
+@pytest.mark.parametrize("form", ["tail", "bracket", "compact", "full"])
 def test_octav_golden(dev, kl, form):
-    """All forms against the reference's own outputs: exact tail / bounded bulk (the default), and the four that walk the
-    reference's iterate sequence (one-read, two-read bracket, tail compaction, full re-reads)."""
+    """All forms against the reference's own outputs: exact tail / bounded bulk (the default), and the three that walk the
+    reference's iterate sequence (two-read bracket, tail compaction, full re-reads)."""
     from dipoorlet_amd import ops
     meta, g = kl
     for c in meta["cases"]:
@@ -193,15 +185,14 @@ def test_octav_non_monotone_pairs_fall_back_to_full_passes(dev):
     a = ops.octav_batch(plan, tensors, False, form="compact").cpu().numpy()
     f = ops.octav_batch(plan, tensors, False, form="full").cpu().numpy()
     k = ops.octav_batch(plan, tensors, False, form="bracket").cpu().numpy()
-    r = _octav(ops, plan, tensors, False, "oneread") if has_oneread() else k
     e = _octav(ops, plan, tensors, False, "tail")      # (refuses such pairs: the rescue / the compaction route finishes them)
     for t in range(len(sizes)):
         for b in range(B):
             with warnings.catch_warnings():
                 warnings.simplefilter("ignore")
                 s = O.octav_scale(tensors[t][b].cpu().numpy(), 1)
-            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s) and _close(r[b, t, 0], s) \
-                and _close(e[b, t, 0], s), (t, b, a[b, t], f[b, t], k[b, t], r[b, t], e[b, t], s)
+            assert _close(a[b, t, 0], s) and _close(f[b, t, 0], s) and _close(k[b, t, 0], s) \
+                and _close(e[b, t, 0], s), (t, b, a[b, t], f[b, t], k[b, t], e[b, t], s)
 
 
 def test_batched_tensor_set_vs_golden_pipeline_stats(dev, golden_dir):
@@ -432,7 +423,7 @@ def test_empty_and_tiny_spans(dev):
                 assert _close(oc[b, t, 0], s), (t, b, oc[b, t], s)
 
 
-@pytest.mark.parametrize("form", ["tail", ONEREAD, "bracket"])
+@pytest.mark.parametrize("form", ["tail", "bracket"])
 def test_octav_bracket_routes(dev, form):
     """The histogram forms on data that exercises each route: ordinary tensors (bracket), a flat distribution whose
     bracket explodes, values beyond the 2^14 window, a huge dynamic range, all in one batched launch."""
@@ -456,12 +447,9 @@ def test_octav_bracket_routes(dev, form):
             assert _close(got[b, t, 0], s), (t, b, got[b, t], s)
 
 
-@pytest.mark.parametrize("form", ["tail", ONEREAD, "bracket"])
-def test_octav_exact_walk_restart_path(dev, form, monkeypatch):
+@pytest.mark.parametrize("form", ["tail", "bracket"])
+def test_octav_exact_walk_restart_path(dev, form):
     _restart_path(dev, form)
-    if form == "oneread":      # ... and with the sorted-run walk, whose misses a second kernel takes care of
-        monkeypatch.setenv("DPL_OCTAV_WALK", "sorted")
-        _restart_path(dev, form)
 
 
 def _restart_path(dev, form):
@@ -474,7 +462,7 @@ def _restart_path(dev, form):
                                           np.maximum(rng.standard_normal(n), 0).astype(np.float32) * 2.5
                                           for _ in range(B)])).to(dev) for t, n in enumerate(sizes)]
     plan = ops.TensorSetPlan(sizes, B, dev)
-    want = _octav(ops, plan, tensors, False, form)     # (one-read: also warms the prediction up, so that only the hook fails pairs)
+    want = _octav(ops, plan, tensors, False, form)     # (exact tail: also warms the threshold history up, so that only the hook fails pairs)
     states = torch.empty((plan.n_pairs + 1) * 80, dtype=torch.uint8, device=dev)
 
     def hooked(rescue_fail):
@@ -489,14 +477,14 @@ def _restart_path(dev, form):
         return got, ctl
 
     got, ctl = hooked(0)
-    if form in ("oneread", "tail"):
-        # the one-read form RESCUES a rejected pair (its exact bracket, a re-read of that pair alone, a second walk); only
+    if form == "tail":
+        # the exact-tail form RESCUES a rejected pair (its exact bracket, a re-read of that pair alone, a second walk); only
         # the pairs that gather their whole window anyway (here: the 1000-element tensor) go straight to the compaction route
         assert int(ctl.len0) + int(ctl.cnt_le) >= plan.n_pairs // 2 and int(ctl.len0) >= plan.n_pairs // 4
         assert int(ctl.len1) >= int(ctl.len0)                # units of the re-read
         got2, ctl2 = hooked(2)                               # ... and when the rescue walk rejects them too: compaction route
         assert int(ctl2.cnt_le) >= plan.n_pairs // 2
-        assert _same_steps(got2, want) if form == "oneread" else _close(got2[..., 0], want[..., 0])
+        assert _close(got2[..., 0], want[..., 0])
     else:
         assert int(ctl.cnt_le) == plan.n_pairs // 2          # control block: pairs that took the compaction route
     # (exact tail: a rescued pair walks the reference's whole iterate sequence, an accepted one only its end: same fixed point)
@@ -528,14 +516,11 @@ def test_channel_diff_sum(dev):
     np.testing.assert_allclose(ops.channel_diff_sum(a, b).cpu().numpy(), a.double().sum((0, 2)).cpu().numpy(), rtol=1e-12)
 
 
-@pytest.mark.parametrize("walk", ["group", "sorted"] if has_oneread() else ["group"])
-def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
-    """(Both walks of the one-read form: whole lists scanned from registers by a workgroup per pair / one wave per pair over
-    sorted runs.)  A seeded sweep over odd sizes (not multiples of 4, below / above the small-pair threshold, split over several
+def test_octav_randomised_shapes_and_distributions(dev):
+    """A seeded sweep over odd sizes (not multiples of 4, below / above the small-pair threshold, split over several
     workgroups) and distributions (discrete-valued, sparse, constant, huge / tiny scale, heavy tails): the three forms
     agree with each other and with the numpy oracle, for both `dynamic_sym` settings, in batched launches."""
     from dipoorlet_amd import ops
-    monkeypatch.setenv("DPL_OCTAV_WALK", walk)
     rng = np.random.default_rng(20260)
     sizes = [1, 3, 17, 1023, 1025, 4099, 16383, 16385, 50001, 131071, 300003, 1200007]
 
@@ -564,9 +549,7 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
         tensors.append(torch.from_numpy(data).to(dev))
     plan = ops.TensorSetPlan(elems, B, dev)
     for dyn in (False, True):
-        got = {form: _octav(ops, plan, tensors, dyn, form) for form in (("oneread",) if has_oneread() else ()) + ("bracket", "compact", "full")}
-        if has_oneread():
-            assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)   # (both: exact integer sums)
+        got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("bracket", "compact", "full")}
         assert _same_steps(got["bracket"], got["compact"])
         assert _same_steps(got["bracket"], got["full"])
         for t, n in enumerate(sizes):
@@ -580,20 +563,15 @@ def test_octav_randomised_shapes_and_distributions(dev, monkeypatch, walk):
                 assert g[1] == x.min() and g[2] == x.max()
 
 
-@pytest.mark.parametrize("form,walk,sets,lanes", [("tail", "auto", 3, 2), ("tail", "auto", 2, 2), ("tail", "auto", 4, 2), ("tail", "auto", 3, 1),
-                                                  ("tail", "auto", 3, 3), ("tail", "auto", 2, 3)] + ([("oneread", "group", 3, 2),
-                                                  ("oneread", "sorted", 3, 2), ("oneread", "auto", 3, 1), ("oneread", "auto", 2, 2),
-                                                  ("oneread", "auto", 4, 3)] if has_oneread() else []))
-def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, sets, lanes):
-    """(form: the exact-tail form — the default — or the round-3 one-read form; walk: as above, auto = chosen by the listed share.
-    sets: how many batches the host runs ahead = sets of per-batch scratch, ops._PIPE_SETS.  lanes: the streams the streaming
+@pytest.mark.parametrize("sets,lanes", [(3, 2), (2, 2), (4, 2), (3, 1), (3, 3), (2, 3)])
+def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, sets, lanes):
+    """(sets: how many batches the host runs ahead = sets of per-batch scratch, ops._PIPE_SETS.  lanes: the streams the streaming
     kernels of consecutive batches rotate over — 2 by default: batch i + 1 starts while batch i drains; 1: the caller's stream.)
     OctavPipeline (rescue / walk of batch i on a side stream beside the streaming kernel of batch i + 1, rotating scratch)
     returns what the two-read form returns batch by batch — including the first batches, which run without any history — and
     the oracle's scales."""
     from dipoorlet_amd import ops
-    monkeypatch.setenv("DPL_OCTAV_FORM", form)
-    monkeypatch.setenv("DPL_OCTAV_WALK", walk)
+    monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
     monkeypatch.setenv("DPL_OCTAV_LANES", str(lanes))
     monkeypatch.setattr(ops, "_PIPE_SETS", sets)
     rng = np.random.default_rng(41)
@@ -613,9 +591,8 @@ def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, 
     for k, (o, w) in enumerate(zip(outs, want)):
         got = o.cpu().numpy()
         assert np.array_equal(got[:, :, 1:], w[:, :, 1:]), k
-        # (one-read: the reference's iterate sequence, up to the order of atomically merged sums; exact tail: its fixed point)
-        assert np.allclose(got[:, :, 0], w[:, :, 0], rtol=2e-7, atol=0) if form == "oneread" else _close(got[:, :, 0], w[:, :, 0]), k
-    # a second run on the same plan (prediction warmed up), interleaved with a ragged plan
+        assert _close(got[:, :, 0], w[:, :, 0]), k      # (the two-read form walks the reference's iterates, the exact tail reaches their fixed point)
+    # a second run on the same plan (threshold history warmed up), interleaved with a ragged plan
     plan2 = ops.TensorSetPlan(sizes, 2, dev)
     x = [torch.from_numpy(np.stack([(rng.standard_normal(n) * (1 + t)).astype(np.float32) for _ in range(B)])).to(dev)
          for t, n in enumerate(sizes)]
@@ -623,66 +600,21 @@ def test_octav_pipeline_matches_single_stream(dev, kl, monkeypatch, form, walk, 
     b = pipe.submit(plan2, [v[:2].contiguous() for v in x])
     c = pipe.submit(plan, x)
     pipe.sync()
-    if form == "oneread":
-        assert np.array_equal(a.cpu().numpy(), c.cpu().numpy())
-        assert np.array_equal(a.cpu().numpy()[:2], b.cpu().numpy())
-    else:
-        assert np.array_equal(a.cpu().numpy()[..., 1:], c.cpu().numpy()[..., 1:]) and _close(a.cpu().numpy()[..., 0], c.cpu().numpy()[..., 0])
-        assert _close(a.cpu().numpy()[:2, :, 0], b.cpu().numpy()[..., 0])
+    assert np.array_equal(a.cpu().numpy()[..., 1:], c.cpu().numpy()[..., 1:]) and _close(a.cpu().numpy()[..., 0], c.cpu().numpy()[..., 0])
+    assert _close(a.cpu().numpy()[:2, :, 0], b.cpu().numpy()[..., 0])
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         for t in range(len(sizes)):
             assert _close(a[1, t, 0].item(), O.octav_scale(x[t][1].cpu().numpy(), 1))
 
 
-@pytest.mark.skipif(not has_oneread(), reason="built without -DDPL_WITH_ONEREAD")
-def test_octav_oneread_schedules_and_predictions_agree(dev, monkeypatch):
-    """The one-read form's variants walk the same exact integer sums: the walk inside the streaming kernel (DPL_OCTAV_FUSE=1,
-    the default) or in its own kernel (=0); the prediction from earlier batches, from a sample of the pair itself, or chosen
-    per tensor (DPL_OCTAV_PREDICT) — bit-identical rows over a run of batches whose images differ in scale (so that the
-    prediction from earlier batches misses and pairs are rescued), through the pipeline and on one stream."""
-    from dipoorlet_amd import ops
-    monkeypatch.setenv("DPL_OCTAV_FORM", "oneread")
-    rng = np.random.default_rng(41)
-    B, sizes = 3, [150528, 40000, 802816, 1000, 200704, 1200007]
-    batches = [[torch.from_numpy((rng.standard_normal((B, n)) * (1 + 0.3 * t) * (1 + 0.25 * k)).astype(np.float32)
-                                 * (1 if t % 2 else np.float32(1)) ).clamp_(min=0 if t % 2 else -1e30).to(dev)
-                for t, n in enumerate(sizes)] for k in range(4)]
-    ref = None
-    for fuse in ("1", "0"):
-        for predict in ("auto", "probe", "learned"):
-            monkeypatch.setenv("DPL_OCTAV_FUSE", fuse)
-            monkeypatch.setenv("DPL_OCTAV_PREDICT", predict)
-            plan = ops.TensorSetPlan(sizes, B, dev)
-            pipe = ops.OctavPipeline(False, dev)
-            rows = [pipe.submit(plan, b) for b in batches]
-            pipe.sync()
-            torch.cuda.synchronize()
-            got = np.stack([r.cpu().numpy() for r in rows])
-            plan1 = ops.TensorSetPlan(sizes, B, dev)
-            single = np.stack([ops.octav_batch(plan1, b, False).cpu().numpy() for b in batches])
-            assert np.array_equal(got, single), (fuse, predict)
-            if ref is None:
-                ref = got
-                with warnings.catch_warnings():
-                    warnings.simplefilter("ignore")
-                    for t in range(len(sizes)):
-                        assert _close(got[3, 1, t, 0], O.octav_scale(batches[3][t][1].cpu().numpy(), 1)), t
-            else:
-                assert np.array_equal(got, ref), (fuse, predict)
-            if predict == "learned":   # differing scales: the earlier batches' bins do not cover the later ones -> rescues
-                assert pipe.fallback_pairs > 0
-
-
-@pytest.mark.parametrize("predict", ["auto", "probe", "learned"] if has_oneread() else ["auto"])
-def test_octav_special_values(dev, monkeypatch, predict):
+def test_octav_special_values(dev, monkeypatch):
     """Values the histogram window (2^-18 .. 2^14) does not hold, and the ones IEEE sets apart: all zeros, signed zeros, NaN,
     +-inf, denormals, tiny normals below the window mixed into ordinary data, a pair that lies below the window entirely,
     values on the window's two edges, one huge outlier, a single non-zero — every form against the numpy oracle
-    (forward_net.py:315-330 on such data: NaN and inf propagate through the sums, 0 / 0 is NaN), the one-read form with each
-    prediction source, fused and unfused, and through the pipeline."""
+    (forward_net.py:315-330 on such data: NaN and inf propagate through the sums, 0 / 0 is NaN), on one stream and through the
+    pipeline."""
     from dipoorlet_amd import ops
-    monkeypatch.setenv("DPL_OCTAV_PREDICT", predict)
     rng = np.random.default_rng(77)
     n = 70001
 
@@ -716,34 +648,25 @@ def test_octav_special_values(dev, monkeypatch, predict):
         for dyn in (False, True):
             want = np.array([[O.octav_scale(t[b].cpu().numpy(), O.octav_unsigned(t[b].cpu().numpy().min(), dyn)) for t in tensors]
                              for b in range(B)], np.float64)
-            for fuse in ("1", "0") if has_oneread() else ("1",):
-                monkeypatch.setenv("DPL_OCTAV_FUSE", fuse)
-                plan = ops.TensorSetPlan(sizes, B, dev)
-                got = {form: _octav(ops, plan, tensors, dyn, form) for form in (("oneread",) if has_oneread() else ()) + ("bracket", "compact", "full")}
-                if fuse == "1":     # (the exact-tail form has no unfused variant)
-                    got["tail"] = _octav(ops, ops.TensorSetPlan(sizes, B, dev), tensors, dyn, "tail")
-                for form, g in got.items():
-                    for t in range(len(mk)):
-                        for b in range(B):
-                            assert _close(g[b, t, 0], want[b, t]), (form, fuse, dyn, t, b, g[b, t], want[b, t])
-                            x = tensors[t][b].cpu().numpy()
-                            if not np.isnan(x).any():
-                                assert g[b, t, 1] == x.min() and g[b, t, 2] == x.max(), (form, t, b)
-                if has_oneread():
-                    assert np.array_equal(got["bracket"], got["oneread"], equal_nan=True)
-                for pform in ((("oneread", "tail") if fuse == "1" else ("oneread",)) if has_oneread() else ("tail",)):
-                    monkeypatch.setenv("DPL_OCTAV_FORM", pform)
-                    pipe = ops.OctavPipeline(dyn, dev)
-                    plan2 = ops.TensorSetPlan(sizes, B, dev)
-                    rows = [pipe.submit(plan2, tensors) for _ in range(3)]
-                    pipe.sync()
-                    for r in rows:
-                        if pform == "oneread":
-                            assert np.array_equal(r.cpu().numpy(), got["oneread"], equal_nan=True), (fuse, dyn)
-                        else:
-                            assert np.array_equal(r.cpu().numpy()[..., 1:], got["tail"][..., 1:], equal_nan=True)
-                            assert _close(r.cpu().numpy()[..., 0], got["tail"][..., 0]), (fuse, dyn)
-                monkeypatch.delenv("DPL_OCTAV_FORM")
+            plan = ops.TensorSetPlan(sizes, B, dev)
+            got = {form: _octav(ops, plan, tensors, dyn, form) for form in ("bracket", "compact", "full")}
+            got["tail"] = _octav(ops, ops.TensorSetPlan(sizes, B, dev), tensors, dyn, "tail")
+            for form, g in got.items():
+                for t in range(len(mk)):
+                    for b in range(B):
+                        assert _close(g[b, t, 0], want[b, t]), (form, dyn, t, b, g[b, t], want[b, t])
+                        x = tensors[t][b].cpu().numpy()
+                        if not np.isnan(x).any():
+                            assert g[b, t, 1] == x.min() and g[b, t, 2] == x.max(), (form, t, b)
+            monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
+            pipe = ops.OctavPipeline(dyn, dev)
+            plan2 = ops.TensorSetPlan(sizes, B, dev)
+            rows = [pipe.submit(plan2, tensors) for _ in range(3)]
+            pipe.sync()
+            for r in rows:
+                assert np.array_equal(r.cpu().numpy()[..., 1:], got["tail"][..., 1:], equal_nan=True)
+                assert _close(r.cpu().numpy()[..., 0], got["tail"][..., 0]), dyn
+            monkeypatch.delenv("DPL_OCTAV_FORM")
 
 
 def test_octav_tail_randomised_shapes_and_distributions(dev):
@@ -838,13 +761,12 @@ def test_octav_tail_thresholds_follow_the_images(dev, monkeypatch):
                         assert got[b, t, 1] == x.min() and got[b, t, 2] == x.max()
 
 
-@pytest.mark.parametrize("form", ["tail", ONEREAD])
-def test_two_pipelines_share_a_plan(dev, monkeypatch, form):
+def test_two_pipelines_share_a_plan(dev, monkeypatch):
     """An OctavPipeline owns its rotation state (scratch sets, state arrays, snapshots, call counter) per plan: two pipelines —
     calibration and profiling, or two threads — may run the same TensorSetPlan interleaved without corrupting each other
     (re-entrant ops, no hidden mutable state on the plan)."""
     from dipoorlet_amd import ops
-    monkeypatch.setenv("DPL_OCTAV_FORM", form)
+    monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
     rng = np.random.default_rng(77)
     B, sizes = 2, [200704, 30000, 802816]
     plan = ops.TensorSetPlan(sizes, B, dev)
@@ -1000,7 +922,7 @@ def test_octav_tail_pairs_above_one_slice(dev, monkeypatch, fail_every):
     path + k_octav_tail_merge) next to ordinary ones: every route — accepted walks, the rescue (forced by the C ABI's test hook for every
     second pair), a bin of 2^20 values or more (a constant tensor: the merged packed words do not hold it, compaction route),
     values >= 2^14, NaN, an all-zero tensor, dynamic_sym — through the pipeline over batches that differ in scale, against the
-    two-read form and the numpy oracle; DPL_OCTAV_TAIL_MULTI=0 (the round-3 form serves such a set) gives the same."""
+    two-read form and the numpy oracle."""
     from dipoorlet_amd import _hip, ops
     monkeypatch.setenv("DPL_OCTAV_FORM", "tail")
     rng = np.random.default_rng(31)
@@ -1055,9 +977,6 @@ def test_octav_tail_pairs_above_one_slice(dev, monkeypatch, fail_every):
                 for b in range(B):
                     x = batches[-1][t][b].cpu().numpy()
                     assert _close(got[b, t, 0], O.octav_scale(x, 4 if (dyn and abs(float(np.nanmin(x))) < 1e-6 and not np.isnan(x).any()) else 1)), (t, b)
-    monkeypatch.setenv("DPL_OCTAV_TAIL_MULTI", "0")
-    r3 = ops.octav_batch(ops.TensorSetPlan(sizes, B, dev), batches[0], True).cpu().numpy()      # (dyn = True: the loop's last `want`)
-    assert _close(r3[..., 0], want[0][..., 0]) and np.array_equal(r3[..., 1:], want[0][..., 1:], equal_nan=True)
 
 
 def test_octav_tail_soak_short():

@@ -123,7 +123,7 @@ def _main(argv=None):
         # the HIP context and the libraries' first calls: on a helper thread from here on, beside the model load and the
         # session build (executor.warm_libraries; its own clock reports the context's seconds)
         from . import executor
-        executor.warm_libraries(torch.device("cuda", rank % max(1, torch.cuda.device_count())))
+        executor.warm_libraries(torch.device("cuda", rank % max(1, torch.cuda.device_count())), blas=False)
         warm = executor._WARM
     t_ctx = time.time()
     if args.output_dir is None:
@@ -141,6 +141,10 @@ def _main(argv=None):
         n_folded = onnx_graph.fold_batchnorm()
         if n_folded and rank == 0:
             logger.info("Folded {} BatchNormalization nodes into their producers.".format(n_folded))
+    if warm is not None and sum(n.op_type in ("MatMul", "Gemm") for n in onnx_graph.graph.node) > 4:
+        # a transformer: its matrix products go to the BLAS library, whose first call (0.2 s) starts now, beside the session build.
+        # (A convolutional network's one or two run on ops.gemm_small; the session starts this thread if they turn out not to.)
+        executor.warm_blas(torch.device("cuda", rank % max(1, torch.cuda.device_count())))
     args.rank, args.world_size = rank, world
     args.local_rank = rank % max(1, torch.cuda.device_count())
     if rank == 0:

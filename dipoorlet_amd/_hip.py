@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_BINS = 16384
 
 
@@ -121,6 +121,8 @@ SIGNATURES = {
     "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
     "dpl_channel_diff_sum": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),
     "dpl_cos_items_accumulate": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "dpl_gemm_small_workspace": (_U64, [_I64, _I64, _I64]),
+    "dpl_gemm_small": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, C.c_float, C.c_float, _P, _P]),
     "dpl_round_init": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P, _P]),
     "dpl_round_quant": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _I64, C.c_int, C.c_int, _P, _P]),
     "dpl_round_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, C.POINTER(RoundStepParams), _P, _P,

@@ -30,20 +30,23 @@ _OPS = {}
 _WARM = {}     # "kernels" / "blas": the helper threads (True once joined); "context_s", "kernels_s", "blas_s": their own clocks
 
 
-def warm_libraries(device=None):
+def warm_libraries(device=None, blas=True):
     """Starts (once per process) two helper threads that make the FIRST calls of the libraries a forward uses, on tiny tensors
     and streams of their own, while the main thread reads the model, packs the initializers and starts the .bin reader (torch
     ops release the GIL; measured on MI355X, scripts/warm_probe.py: made one after the other the first calls take 0.39 s after
     hipInit, from two threads 0.26 s):
       'blas'     the first GEMM — hipBLASLt (rocBLAS alike) loads its kernel library for gfx950 then: 0.17 - 0.2 s.  Only an op that
-                 multiplies matrices waits for it (wait_warm('blas') in MatMul / Gemm): ResNet-50's one Gemm is its last node, the
-                 first batch's convolutions are issued while this thread is still loading
+                 multiplies matrices THROUGH THE LIBRARY waits for it (wait_warm('blas') in MatMul / Gemm).  While it loads, every
+                 other code object the first forward needs queues behind it (scripts/e2e_blas_ab.sh: the first forward is issued
+                 70 - 80 ms later), so the CLI passes blas=False here and starts this thread (warm_blas) only for a graph that
+                 needs the library: a convolutional network's classifier head runs on ops.gemm_small instead
       'kernels'  the first launch of each family of torch's own kernels (code objects are loaded lazily: 10 - 25 ms each) and
                  MIOpen's first convolution; a session's first forward waits for it (wait_warm('kernels'))
     A fresh ResNet-50 process: first forward 248 ms -> 52 - 92 ms (scripts/startup_probe.py)."""
-    if "kernels" in _WARM or not torch.cuda.is_available():
+    if not torch.cuda.is_available():
         return
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    todo = []
 
     def run(name, body):
         import time
@@ -59,7 +62,7 @@ def warm_libraries(device=None):
         _WARM[name + "_s"] = time.perf_counter() - t0
         mark(f"warm:{name}:end")
 
-    def blas(t0):
+    def blas_body(t0):
         a = torch.zeros(8, 64, device=dev)
         torch.addmm(torch.zeros(64, device=dev), a, torch.zeros(64, 64, device=dev))
         torch.matmul(torch.zeros(2, 4, 8, 8, device=dev), torch.zeros(2, 4, 8, 8, device=dev))
@@ -81,10 +84,20 @@ def warm_libraries(device=None):
         torch.cat([y, y], 1)
 
     import threading
-    for name, body in (("blas", blas), ("kernels", kernels)):
+    if blas and "blas" not in _WARM:
+        todo.append(("blas", blas_body))
+    if "kernels" not in _WARM:
+        todo.append(("kernels", kernels))
+    for name, body in todo:
         _WARM[name] = threading.Thread(target=run, args=(name, body), daemon=True, name="dpl-warm-" + name)
         _HELPERS.append(_WARM[name])
         _WARM[name].start()
+
+
+def warm_blas(device=None):
+    """The 'blas' helper thread of warm_libraries alone (no-op if it has been started): for a graph whose matrix products go to
+    the library."""
+    warm_libraries(device, blas=True)
 
 
 _HELPERS = []      # every helper thread this module has started (warm-up, convolution pre-warm)
@@ -305,8 +318,22 @@ def _gmp(s, node, x):
     return x.amax(tuple(range(2, x.dim())), keepdim=True)
 
 
+def small_gemm(m, n, k, *tensors):
+    """Does a product of these sizes run on ops.gemm_small (the library's own kernel: no BLAS library to load) rather than
+    hipBLASLt?  The classifier head of a convolutional network does; a transformer's products do not, nor does a product that
+    autograd has to see (AdaRound / BRECQ reconstruct a Gemm layer through this executor).  DPL_GEMM_SMALL=0: never."""
+    from .ops import GEMM_SMALL_MAX
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        return False
+    return m * n * max(k, 1) <= GEMM_SMALL_MAX and os.environ.get("DPL_GEMM_SMALL", "1") != "0"
+
+
 @op("MatMul")
 def _matmul(s, node, a, b):
+    if a.is_cuda and b.dim() == 2 and a.dim() >= 2 and a.dtype == torch.float32 and b.dtype == torch.float32 \
+            and small_gemm(a.numel() // a.shape[-1], b.shape[1], a.shape[-1], a, b):
+        from . import ops
+        return ops.gemm_small(a.reshape(-1, a.shape[-1]), b).reshape(*a.shape[:-1], b.shape[1])
     if a.is_cuda:
         wait_warm("blas")
     return torch.matmul(a, b)
@@ -314,13 +341,17 @@ def _matmul(s, node, a, b):
 
 @op("Gemm")
 def _gemm(s, node, a, b, c=None):
-    if a.is_cuda:
-        wait_warm("blas")
     if node.attrs.get("transA", 0):
         a = a.t()
     if node.attrs.get("transB", 0):
         b = b.t()
     alpha, beta = float(node.attrs.get("alpha", 1.0)), float(node.attrs.get("beta", 1.0))
+    if a.is_cuda and a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype == torch.float32 \
+            and (c is None or (c.dim() <= 2 and c.dtype == torch.float32)) and small_gemm(a.shape[0], b.shape[1], a.shape[1], a, b, c):
+        from . import ops
+        return ops.gemm_small(a, b, c, alpha, beta)       # (b: a transposed VIEW for transB = 1 — the kernel takes strides)
+    if a.is_cuda:
+        wait_warm("blas")
     if c is not None and a.dim() == 2 and b.dim() == 2 and c.dim() <= 2:
         return torch.addmm(c, a, b, beta=beta, alpha=alpha)      # one hipBLASLt call, bias in the epilogue
     y = torch.matmul(a, b)
@@ -538,7 +569,12 @@ def _fake_quant(s, node, x):
 class GraphSession(ActivationSession):
     """All-outputs session over an ONNXGraph."""
 
-    def __init__(self, graph, device=None, expose_fake_quant=False):
+    def __init__(self, graph, device=None, expose_fake_quant=False, first_batch=None):
+        """first_batch (optional): a function of the session, called once the per-image shapes are known (before the weights are on
+        the device), that returns the number of images the caller's first forward will carry — the session then starts what
+        that forward needs at once, beside its own build: the first call of every convolution configuration at that batch size
+        (prewarm_convs, on zero weights) and — only if a matrix product of the graph is too large for ops.gemm_small at that
+        batch size — the BLAS library's (warm_blas).  Without it the caller may call prewarm_convs itself."""
         self.graph = graph
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
@@ -546,10 +582,7 @@ class GraphSession(ActivationSession):
         self.batch = 1
         self.consts = {}
         if self.device.type == "cuda":
-            warm_libraries(self.device)     # (no-op when the CLI has started it already)
-        with _wall("session_consts_s"):
-            self._upload_consts()
-        mark("session:consts_issued")
+            warm_libraries(self.device, blas=first_batch is None)     # (no-op for what the CLI has started already)
         missing = sorted({n.op_type for n in graph.graph.node if n.op_type not in _OPS})
         if missing:
             raise NotImplementedError(f"executor: unsupported ONNX ops {missing}")
@@ -558,11 +591,55 @@ class GraphSession(ActivationSession):
         # fake-quantised WEIGHTS are constants: quantise them once here instead of on every forward
         self._folded = set()
         self._batched_ok = None   # decided by batched_ok() at the first batched run
-        fold = [n for n in graph.graph.node if n.op_type == "FakeQuant" and n.input[0] in self.consts]
+        fold = [n for n in graph.graph.node if n.op_type == "FakeQuant" and n.input[0] in graph.initializer]
         for node in fold:
             self._folded.add(node.name)
-        self._fold_weights(fold)
-        self._infer()
+        # shapes first (host rules: no device work), so that the libraries' first calls for THIS graph start before the weights
+        # travel; a graph the rules do not cover needs its weights on the device for the batch-1 forward that replaces them
+        uploaded = False
+        if not self._infer(host_only=True):
+            with _wall("session_consts_s"):
+                self._upload_consts()
+            uploaded = True
+            self._fold_weights(fold)
+            self._infer()
+        if first_batch is not None and self.device.type == "cuda":
+            nb = int(first_batch(self))
+            if self.needs_blas(nb):
+                warm_blas(self.device)
+            self.prewarm_convs(nb)
+        if not uploaded:
+            with _wall("session_consts_s"):
+                self._upload_consts()
+            self._fold_weights(fold)
+        mark("session:consts_issued")
+
+    def needs_blas(self, batch):
+        """Does a forward of `batch` images multiply matrices through the BLAS library — a MatMul / Gemm that small_gemm()
+        refuses (or whose shapes are not both known here)?"""
+        for node in self.graph.graph.node:
+            if node.op_type not in ("MatMul", "Gemm") or node.name in self._folded:
+                continue
+            a, b = self._any_shape(node.input[0], batch), self._any_shape(node.input[1], 1)
+            if a is None or b is None or len(b) != 2 or len(a) < 2 or (node.op_type == "Gemm" and len(a) != 2):
+                return True
+            if node.op_type == "Gemm" and node.attrs.get("transA", 0):
+                a = a[::-1]
+            k = a[-1]
+            n = b[0] if (node.op_type == "Gemm" and node.attrs.get("transB", 0)) else b[1]
+            if not small_gemm(int(np.prod(a[:-1])), int(n), int(k)):
+                return True
+        return False
+
+    def _any_shape(self, name, batch):
+        """Shape of an initializer, of a folded fake-quantised one, or of an activation at `batch` images; None if unknown."""
+        if name in self.graph.initializer:
+            return tuple(np.asarray(self.graph.initializer[name]).shape)
+        for node in self.graph.graph.node:
+            if node.name in self._folded and node.output[0] == name:
+                return tuple(np.asarray(self.graph.initializer[node.input[0]]).shape)
+        shp = self.shape1.get(name)
+        return None if shp is None else (batch * shp[0],) + tuple(shp[1:])
 
     def _fold_weights(self, nodes):
         """Fake-quantised WEIGHTS are constants: quantised once, here, instead of on every forward — every weight of the graph
@@ -630,8 +707,9 @@ class GraphSession(ActivationSession):
             t = torch.from_numpy(a.astype(np.float32)) if a.dtype == np.float16 else torch.from_numpy(a)
             self.consts[name] = _host_ints(t.to(self.device), t)
 
-    def _infer(self):
-        """Every tensor's per-image shape (replaces onnx shape inference): on the host, shape_infer's rule per op — no device
+    def _infer(self, host_only=False):
+        """(host_only: return False instead of running the device forward when the host rules do not cover the graph.)
+        Every tensor's per-image shape (replaces onnx shape inference): on the host, shape_infer's rule per op — no device
         work (a batch-1 forward on zeros cost a fresh process 0.3 s: the libraries load and choose kernels for a batch size
         the run never uses).  A graph with an op that has no rule runs that batch-1 forward instead (DPL_INFER_DEVICE=1
         forces it)."""
@@ -644,6 +722,8 @@ class GraphSession(ActivationSession):
             except shape_infer.Unsupported as e:
                 logger.info("executor: shapes from a batch-1 forward on the device (%s)", e)
                 env = None
+        if env is None and host_only:
+            return False
         if env is None:
             with _wall("session_infer_device_s"):
                 feeds = {n: torch.zeros([max(1, int(d)) for d in self.graph.get_tensor_shape(n)], dtype=torch.float32,
@@ -675,6 +755,7 @@ class GraphSession(ActivationSession):
                     elems.append(t.numel())
                     self.shape1[o] = tuple(t.shape)
         self.tensor_names, self.elems_per_image = names, elems
+        return True
 
     def match_batch(self, a, b):
         return a, b
@@ -685,16 +766,18 @@ class GraphSession(ActivationSession):
         resolves a configuration's solver and loads its code object on first use — 2.7 ms per configuration, 63 ms for
         ResNet-50's 23 from one thread, 18 ms from three, and the main thread's own first forward then finds them loaded
         (scripts/miopen_probe.py).  Returns at once; the session's first forward joins the threads."""
-        if self.device.type != "cuda" or batch < 1 or os.environ.get("DPL_PREWARM_CONVS", "1") == "0":
+        if self.device.type != "cuda" or batch < 1 or os.environ.get("DPL_PREWARM_CONVS", "1") == "0" \
+                or getattr(self, "_prewarmed", False):
             return
+        self._prewarmed = True
         seen, todo = set(), []
         for node in self.graph.graph.node:
             if node.op_type != "Conv" or node.name in self._folded:
                 continue
-            shp, w = self.shape1.get(node.input[0]), self.consts.get(node.input[1])
-            if shp is None or w is None or len(shp) != w.dim() or shp[0] != 1:
+            shp, w = self.shape1.get(node.input[0]), self._any_shape(node.input[1], 1)
+            if shp is None or w is None or len(shp) != len(w) or shp[0] != 1:
                 continue
-            key = (tuple(shp), tuple(w.shape), tuple(node.attrs.get("strides", ())), tuple(node.attrs.get("pads", ())),
+            key = (tuple(shp), tuple(w), tuple(node.attrs.get("strides", ())), tuple(node.attrs.get("pads", ())),
                    tuple(node.attrs.get("dilations", ())), int(node.attrs.get("group", 1)), node.attrs.get("auto_pad", ""), len(node.input))
             if key not in seen:
                 seen.add(key)
@@ -705,8 +788,8 @@ class GraphSession(ActivationSession):
             try:
                 torch.cuda.set_device(self.device)
                 with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream(self.device)):
-                    for node, shape in part:
-                        args = [self.consts[i] for i in node.input[1:] if i != ""]
+                    for node, shape in part:      # (zero weights of the right shapes: the solver is chosen by the configuration)
+                        args = [torch.zeros(self._any_shape(i, 1), device=self.device) for i in node.input[1:] if i != ""]
                         _OPS["Conv"](self, node, torch.zeros(shape, device=self.device), *args)
                     torch.cuda.current_stream(self.device).synchronize()
             except Exception:   # noqa: BLE001  (best effort)

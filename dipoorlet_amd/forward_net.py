@@ -126,8 +126,13 @@ class CalibrationRun:
         self._reader = self._start_reader(torch.cuda.is_available()) if self.batch else None
         mark("run:reader_started")
         if session is None:
-            with wall("session_build_s"):      # weights to the device (one transfer), node schedule, shapes (host rules)
-                session = onnx_graph.make_session(args)
+            def first_batch(sess):     # images of this run's first forward: the session warms the libraries up for that, beside its build
+                b = self.batch or auto_batch(sess.elems_per_image)
+                return max(0, min(b, self.ed - self.st))
+            import inspect      # (a graph object of the caller's own may offer the reference's make_session(args) only)
+            kw = {"first_batch": first_batch} if "first_batch" in inspect.signature(onnx_graph.make_session).parameters else {}
+            with wall("session_build_s"):      # shapes (host rules), node schedule, weights to the device (one transfer)
+                session = onnx_graph.make_session(args, **kw)
         mark("run:session_built")
         if not self.batch:
             self.batch = auto_batch(session.elems_per_image)

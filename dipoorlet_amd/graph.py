@@ -248,6 +248,6 @@ class ONNXGraph:
         return path
 
     # ------------------------------------------------------------------ execution
-    def make_session(self, args=None, device=None):
+    def make_session(self, args=None, device=None, first_batch=None):
         from .executor import GraphSession
-        return GraphSession(self, device=device)
+        return GraphSession(self, device=device, first_batch=first_batch)

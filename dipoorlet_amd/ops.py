@@ -818,6 +818,36 @@ def channel_diff_sum(a, b, acc=None):
     return acc
 
 
+GEMM_SMALL_MAX = 1 << 28      # DPL_GEMM_SMALL_MAX (include/dipoorlet_hip.h)
+
+
+def gemm_small(a, b, bias=None, alpha=1.0, beta=1.0):
+    """alpha * a @ b + beta * bias through dpl_gemm_small (csrc/gemm_small.hip: the classifier head of a convolutional network,
+    so that a calibration run of one needs no BLAS library).  a: [M, K] fp32 contiguous; b: [K, N] fp32, any strides (a transposed
+    view of an [N, K] weight is what an ONNX Gemm with transB = 1 gives); bias: None, [N], [1, N], [M, 1] or [M, N].
+    M * N * K <= GEMM_SMALL_MAX."""
+    for t, name in ((a, "a"), (b, "b")) + (((bias, "bias"),) if bias is not None else ()):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda):
+            raise _hip.DipoorletHipError(f"gemm_small: {name} must be a ROCm device tensor; dipoorlet_amd has no CPU path")
+        if t.dtype != torch.float32:
+            raise _hip.DipoorletHipError(f"gemm_small: {name} must be float32")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != b.shape[0]:
+        raise _hip.DipoorletHipError("gemm_small: a [M, K] and b [K, N]")
+    a = a.contiguous()
+    M, K, N = int(a.shape[0]), int(a.shape[1]), int(b.shape[1])
+    bp, sm, sn = None, 0, 0
+    if bias is not None:
+        bias = bias.expand(M, N)       # (broadcast axes get stride 0; raises if it does not broadcast)
+        bp, sm, sn = _ptr(bias), int(bias.stride(0)), int(bias.stride(1))
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    L = _hip.lib()
+    need = int(L.dpl_gemm_small_workspace(M, N, K))
+    ws = torch.empty(need // 4, dtype=torch.float32, device=a.device) if need else None
+    _hip.check(L.dpl_gemm_small(_ptr(a), _ptr(b), bp, _ptr(out), M, N, K, int(b.stride(0)), int(b.stride(1)), sm, sn,
+                                float(alpha), float(beta), _ptr(ws) if need else None, _stream()), "dpl_gemm_small")
+    return out
+
+
 def cos_per_image(plan, tensors_a, tensors_b):
     """Cosine partial sums for every (image, tensor) pair of two tensor sets with the same geometry ->
     fp64 device tensor [B, T, 3] = (sum a*b, sum a*a, sum b*b)."""

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 18
+#define DPL_ABI_VERSION 19
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -316,6 +316,19 @@ int dpl_cos_accumulate(const float* d_a, const float* d_b, int64_t n, double* d_
  * d_acc[c] += sum over outer and inner of (a - b), accumulated in fp64. */
 int dpl_channel_diff_sum(const float* d_a, const float* d_b, int64_t outer, int64_t n_channels, int64_t inner,
                          double* d_acc, dpl_stream_t s);
+
+/* The classifier head of a convolutional network in the calibration forward (forward_net.py:192-237 runs the graph with
+ * onnxruntime; here: MIOpen + this): C[m, n] = alpha * sum_k A[m, k] * B(k, n) + beta * bias(m, n), fp32, sums over k in ascending
+ * order with one fused multiply-add per term.  A: [m, k] row-major; B(k, n) = d_b[k * b_stride_k + n * b_stride_n] (an ONNX Gemm with
+ * transB = 1 passes (1, k)); bias(m, n) = d_bias[m * bias_stride_m + n * bias_stride_n] or no bias (NULL).  Products of at most
+ * DPL_GEMM_SMALL_MAX multiply-adds only (csrc/gemm_small.hip says why this exists and what it is not). */
+#define DPL_GEMM_SMALL_MAX (1ull << 28)
+/* A product with few tiles of C is cut along k (the partial sums are added in ascending order: the result depends on the shapes
+ * only): d_workspace = dpl_gemm_small_workspace(m, n, k) bytes of device memory (0: none needed, NULL is fine). */
+uint64_t dpl_gemm_small_workspace(int64_t m, int64_t n, int64_t k);
+int dpl_gemm_small(const float* d_a, const float* d_b, const float* d_bias, float* d_c, int64_t m, int64_t n, int64_t k,
+                   int64_t b_stride_k, int64_t b_stride_n, int64_t bias_stride_m, int64_t bias_stride_n, float alpha, float beta,
+                   float* d_workspace, dpl_stream_t s);
 
 /* Same sums per work-item slot (slot = (image, tensor) pair in the profiling flow, profiling.py:57-64):
  * d_acc[slot*3 + {0,1,2}] += sum(a*b), sum(a*a), sum(b*b); a from d_seg_a, b from d_seg_b (same geometry). */

@@ -363,3 +363,15 @@ def test_static_batching_proof_never_contradicts_the_dynamic_check(tmp_path, mon
         from dipoorlet_amd import shape_infer
         env = shape_infer.infer(g, set(), ["x"], 1)
         assert shape_infer.batch_transparent(g, set(), ["x"], env) is False, nodes[0].op_type
+
+
+def test_session_knows_whether_a_forward_needs_the_blas_library():
+    """GraphSession.needs_blas (decides whether a fresh process loads hipBLASLt at all): a convolutional network's classifier head
+    is a small product at calibration batch sizes, a transformer's attention is not (activation x activation)."""
+    from dipoorlet_amd import models
+    from dipoorlet_amd.executor import GraphSession, small_gemm
+    s = GraphSession(models.resnet50(), device="cpu")
+    assert not s.needs_blas(64) and not s.needs_blas(1) and s.needs_blas(4096)
+    assert small_gemm(64, 1000, 2048) and not small_gemm(64 * 197, 3072, 768)
+    v = GraphSession(models.vit(depth=2, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10), device="cpu")
+    assert v.needs_blas(1)

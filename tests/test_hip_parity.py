@@ -495,6 +495,63 @@ def _restart_path(dev, form):
             assert _close(got[0, t, 0], O.octav_scale(tensors[t][0].cpu().numpy(), 1))
 
 
+def test_gemm_small(dev):
+    """dpl_gemm_small (the classifier head of a convolutional network: csrc/gemm_small.hip) against numpy in fp64: ResNet-50's
+    head at the default batch (a transposed VIEW of the [N, K] weight, as an ONNX Gemm with transB = 1 gives), sizes that are not
+    multiples of the tile, every bias broadcast, alpha / beta, K = 0, K cut into 1 ... 64 splits (some of them empty); the result does not depend on the launch (bit-equal
+    repeats); a product above DPL_GEMM_SMALL_MAX is refused."""
+    from dipoorlet_amd import _hip, ops
+    rng = np.random.default_rng(61)
+    for M, K, N, trans_b, bias_kind, alpha, beta in [(64, 2048, 1000, True, "n", 1.0, 1.0), (1, 1, 1, False, None, 1.0, 1.0),
+                                                     (33, 65, 31, False, "1n", 0.5, 2.0), (7, 300, 129, True, "mn", 1.0, -1.0),
+                                                     (32, 32, 64, False, "m1", 1.0, 1.0), (5, 0, 9, False, "n", 1.0, 1.0),
+                                                     (200, 1280, 1001, True, "n", 1.0, 1.0), (64, 512, 10, True, None, 1.0, 1.0),
+                                                     (8, 8200, 64, False, "n", 1.0, 1.0), (300, 96, 600, False, "1n", 1.0, 1.0)]:
+        a = rng.standard_normal((M, K)).astype(np.float32)
+        w = rng.standard_normal((N, K) if trans_b else (K, N)).astype(np.float32)
+        bias = {None: None, "n": (N,), "1n": (1, N), "mn": (M, N), "m1": (M, 1)}[bias_kind]
+        bias = None if bias is None else rng.standard_normal(bias).astype(np.float32)
+        wt = torch.from_numpy(w).to(dev)
+        b = wt.t() if trans_b else wt
+        bt = None if bias is None else torch.from_numpy(bias).to(dev)
+        got = ops.gemm_small(torch.from_numpy(a).to(dev), b, bt, alpha, beta)
+        again = ops.gemm_small(torch.from_numpy(a).to(dev), b, bt, alpha, beta)
+        want = alpha * (a.astype(np.float64) @ (w.T if trans_b else w).astype(np.float64))
+        if bias is not None:
+            want = want + beta * bias.astype(np.float64)
+        assert got.shape == (M, N) and torch.equal(got, again)
+        scale = np.sqrt(max(K, 1)) * abs(alpha) + abs(beta)
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6 * scale * max(1.0, np.sqrt(K) / 8))
+    big = torch.zeros(1 << 10, 1 << 10, device=dev)
+    with pytest.raises(_hip.DipoorletHipError):
+        ops.gemm_small(big, torch.zeros(1 << 10, 1 << 9, device=dev))        # 2^29 multiply-adds
+    with pytest.raises(_hip.DipoorletHipError):
+        ops.gemm_small(torch.zeros(4, 8), torch.zeros(8, 2, device=dev))     # a CPU tensor
+
+
+def test_executor_small_products_need_no_blas(dev, monkeypatch):
+    """The executor's Gemm / MatMul take ops.gemm_small for a small product (same values as the library's to fp32 rounding) and
+    hipBLASLt for a large one or with DPL_GEMM_SMALL=0; GraphSession.needs_blas says which at session build."""
+    from dipoorlet_amd import executor, models
+    from dipoorlet_amd.executor import GraphSession
+    g = models.resnet18(num_classes=37)
+    x = torch.randn(8, 3, 224, 224, device=dev)
+    s = GraphSession(g, device=dev)
+    assert not s.needs_blas(64) and s.needs_blas(1 << 20)
+    feeds = {s.input_names[0]: x}
+    b = s.run(feeds)[-1]                           # (the graph's last tensor: the Gemm's output)
+    monkeypatch.setenv("DPL_GEMM_SMALL", "0")
+    assert s.needs_blas(1)
+    a = s.run(feeds)[-1]
+    monkeypatch.delenv("DPL_GEMM_SMALL")
+    assert a.shape == b.shape == (8, 37) and float(a.abs().max()) > 0
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+    # MatMul with leading axes: [2, 5, 16] x [16, 12]
+    w = torch.randn(16, 12, device=dev)
+    y = torch.randn(2, 5, 16, device=dev)
+    torch.testing.assert_close(executor._OPS["MatMul"](None, None, y, w), torch.matmul(y, w), rtol=1e-5, atol=1e-5)
+
+
 def test_channel_diff_sum(dev):
     """dpl_channel_diff_sum (bias correction's mean(fp - q) per channel) against numpy in fp64: conv maps with rows of
     every alignment class, a Gemm output, accumulation over several chunks."""

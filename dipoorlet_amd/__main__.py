@@ -123,8 +123,18 @@ def _main(argv=None):
         # the HIP context and the libraries' first calls: on a helper thread from here on, beside the model load and the
         # session build (executor.warm_libraries; its own clock reports the context's seconds)
         from . import executor
-        executor.warm_libraries(torch.device("cuda", rank % max(1, torch.cuda.device_count())), blas=False)
+        dev0 = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
+        executor.warm_libraries(dev0, blas=False)
         warm = executor._WARM
+        try:    # the op types of the model file, without its tensors (milliseconds): a transformer's matrix products go to the BLAS
+            # library, whose first call (0.2 s) then starts now, beside the model load.  (A convolutional network's one or two run
+            # on ops.gemm_small; the session starts this thread if they turn out not to.)
+            from . import onnx_io
+            ops_seen = onnx_io.scan_op_types(args.model)
+            if ops_seen.get("MatMul", 0) + ops_seen.get("Gemm", 0) > 4:
+                executor.warm_blas(dev0)
+        except Exception:   # noqa: BLE001  (best effort: the load below reports what is wrong with the file)
+            pass
     t_ctx = time.time()
     if args.output_dir is None:
         args.output_dir = os.path.join(os.path.abspath(os.path.dirname(args.model)), "results")
@@ -141,10 +151,6 @@ def _main(argv=None):
         n_folded = onnx_graph.fold_batchnorm()
         if n_folded and rank == 0:
             logger.info("Folded {} BatchNormalization nodes into their producers.".format(n_folded))
-    if warm is not None and sum(n.op_type in ("MatMul", "Gemm") for n in onnx_graph.graph.node) > 4:
-        # a transformer: its matrix products go to the BLAS library, whose first call (0.2 s) starts now, beside the session build.
-        # (A convolutional network's one or two run on ops.gemm_small; the session starts this thread if they turn out not to.)
-        executor.warm_blas(torch.device("cuda", rank % max(1, torch.cuda.device_count())))
     args.rank, args.world_size = rank, world
     args.local_rank = rank % max(1, torch.cuda.device_count())
     if rank == 0:

@@ -603,11 +603,13 @@ class GraphSession(ActivationSession):
             uploaded = True
             self._fold_weights(fold)
             self._infer()
+        mark("session:shapes_known")
         if first_batch is not None and self.device.type == "cuda":
             nb = int(first_batch(self))
             if self.needs_blas(nb):
                 warm_blas(self.device)
             self.prewarm_convs(nb)
+            mark("session:conv_threads_started")
         if not uploaded:
             with _wall("session_consts_s"):
                 self._upload_consts()

@@ -375,3 +375,16 @@ def test_session_knows_whether_a_forward_needs_the_blas_library():
     assert small_gemm(64, 1000, 2048) and not small_gemm(64 * 197, 3072, 768)
     v = GraphSession(models.vit(depth=2, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10), device="cpu")
     assert v.needs_blas(1)
+
+
+
+def test_scan_op_types_reads_no_tensors(tmp_path):
+    """onnx_io.scan_op_types: the op types of a model file counted from the mapped file, tensors stepped over — the same counts as a
+    full load gives."""
+    from collections import Counter
+    from dipoorlet_amd import models, onnx_io
+    for g, name in ((models.resnet18(), "r18"), (models.vit(depth=2, dim=64, heads=4, mlp=128, image=32, patch=8, num_classes=10), "vit")):
+        g.output_dir = str(tmp_path)
+        g.save_onnx_model(name)
+        path = os.path.join(str(tmp_path), name + ".onnx")
+        assert onnx_io.scan_op_types(path) == dict(Counter(n.op_type for n in onnx_io.load_model(path).nodes))

@@ -781,17 +781,18 @@ class GraphSession(ActivationSession):
                 continue
             key = (tuple(shp), tuple(w), tuple(node.attrs.get("strides", ())), tuple(node.attrs.get("pads", ())),
                    tuple(node.attrs.get("dilations", ())), int(node.attrs.get("group", 1)), node.attrs.get("auto_pad", ""), len(node.input))
-            if key not in seen:
+            rest = [self._any_shape(i, 1) for i in node.input[1:] if i != ""]
+            if key not in seen and all(r is not None for r in rest):
                 seen.add(key)
-                todo.append((node, (batch,) + tuple(shp[1:])))
+                todo.append((node, (batch,) + tuple(shp[1:]), rest))
         todo.reverse()
 
         def work(part):
             try:
                 torch.cuda.set_device(self.device)
                 with torch.no_grad(), torch.cuda.stream(torch.cuda.Stream(self.device)):
-                    for node, shape in part:      # (zero weights of the right shapes: the solver is chosen by the configuration)
-                        args = [torch.zeros(self._any_shape(i, 1), device=self.device) for i in node.input[1:] if i != ""]
+                    for node, shape, rest in part:      # (zero weights of the right shapes: the solver is chosen by the configuration)
+                        args = [torch.zeros(r, device=self.device) for r in rest]
                         _OPS["Conv"](self, node, torch.zeros(shape, device=self.device), *args)
                     torch.cuda.current_stream(self.device).synchronize()
             except Exception:   # noqa: BLE001  (best effort)

@@ -1229,9 +1229,8 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
     if (n_items <= 0 || n_pairs <= 0) return 0;
     if (int e = check_blocks("dpl_octav_run_bracket", n_items, d_block_begin, n_blocks)) return e;
     hipStream_t st = (hipStream_t)s;
-    const dim3 ug(grid_for(n_pairs, 256)), ub(256), pg((unsigned)n_blocks), pb(kBlock), pairs((unsigned)n_pairs);
+    const dim3 pg((unsigned)n_blocks), pb(kBlock), pairs((unsigned)n_pairs);
     dpl_octav_state* ctl = d_states + n_pairs;
-    const size_t stage_bytes = (size_t)(kBlock / kWave) * kStageCap * sizeof(float);
     hipError_t e1 = hipMemsetAsync(d_lh_cnt, 0, (size_t)n_pairs * kLogNB * sizeof(uint32_t), st);
     hipError_t e2 = hipMemsetAsync(d_lh_sum, 0, (size_t)n_pairs * kLogNB * sizeof(uint64_t), st);
     if (e1 != hipSuccess || e2 != hipSuccess) return fail("hipMemsetAsync", e1 != hipSuccess ? e1 : e2);

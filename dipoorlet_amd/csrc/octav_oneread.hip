@@ -185,10 +185,6 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
-__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {   // per-lane values below 2^56
-    const uint32_t lo = wave_sum_dpp((uint32_t)v & 0xFFFFFFu), hi = wave_sum_dpp((uint32_t)(v >> 24));
-    return (unsigned long long)lo + ((unsigned long long)hi << 24);
-}
 
 // The RESCUE walk of one pair (one workgroup; phase 2 of rounds 3 - 4's walk_pair, which also served the forms that round 5
 // removed): a pair whose exact-tail walk was refused restarts from s_0 and walks the reference's WHOLE iterate sequence

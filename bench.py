@@ -770,6 +770,13 @@ def main():
                                    "numpy_1_thread": round(cb["numpy_single_thread_images_per_s"], 2)}
         else:
             out["cpu_baseline"] = None
+        # RCCL prints a version banner through C stdio, which — stdout being a pipe — would leave its buffer only at exit, BEHIND the
+        # record line: flush C's buffers first so that the record line stays the last line of stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
         print(json.dumps({"details": full}), flush=True)
         line = json.dumps(out)
         # (the driver keeps the last 2 000 characters of stdout as `tail`: should the line ever outgrow that, the side objects go
@@ -782,6 +789,11 @@ def main():
         print(line, flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank != 0:          # (only rank 0's stdout carries lines; nothing a library still holds may follow them on the others' either)
+        try:
+            sys.stdout.flush()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 if __name__ == "__main__":

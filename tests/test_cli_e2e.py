@@ -380,8 +380,9 @@ def test_session_warms_up_for_the_callers_first_batch(workdir):
     assert asked == [(len(plain.tensor_names), 0)] and warm._prewarmed
     assert MARKS["session:conv_threads_started"] <= MARKS["session:consts_issued"]
     x = {n: torch.randn([4] + [int(d) for d in g.get_tensor_shape(n)[1:]], device="cuda") for n in plain.input_names}
-    for a, b in zip(plain.run(x), warm.run(x)):
-        assert torch.equal(a, b)
+    def same(u, v):     # (MIOpen's convolutions are not bit-reproducible from call to call: 2e-6 between two runs of ONE session)
+        return all(torch.allclose(a, b, rtol=1e-4, atol=1e-5 * max(1.0, float(a.abs().max()))) for a, b in zip(u, v))
+    assert same(plain.run(x), warm.run(x))
     executor.join_helpers()
     clip = {n: [-3.0, 3.0] for n in plain.tensor_names}
     from dipoorlet_amd.tensor_cali import find_clip_val_minmax_weight
@@ -389,6 +390,5 @@ def test_session_warms_up_for_the_callers_first_batch(workdir):
     gq, _ = quant_graph(g, clip, types.SimpleNamespace(deploy="trt", skip_layers=[]))
     q1, q2 = gq.make_session(), gq.make_session(first_batch=lambda s: 4)
     assert q2._prewarmed and q2._folded == q1._folded and len(q2._folded) > 0
-    for a, b in zip(q1.run(x), q2.run(x)):
-        assert torch.equal(a, b)
+    assert same(q1.run(x), q2.run(x))
     executor.join_helpers()

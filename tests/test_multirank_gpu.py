@@ -82,6 +82,84 @@ def test_bench_two_ranks_on_one_gpu():
     assert line["roofline"]["mse"]["ok"] is True and line["value"] > 0
 
 
+def test_bench_one_rank_over_rccl():
+    """RCCL for real, as far as one GPU allows: `bench.py` as ONE rank of a torch.distributed.run-style launch with backend
+    'nccl' — communicator set-up on the device, the barriers, the merge collectives of the hist sweep (min / max as encoded
+    uint32 -> int64, int64 histograms) and of the mse sweep (all_gather of the [n, T, 3] rows), the max-over-ranks timing on a
+    device tensor: every dtype / reduce-op pair the N = 2 / 4 / 8 runs hand to RCCL goes through its API here."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.pop("DPL_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--mse-steps", "1",
+                        "--e2e-images", "0", "--vit-images", "0", "--real-images", "0", "--fq-reps", "0", "--mse-jitter", "", "--pool", "5",
+                        "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])       # (RCCL's version banner must not end up behind the record line)
+    assert line["config"]["backend"] == "nccl (RCCL)" and line["config"]["world_size_seen_by_backend"] == 1
+    assert line["config"]["hist_checksum_ok"] is True and line["roofline"]["mse"]["ok"] is True and line["value"] > 0
+
+
+def _rccl_worker(rank, port):
+    """Every collective the path hands to the backend, through RCCL itself on a one-rank group (the merge functions are called
+    with world_size = 2 so that they do not short-circuit: over one rank every reduction returns its input)."""
+    import torch.distributed as dist
+    from dipoorlet_amd import dist_helper
+    from dipoorlet_amd.weight_transform.bias_correction import _channel_mean_diff
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    # running min / max with a NaN tensor: fp32 MIN / MAX + int32 MAX (dist_helper.merge_ranges)
+    gmin = torch.tensor([-1.5, float("nan"), 2.0, -0.0], device=dev)
+    gmax = torch.tensor([3.0, 1.0, 2.0, float("inf")], device=dev)
+    lo, hi = dist_helper.merge_ranges(gmin.clone(), gmax.clone(), 2)
+    assert torch.equal(torch.isnan(lo), torch.tensor([False, True, False, False], device=dev)) and torch.isnan(hi[1])
+    assert lo[0] == -1.5 and hi[0] == 3.0 and hi[3] == float("inf")
+    # histograms: int64 SUM, counts above 2^31
+    hist = torch.randint(0, 1 << 40, (123, 2048), dtype=torch.int64, device=dev, generator=g)
+    assert torch.equal(dist_helper.merge_hist(hist.clone(), 2), hist)
+    # OCTAV rows: the fused all-gather and the list form gather_rows falls back to
+    rows = torch.randn(5, 123, 3, device=dev, generator=g)
+    out = torch.empty_like(rows)
+    dist.all_gather_into_tensor(out, rows)
+    parts = [torch.empty_like(rows)]
+    dist.all_gather(parts, rows)
+    assert torch.equal(out, rows) and torch.equal(parts[0], rows) and torch.equal(dist_helper.gather_rows(rows, 1), rows)
+    # --bc: one fp64 SUM of [C + 1] per node (Conv and Gemm outputs)
+    for shape, is_conv in (((4, 16, 7, 7), True), ((4, 10), False)):
+        fp = [torch.randn(shape, device=dev, generator=g) for _ in range(2)]
+        q = [x + 0.01 * torch.randn(shape, device=dev, generator=g) for x in fp]
+        one = _channel_mean_diff(fp, q, is_conv)
+        merged = _channel_mean_diff(fp, q, is_conv, world_size=2, n_ch=shape[1])
+        assert torch.equal(one, merged)
+    # bench.py's timing exchange: fp64 MAX and a gather of per-rank rates on device tensors, between two barriers
+    dist.barrier()
+    t = torch.tensor([1.25], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rates = [torch.zeros(1, dtype=torch.float64, device=dev)]
+    dist.all_gather(rates, t)
+    dist.barrier()
+    torch.cuda.synchronize()
+    assert t.item() == 1.25 and rates[0].item() == 1.25
+    dist.destroy_process_group()
+
+
+def test_every_collective_of_the_path_through_rccl():
+    """No node with more than one GPU was ever available to the rounds: RCCL has never run at N > 1.  What one GPU can prove is
+    that RCCL accepts every (dtype, reduce-op) pair and gather form the path uses — fp32 MIN / MAX, int32 MAX, int64 SUM, fp64
+    SUM / MAX, all_gather_into_tensor, list all_gather, barrier — on device tensors, in this image, with the IPC mode the pool
+    needs (_rccl_worker: a one-rank 'nccl' group)."""
+    port = 29100 + os.getpid() % 200
+    mp.spawn(_rccl_worker, args=(port,), nprocs=1, join=True)
+
+
 def _bc_worker(rank, world, port, model, calib, out_dir, n, clips_from=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       DPL_DIST_BACKEND="gloo")

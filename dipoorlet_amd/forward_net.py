@@ -389,9 +389,11 @@ def hist_pass(run, gmin, gmax, bins):
     return acc
 
 
-def forward_net_octav(onnx_graph, args, run=None):
+def forward_net_octav(onnx_graph, args, run=None, as_dict=True):
     """forward_net.py:284-342 — {name: {'optimal_s': [...], 'min': [...], 'max': [...]}}, one entry per
-    image of the shard."""
+    image of the shard.  as_dict=False: the rows stay on the device (run.octav_rows, [n, T, 3]) and nothing is returned — the
+    reference's dictionary is 3 T n Python floats, 10 ms of host work per thousand ResNet-50 images that find_clip_val_octav, which
+    reads the rows, has no use for."""
     run = _run_of(onnx_graph, args, run)
     dynamic_sym = "dynamic_sym" in platform_setting_table[args.deploy]["qi_params"]
     rows = []
@@ -408,6 +410,8 @@ def forward_net_octav(onnx_graph, args, run=None):
     run._events["statistics"] += pipe.events
     WALL["pass1_loop_s"] = WALL.get("pass1_loop_s", 0.0) + __import__("time").perf_counter() - t_loop
     run.octav_rows = torch.cat(rows) if rows else torch.zeros(0, run.T, 3, device=run.device)
+    if not as_dict:
+        return None
     with wall("results_to_host_s"):
         r = _np32(run.octav_rows)
     return {n: {"optimal_s": list(r[:, t, 0]), "min": list(r[:, t, 1]), "max": list(r[:, t, 2])}

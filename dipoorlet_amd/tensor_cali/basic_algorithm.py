@@ -85,17 +85,20 @@ def find_clip_val_octav(onnx_graph, args, run=None, **kwargs):
     The mean is taken with numpy in fp32 over the per-image list exactly as the reference does, so it is
     reproduced bit for bit given the per-image scales (python max/min: a NaN mean falls back to the range)."""
     run = run or CalibrationRun(onnx_graph, args)
-    forward_net_octav(onnx_graph, args, run=run)
+    forward_net_octav(onnx_graph, args, run=run, as_dict=False)
     rows = run.octav_rows
     if _merged(args):
         rows = gather_rows(rows, args.world_size)
     r = rows.detach().cpu().numpy().astype(np.float32, copy=False)
+    # [3, T, n] contiguous: row [k, t] is what the reference's np.array(list_of_per_image_values) holds — a contiguous fp32
+    # vector in image order — so numpy's mean / max / min over it are the reference's, bit for bit
+    cols = np.ascontiguousarray(r.transpose(2, 1, 0))
     clip_val = {}
     for t, name in enumerate(run.names):
         with np.errstate(all="ignore"):
-            mean_s = np.array(list(r[:, t, 0])).mean()
-        data_max = np.array(list(r[:, t, 2])).max()
-        data_min = np.array(list(r[:, t, 1])).min()
+            mean_s = cols[0, t].mean()
+        data_max = cols[2, t].max()
+        data_min = cols[1, t].min()
         clip_val[name] = [max(data_min, -mean_s), min(data_max, mean_s)]
     return clip_val
 

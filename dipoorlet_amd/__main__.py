@@ -30,7 +30,9 @@ def build_parser():
     for flag in ("--we", "--bc", "--update_bn", "--adaround", "--brecq", "--drop", "--savefp", "--stpu_wg",
                  "--skip_prof_layer", "--slurm", "--mpirun", "--sparse", "--optim_transformer"):
         p.add_argument(flag, default=False, action="store_true")
-    p.add_argument("-A", "--act_quant", choices=["minmax", "hist", "mse"], default="mse")
+    p.add_argument("-A", "--act_quant", choices=["minmax", "hist", "mse"], default="mse",
+                   help="minmax / hist: bit-exact clip ranges; mse (OCTAV): within 1e-5 * max(1, |ref|) of the reference's, repeating "
+                        "to about 1e-6 relative from run to run (DPL_OCTAV_FORM=bracket: the bit-stable two-read form)")
     p.add_argument("-D", "--deploy", choices=["trt", "stpu", "magicmind", "rv", "atlas", "snpe", "ti", "imx"],
                    required=True)
     p.add_argument("--bins", default=2048, type=int)  # the reference omits type= and crashes on a CLI value

@@ -404,6 +404,11 @@ def octav_batch(plan, tensors, dynamic_sym, states=None, compact=None, form=None
       'compact'            evaluation at s_0 + tail compaction, then per-pair iteration over shrinking lists
       'full'               every evaluation re-reads the full data (21 passes)
     `compact=True/False` is the older spelling of 'compact' / 'full'.  DPL_OCTAV_FORM overrides the default.
+    Tolerance: every form is within 1e-5 * max(1, |ref|) of the reference's optimal_s (the tests' bound; the reference's own stop
+    rule is an absolute 1e-6); min / max are exact.  'tail' repeats to about 1e-6 relative from run to run, not bit for bit — the
+    threshold history and wave timing decide which early iterates are taken as bounds, and with them the iterate on which
+    |s' - s| < 1e-6 fires — while 'bracket' walks the reference's whole iterate sequence over exact integer sums and is bit-stable
+    (the exact fall-back, and the reference point of the golden tests).
     states (optional): a uint8 device buffer of (B * T + 1) * 80 bytes that receives the pairs' states and the control block."""
     if form is None:
         form = ("compact" if compact else "full") if compact is not None else _default_form()

@@ -319,7 +319,7 @@ def _gmp(s, node, x):
 
 
 def small_gemm(m, n, k, *tensors):
-    """Does a product of these sizes run on ops.gemm_small (the library's own kernel: no BLAS library to load) rather than
+    """Does a product of these sizes run on ops.gemm_small (the library's own kernel: torch's BLAS path — hipBLASLt — is not initialised for it) rather than
     hipBLASLt?  The classifier head of a convolutional network does; a transformer's products do not, nor does a product that
     autograd has to see (AdaRound / BRECQ reconstruct a Gemm layer through this executor).  DPL_GEMM_SMALL=0: never."""
     from .ops import GEMM_SMALL_MAX

@@ -828,7 +828,7 @@ GEMM_SMALL_MAX = 1 << 28      # DPL_GEMM_SMALL_MAX (include/dipoorlet_hip.h)
 
 def gemm_small(a, b, bias=None, alpha=1.0, beta=1.0):
     """alpha * a @ b + beta * bias through dpl_gemm_small (csrc/gemm_small.hip: the classifier head of a convolutional network,
-    so that a calibration run of one needs no BLAS library).  a: [M, K] fp32 contiguous; b: [K, N] fp32, any strides (a transposed
+    so that a calibration run of one never initialises torch's BLAS path).  a: [M, K] fp32 contiguous; b: [K, N] fp32, any strides (a transposed
     view of an [N, K] weight is what an ONNX Gemm with transB = 1 gives); bias: None, [N], [1, N], [M, 1] or [M, N].
     M * N * K <= GEMM_SMALL_MAX."""
     for t, name in ((a, "a"), (b, "b")) + (((bias, "bias"),) if bias is not None else ()):

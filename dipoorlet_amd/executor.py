@@ -112,6 +112,10 @@ def join_helpers(timeout=10.0):
     _HELPERS.clear()
 
 
+import atexit  # noqa: E402
+atexit.register(join_helpers)     # (any process that started helper threads — a script, a test — leaves only after them)
+
+
 def wait_warm(name):
     t = _WARM.get(name)
     if t is not None and t is not True:

@@ -120,6 +120,10 @@ def _main(argv=None):
     mark("main:group_and_device")
     rank, world = dist.get_rank(), dist.get_world_size()
     import torch
+    if os.environ.get("DPL_DETERMINISTIC") == "1":
+        # MIOpen's default convolution kernels are not bit-reproducible from call to call (1e-6 relative on an activation): a run
+        # that has to repeat bit for bit asks the library for its deterministic algorithms (slower; the first use compiles them)
+        torch.backends.cudnn.deterministic = True
     warm = None
     if torch.cuda.is_available():
         # the HIP context and the libraries' first calls: on a helper thread from here on, beside the model load and the

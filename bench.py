@@ -562,12 +562,28 @@ def main():
                 _ex._OPS["FakeQuant"] = orig
             ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / a.fq_reps
             fwd_ms = f0.elapsed_time(f1) / a.fq_reps
+            # what an (e0, e1) pair measures with NOTHING between the two records, on a stream that is kept busy the same way: the
+            # events' own packets — reported beside the raw figure, never subtracted from it
+            empty = []
+            big = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            for _ in range(64):
+                big.add_(1.0)                              # (1 GB read + written: the stream stays busy)
+                p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                p0.record()
+                p1.record()
+                empty.append((p0, p1))
+            torch.cuda.synchronize()
+            pair_us = 1e3 * sorted(p0.elapsed_time(p1) for p0, p1 in empty)[len(empty) // 2]
+            del big
             nbytes = 8 * sum(n for _, _, n in evs) / a.fq_reps
             # (a Q/DQ node of this forward moves 106 MB on average: 18 us at 6 TB/s + the 2 - 3 us any launch takes to fill and
             # drain the chip; the nodes are a chain — conv, relu, Q/DQ, conv — so they cannot share a launch)
             fq["product_forward"] = {"batch": _PB, "nodes": len(evs) // a.fq_reps, "bytes": nbytes, "ms": ms,
                                      "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                     "forward_ms": fwd_ms, "share_of_the_quantised_forward": ms / fwd_ms}
+                                     "forward_ms": fwd_ms, "share_of_the_quantised_forward": ms / fwd_ms,
+                                     # (the kernels' own durations, rocprofv3 --kernel-trace over the same forward: 17.7 us per node =
+                                     # 0.748 of 8 TB/s — scripts/fq_forward_prof.sh, profiles/r05/kernel_stats_fq_forward.md)
+                                     "empty_event_pair_us": pair_us}
             del sq, gq, gfp, xin
             torch.cuda.empty_cache()
         except Exception as e:   # noqa: BLE001  (a side object: the line goes out without it)

@@ -706,12 +706,15 @@ def main():
     hist_rate = images / dt_hist
     headline_mse = a.algo == "mse" and mse is not None
 
-    def brief(o):
-        """The scalars of an mse object the record must carry (the whole object goes to the `details` line)."""
+    def brief(o, short=False):
+        """The scalars of an mse object the record must carry (the whole object goes to the `details` line; short: the fraction,
+        the milliseconds and the spot check only)."""
         if not o:
             return None
         r, p = o["roofline"], o.get("prediction") or {}
         b = {"frac": round(r["frac"], 4), "ms": round(r["avg_batch_ms"], 4), "ok": o["sample_ok"]}
+        if short:
+            return b
         if r.get("traffic"):
             b["traffic_ratio"] = round(r["traffic"] / r["bytes_per_launch"], 4)
         if p:
@@ -735,7 +738,7 @@ def main():
     roof = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in (mse["roofline"] if headline_mse else hist_roof).items()}
     roof["mse"] = brief(mse)                                                     # BASELINE configs[2]: -A mse, N = 4096, images alike
     roof["mse_lanes1"] = brief(mse_lanes1)                                       # ... on one stream, as forward_net_octav schedules it
-    roof["mse_jitter"] = {k: brief(v) for k, v in mse_jitter.items()} or None    # ... with per-image contrast jitter
+    roof["mse_jitter"] = {k: brief(v, short=True) for k, v in mse_jitter.items()} or None    # ... with per-image contrast jitter
     roof["mse_feature_maps"] = {k: brief(v) for k, v in mse_real.items()} or None   # ... executor-produced ResNet-50 activations
     roof["mse_vit"] = brief(vit_mse)                                             # configs[4]'s workload on one GPU
     roof["mse_448"] = brief(mse_big)                                             # tensors above one OCTAV slice (ResNet-50 at 448 x 448)
@@ -746,6 +749,19 @@ def main():
         # the 4th: the Q/DQ nodes of a fake-quantised ResNet-50 forward through the product's executor (per tensor, -D trt)
         if "frac" in fake_quant.get("product_forward", {}):
             roof["fake_quant"]["product_forward"] = round(fake_quant["product_forward"]["frac"], 4)
+            # the same nodes by the KERNELS' durations (rocprofv3 kernel trace, scripts/fq_forward_prof.sh): quoted from the committed
+            # record while the kernel sources are the ones it was taken on (the live figure above brackets every node with HIP events)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "scripts"))
+                from summarize_prof import source_sha as _sha
+                with open(os.path.join(ROOT, "profiles", "r05", "fq_forward.json")) as f:
+                    _fq = json.load(f)
+                if _fq.get("source_sha") == _sha():
+                    roof["fake_quant"]["product_forward_kernel_trace"] = round(_fq["frac_of_8TBps"], 4)
+                    fake_quant["product_forward"]["kernel_trace"] = {"frac": _fq["frac_of_8TBps"], "us_per_forward": _fq["us_per_forward"],
+                                                                     "from": "profiles/r05/fq_forward.json"}
+            except Exception:   # noqa: BLE001
+                pass
     if e2e and "error" not in e2e:
         # per run: [images/s of calibration (fresh CLI process over .bin files), images/s of the network forward in steady state]
         def pair(o):

@@ -19,5 +19,11 @@ calls,total=int(c[2]),int(c[3])
 # 13 forwards ran the kernel (3 warm-up + 10 counted) + the clip pass has none: calls = 13 x nodes
 per_fwd_ns=total/(calls/nodes)
 print("k_fake_quant: %d calls, %.1f us per forward over %d nodes = %.2f us per node; %.3f GB per forward -> %.0f GB/s = %.3f of 8 TB/s"%(calls,per_fwd_ns/1e3,nodes,per_fwd_ns/1e3/nodes,nbytes/1e9,nbytes/per_fwd_ns,nbytes/per_fwd_ns/8000))
+import json, sys
+sys.path.insert(0, "scripts")
+from summarize_prof import source_sha
+json.dump({"source_sha": source_sha(), "kernel": "k_fake_quant", "calls": calls, "nodes_per_forward": nodes, "bytes_per_forward": nbytes,
+           "us_per_forward": per_fwd_ns / 1e3, "frac_of_8TBps": nbytes / per_fwd_ns / 8000,
+           "how": "rocprofv3 --kernel-trace --stats over scripts/fq_forward_run.py: total kernel duration / forwards"}, open("$OUT/fq_forward.json", "w"), indent=1)
 PY
 rm -rf $OUT/s

@@ -606,7 +606,7 @@ class GraphSession(ActivationSession):
                 self._upload_consts()
             uploaded = True
             self._fold_weights(fold)
-            self._infer()
+            self._infer(skip_host=True)
         mark("session:shapes_known")
         if first_batch is not None and self.device.type == "cuda":
             nb = int(first_batch(self))
@@ -713,14 +713,15 @@ class GraphSession(ActivationSession):
             t = torch.from_numpy(a.astype(np.float32)) if a.dtype == np.float16 else torch.from_numpy(a)
             self.consts[name] = _host_ints(t.to(self.device), t)
 
-    def _infer(self, host_only=False):
-        """(host_only: return False instead of running the device forward when the host rules do not cover the graph.)
+    def _infer(self, host_only=False, skip_host=False):
+        """(host_only: return False instead of running the device forward when the host rules do not cover the graph; skip_host:
+        the rules have been tried.)
         Every tensor's per-image shape (replaces onnx shape inference): on the host, shape_infer's rule per op — no device
         work (a batch-1 forward on zeros cost a fresh process 0.3 s: the libraries load and choose kernels for a batch size
         the run never uses).  A graph with an op that has no rule runs that batch-1 forward instead (DPL_INFER_DEVICE=1
         forces it)."""
         env = None
-        if os.environ.get("DPL_INFER_DEVICE", "0") != "1":
+        if os.environ.get("DPL_INFER_DEVICE", "0") != "1" and not skip_host:
             from . import shape_infer
             try:
                 with _wall("session_infer_host_s"):

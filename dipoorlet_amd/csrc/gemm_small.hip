@@ -12,8 +12,8 @@
 // One workgroup of 256 threads per 32 x 64 tile of C and per SPLIT of K (a 64 x 1000 result has 32 tiles: with one workgroup per
 // tile 224 of the 256 CUs idle and each tile pays 64 exposed load latencies — 200 us; K cut into 8 splits: 256 workgroups, 8
 // latencies each), K in steps of 32 through LDS; a thread owns 2 x 4 outputs.  Sums run over k in ascending order with one fused
-// multiply-add per term, the splits' partial sums are added in ascending order by a second kernel: the result depends on the
-// shapes only, not on the launch.
+// multiply-add per term, the splits' partial sums are added in ascending order by a second kernel, and the number of splits is a
+// function of N and K only: a row of C depends on that row of A and on B — not on the launch, not on M (the batch it came in).
 #include "common.hpp"
 #include <algorithm>
 
@@ -94,10 +94,11 @@ __global__ __launch_bounds__(kBlock) void k_gemm_small_sum(const float* __restri
     C[i] = v;
 }
 
-// splits of K: enough workgroups to fill the chip, at least 4 steps of kGK each
-int gemm_splits(int64_t m, int64_t n, int64_t k) {
-    int64_t tiles = ((m + kGM - 1) / kGM) * ((n + kGN - 1) / kGN);
-    int64_t want = tiles >= 256 ? 1 : (256 + tiles - 1) / tiles;
+// splits of K: enough workgroups to fill the chip when M is one row of tiles, at least 4 steps of kGK each — a function of N and K
+// ONLY, so that a row of C (an image's logits) is the same sum whatever batch the image came in
+int gemm_splits(int64_t n, int64_t k) {
+    int64_t tiles_n = (n + kGN - 1) / kGN;
+    int64_t want = tiles_n >= 256 ? 1 : (256 + tiles_n - 1) / tiles_n;
     int64_t most = k / (4 * kGK);
     return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(want, most), 64));
 }
@@ -106,7 +107,7 @@ int gemm_splits(int64_t m, int64_t n, int64_t k) {
 
 extern "C" uint64_t dpl_gemm_small_workspace(int64_t m, int64_t n, int64_t k) {
     if (m <= 0 || n <= 0 || k < 0) return 0;
-    int sp = gemm_splits(m, n, k);
+    int sp = gemm_splits(n, k);
     return sp > 1 ? (uint64_t)sp * (uint64_t)m * (uint64_t)n * sizeof(float) : 0;
 }
 
@@ -118,7 +119,7 @@ extern "C" int dpl_gemm_small(const float* d_a, const float* d_b, const float* d
     if (!d_c || (k > 0 && (!d_a || !d_b))) return fail_msg("dpl_gemm_small: null pointer");
     if ((uint64_t)m * (uint64_t)n * (uint64_t)(k ? k : 1) > DPL_GEMM_SMALL_MAX)
         return fail_msg("dpl_gemm_small: more than DPL_GEMM_SMALL_MAX multiply-adds (this is not a GEMM library: use hipBLASLt)");
-    int sp = gemm_splits(m, n, k);
+    int sp = gemm_splits(n, k);
     if (sp > 1 && !d_workspace) return fail_msg("dpl_gemm_small: this product needs dpl_gemm_small_workspace(m, n, k) bytes of workspace");
     int k_per = sp > 1 ? (int)((((k + sp - 1) / sp) + kGK - 1) / kGK * kGK) : (int)k;
     dim3 grid((unsigned)((n + kGN - 1) / kGN), (unsigned)((m + kGM - 1) / kGM), (unsigned)sp);

@@ -323,8 +323,8 @@ int dpl_channel_diff_sum(const float* d_a, const float* d_b, int64_t outer, int6
  * transB = 1 passes (1, k)); bias(m, n) = d_bias[m * bias_stride_m + n * bias_stride_n] or no bias (NULL).  Products of at most
  * DPL_GEMM_SMALL_MAX multiply-adds only (csrc/gemm_small.hip says why this exists and what it is not). */
 #define DPL_GEMM_SMALL_MAX (1ull << 28)
-/* A product with few tiles of C is cut along k (the partial sums are added in ascending order: the result depends on the shapes
- * only): d_workspace = dpl_gemm_small_workspace(m, n, k) bytes of device memory (0: none needed, NULL is fine). */
+/* A product with few column tiles of C is cut along k (the partial sums are added in ascending order; the number of cuts depends on
+ * n and k only, so a row of C is the same sum whatever m is): d_workspace = dpl_gemm_small_workspace(m, n, k) bytes of device memory (0: none needed, NULL is fine). */
 uint64_t dpl_gemm_small_workspace(int64_t m, int64_t n, int64_t k);
 int dpl_gemm_small(const float* d_a, const float* d_b, const float* d_bias, float* d_c, int64_t m, int64_t n, int64_t k,
                    int64_t b_stride_k, int64_t b_stride_n, int64_t bias_stride_m, int64_t bias_stride_n, float alpha, float beta,

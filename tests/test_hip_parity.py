@@ -505,7 +505,7 @@ def test_gemm_small(dev):
     """dpl_gemm_small (the classifier head of a convolutional network: csrc/gemm_small.hip) against numpy in fp64: ResNet-50's
     head at the default batch (a transposed VIEW of the [N, K] weight, as an ONNX Gemm with transB = 1 gives), sizes that are not
     multiples of the tile, every bias broadcast, alpha / beta, K = 0, K cut into 1 ... 64 splits (some of them empty); the result does not depend on the launch (bit-equal
-    repeats); a product above DPL_GEMM_SMALL_MAX is refused."""
+    repeats) nor a row on the batch it came in; a product above DPL_GEMM_SMALL_MAX is refused."""
     from dipoorlet_amd import _hip, ops
     rng = np.random.default_rng(61)
     for M, K, N, trans_b, bias_kind, alpha, beta in [(64, 2048, 1000, True, "n", 1.0, 1.0), (1, 1, 1, False, None, 1.0, 1.0),
@@ -528,6 +528,13 @@ def test_gemm_small(dev):
         assert got.shape == (M, N) and torch.equal(got, again)
         scale = np.sqrt(max(K, 1)) * abs(alpha) + abs(beta)
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=0, atol=2e-6 * scale * max(1.0, np.sqrt(K) / 8))
+    # a row of the result is the same sum whatever batch it came in (the number of splits of K depends on N and K only)
+    a = torch.randn(120, 2048, device=dev)
+    w = torch.randn(1000, 2048, device=dev)
+    c = torch.randn(1000, device=dev)
+    full = ops.gemm_small(a, w.t(), c)
+    for lo, hi in ((0, 1), (3, 7), (0, 64), (64, 120), (17, 50)):
+        assert torch.equal(ops.gemm_small(a[lo:hi], w.t(), c), full[lo:hi]), (lo, hi)
     big = torch.zeros(1 << 10, 1 << 10, device=dev)
     with pytest.raises(_hip.DipoorletHipError):
         ops.gemm_small(big, torch.zeros(1 << 10, 1 << 9, device=dev))        # 2^29 multiply-adds

@@ -10,10 +10,10 @@
 //
 // Shape of the work: M = batch (<= 64 by default), N = classes, K = features — 0.13 GFMA for ResNet-50, read-bound on B (8 MB).
 // One workgroup of 256 threads per 32 x 64 tile of C and per SPLIT of K (a 64 x 1000 result has 32 tiles: with one workgroup per
-// tile 224 of the 256 CUs idle and each tile pays 64 exposed load latencies — 200 us; K cut into 8 splits: 256 workgroups, 8
-// latencies each), K in steps of 32 through LDS; a thread owns 2 x 4 outputs.  Sums run over k in ascending order with one fused
-// multiply-add per term, the splits' partial sums are added in ascending order by a second kernel, and the number of splits is a
-// function of N and K only: a row of C depends on that row of A and on B — not on the launch, not on M (the batch it came in).
+// tile 224 of the 256 CUs idle and each tile pays 64 exposed load latencies — 200 us; K cut into 16 splits: 512 workgroups, 4
+// latencies each — 24 us), K in steps of 32 through LDS; a thread owns 2 x 4 outputs.  Sums run over k in ascending order with one
+// fused multiply-add per term, the splits' partial sums are added in ascending order by a second kernel, and the number of splits is
+// a function of N and K only: a row of C depends on that row of A and on B — not on the launch, not on M (the batch it came in).
 #include "common.hpp"
 #include <algorithm>
 

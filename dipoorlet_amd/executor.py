@@ -10,6 +10,7 @@ Batching: the reference feeds one image per forward (model input batch dim 1).  
 stacked on dim 0; Reshape targets and dim-0 broadcasts that were constant-folded for batch 1 are
 re-scaled to B.
 """
+import atexit
 import os
 
 import numpy as np
@@ -112,7 +113,6 @@ def join_helpers(timeout=10.0):
     _HELPERS.clear()
 
 
-import atexit  # noqa: E402
 atexit.register(join_helpers)     # (any process that started helper threads — a script, a test — leaves only after them)
 
 

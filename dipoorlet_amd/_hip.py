@@ -117,6 +117,7 @@ SIGNATURES = {
     "dpl_octav_finalize": (C.c_int, [_P, _I64, _P, _P]),
     "dpl_rowwise_minmax": (C.c_int, [_P, _I64, _I64, _P, _P, _P]),
     "dpl_fake_quant": (C.c_int, [_P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    "dpl_fake_quant_pre": (C.c_int, [_I32, _P, _P, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     "dpl_fake_quant_items": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _P, _P]),
     "dpl_cos_accumulate": (C.c_int, [_P, _P, _I64, _P, _I64, _P]),
     "dpl_channel_diff_sum": (C.c_int, [_P, _P, _I64, _I64, _I64, _P, _P]),

@@ -360,27 +360,41 @@ __device__ __forceinline__ float fq_one(float x, float scale, float zp, float ql
     return __fmul_rn(__fsub_rn(q, zp), scale);
 }
 
+// What the producer of a fake-quantised tensor would have written, applied on the way in (the reference's merge-ReLU rule puts
+// most activation Q/DQ pairs directly behind a ReLU, quantize.py:50-55): kFqPreNone x; kFqPreRelu torch.relu(x) = np.maximum(x, 0)
+// (NaN stays NaN; -0 and +0 quantise alike); kFqPreAddRelu relu(x + x2), the residual Add of a bottleneck and its ReLU (one fp32
+// addition, rounded to nearest, as torch.add).
+enum { kFqPreNone = 0, kFqPreRelu = 1, kFqPreAddRelu = 2 };
+template <int PRE>
+__device__ __forceinline__ float fq_pre(float x, float x2) {
+    if (PRE == kFqPreAddRelu) x = __fadd_rn(x, x2);
+    if (PRE != kFqPreNone) x = x < 0.f ? 0.f : x;
+    return x;
+}
+
 // One workgroup fake-quantises elements [e0, e0 + cnt) of a tensor viewed as [outer, n_channels, inner] (n_channels == 1: per
 // tensor).  A CONTIGUOUS chunk per workgroup (few large equal shares stream faster from HBM than a grid-stride walk), four
 // 16-byte vectors per lane in flight, non-temporal loads and stores (each byte is touched once).  The channel of a vector needs no
 // division in the loop: a lane's (column, channel) advance by a constant per step — 1024 elements = (1024 / inner) rows and
 // (1024 % inner) columns, both computed once per chunk on the scalar unit — with one conditional wrap each.
-__device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __restrict__ y, uint64_t e0, uint32_t cnt,
-                                        const float* __restrict__ scale_p, const int32_t* __restrict__ zp_p, uint32_t n_channels,
-                                        uint32_t inner, float qlo, float qhi) {
+template <int PRE>
+__device__ __forceinline__ void fq_span(const float* __restrict__ x, const float* __restrict__ x2, float* __restrict__ y, uint64_t e0,
+                                        uint32_t cnt, const float* __restrict__ scale_p, const int32_t* __restrict__ zp_p,
+                                        uint32_t n_channels, uint32_t inner, float qlo, float qhi) {
     typedef __attribute__((address_space(1))) f4* gptr_f4w;
     const uint32_t tid = threadIdx.x;
     const float* xs = x + e0;
+    const float* x2s = PRE == kFqPreAddRelu ? x2 + e0 : xs;
     float* ys = y + e0;
     // 16-byte vectors whatever the rows' length: a vector of a row that is no multiple of four long (7 x 7 maps: 49) may straddle two
     // channels — it carries the parameters of both and picks per element (rows shorter than a vector: element by element)
-    const bool vec = ((((uintptr_t)xs | (uintptr_t)ys) & 15u) == 0u) && (n_channels == 1u || inner >= 4u);
+    const bool vec = ((((uintptr_t)xs | (uintptr_t)x2s | (uintptr_t)ys) & 15u) == 0u) && (n_channels == 1u || inner >= 4u);
     if (!vec) {   // unaligned views / rows shorter than a vector: element by element, same bookkeeping
         const uint64_t e = e0 + tid;
         uint32_t col = (uint32_t)(e % inner), c = (uint32_t)((e / inner) % n_channels);
         const uint32_t step_cols = (uint32_t)kBlock % inner, step_ch = ((uint32_t)kBlock / inner) % n_channels;
         for (uint32_t i = tid; i < cnt; i += kBlock) {
-            ys[i] = fq_one(xs[i], scale_p[c], (float)zp_p[c], qlo, qhi);
+            ys[i] = fq_one(fq_pre<PRE>(xs[i], x2s[i]), scale_p[c], (float)zp_p[c], qlo, qhi);
             col += step_cols;
             c += step_ch;
             if (col >= inner) {
@@ -393,6 +407,7 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
     }
     const uint32_t nvec = cnt >> 2;
     gptr_f4 xv = (gptr_f4)xs;
+    gptr_f4 x2v = (gptr_f4)x2s;
     gptr_f4w yv = (gptr_f4w)ys;
     // Two register sets in rotation (as stream_span): the NEXT four vectors of a lane — and, per channel, their parameters — are
     // requested before the current four are computed and stored: eight loads in flight per lane, and a parameter look-up never
@@ -410,6 +425,7 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
     const bool straddle = per_channel && (inner & 3u) != 0u;   // (uniform) a vector may end in the next channel's row
     struct Set {
         f4 v[4];
+        f4 w[PRE == kFqPreAddRelu ? 4 : 1];   // the second operand of the residual Add
         float sc[4], sc2[4];
         int32_t zp[4], zp2[4];
         uint32_t left[4];   // elements of the vector that still belong to the first channel's row (>= 4: all of them)
@@ -418,6 +434,9 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             st.v[u] = i0 + u * kBlock < nvec ? __builtin_nontemporal_load(xv + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
+            if (PRE == kFqPreAddRelu)
+                st.w[PRE == kFqPreAddRelu ? u : 0] =
+                    i0 + u * kBlock < nvec ? __builtin_nontemporal_load(x2v + i0 + u * kBlock) : f4{0.f, 0.f, 0.f, 0.f};
             if (per_channel) {   // (uniform)
                 st.sc[u] = scale_p[c];
                 st.zp[u] = zp_p[c];
@@ -442,6 +461,13 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
         for (int u = 0; u < 4; ++u) {
             if (i0 + u * kBlock < nvec) {
                 const float sc = per_channel ? st.sc[u] : sc1, zp = per_channel ? (float)st.zp[u] : zp1;
+                if (PRE != kFqPreNone) {
+                    const f4 w = st.w[PRE == kFqPreAddRelu ? u : 0];
+                    st.v[u].x = fq_pre<PRE>(st.v[u].x, w.x);
+                    st.v[u].y = fq_pre<PRE>(st.v[u].y, w.y);
+                    st.v[u].z = fq_pre<PRE>(st.v[u].z, w.z);
+                    st.v[u].w = fq_pre<PRE>(st.v[u].w, w.w);
+                }
                 if (straddle) {   // (uniform)
                     const float scb = st.sc2[u], zpb = (float)st.zp2[u];
                     const uint32_t l = st.left[u];
@@ -481,18 +507,21 @@ __device__ __forceinline__ void fq_span(const float* __restrict__ x, float* __re
     const uint32_t t = (nvec << 2) + tid;   // (a chunk that is no multiple of four long: the tensor's last elements)
     if (t < cnt) {
         const uint32_t c = n_channels == 1u ? 0u : (uint32_t)(((e0 + t) / inner) % n_channels);
-        ys[t] = fq_one(xs[t], scale_p[c], (float)zp_p[c], qlo, qhi);
+        ys[t] = fq_one(fq_pre<PRE>(xs[t], x2s[t]), scale_p[c], (float)zp_p[c], qlo, qhi);
     }
 }
 
 // one tensor: workgroup b takes elements [b * chunk, (b + 1) * chunk) (chunk a multiple of 1024)
-__global__ __launch_bounds__(kBlock) void k_fake_quant(const float* __restrict__ x, float* __restrict__ y, uint64_t n, uint64_t chunk,
-                                                        const float* __restrict__ scale_p, const int32_t* __restrict__ zp_p,
-                                                        uint32_t n_channels, uint32_t inner, float qlo, float qhi) {
+// (PRE: the producer's ReLU / Add + ReLU on the way in, fq_pre; x2 is read for kFqPreAddRelu only)
+template <int PRE>
+__global__ __launch_bounds__(kBlock) void k_fake_quant(const float* __restrict__ x, const float* __restrict__ x2, float* __restrict__ y,
+                                                        uint64_t n, uint64_t chunk, const float* __restrict__ scale_p,
+                                                        const int32_t* __restrict__ zp_p, uint32_t n_channels, uint32_t inner, float qlo,
+                                                        float qhi) {
     const uint64_t e0 = (uint64_t)blockIdx.x * chunk;
     if (e0 >= n) return;
     const uint64_t cnt = n - e0 < chunk ? n - e0 : chunk;
-    fq_span(x, y, e0, (uint32_t)cnt, scale_p, zp_p, n_channels, inner, qlo, qhi);
+    fq_span<PRE>(x, x2, y, e0, (uint32_t)cnt, scale_p, zp_p, n_channels, inner, qlo, qhi);
 }
 
 // a whole tensor set in ONE launch: the balanced partition's items (item.seg = tensor, item.offset / count = the elements) over
@@ -505,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void k_fake_quant_items(const dpl_work_item
     for (uint32_t k = k0; k < k1; ++k) {
         const dpl_work_item it = items[k];
         const dpl_fake_quant_params p = prm[it.seg];
-        fq_span(seg_x[it.seg], seg_y[it.seg], it.offset, it.count, p.d_scale, p.d_zero_point, (uint32_t)p.n_channels, (uint32_t)p.inner,
+        fq_span<kFqPreNone>(seg_x[it.seg], nullptr, seg_y[it.seg], it.offset, it.count, p.d_scale, p.d_zero_point, (uint32_t)p.n_channels, (uint32_t)p.inner,
                 (float)p.qlo, (float)p.qhi);
     }
 }
@@ -881,9 +910,17 @@ int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_mi
 
 int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
                    int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s) {
+    return dpl_fake_quant_pre(DPL_FQ_PRE_NONE, d_x, nullptr, d_y, n, d_scale, d_zp, n_channels, inner, qlo, qhi, s);
+}
+
+int dpl_fake_quant_pre(int32_t pre, const float* d_x, const float* d_x2, float* d_y, int64_t n, const float* d_scale,
+                       const int32_t* d_zp, int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s) {
+    if (pre != DPL_FQ_PRE_NONE && pre != DPL_FQ_PRE_RELU && pre != DPL_FQ_PRE_ADD_RELU)
+        return fail_msg("dpl_fake_quant_pre: pre must be DPL_FQ_PRE_NONE, _RELU or _ADD_RELU");
     if (n <= 0) return 0;
+    if (pre == DPL_FQ_PRE_ADD_RELU && d_x2 == nullptr) return fail_msg("dpl_fake_quant_pre: DPL_FQ_PRE_ADD_RELU needs d_x2");
     if (n_channels < 1 || inner < 1 || n_channels > 0xFFFFFFFFll || inner > 0xFFFFFFFFll)
-        return fail_msg("dpl_fake_quant: n_channels and inner must be in [1, 2^32)");
+        return fail_msg("dpl_fake_quant_pre: n_channels and inner must be in [1, 2^32)");
     // A contiguous chunk of 3072 elements (12 KiB read + 12 KiB written) per workgroup, whatever the tensor's size (a multiple of
     // 1024 elements: every chunk starts on a 16-byte boundary of an aligned tensor).  Measured on the tensors a fake-quantised
     // ResNet-50 forward at batch 64 runs this on (26 - 205 MB, distinct buffers in rotation, scripts/fq_blocks_ab.py), fraction of
@@ -900,9 +937,14 @@ int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale
     if ((n + chunk - 1) / chunk > 0x40000000ll) chunk = ((n + 0x3FFFFFFFll) / 0x40000000ll + 1023) / 1024 * 1024;
     if (chunk > 0xFFFFFC00ll) chunk = 0xFFFFFC00ll;
     const int64_t blocks = (n + chunk - 1) / chunk;
-    if (blocks > 0x7FFFFFFFll) return fail_msg("dpl_fake_quant: tensor too large");
-    hipLaunchKernelGGL(k_fake_quant, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_y, (uint64_t)n, (uint64_t)chunk,
-                       d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo, (float)qhi);
+    if (blocks > 0x7FFFFFFFll) return fail_msg("dpl_fake_quant_pre: tensor too large");
+#define DPL_FQ_LAUNCH(PRE)                                                                                                    \
+    hipLaunchKernelGGL(k_fake_quant<PRE>, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)s, d_x, d_x2, d_y, (uint64_t)n,   \
+                       (uint64_t)chunk, d_scale, d_zp, (uint32_t)n_channels, (uint32_t)inner, (float)qlo, (float)qhi)
+    if (pre == DPL_FQ_PRE_ADD_RELU) DPL_FQ_LAUNCH(kFqPreAddRelu);
+    else if (pre == DPL_FQ_PRE_RELU) DPL_FQ_LAUNCH(kFqPreRelu);
+    else DPL_FQ_LAUNCH(kFqPreNone);
+#undef DPL_FQ_LAUNCH
     DPL_LAUNCH_CHECK("k_fake_quant");
     return 0;
 }

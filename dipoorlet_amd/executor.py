@@ -21,6 +21,13 @@ import torch.nn.functional as F
 # (convolutions default to allow_tf32 = True in PyTorch)
 torch.backends.cudnn.allow_tf32 = False
 torch.backends.cuda.matmul.allow_tf32 = False
+# DPL_DETERMINISTIC=1: the library's deterministic algorithms in every process that executes graphs (the CLI, its workers, tests).
+# MIOpen's default for a 3 x 3 stride-2 convolution on gfx950 — igemm_fwd_gtcx35_nhwc_fp32_*, split over the reduction with fp32
+# atomic adds into a zeroed output — differs by 1e-6 from call to call; with this set the Winograd kernel runs instead (181 us
+# against 135 us at batch 32, three convolutions of a ResNet-50 forward) and every convolution repeats bit for bit (DESIGN.md
+# section 4; scripts/conv_repro_probe.py)
+if os.environ.get("DPL_DETERMINISTIC") == "1":
+    torch.backends.cudnn.deterministic = True
 
 from .forward_net import ActivationSession
 from .forward_net import wall as _wall
@@ -570,6 +577,58 @@ def _fake_quant(s, node, x):
     return q.apply(x.contiguous())
 
 
+def fused_fake_quant(s, node, pre, *xs):
+    """A FakeQuant node with its producer's ReLU / Add + ReLU applied on the way in (relu_fusion): one k_fake_quant<PRE> launch."""
+    q = s.graph._qdq[node.name]
+    if pre == "add_relu":
+        return q.apply(xs[0].contiguous(), pre=pre, x2=xs[1].contiguous())
+    return q.apply(xs[0].contiguous(), pre=pre)
+
+
+def relu_fusion(graph, folded, consts, keep=(), shape1=None):
+    """Which activation FakeQuant nodes of a fake-quantised graph can take their producer's ReLU — or residual Add + ReLU — inside
+    the Q/DQ kernel (k_fake_quant<PRE>): the reference's merge-ReLU rule leaves a ReLU behind Conv / Gemm / Add unquantised at its
+    input (quantize.py:50-55), so the Q/DQ pair of the next layer's input sits directly behind that ReLU (:74-93).  Separate
+    launches move 16 B per element for the pair (ReLU 4 + 4, Q/DQ 4 + 4) and 28 B with the Add in front; fused 8 B / 12 B.
+
+    A ReLU is fused when its output has exactly one consumer — the FakeQuant node —, is no network output and is not asked for by
+    name (`keep`: the tensors the caller wants to see; a session that exposes every tensor fuses nothing).  The Add in front of it
+    joins under the same conditions when both operands are activations of the output's shape (`shape1`: per-image shapes; no
+    broadcast).  DPL_FUSE_RELU=0: never (A/B).
+
+    Returns (fused, skipped): fused[fq_node_name] = (pre, [input names]); skipped = names of the Relu / Add nodes that do not run."""
+    if os.environ.get("DPL_FUSE_RELU", "1") == "0":
+        return {}, set()
+    keep = set(keep) | set(graph.network_outputs)
+    nodes = [n for n in graph.graph.node if n.name not in folded]
+    uses, producer = {}, {}
+    for n in nodes:
+        for i in n.input:
+            if i != "":
+                uses.setdefault(i, []).append(n)
+        for o in n.output:
+            producer[o] = n
+    fused, skipped = {}, set()
+
+    def sole(name, consumer):
+        return name not in keep and len(uses.get(name, ())) == 1 and uses[name][0] is consumer
+
+    for q in nodes:
+        if q.op_type != "FakeQuant" or q.input[0] in consts:
+            continue
+        r = producer.get(q.input[0])
+        if r is None or r.op_type != "Relu" or len(r.output) != 1 or not sole(r.output[0], q):
+            continue
+        pre, ins, skip = "relu", [r.input[0]], [r.name]
+        a = producer.get(r.input[0])
+        if a is not None and a.op_type == "Add" and len(a.input) == 2 and sole(a.output[0], r) and shape1 is not None \
+                and all(i not in consts and shape1.get(i) is not None and shape1.get(i) == shape1.get(a.output[0]) for i in a.input):
+            pre, ins, skip = "add_relu", list(a.input), [a.name, r.name]
+        fused[q.name] = (pre, ins)
+        skipped.update(skip)
+    return fused, skipped
+
+
 class GraphSession(ActivationSession):
     """All-outputs session over an ONNXGraph."""
 
@@ -819,12 +878,27 @@ class GraphSession(ActivationSession):
             if node.name in self._folded and node.input[0] == name:
                 self.consts[node.output[0]] = _OPS["FakeQuant"](self, node, self.consts[name])
 
-    def _forward(self, feeds, batch):
+    def fusion(self, keep):
+        """relu_fusion for a forward that hands out the tensors `keep` only (cached per set of names)."""
+        key = frozenset(keep)
+        cache = self.__dict__.setdefault("_fusion_cache", {})
+        if key not in cache:
+            cache[key] = relu_fusion(self.graph, self._folded, self.consts, key, getattr(self, "shape1", None))
+        return cache[key]
+
+    def _forward(self, feeds, batch, keep=None):
+        """keep: the tensors the caller will read (None: any of them — every node runs on its own); a fake-quantised graph then
+        runs ReLU -> Q/DQ and Add -> ReLU -> Q/DQ chains as one launch where nothing else reads the tensors in between."""
         self.batch = batch
         env = dict(self.consts)
         env.update(feeds)
+        fused, skipped = self.fusion(keep) if keep is not None and self.device.type == "cuda" else ({}, ())
         for node in self.graph.graph.node:
-            if node.name in self._folded:
+            if node.name in self._folded or node.name in skipped:
+                continue
+            if node.name in fused:
+                pre, ins = fused[node.name]
+                env[node.output[0]] = fused_fake_quant(self, node, pre, *[env[i] for i in ins])
                 continue
             args = [env[i] if i != "" else None for i in node.input]
             while args and args[-1] is None:
@@ -841,7 +915,7 @@ class GraphSession(ActivationSession):
         return max(1, int(self.graph.get_tensor_shape(self.input_names[0])[0]))
 
     @torch.no_grad()
-    def _run_env(self, inputs, batch):
+    def _run_env(self, inputs, batch, keep=None):
         if getattr(self, "_conv_threads", None):
             # the first forward WAITS for the convolution threads instead of racing them (two threads resolving the same
             # configuration at the same time both pay for it): DPL_PREWARM_WAIT=0 races, for A/B
@@ -851,7 +925,7 @@ class GraphSession(ActivationSession):
                         t.join()
             self._conv_threads = None
         mark("first_forward:start")     # (the other helper threads are not waited for: first calls are serialised by the libraries' own locks)
-        return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch)
+        return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch, keep)
 
     def _collect(self, env, names, batch):
         out = []
@@ -907,17 +981,17 @@ class GraphSession(ActivationSession):
             WALL["batched_check_s"] = WALL.get("batched_check_s", 0.0) + time.perf_counter() - t_check
         return self._batched_ok
 
-    def _run_any(self, inputs, names):
+    def _run_any(self, inputs, names, keep=None):
         first = inputs[self.input_names[0]]
         lead = self._lead()
         batch = first.shape[0] // lead
         if batch > 1 and not self.batched_ok():
-            per = [self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in inputs.items()}, 1), names, 1)
+            per = [self._collect(self._run_env({n: v[k * lead:(k + 1) * lead] for n, v in inputs.items()}, 1, keep), names, 1)
                    for k in range(batch)]
             # [B, per-image ...] like the batched path: images stack on the leading 1 of the per-image shape, or on a new axis
             return [torch.cat([p[i] for p in per]) if (per[0][i].dim() > 0 and per[0][i].shape[0] == 1)
                     else torch.stack([p[i] for p in per]) for i in range(len(names))]
-        return self._collect(self._run_env(inputs, batch), names, batch)
+        return self._collect(self._run_env(inputs, batch, keep), names, batch)
 
     @torch.no_grad()
     def run(self, inputs):
@@ -944,5 +1018,8 @@ class GraphSession(ActivationSession):
 
     @torch.no_grad()
     def run_named(self, inputs, names):
-        """Chosen tensors by name, laid out like run()'s ([B, per-image ...], checked batching)."""
-        return self._run_any(inputs, list(names))
+        """Chosen tensors by name, laid out like run()'s ([B, per-image ...], checked batching).  Only these are promised to exist:
+        a fake-quantised graph fuses the ReLU (and residual Add) in front of a Q/DQ pair into its kernel when their outputs are
+        not among `names` (relu_fusion)."""
+        names = list(names)
+        return self._run_any(inputs, names, keep=names)

@@ -722,13 +722,24 @@ def rowwise_minmax(w2d, out=None):
     return lo, hi
 
 
-def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None):
+FQ_PRE = {None: 0, "none": 0, "relu": 1, "add_relu": 2}     # include/dipoorlet_hip.h DPL_FQ_PRE_*
+
+
+def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None, pre=None, x2=None):
     """Fused QuantizeLinear -> DequantizeLinear (quantize.py:197-239) on the device.
 
     scale: fp32 device tensor [1] or [C]; zero_point: int32 device tensor of the same length;
     axis: channel axis when len(scale) > 1.  y = (clamp(rint(x/scale)+zp, qlo, qhi) - zp) * scale.
+    pre: the producer's activation applied on the way in (dpl_fake_quant_pre) — 'relu': fq(max(x, 0)); 'add_relu':
+    fq(max(x + x2, 0)), x2 of x's shape (the residual Add of a bottleneck and its ReLU) — for a forward that does not expose the
+    producer's output (the merge-ReLU rule, quantize.py:50-55, puts the Q/DQ pair directly behind that ReLU).
     """
     _require_cuda(x, "x")
+    code = FQ_PRE[pre]
+    if code == 2:
+        _require_cuda(x2, "x2")
+        if x2.shape != x.shape or x2.dtype != torch.float32 or not x2.is_contiguous():
+            raise _hip.DipoorletHipError("fake_quant(pre='add_relu'): x2 must be a contiguous fp32 tensor of x's shape")
     # (a graph walk issues one of these per tensor: no conversion calls when the parameters already are what the kernel takes)
     if not (scale.device == x.device and scale.dtype == torch.float32 and scale.dim() == 1 and scale.is_contiguous()):
         scale = scale.to(device=x.device, dtype=torch.float32).contiguous().reshape(-1)
@@ -746,8 +757,8 @@ def fake_quant(x, scale, zero_point, qlo, qhi, axis=None, out=None):
         for d in x.shape[axis + 1:]:
             inner *= int(d)
     y = torch.empty_like(x) if out is None else out
-    _hip.check(_hip.lib().dpl_fake_quant(_ptr(x), _ptr(y), x.numel(), _ptr(scale), _ptr(zero_point), nch, inner,
-                                         int(qlo), int(qhi), _stream()), "dpl_fake_quant")
+    _hip.check(_hip.lib().dpl_fake_quant_pre(code, _ptr(x), _ptr(x2) if code == 2 else None, _ptr(y), x.numel(), _ptr(scale),
+                                             _ptr(zero_point), nch, inner, int(qlo), int(qhi), _stream()), "dpl_fake_quant_pre")
     return y
 
 

@@ -51,14 +51,15 @@ class QDQNode:
         not the q_min = -127 the reference computes at :134 for its torch-side code."""
         return (-128, 127) if self.symmetric else (0, 255)
 
-    def apply(self, x, out=None):
-        """Fake-quantise a device tensor: QuantizeLinear -> DequantizeLinear semantics, one kernel."""
+    def apply(self, x, out=None, pre=None, x2=None):
+        """Fake-quantise a device tensor: QuantizeLinear -> DequantizeLinear semantics, one kernel (pre / x2: the producer's
+        ReLU or Add + ReLU fused in, ops.fake_quant)."""
         if self._dev is None or self._dev[0].device != x.device:
             self._dev = (torch.from_numpy(self.scale).to(x.device),
                          torch.from_numpy(self.zero_point_as_stored()).to(x.device))
         lo, hi = self.saturation()
         axis = self.axis if self.scale.size > 1 else None
-        return ops.fake_quant(x, self._dev[0], self._dev[1], lo, hi, axis=axis, out=out)
+        return ops.fake_quant(x, self._dev[0], self._dev[1], lo, hi, axis=axis, out=out, pre=pre, x2=x2)
 
 
 def _int8_wrap(zero_point, shape):

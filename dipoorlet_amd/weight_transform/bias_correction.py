@@ -14,12 +14,14 @@ executions instead of O(nodes^2).  The bias enters a Conv / Gemm output linearly
 already computed quantised output is fixed up in place (q_out += diff) instead of being recomputed.
 The fake-quant structure does not depend on bias values, so the quantised graph is built once.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from .. import ops
-from ..executor import _OPS, GraphSession
+from ..executor import _OPS, GraphSession, fused_fake_quant, relu_fusion
 from ..forward_net import load_input_batch
 from ..graph import ONNXGraph
 from ..quantize import quant_graph
@@ -115,39 +117,53 @@ def _frontier_peak_elems(graph, session):
 class _Frontier:
     """Activations of every live tensor for the whole calibration set, as lists of per-chunk tensors."""
 
-    def __init__(self, session, graph, on_host=False):
+    def __init__(self, session, graph, on_host=False, keep=()):
+        """keep: tensors the caller reads from `env` by name besides a node's own inputs / outputs while it runs.  On a
+        fake-quantised graph a ReLU (and the residual Add in front of it) whose only reader is a Q/DQ pair runs inside that pair's
+        kernel (executor.relu_fusion): its output is never in `env`."""
         self.sess, self.graph = session, graph
         self.env = {}
         self.ref = {}
+        self.fused, self.skipped = relu_fusion(graph, session._folded, session.consts, keep, getattr(session, "shape1", None))
         # on_host: the live activations of the whole set do not fit the HBM budget — chunks wait in (pinned) host memory and
         # come back to the device one at a time when a node consumes them: slower (PCIe both ways), same values
         self.on_host = on_host
         self.dev = torch.device("cuda", torch.cuda.current_device())
         for node in graph.graph.node:
-            if node.name in session._folded:
+            if node.name in session._folded or node.name in self.skipped:
                 continue
-            for i in node.input:
+            for i in self.inputs_of(node):
                 if i != "" and i not in session.consts:
                     self.ref[i] = self.ref.get(i, 0) + 1
         for o in graph.network_outputs:
             self.ref[o] = self.ref.get(o, 0) + 1
 
+    def inputs_of(self, node):
+        """The tensors `node` reads: its inputs, or — a Q/DQ pair that runs its producers' Add / ReLU — theirs."""
+        return self.fused[node.name][1] if node.name in self.fused else node.input
+
     def run(self, node, n_chunks, chunk_sizes):
+        if node.name in self.skipped:       # runs inside the Q/DQ kernel behind it
+            return
+        ins = self.inputs_of(node)
         outs = [[] for _ in node.output]
         for c in range(n_chunks):
             self.sess.batch = chunk_sizes[c]
             args = [None if i == "" else (self.sess.consts[i] if i in self.sess.consts else self.env[i][c].to(self.dev))
-                    for i in node.input]
+                    for i in ins]
             while args and args[-1] is None:
                 args.pop()
-            r = _OPS[node.op_type](self.sess, node, *args)
+            if node.name in self.fused:
+                r = fused_fake_quant(self.sess, node, self.fused[node.name][0], *args)
+            else:
+                r = _OPS[node.op_type](self.sess, node, *args)
             r = list(r) if isinstance(r, (list, tuple)) else [r]
             for k, v in enumerate(r[:len(outs)]):
                 outs[k].append(v.cpu() if self.on_host else v)
         for o, v in zip(node.output, outs):
             if o != "":
                 self.env[o] = v
-        for i in node.input:
+        for i in ins:
             if i in self.ref:
                 self.ref[i] -= 1
                 if self.ref[i] == 0:
@@ -199,6 +215,11 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
         fp.env[n] = chunks
         qf.env[n] = chunks
     fp_nodes = {n.name: n for n in graph.graph.node}
+    # DPL_BC_RECOMPUTE=1 (a testing aid): a corrected node's quantised output is computed AGAIN with the corrected bias instead of
+    # being fixed up in place (q_out + diff).  The two are the same value up to one fp32 rounding — conv(x, w, b) + d against
+    # conv(x, w, b + d) — but a last-bit difference flips a rounding step of a fake-quantised layer downstream now and then; with
+    # the recomputation the walk IS the reference's definition evaluated node-major (tests/test_cli_e2e.py compares them exactly).
+    recompute = os.environ.get("DPL_BC_RECOMPUTE") == "1"
     for node in graph_q.graph.node:
         if node.name in s_q._folded:
             continue
@@ -206,15 +227,29 @@ def bias_correction(graph, act_clip_val, weight_clip_val, args):
             qf.run(node, len(bounds), sizes)
             continue  # a FakeQuant node
         fp_node = fp_nodes[node.name]
-        keep_fp = fp.env  # outputs needed below are still referenced until their consumers ran
-        fp.ref[fp_node.output[0]] = fp.ref.get(fp_node.output[0], 0) + 1  # hold both outputs for the diff BEFORE the nodes
-        qf.ref[node.output[0]] = qf.ref.get(node.output[0], 0) + 1        # run: an output nobody consumes is dropped at once
+        corrected = node.op_type in BIAS_CORRECTION_NODE_TYPE
+        out = node.output[0]
+        if corrected:
+            fp.ref[fp_node.output[0]] = fp.ref.get(fp_node.output[0], 0) + 1  # hold both outputs for the diff BEFORE the nodes
+            qf.ref[out] = qf.ref.get(out, 0) + 1                              # run: an output nobody consumes is dropped at once
+            if recompute:                                                     # (... and the inputs for the second run)
+                for i in qf.inputs_of(node):
+                    if i in qf.ref:
+                        qf.ref[i] += 1
         qf.run(node, len(bounds), sizes)
         fp.run(fp_node, len(bounds), sizes)
-        out = node.output[0]
-        if node.op_type in BIAS_CORRECTION_NODE_TYPE:
-            logger.info("Update bias for node: {}".format(node.name))
-            diff = update_conv_node_bias(graph_bc, node, keep_fp[out], qf.env[out], world)
+        if not corrected:
+            continue
+        logger.info("Update bias for node: {}".format(node.name))
+        bc_node = next(n for n in graph_bc.graph.node if n.name == node.name)
+        diff = update_conv_node_bias(graph_bc, node, fp.env[out], qf.env[out], world)
+        if recompute:
+            bname = bc_node.input[2]
+            if len(node.input) < 3:       # (a node without a bias has just been given one)
+                node.input.append(bname)
+            s_q.set_const(bname, torch.from_numpy(np.ascontiguousarray(graph_bc.get_initializer(bname), dtype=np.float32)))
+            qf.run(node, len(bounds), sizes)
+        elif qf.env[out]:
             shape = [1, -1] + [1] * (qf.env[out][0].dim() - 2)
             d_host = diff.reshape(shape).cpu() if on_host else None
             for t in qf.env[out]:  # the bias is additive in the output: fix the computed q output in place

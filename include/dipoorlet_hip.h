@@ -292,6 +292,17 @@ int dpl_rowwise_minmax(const float* d_w, int64_t rows, int64_t cols, float* d_mi
  *      n_channels == 1: per tensor.  Otherwise channel c = (i / inner) % n_channels. */
 int dpl_fake_quant(const float* d_x, float* d_y, int64_t n, const float* d_scale, const int32_t* d_zp,
                    int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s);
+/* The same pair with its producer's activation applied on the way in, so that a forward that does not expose the producer's output
+ * moves 8 B per element for ReLU -> Q/DQ instead of 16 (the reference's merge-ReLU rule leaves a ReLU behind Conv / Gemm / Add
+ * unquantised at its input, quantize.py:50-55, so its OUTPUT carries the Q/DQ pair of the next layer, :74-93):
+ *   DPL_FQ_PRE_NONE      y = fq(x)                        (d_x2 ignored)
+ *   DPL_FQ_PRE_RELU      y = fq(max(x, 0))                NaN stays NaN, as np.maximum / torch.relu
+ *   DPL_FQ_PRE_ADD_RELU  y = fq(max(x + x2, 0))           one fp32 addition (round to nearest); d_x2: n floats, no broadcast */
+#define DPL_FQ_PRE_NONE 0
+#define DPL_FQ_PRE_RELU 1
+#define DPL_FQ_PRE_ADD_RELU 2
+int dpl_fake_quant_pre(int32_t pre, const float* d_x, const float* d_x2, float* d_y, int64_t n, const float* d_scale,
+                       const int32_t* d_zp, int64_t n_channels, int64_t inner, int32_t qlo, int32_t qhi, dpl_stream_t s);
 /* The same arithmetic over a WHOLE tensor set in one launch (a caller that holds every tensor of a forward: one launch instead
  * of one per Q/DQ pair — 123 for ResNet-50, most of them launch-bound): d_items / d_block_begin = a partition of the tensors'
  * elements (dpl_build_balanced_items over one span per tensor: item.seg = tensor, offset / count in elements; items are cut on

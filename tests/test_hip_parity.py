@@ -321,6 +321,68 @@ def test_fake_quant_per_channel_vectorised_kernel_vs_oracle(dev, shape, axis):
                                                                                int((got.view(np.uint32) != ref.view(np.uint32)).sum()))
 
 
+@pytest.mark.parametrize("shape,axis", [((4, 64, 56, 56), None), ((4, 64, 56, 56), 1), ((3, 32, 7, 7), 1), ((5, 1001), None), ((2, 6, 3), 1)])
+def test_fake_quant_with_producer_relu_and_add_relu_vs_oracle(dev, shape, axis):
+    """a12 + the merge-ReLU rule (quantize.py:50-55, 74-93): k_fake_quant<PRE> — the Q/DQ pair with its producer's ReLU, or residual
+    Add + ReLU, applied on the way in — against the oracle's Q -> DQ of np.maximum(x, 0) / np.maximum(x + x2, 0), bit for bit: per
+    tensor and per channel (rows of 3136 / 49 / 3 elements: whole vectors, vectors that straddle two channels, element by element),
+    zero points != 0 on the uint8 grid and their int8 storage forms, saturation at both ends, exact .5 ties, -0.0, +-inf, sums that
+    cancel to +-0 and sums that round; aligned buffers and 4-byte-aligned views."""
+    from dipoorlet_amd import ops
+    rng = np.random.default_rng(abs(hash((shape, axis))) % (1 << 31))
+    n_ch = shape[axis] if axis is not None else 1
+    scale = rng.uniform(0.01, 0.1, n_ch).astype(np.float32)
+    scale[::3] = np.float32(2.0) ** rng.integers(-6, -2, scale[::3].size)
+    x = (rng.standard_normal(shape) * 4).astype(np.float32)
+    x2 = (rng.standard_normal(shape) * 4).astype(np.float32)
+    f, f2 = x.reshape(-1), x2.reshape(-1)
+    sc_full = (np.broadcast_to(scale.reshape([-1 if i == axis else 1 for i in range(len(shape))]), shape).reshape(-1) if axis is not None
+               else np.full(f.size, scale[0], np.float32))
+    m = max(4, f.size // 8)
+    idx = rng.choice(f.size, m, replace=False)
+    f[idx] = (rng.integers(0, 300, m).astype(np.float32) + np.float32(0.5)) * sc_full[idx]        # ties
+    sp = rng.choice(f.size, min(f.size, 40), replace=False)
+    f[sp[0:8]] = np.float32(1e6)
+    f[sp[8:16]] = np.float32(-1e6)
+    f[sp[16:24]] = np.float32(-0.0)
+    f[sp[24:28]] = np.float32(np.inf)
+    f[sp[28:32]] = np.float32(-np.inf)
+    f2[sp[28:32]] = np.float32(1.0)                       # (-inf + 1: no NaN from inf - inf)
+    f2[sp[24:28]] = np.float32(1.0)
+    f2[sp[32:36]] = -f[sp[32:36]]                         # x + x2 = +0 exactly
+    f2[sp[36:40]] = np.float32(1e-9)                      # absorbed by the rounding of the sum
+    xt, x2t = torch.from_numpy(x).to(dev), torch.from_numpy(x2).to(dev)
+    buf = torch.empty(2 * (x.size + 1), dtype=torch.float32, device=dev)
+    xu, x2u = buf[1:x.size + 1].view(shape), buf[x.size + 2:2 * x.size + 2].view(shape)
+    xu.copy_(xt)
+    x2u.copy_(x2t)
+    zps = np.array([0, 3, 128, 191, 255], np.int32)
+    with np.errstate(invalid="ignore"):
+        relu, add_relu = np.maximum(x, np.float32(0)), np.maximum((x + x2).astype(np.float32), np.float32(0))
+    for signed in (False, True):
+        zp_u = zps[rng.integers(0, 5, n_ch)]
+        zp = np.where(zp_u > 127, zp_u - 256, zp_u).astype(np.int32) if signed else zp_u
+        qlo, qhi = (-128, 127) if signed else (0, 255)
+        sc_t, zp_t = torch.from_numpy(scale).to(dev), torch.from_numpy(zp).to(dev)
+        want = {None: O.fake_quant_qdq(x, scale, zp, axis=axis, signed=signed),
+                "relu": O.fake_quant_qdq(relu, scale, zp, axis=axis, signed=signed),
+                "add_relu": O.fake_quant_qdq(add_relu, scale, zp, axis=axis, signed=signed)}
+        for tag, a, b in (("aligned", xt, x2t), ("unaligned", xu, x2u)):
+            for pre in (None, "relu", "add_relu"):
+                y = ops.fake_quant(a, sc_t, zp_t, qlo, qhi, axis=axis, pre=pre, x2=b if pre == "add_relu" else None)
+                got = y.cpu().numpy()
+                bad = int((got.view(np.uint32) != want[pre].view(np.uint32)).sum())
+                assert bad == 0, (tag, pre, signed, shape, axis, bad)
+                # ... and what the two (three) launches of the unfused chain write
+                if pre is not None:
+                    chain = ops.fake_quant(torch.relu(a if pre == "relu" else a + b).contiguous(), sc_t, zp_t, qlo, qhi, axis=axis)
+                    assert torch.equal(chain, y), (tag, pre)
+    with pytest.raises(Exception):
+        ops.fake_quant(xt, sc_t, zp_t, qlo, qhi, axis=axis, pre="add_relu", x2=x2t.reshape(-1)[:-1])
+    with pytest.raises(Exception):
+        ops.fake_quant(xt, sc_t, zp_t, qlo, qhi, axis=axis, pre="add_relu")
+
+
 def test_cos_accumulate(dev):
     from dipoorlet_amd import ops
     a = make_tensor("normal", 123457, 1)

@@ -13,7 +13,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+# (every test here re-runs or compares library forwards: deterministic algorithms, tests/conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.two_forwards]
 
 N, IMG, BS, EPOCHS = 16, 32, 8, 60
 
@@ -92,6 +93,7 @@ def _check_on_grid(model_path, workdir, args, bits=4):
 
 def _cli(workdir, out, extra):
     from dipoorlet_amd.__main__ import main
+    torch.manual_seed(1234)      # (mini-batch order and QDrop masks come from torch's generator: one trajectory per box, not one per run)
     rc = main(["-M", str(workdir / "model.onnx"), "-I", str(workdir / "calib"), "-N", str(N), "-A", "minmax", "-D",
                "trt", "-O", str(out), "--calib_batch", "8", "--skip_profiling", "--ada_bs", str(BS), "--ada_epoch",
                str(EPOCHS), *extra])

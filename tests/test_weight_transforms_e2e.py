@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# (every test here re-runs or compares library forwards: deterministic algorithms, tests/conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.two_forwards]
 
 N, IMG = 12, 16
 

@@ -50,7 +50,7 @@ def parse():
     p.add_argument("--mse-steps", type=int, default=4, help="timed mse sweeps (N = 4096 images each); 0 skips the mse object")
     p.add_argument("--bins", type=int, default=2048)
     p.add_argument("--pool", type=int, default=17, help="distinct resident batches of 32 images cycled through (3.4 GB each); "
-                   "17 = more than the one-read OCTAV prediction remembers (2 x 8 batches)")
+                   "17 = more than the exact-tail OCTAV form's threshold history remembers (2 epochs of 8 batches)")
     p.add_argument("--mse-jitter", default="0.03,0.1", help="extra one-sweep mse objects with per-image contrast jitter (comma list; '' = none)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget; 0 disables")
     p.add_argument("--e2e-images", type=int, default=1024, help="N of the end-to-end CLI object (real .onnx + .bin files, fresh process; 0 skips it)")
@@ -397,8 +397,18 @@ def main():
 
         if len(pool) < min_pool and rank == 0:
             print(f"bench.py: --pool {len(pool)} < {min_pool}: batches repeat inside the prediction's memory", file=sys.stderr)
+        if os.environ.get("DPL_BENCH_L1_FIRST") and world == 1:     # (A/B aid: does the order of the two objects matter?)
+            mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
         mse = run_mse(pool, a.mse_steps, jitter)
-        mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
+        # Everything below characterises ONE GPU (other schedules, other activations, other shapes, the fake-quant kernels, the CLI end
+        # to end, the CPU baseline) and is reported by the N = 1 run.  A run over several ranks measures the sharded path — the hist
+        # sweep and the mse sweep with their collectives — and nothing else: N processes building ViT sessions, 448 x 448 pools and
+        # fake-quantised forwards side by side would only lengthen the run and fight over the host's cores.
+        side = world == 1
+        if not side:
+            a.mse_jitter, a.real_images, a.vit_images, a.big_images, a.fq_reps, pipe1 = "", 0, 0, 0, 0, None
+        if not os.environ.get("DPL_BENCH_L1_FIRST"):
+            mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
         # the same sweep over images that differ in contrast (one sweep each): what a prediction from other images costs
         for jit in ([float(x) for x in a.mse_jitter.split(",") if x] if jitter == 0.0 else []):
             jp = [synth_activations(spec, B, dev, seed=99 + 1000 * rank + j, image_jitter=jit) for j in range(len(pool))]
@@ -458,6 +468,8 @@ def main():
     # per tensor as the graph walk issues them, timed by HIP events on the launch stream around the whole sequence (123
     # launches of 0.1 .. 103 MB: the small ones are launch-bound) and around the large tensors alone.
     fake_quant = None
+    if world > 1:
+        a.fq_reps = 0
     if a.fq_reps > 0:
         from dipoorlet_amd.synthetic import resnet50_tensor_shapes
         shapes = resnet50_tensor_shapes()
@@ -539,29 +551,43 @@ def main():
             del sfp
             gq, _ = _quant_graph(gfp, clipv, _types.SimpleNamespace(deploy="trt", skip_layers=[]))
             sq = gq.make_session()
-            evs, orig = [], _ex._OPS["FakeQuant"]
+            out_name = gq.network_outputs[0]
+            orig, orig_fused = _ex._OPS["FakeQuant"], _ex.fused_fake_quant
 
-            def timed_fq(sess, node, x):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                y = orig(sess, node, x)
-                e1.record()
-                evs.append((e0, e1, x.numel()))
-                return y
-            sq.run({"input": xin})
-            sq.run({"input": xin})
-            _ex._OPS["FakeQuant"] = timed_fq
-            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            try:
-                f0.record()
-                for _ in range(a.fq_reps):
-                    sq.run({"input": xin})
-                f1.record()
-                torch.cuda.synchronize()
-            finally:
-                _ex._OPS["FakeQuant"] = orig
-            ms = sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / a.fq_reps
-            fwd_ms = f0.elapsed_time(f1) / a.fq_reps
+            def timed_forward(fwd):
+                """HIP events around every Q/DQ launch of `a.fq_reps` forwards (and around the forwards): (bytes of the Q/DQ nodes per
+                forward — 8 per element, 12 where the residual Add is read too —, their summed milliseconds, forward ms, nodes)."""
+                evs = []
+
+                def timed(call, nbytes):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    y = call()
+                    e1.record()
+                    evs.append((e0, e1, nbytes))
+                    return y
+                fwd()
+                fwd()
+                _ex._OPS["FakeQuant"] = lambda sess, node, x: timed(lambda: orig(sess, node, x), 8 * x.numel())
+                _ex.fused_fake_quant = lambda sess, node, pre, *xs: timed(lambda: orig_fused(sess, node, pre, *xs),
+                                                                           (12 if pre == "add_relu" else 8) * xs[0].numel())
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                try:
+                    f0.record()
+                    for _ in range(a.fq_reps):
+                        fwd()
+                    f1.record()
+                    torch.cuda.synchronize()
+                finally:
+                    _ex._OPS["FakeQuant"], _ex.fused_fake_quant = orig, orig_fused
+                return (sum(n for _, _, n in evs) / a.fq_reps, sum(e0.elapsed_time(e1) for e0, e1, _ in evs) / a.fq_reps,
+                        f0.elapsed_time(f1) / a.fq_reps, len(evs) // a.fq_reps)
+            # every tensor exposed (profiling's per-layer pass: ReLU, Add, Q/DQ are separate launches) ...
+            ub, ums, ufwd, unodes = timed_forward(lambda: sq.run({"input": xin}))
+            # ... and only the output asked for (the walks of --bc / update_bn / AdaRound, a caller of the quantised network): a ReLU or
+            # Add + ReLU whose only reader is a Q/DQ pair runs inside k_fake_quant<PRE> (executor.relu_fusion)
+            nbytes, ms, fwd_ms, nodes = timed_forward(lambda: sq.run_named({"input": xin}, [out_name]))
+            fused, skipped = sq.fusion([out_name])
             # what an (e0, e1) pair measures with NOTHING between the two records, on a stream that is kept busy the same way: the
             # events' own packets — reported beside the raw figure, never subtracted from it
             empty = []
@@ -575,14 +601,20 @@ def main():
             torch.cuda.synchronize()
             pair_us = 1e3 * sorted(p0.elapsed_time(p1) for p0, p1 in empty)[len(empty) // 2]
             del big
-            nbytes = 8 * sum(n for _, _, n in evs) / a.fq_reps
             # (a Q/DQ node of this forward moves 106 MB on average: 18 us at 6 TB/s + the 2 - 3 us any launch takes to fill and
-            # drain the chip; the nodes are a chain — conv, relu, Q/DQ, conv — so they cannot share a launch)
-            fq["product_forward"] = {"batch": _PB, "nodes": len(evs) // a.fq_reps, "bytes": nbytes, "ms": ms,
+            # drain the chip; the nodes are a chain — conv, [add,] [relu +] Q/DQ, conv — so they cannot share a launch)
+            fq["product_forward"] = {"batch": _PB, "form": "ReLU / Add + ReLU fused into the Q/DQ kernel (run_named: only the output asked for)",
+                                     "nodes": nodes, "bytes": nbytes, "ms": ms,
                                      "achieved": nbytes / (ms * 1e-3) / 1e9, "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                      "forward_ms": fwd_ms, "share_of_the_quantised_forward": ms / fwd_ms,
-                                     # (the kernels' own durations, rocprofv3 --kernel-trace over the same forward: 17.7 us per node =
-                                     # 0.748 of 8 TB/s — scripts/fq_forward_prof.sh, profiles/r05/kernel_stats_fq_forward.md)
+                                     "fused_pairs": {"relu": sum(1 for p, _ in fused.values() if p == "relu"),
+                                                     "add_relu": sum(1 for p, _ in fused.values() if p == "add_relu"),
+                                                     "launches_saved_per_forward": len(skipped)},
+                                     "every_tensor_exposed": {"nodes": unodes, "bytes": ub, "ms": ums, "frac": ub / (ums * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                              "forward_ms": ufwd},
+                                     "forward_ms_saved": 1.0 - fwd_ms / ufwd,
+                                     # (the kernels' own durations, rocprofv3 --kernel-trace over the same forwards:
+                                     # scripts/fq_forward_prof.sh, profiles/r06/kernel_stats_fq_forward.md)
                                      "empty_event_pair_us": pair_us}
             del sq, gq, gfp, xin
             torch.cuda.empty_cache()
@@ -672,7 +704,7 @@ def main():
     # HBM bytes per launch by the PMC counters (scripts/profile_gpu.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over
     # this very script).  Quoted only when the record was measured on the kernel sources this run uses (sha over csrc/), else null.
     def traffic_record():
-        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r05", "traffic.json"))
+        tj = os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r06", "traffic.json"))
         try:
             sys.path.insert(0, os.path.join(ROOT, "scripts"))
             from summarize_prof import source_sha
@@ -687,7 +719,7 @@ def main():
     traffic = tk["k_abs_hist"]["hbm_bytes_per_launch"] if tk and "k_abs_hist" in tk else None
     # (`traffic` is NOT counted in this run: it is the PMC record of scripts/profile_gpu.sh over this script, replayed when its
     # source hash matches the kernels this run uses — the line names the file)
-    traffic_from = os.path.relpath(os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r05", "traffic.json")), ROOT) if tk else None
+    traffic_from = os.path.relpath(os.environ.get("DPL_TRAFFIC_JSON", os.path.join(ROOT, "profiles", "r06", "traffic.json")), ROOT) if tk else None
 
     def mse_batch_traffic():
         """HBM bytes of ONE mse batch: every k_octav_* kernel of the profiled run, per launch of the streaming kernel."""
@@ -754,12 +786,13 @@ def main():
             try:
                 sys.path.insert(0, os.path.join(ROOT, "scripts"))
                 from summarize_prof import source_sha as _sha
-                with open(os.path.join(ROOT, "profiles", "r05", "fq_forward.json")) as f:
+                with open(os.path.join(ROOT, "profiles", "r06", "fq_forward.json")) as f:
                     _fq = json.load(f)
                 if _fq.get("source_sha") == _sha():
                     roof["fake_quant"]["product_forward_kernel_trace"] = round(_fq["frac_of_8TBps"], 4)
                     fake_quant["product_forward"]["kernel_trace"] = {"frac": _fq["frac_of_8TBps"], "us_per_forward": _fq["us_per_forward"],
-                                                                     "from": "profiles/r05/fq_forward.json"}
+                                                                     "forward_gpu_time_saved": _fq.get("gpu_time_saved"),
+                                                                     "from": "profiles/r06/fq_forward.json"}
             except Exception:   # noqa: BLE001
                 pass
     if e2e and "error" not in e2e:
@@ -773,6 +806,15 @@ def main():
         sp = e2e["split"]
         # the headline run's wall against its GPU work: tensor_calibration_wall_s - (forward_gpu_s + statistics_gpu_s)
         roof["e2e"]["hist_host_s"] = round(sp["tensor_calibration_wall_s"] - sp["forward_gpu_s"] - sp["statistics_gpu_s"], 3)
+        # the statistics kernels INSIDE the product (one stream, between two network forwards): one read of every image's activation
+        # set / the GPU seconds the child's HIP events give them, as a fraction of 8 TB/s — [hist: two reads, mse, mse N = 4096]
+        def stats_frac(o, reads):
+            sp_ = o["split"]
+            return round(reads * 4.0 * E * sp_["images"] / max(sp_["statistics_gpu_s"], 1e-9) / 1e9 / HBM_PEAK_GBPS, 4)
+        roof["e2e"]["hist_stats_frac"] = stats_frac(e2e, 2)
+        for k in ("mse", "mse_4096"):
+            if k in e2e and "error" not in e2e[k]:
+                roof["e2e"][k + "_stats_frac"] = stats_frac(e2e[k], 1)
     out = {
         # BASELINE.json's metric; images/s is `value`, the achieved HBM GB/s of the dominant kernel is `roofline.achieved`
         "metric": "calibration images/sec (whole node) + achieved HBM GB/s, ResNet-50 ONNX N=%d, -A %s"
@@ -788,6 +830,7 @@ def main():
                    "device": devname, "hist_checksum_ok": hist_checksum == E * N_HIST * world,
                    "world_size_seen_by_backend": dist.get_world_size() if use_dist else 1,
                    "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if use_dist else None,
+                   "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if (use_dist and backend == "nccl") else None,
                    "per_rank_images_per_s": [round(r) for r in per_rank_rates],
                    "collectives_ms_per_sweep": coll_ms},
         "roofline": roof,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 MAX_BINS = 16384
 
 

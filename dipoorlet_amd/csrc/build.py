@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = [os.path.join(HERE, f) for f in ("calib_kernels.hip", "octav_kernels.hip", "octav_oneread.hip", "round_kernels.hip", "gemm_small.hip")]
+SRC = [os.path.join(HERE, f) for f in ("calib_kernels.hip", "octav_kernels.hip", "octav_tail_host.hip", "round_kernels.hip", "gemm_small.hip")]
 HDR = [os.path.join(HERE, "..", "..", "include", "dipoorlet_hip.h"), os.path.join(HERE, "common.hpp"),
        os.path.join(HERE, "octav_common.hpp"), os.path.join(HERE, "octav_tail.hpp")]
 OUT = os.path.join(HERE, "libdipoorlet_hip.so")

@@ -56,7 +56,7 @@ constexpr uint32_t kRescueUnit = 16384;                     // elements of a pai
 // size in every list: 4 x the batch's activations in scratch.  (n / 32 + 16384 was too tight for the rescue: the bracket of a
 // cold 802 816-element pair holds 5 - 6 % of it, and 14 pairs of every cold ResNet-50 sweep ended on the compaction route.)
 constexpr uint32_t kListCapShift = 4, kListCapConst = 16384;
-constexpr uint32_t kListWhole = 20480;   // a pair this small lists its whole window (octav_oneread.hip: kSmallCap): its region holds all of it
+constexpr uint32_t kListWhole = 20480;   // a pair this small lists its whole window (octav_tail_host.hip: kSmallCap): its region holds all of it
 __host__ __device__ inline uint32_t list_cap_of(unsigned long long n) {
     const unsigned long long whole = (n + 31ull) & ~31ull, part = ((n >> kListCapShift) + kListCapConst + 31ull) & ~31ull;
     return (uint32_t)((whole < part || n <= kListWhole) ? whole : part);

@@ -842,7 +842,7 @@ __global__ __launch_bounds__(kBlock) void k_octav_gather(const dpl_work_item* __
     }
 }
 
-// The RESCUE of the one-read form (octav_oneread.hip): the pairs whose walk stepped outside the gathered bins are listed in
+// The RESCUE of the one-read form (octav_tail_host.hip): the pairs whose walk stepped outside the gathered bins are listed in
 // `missed` (pair, first unit, units: a unit = kRescueUnit elements of the pair) with their exact bracket in `bm_rows`; this
 // kernel re-reads those pairs ALONE and gathers the bracket's bins into list 1 — many workgroups per pair (a single
 // workgroup pulls ~20 GB/s: the compaction route, whose workgroups own a fixed share of the batch, took 470 us for 70
@@ -1123,7 +1123,7 @@ int g_rescue_fail_every = 0;  // dpl_test_hook_rescue_fail_every
 #ifndef DPL_RESCUE_GRID
 #define DPL_RESCUE_GRID 512
 #endif
-// (octav_oneread.hip) gather pass of the rescue: see k_octav_rescue_gather
+// (octav_tail_host.hip) gather pass of the rescue: see k_octav_rescue_gather
 int dpl_octav_rescue_gather_launch(const uint32_t* d_missed, dpl_octav_state* d_states, int64_t n_pairs, const dpl_span* d_pair_spans,
                                    const float* const* d_seg_ptrs, const uint32_t* d_bm_rows, const uint64_t* d_pair_base,
                                    float* d_list1, hipStream_t st) {

@@ -1,4 +1,4 @@
-// OCTAV ('-A mse', forward_net.py:323-330) in one read: EXACT TAIL, BOUNDED BULK (round 4).  Included by octav_oneread.hip
+// OCTAV ('-A mse', forward_net.py:323-330) in one read: EXACT TAIL, BOUNDED BULK (round 4).  Included by octav_tail_host.hip
 // (shares its LDS layout, scans, the walk's counting idiom and the rescue of pairs a walk cannot finish).
 //
 // The reference's loop s' = sum_{|x|>s} |x| / (c #{|x|<=s} + #{|x|>s}) climbs from s_0 = mean of the non-zero |x| to the

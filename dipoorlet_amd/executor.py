@@ -613,6 +613,16 @@ def relu_fusion(graph, folded, consts, keep=(), shape1=None):
     def sole(name, consumer):
         return name not in keep and len(uses.get(name, ())) == 1 and uses[name][0] is consumer
 
+    def shape_of(name):
+        """Per-image shape of an activation; a fake-quantised tensor (not listed by a session that does not expose them) has its
+        source's."""
+        if shape1 is None or name in consts:
+            return None
+        if shape1.get(name) is not None:
+            return shape1[name]
+        p = producer.get(name)
+        return shape_of(p.input[0]) if p is not None and p.op_type == "FakeQuant" else None
+
     for q in nodes:
         if q.op_type != "FakeQuant" or q.input[0] in consts:
             continue
@@ -621,8 +631,8 @@ def relu_fusion(graph, folded, consts, keep=(), shape1=None):
             continue
         pre, ins, skip = "relu", [r.input[0]], [r.name]
         a = producer.get(r.input[0])
-        if a is not None and a.op_type == "Add" and len(a.input) == 2 and sole(a.output[0], r) and shape1 is not None \
-                and all(i not in consts and shape1.get(i) is not None and shape1.get(i) == shape1.get(a.output[0]) for i in a.input):
+        if a is not None and a.op_type == "Add" and len(a.input) == 2 and sole(a.output[0], r) and shape_of(a.output[0]) is not None \
+                and all(shape_of(i) == shape_of(a.output[0]) for i in a.input):
             pre, ins, skip = "add_relu", list(a.input), [a.name, r.name]
         fused[q.name] = (pre, ins)
         skipped.update(skip)

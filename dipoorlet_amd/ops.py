@@ -184,22 +184,44 @@ class TensorSetPlan:
     def seg_table(self, tensors):
         """Device table of base pointers for this launch.  A list of tensors is checked on EVERY call (device, dtype, contiguity,
         element count: the allocator hands a freed set's addresses to other tensors, so a pointer seen before proves nothing);
-        the table itself is cached per pointer tuple.  A BoundSet (bind()) was checked when it was bound."""
+        the table itself is cached per pointer tuple.  A BoundSet (bind()) was checked when it was bound.
+
+        The tables live in ONE block allocated with the plan's first launch — _SEG_CACHE_MAX slots of T pointers on the device and
+        the same in pinned host memory: a pointer tuple not seen before takes the next slot in rotation (written on the host,
+        copied asynchronously on the current stream), so a launch over new tensors allocates nothing and does not wait for the
+        device.  A slot is rewritten _SEG_CACHE_MAX distinct tensor sets later; no launch of this library is that far behind the
+        host (the OCTAV pipeline runs at most DPL_OCTAV_PIPE_SETS batches ahead)."""
         if isinstance(tensors, BoundSet):
             if tensors.plan is not self:
                 raise _hip.DipoorletHipError("this tensor set is bound to another plan")
             return tensors.table
         self._validate(tensors)
         key = tuple(x.data_ptr() for x in tensors)
-        tab = self._seg_cache.get(key)
-        if tab is None:
-            if len(self._seg_cache) >= _SEG_CACHE_MAX:
-                self._seg_cache.clear()
-            host = torch.tensor(key, dtype=torch.int64).pin_memory()
-            tab = host.to(self.device, non_blocking=True)
-            self._seg_cache[key] = (tab, host)  # keep the pinned source alive until the copy has run
-            return tab
-        return tab[0]
+        slot = self._seg_cache.get(key)
+        if slot is not None:
+            return self._seg_dev[slot]
+        if getattr(self, "_seg_dev", None) is None:
+            self._seg_host = torch.empty(_SEG_CACHE_MAX, max(self.T, 1), dtype=torch.int64).pin_memory()
+            self._seg_np = self._seg_host.numpy()
+            self._seg_dev = torch.empty(_SEG_CACHE_MAX, max(self.T, 1), dtype=torch.int64, device=self.device)
+            self._seg_copied = [None] * _SEG_CACHE_MAX      # per slot: the event behind its last host -> device copy
+            self._seg_keys = [None] * _SEG_CACHE_MAX
+            self._seg_next = 0
+        slot = self._seg_next % _SEG_CACHE_MAX
+        self._seg_next += 1
+        if self._seg_keys[slot] is not None:
+            self._seg_cache.pop(self._seg_keys[slot], None)
+        ev = self._seg_copied[slot]
+        if ev is not None and not ev.query():       # (the copy that last read this pinned row has not run yet: 64 sets ago)
+            ev.synchronize()
+        self._seg_np[slot, :len(key)] = key
+        self._seg_dev[slot].copy_(self._seg_host[slot], non_blocking=True)
+        if ev is None:
+            ev = self._seg_copied[slot] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._seg_keys[slot] = key
+        self._seg_cache[key] = slot
+        return self._seg_dev[slot]
 
 
 class OctavTailPlan:
@@ -235,17 +257,25 @@ class OctavTailPlan:
         n = int(getattr(self.sizes, what + "_bytes"))
         return torch.empty(max(n, 256), dtype=torch.uint8, device=self.plan.device)
 
-    def compaction(self, job, states, stream, arena=None):
+    def compaction(self, job, states, stream, arena=None, host_states=None, base_host=None):
         """The compaction route for the pairs of `job`'s batch that neither their walk nor the rescue finished (its control block
-        said so): the states are read back (a host synchronisation on `stream`: rare — flat distributions, values beyond 2^14,
-        lists beyond their regions, a dozen pairs of a cold first batch), dpl_octav_fallback_layout gives regions to just those
-        pairs, and the route's two lists are that small (arena: a buffer to reuse; returned, grown if need be)."""
+        said so; rare — flat distributions, values beyond 2^14, lists beyond their regions, a dozen pairs of a cold first batch):
+        dpl_octav_fallback_layout gives regions to just those pairs, and the route's two lists are that small (arena: a buffer to
+        reuse; returned, grown if need be).
+        host_states: the batch's states in PINNED host memory, already valid (the pipeline copies them behind every batch's rescue
+        and reads them when the set comes up for reuse) — nothing here waits for the device then; without it the states are read
+        back now (one host synchronisation on `stream`: octav_batch).  base_host: a pinned buffer of 8 (n_pairs + 1) bytes for the
+        region table's upload (same rule)."""
         L = _hip.lib()
         n = self.plan.n_pairs
-        with torch.cuda.stream(stream):
-            host = states[:(n + 1) * C.sizeof(_hip.OctavState)].cpu()
-        base = np.zeros(n + 1, np.uint64)
-        total = int(L.dpl_octav_fallback_layout(host.data_ptr(), n, base.ctypes.data))
+        if host_states is None:
+            with torch.cuda.stream(stream):
+                host_states = states[:(n + 1) * C.sizeof(_hip.OctavState)].cpu()
+        if base_host is None:
+            base = np.zeros(n + 1, np.uint64)
+        else:
+            base = base_host.numpy().view(np.uint64)[:n + 1]
+        total = int(L.dpl_octav_fallback_layout(host_states.data_ptr(), n, base.ctypes.data))
         if total < 0:
             _hip.check(total, "dpl_octav_fallback_layout")
         if total == 0:
@@ -255,7 +285,10 @@ class OctavTailPlan:
             if arena is None or arena.numel() < need:
                 arena = torch.empty(need + need // 2, dtype=torch.uint8, device=self.plan.device)
             tab = arena[2 * 4 * total:2 * 4 * total + 8 * (n + 1)]
-            tab.copy_(torch.from_numpy(base.view(np.uint8)))       # (a blocking copy of 8 (n + 1) bytes)
+            if base_host is None:
+                tab.copy_(torch.from_numpy(base.view(np.uint8)))       # (a blocking copy of 8 (n + 1) bytes)
+            else:
+                tab.copy_(base_host[:8 * (n + 1)], non_blocking=True)
         job.d_pair_base_full = tab.data_ptr()
         job.d_clist0 = arena.data_ptr()
         job.d_clist1 = arena.data_ptr() + 4 * total
@@ -499,7 +532,11 @@ class OctavPipeline:
     def __init__(self, dynamic_sym, device=None, lanes=None):
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "-1")))
+        # (normal priority: a high-priority side stream — rounds 4 - 5 — takes the workgroup slots the streaming kernel's next
+        # workgroups are waiting for; same-box A/B on the ResNet-50 sweep, scripts/lanes1_after_lanes2.py: one stream 0.691 ->
+        # 0.602 ms per batch, two lanes 0.587 -> 0.580; bench.py, two runs each: mse_lanes1 0.666 / 0.681 -> 0.616 / 0.627, mse,
+        # jitter and ViT-B/16 within the runs' spread.  DPL_OCTAV_SIDE_PRIO=-1: the old setting)
+        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "0")))
         # The streaming kernels of consecutive batches go to two streams of the pipeline's own in rotation (each behind the
         # caller's stream as of its submit), so that batch i + 1 starts while batch i drains: the last workgroups of a batch are
         # the pairs whose walks took longest (raised thresholds, long lists) and hold a few slots while the rest of the chip idles
@@ -540,7 +577,11 @@ class OctavPipeline:
             ps = dict(plan=plan, tp=tp, calls=0, states=states, failed=[x[off:off + csz] for x in states],
                       list0=[tp.new("list") for _ in range(max(1, len(self.lanes)))], list1=tp.new("list"), fallback=None, sets=[])
             for _ in range(S):
+                # (pinned: the control block — statistics —, the whole state block and the compaction route's region table: what
+                # _settle needs of a batch is on the host by the time it looks, and what it uploads leaves without a wait)
                 ps["sets"].append(dict(failed=torch.zeros(csz, dtype=torch.uint8).pin_memory(), rescue=tp.new("rescue"),
+                                       host_states=torch.zeros(off + csz, dtype=torch.uint8).pin_memory(),
+                                       base_host=torch.zeros(8 * (plan.n_pairs + 1), dtype=torch.uint8).pin_memory(),
                                        done=None, refs=None, pending=False, k=-1, prepared=None))
             self._plans[id(plan)] = ps
             if getattr(plan, "_octav_pipes", None) is None:
@@ -614,7 +655,7 @@ class OctavPipeline:
             # beyond 2^14, a list beyond its region): the compaction route, launched only now that the count is known — the set's
             # batch is S submits old, its tensors are still referenced — on lists with regions for just the pairs that need them
             # (the states are read back), its results written over the batch's output rows
-            ps["fallback"] = ps["tp"].compaction(st["job"], st["states"], self.side, ps["fallback"])
+            ps["fallback"] = ps["tp"].compaction(st["job"], st["states"], self.side, ps["fallback"], st["host_states"], st["base_host"])
             self._finish(plan, ps, st)
 
     def submit(self, plan, tensors):
@@ -658,7 +699,11 @@ class OctavPipeline:
         # the rescue of the pairs a walk could not finish, on the device: no host round trip decides anything
         _hip.check(L.dpl_octav_oneread_finish(C.byref(job), C.c_void_p(self.side.cuda_stream)), "dpl_octav_oneread_finish")
         with torch.cuda.stream(self.side):
-            cur["failed"].copy_(ps["failed"][r], non_blocking=True)    # (statistics only: _settle)
+            cur["failed"].copy_(ps["failed"][r], non_blocking=True)    # (statistics, and whether the compaction route is needed: _settle)
+            # ... which lays its lists out from the pairs' states: 80 bytes per pair behind every batch (315 KB for a ResNet-50
+            # batch) instead of a read-back — a host synchronisation with the side stream, 0.3 ms of an idle caller's stream —
+            # when a batch asks for the route
+            cur["host_states"].copy_(cur["states"][:cur["host_states"].numel()], non_blocking=True)
         self._finish(plan, ps, cur)
         cur["pending"] = True
         if all(p is not plan for p in self._touched):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 19
+#define DPL_ABI_VERSION 20 /* 20: dpl_fake_quant_pre (the producer's ReLU / Add + ReLU inside the Q/DQ kernel) */
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -151,7 +151,7 @@ int dpl_octav_run_bracket(const dpl_work_item* d_items, int64_t n_items, const u
                           const uint32_t* d_pair_order, float* d_list0, float* d_list1, uint32_t* d_lh_cnt,
                           uint64_t* d_lh_sum, uint32_t* d_bitmap, int dynamic_sym, int max_iters, dpl_stream_t s);
 /* The reference's result in ONE read of the data and one launch per batch — the EXACT-TAIL form (csrc/octav_tail.hpp, included by
- * csrc/octav_oneread.hip; replaces forward_net.py:323-330's 21 numpy passes):
+ * csrc/octav_tail_host.hip; replaces forward_net.py:323-330's 21 numpy passes):
  *   k_octav_tail — one workgroup per SLICE (at most dpl_octav_slice_cap() elements of one (image, tensor) pair; all but the largest
  *     pairs are one slice): the slice's only HBM read yields min / max, an exact log-scale histogram of |x| in LDS (64 bins per
  *     octave over 2^-18 .. 2^14: per bin a count and an integer mantissa sum) and the LIST of the values at or above a threshold

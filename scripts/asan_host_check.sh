@@ -8,7 +8,7 @@ OUT=${TMPDIR:-/tmp}/dpl_asan
 mkdir -p $OUT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -shared -fPIC -fno-fast-math -ffp-contract=off -munsafe-fp-atomics \
   -Xarch_host -fsanitize=address,undefined -Xarch_host -fno-omit-frame-pointer -o $OUT/libdipoorlet_hip.so \
-  $ROOT/dipoorlet_amd/csrc/calib_kernels.hip $ROOT/dipoorlet_amd/csrc/octav_kernels.hip $ROOT/dipoorlet_amd/csrc/octav_oneread.hip \
+  $ROOT/dipoorlet_amd/csrc/calib_kernels.hip $ROOT/dipoorlet_amd/csrc/octav_kernels.hip $ROOT/dipoorlet_amd/csrc/octav_tail_host.hip \
   $ROOT/dipoorlet_amd/csrc/round_kernels.hip $ROOT/dipoorlet_amd/csrc/gemm_small.hip
 RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1)
 cd $ROOT

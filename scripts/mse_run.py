@@ -32,7 +32,7 @@ def main():
     else:
         spec = resnet50_tensors()
         elems, B = [e for _, e, _ in spec], 32
-        pool = [synth_activations(spec, B, dev, seed=500 + k, image_jitter=jit) for k in range(npool)]
+        pool = [synth_activations(spec, B, dev, seed=int(os.environ.get("DPL_SEED0", "500")) + k, image_jitter=jit) for k in range(npool)]
     plan = ops.TensorSetPlan(elems, B, dev)
     pool = [plan.bind(p) for p in pool]       # resident sets: validated and pinned once
     pipe = ops.OctavPipeline(False, dev)

@@ -420,3 +420,57 @@ def test_session_warms_up_for_the_callers_first_batch(workdir):
     for a, b in zip(q1.run(x), q2.run(x)):
         assert torch.equal(a, b)
     executor.join_helpers()
+
+
+@pytest.mark.two_forwards
+def test_relu_and_add_relu_fused_into_the_fake_quant_kernel(workdir, monkeypatch):
+    """executor.relu_fusion: a fake-quantised session asked for the network output only runs ReLU -> Q/DQ and Add -> ReLU -> Q/DQ
+    chains as ONE k_fake_quant<PRE> launch each (the merge-ReLU rule, quantize.py:50-55, puts the next layer's Q/DQ pair directly
+    behind that ReLU); the output is bit for bit the one of the session that runs every node on its own (run(): every tensor
+    exposed), a tensor asked for by name is never fused away, and --bc — whose node-major walk fuses the same chains — writes the
+    same biases with DPL_FUSE_RELU=0."""
+    import types
+
+    from dipoorlet_amd import dist_helper, executor
+    from dipoorlet_amd.graph import ONNXGraph
+    from dipoorlet_amd.quantize import quant_graph
+    from dipoorlet_amd.tensor_cali import find_clip_val_minmax_weight, tensor_calibration
+    from dipoorlet_amd.weight_transform import bias_correction
+    dist_helper.init_default()
+    g = ONNXGraph.load(str(workdir / "model.onnx"))
+    plain = g.make_session()
+    clip = {n: [-3.0, 3.0] for n in plain.tensor_names}
+    clip.update(find_clip_val_minmax_weight(g, None, session=plain))
+    gq, _ = quant_graph(g, clip, types.SimpleNamespace(deploy="trt", skip_layers=[]))
+    sq = gq.make_session()
+    out = gq.network_outputs[0]
+    fused, skipped = sq.fusion([out])
+    kinds = [p for p, _ in fused.values()]
+    assert kinds.count("relu") >= 8 and kinds.count("add_relu") >= 6 and len(skipped) == kinds.count("relu") + 2 * kinds.count("add_relu")
+    x = {n: torch.randn([4] + [int(d) for d in g.get_tensor_shape(n)[1:]], device="cuda") for n in plain.input_names}
+    launches = []
+    orig = executor.fused_fake_quant
+    monkeypatch.setattr(executor, "fused_fake_quant", lambda s_, node, pre, *xs: (launches.append(pre), orig(s_, node, pre, *xs))[1])
+    every = dict(zip(sq.tensor_names, sq.run(x)))                    # every node on its own
+    assert launches == []
+    (y,) = sq.run_named(x, [out])                                    # fused
+    assert sorted(launches) == sorted(kinds) and torch.equal(y, every[out])
+    # a ReLU output asked for by name is computed (and equals the unfused one); the other chains stay fused
+    relu_out = next(n.output[0] for n in gq.graph.node if n.name in skipped and n.op_type == "Relu")
+    launches.clear()
+    y2, r2 = sq.run_named(x, [out, relu_out])
+    assert torch.equal(y2, every[out]) and torch.equal(r2, every[relu_out]) and len(launches) == len(kinds) - 1
+    monkeypatch.undo()
+    # --bc with and without the fusion
+    o = workdir / "bc_fuse"
+    os.makedirs(o, exist_ok=True)
+    args = types.SimpleNamespace(input_dir=str(workdir / "calib"), data_num=N, rank=0, local_rank=0, world_size=1, bins=2048,
+                                 threshold=0.99999, deploy="trt", act_quant="minmax", calib_batch=BATCH, output_dir=str(o), skip_layers=[])
+    a, w = tensor_calibration(g, args)
+    g_fused = bias_correction(g, a, w, args)
+    monkeypatch.setenv("DPL_FUSE_RELU", "0")
+    g_plain = bias_correction(g, a, w, args)
+    for node in g.graph.node:
+        if node.op_type in ("Conv", "Gemm"):
+            b = next(n for n in g_fused.graph.node if n.name == node.name).input[2]
+            assert np.array_equal(g_fused.get_initializer(b), g_plain.get_initializer(b)), node.name

@@ -261,15 +261,20 @@ def test_bias_correction_with_an_empty_shard(tmp_path):
 def test_bench_four_ranks_on_one_gpu():
     """`bench.py --gpus 4` for real on the box's one GPU (gloo; --pool 3 keeps four ranks' resident batches small): rank-indexed
     seeds, the ranges / histogram all-reduces and the gather of the OCTAV rows at world size 4, four per-rank rates, the
-    collectives' milliseconds of both sweeps in rank 0's line — what the driver's N = 4 run does above the backend string."""
+    collectives' milliseconds of both sweeps in rank 0's line — what the driver's N = 4 run does above the backend string.
+    With the DEFAULT side-object flags, as the driver passes none: over more than one rank the run measures the sharded path
+    (hist + mse with their collectives) and nothing else — no ViT / 448 x 448 / jitter / one-stream / fake-quant objects, no CLI
+    children, no CPU baseline on any rank (they characterise one GPU and are the N = 1 run's)."""
     import subprocess
     import sys
+    import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     env["DPL_DIST_BACKEND"] = "gloo"
+    t0 = time.perf_counter()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--mse-steps", "1",
-                        "--e2e-images", "0", "--vit-images", "0", "--real-images", "0", "--big-images", "0", "--fq-reps", "0",
-                        "--mse-jitter", "", "--pool", "3", "--cpu-seconds", "0"], env=env, capture_output=True, text=True, timeout=1200)
+                        "--pool", "3"], env=env, capture_output=True, text=True, timeout=1200)
+    wall = time.perf_counter() - t0
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.strip().splitlines()
     line = json.loads(lines[-1])
@@ -278,6 +283,10 @@ def test_bench_four_ranks_on_one_gpu():
     assert line["config"]["hist_checksum_ok"] is True and line["config"]["collectives_ms_per_sweep"] > 0
     assert line["roofline"]["mse"]["ok"] is True and details["mse"]["collectives_ms_per_sweep"] > 0
     assert details["hist"]["hist_checksum"] == 4 * 1024 * 26598376
+    for k in ("mse_lanes1", "mse_jitter", "fake_quant", "vit_mse", "mse_448", "mse_feature_maps", "e2e"):
+        assert details[k] is None, k
+    assert line["cpu_baseline"] is None and len(lines[-1]) < 2000
+    assert wall < 240, wall      # (the side objects alone take minutes per rank)
 
 
 def test_bench_refuses_more_rccl_ranks_than_gpus():

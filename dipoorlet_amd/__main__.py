@@ -46,7 +46,8 @@ def build_parser():
     p.add_argument("--quant_format", default="QDQ", type=str, choices=["QOP", "QDQ"])
     # MI355X-side knobs
     p.add_argument("--calib_batch", type=int, default=None,
-                   help="calibration images per forward (default: by the graph's size — about 8 GB of exposed activations per batch, at most 64)")
+                   help="calibration images per forward (default: by the graph's size — about 8 GB of exposed activations per batch, at most 64); "
+                        "--bc, --update_bn, profiling and AdaRound / BRECQ walk the set in chunks of this size too (16 when not given)")
     p.add_argument("--resident_gb", type=float, default=160.0, help="HBM budget for keeping pass-1 activations")
     p.add_argument("--merge", choices=["allreduce", "reference"], default="allreduce")
     p.add_argument("--skip_profiling", default=False, action="store_true")

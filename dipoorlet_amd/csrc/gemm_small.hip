@@ -117,7 +117,9 @@ extern "C" int dpl_gemm_small(const float* d_a, const float* d_b, const float* d
     if (m < 0 || n < 0 || k < 0 || m > INT32_MAX || n > INT32_MAX || k > INT32_MAX) return fail_msg("dpl_gemm_small: bad sizes");
     if (m == 0 || n == 0) return 0;
     if (!d_c || (k > 0 && (!d_a || !d_b))) return fail_msg("dpl_gemm_small: null pointer");
-    if ((uint64_t)m * (uint64_t)n * (uint64_t)(k ? k : 1) > DPL_GEMM_SMALL_MAX)
+    // (in steps: m, n, k are each below 2^31, their product may pass 2^64 and wrap below the bound)
+    const uint64_t mn = (uint64_t)m * (uint64_t)n, kk = (uint64_t)(k ? k : 1);
+    if (mn > DPL_GEMM_SMALL_MAX || mn > DPL_GEMM_SMALL_MAX / kk)
         return fail_msg("dpl_gemm_small: more than DPL_GEMM_SMALL_MAX multiply-adds (this is not a GEMM library: use hipBLASLt)");
     int sp = gemm_splits(n, k);
     if (sp > 1 && !d_workspace) return fail_msg("dpl_gemm_small: this product needs dpl_gemm_small_workspace(m, n, k) bytes of workspace");

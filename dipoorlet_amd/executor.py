@@ -49,7 +49,8 @@ def warm_libraries(device=None, blas=True):
                  70 - 80 ms later), so the CLI passes blas=False here and starts this thread (warm_blas) only for a graph that
                  needs the library: a convolutional network's classifier head runs on ops.gemm_small instead
       'kernels'  the first launch of each family of torch's own kernels (code objects are loaded lazily: 10 - 25 ms each) and
-                 MIOpen's first convolution; a session's first forward waits for it (wait_warm('kernels'))
+                 MIOpen's first convolution; nothing waits for this thread (first calls are serialised by the libraries' own
+                 locks: a forward that gets there first pays the first call itself)
     A fresh ResNet-50 process: first forward 248 ms -> 52 - 92 ms (scripts/startup_probe.py)."""
     if not torch.cuda.is_available():
         return
@@ -430,7 +431,8 @@ def _slice(s, node, x, starts=None, ends=None, axes=None, steps=None):
         if sp < 0:      # (the exporter reverses the pads vector of F.pad this way) start in [0, n-1], end in [-1, n-1]
             st = max(0, min(n - 1, st + n if st < 0 else st))
             en = max(-1, min(n - 1, en + n if en < 0 else en))
-            x = torch.index_select(x, ax, torch.arange(st, en, sp, device=x.device))
+            # (an empty range — start <= end with a negative step — is an empty result in ONNX; torch.arange refuses it)
+            x = torch.index_select(x, ax, torch.tensor(list(range(st, en, sp)), dtype=torch.long, device=x.device))
             continue
         st = max(0, min(n, st + n if st < 0 else st))
         en = max(0, min(n, en + n if en < 0 else en))
@@ -771,7 +773,11 @@ class GraphSession(ActivationSession):
             for (_, a), o in zip(flat, offs):
                 hv[o:o + a.size] = a.reshape(-1)            # (fp16 initializers widen here)
             dev = host.to(self.device, non_blocking=True)
-            self._consts_host = host                       # pinned source: alive until the copy has run
+            # pinned source: alive until the copy has run, then released at the session's first forward (a few hundred MB of
+            # page-locked memory per session for ViT-B/16; --bc builds two sessions, AdaRound more)
+            self._consts_host = host
+            self._consts_copied = torch.cuda.Event()
+            self._consts_copied.record(torch.cuda.current_stream(self.device))
             for (name, a), o in zip(flat, offs):
                 v = dev[o:o + a.size].view(a.shape)
                 self.consts[name] = _host_ints(v, [float(x) for x in a.reshape(-1)]) if a.size <= 16 else v
@@ -934,6 +940,8 @@ class GraphSession(ActivationSession):
                     for t in self._conv_threads:
                         t.join()
             self._conv_threads = None
+        if getattr(self, "_consts_host", None) is not None and self._consts_copied.query():
+            self._consts_host = None
         mark("first_forward:start")     # (the other helper threads are not waited for: first calls are serialised by the libraries' own locks)
         return self._forward({n: inputs[n].to(self.device, torch.float32) for n in self.input_names}, batch, keep)
 

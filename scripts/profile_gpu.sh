@@ -7,13 +7,18 @@
 #   (iv)  the images-alike mse sweep with the streaming kernels NOT overlapped (DPL_OCTAV_LANES=1): the kernel's own duration
 # each of (ii), (iii): kernel stats + the two PMC passes -> traffic_<name>.json.  Usage: scripts/profile_gpu.sh <tag>
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 # counters for this library's kernels only (collecting them for every torch kernel made a torch.rand launch of the jittered set crash
 # inside the profiler)
 KERNELS="k_octav|k_abs_hist|k_minmax|k_hist|k_fake_quant"
+# A warm-up process first: the MIOpen user find-db of a fresh box is empty, and the library's Find benchmark over every convolution
+# configuration of the fake-quantised forward (8 launches of its naive kernel each, profiles/r06/conv_repro.md) would sit in the trace
+python3 scripts/fq_forward_run.py > $OUT/warm.log 2>&1
+python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --big-images 0 --mse-jitter "" --steps 1 --warmup 0 --mse-steps 0 --fq-reps 1 >> $OUT/warm.log 2>&1
+python3 scripts/mse_run.py vit 2 2 >> $OUT/warm.log 2>&1
 BENCH="python3 bench.py --cpu-seconds 0 --e2e-images 0 --vit-images 0 --real-images 0 --big-images 0 --mse-jitter"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $BENCH "" > $OUT/bench_stats.json 2> $OUT/stats.err
 python3 scripts/summarize_prof.py stats $OUT/stats $OUT/kernel_stats.md > /dev/null
@@ -40,4 +45,9 @@ sweep jitter0.1 resnet50 64 DPL_BENCH_JITTER=0.1
 # by default the kernels of consecutive batches overlap (two lane streams), their elapsed times then add up to more than the sweep
 sweep alike_lanes1 resnet50 64 DPL_OCTAV_LANES=1
 sweep vit vit 32 X=1
+# (v) the fake-quantised ResNet-50 forward, every tensor exposed against ReLU / Add + ReLU fused into the Q/DQ kernel
+bash scripts/fq_forward_prof.sh > $OUT/run_fq_forward.log 2>&1
+cp gpurun_out/prof_fqfwd/kernel_stats_fq_forward.md gpurun_out/prof_fqfwd/fq_forward.json $OUT/
+# (vi) same-box A/B of the OCTAV side stream's priority: a two-lane sweep, then a one-stream sweep, per setting, twice
+for p in -1 0 -1 0; do echo "DPL_OCTAV_SIDE_PRIO=$p"; DPL_OCTAV_SIDE_PRIO=$p python3 scripts/lanes1_after_lanes2.py l2_l1; done > $OUT/ab_side_prio.txt 2>&1
 head -12 $OUT/kernel_stats.md; cat $OUT/traffic.json | head -40; tail -c 1200 $OUT/bench_stats.json; tail -1 $OUT/run_jitter0.1.log $OUT/run_vit.log

@@ -388,3 +388,20 @@ def test_scan_op_types_reads_no_tensors(tmp_path):
         g.save_onnx_model(name)
         path = os.path.join(str(tmp_path), name + ".onnx")
         assert onnx_io.scan_op_types(path) == dict(Counter(n.op_type for n in onnx_io.load_model(path).nodes))
+
+
+def test_negative_step_slice_follows_onnx_for_empty_ranges():
+    """Slice with a negative step (the exporter reverses F.pad's vector this way): clamped bounds as ONNX defines them, and an
+    EMPTY result where start <= end — what shape_infer's rule predicts — instead of torch.arange's refusal."""
+    import types
+
+    from dipoorlet_amd import executor, shape_infer
+    node = types.SimpleNamespace(attrs={}, op_type="Slice")
+    x = torch.arange(10.0).reshape(2, 5)
+    t = torch.tensor
+    run = executor._OPS["Slice"]
+    assert run(None, node, x, t([3]), t([0]), t([1]), t([-1])).tolist() == [[3.0, 2.0, 1.0], [8.0, 7.0, 6.0]]
+    assert run(None, node, x, t([-1]), t([-6]), t([1]), t([-1])).tolist() == [[4.0, 3.0, 2.0, 1.0, 0.0], [9.0, 8.0, 7.0, 6.0, 5.0]]
+    assert run(None, node, x, t([4]), t([-100]), t([1]), t([-2])).tolist() == [[4.0, 2.0, 0.0], [9.0, 7.0, 5.0]]
+    assert tuple(run(None, node, x, t([1]), t([3]), t([1]), t([-1])).shape) == (2, 0)
+    assert tuple(run(None, node, x, t([2]), t([2]), t([1]), t([-1])).shape) == (2, 0)

@@ -532,11 +532,14 @@ class OctavPipeline:
     def __init__(self, dynamic_sym, device=None, lanes=None):
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        # (normal priority: a high-priority side stream — rounds 4 - 5 — takes the workgroup slots the streaming kernel's next
-        # workgroups are waiting for; same-box A/B on the ResNet-50 sweep, scripts/lanes1_after_lanes2.py: one stream 0.691 ->
-        # 0.602 ms per batch, two lanes 0.587 -> 0.580; bench.py, two runs each: mse_lanes1 0.666 / 0.681 -> 0.616 / 0.627, mse,
-        # jitter and ViT-B/16 within the runs' spread.  DPL_OCTAV_SIDE_PRIO=-1: the old setting)
-        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "0")))
+        n_lanes = int(os.environ.get("DPL_OCTAV_LANES", "0")) or (2 if lanes is None else int(lanes))
+        # The side stream's priority.  ONE stream (the caller's carries the streaming kernels): normal — a high-priority side stream
+        # (rounds 4 - 5) takes the workgroup slots the streaming kernel's next workgroups are waiting for: same-box A/B on the
+        # ResNet-50 sweep (scripts/lanes1_after_lanes2.py, profiles/r06/ab_side_prio.txt) 0.75 -> 0.60 ms per batch, bench.py's
+        # mse_lanes1 0.67 -> 0.62.  Two lanes: high, as before — the rescue of batch i then ends before batch i + 3 asks for its set
+        # (five runs each: 0.5765 ms mean at high, 0.5814 - 0.5888 at normal priority).  DPL_OCTAV_SIDE_PRIO overrides both.
+        prio = os.environ.get("DPL_OCTAV_SIDE_PRIO")
+        self.side = torch.cuda.Stream(self.device, priority=int(prio) if prio not in (None, "") else (-1 if n_lanes >= 2 else 0))
         # The streaming kernels of consecutive batches go to two streams of the pipeline's own in rotation (each behind the
         # caller's stream as of its submit), so that batch i + 1 starts while batch i drains: the last workgroups of a batch are
         # the pairs whose walks took longest (raised thresholds, long lists) and hold a few slots while the rest of the chip idles
@@ -544,7 +547,6 @@ class OctavPipeline:
         # ViT-B/16 - 0.7 %; three streams: + 3 ... 6 % (three kernels share the slots).  lanes = 1 (or DPL_OCTAV_LANES=1): the
         # caller's stream — what a caller that runs a network forward between two submits wants (forward_net_octav: beside the
         # next forward's convolutions the streaming kernel costs the forward 10 % and the loop 6 %, scripts/e2e_lanes_ab.sh).
-        n_lanes = int(os.environ.get("DPL_OCTAV_LANES", "0")) or (2 if lanes is None else int(lanes))
         self.lanes = [torch.cuda.Stream(self.device) for _ in range(n_lanes)]
         if len(self.lanes) < 2:
             self.lanes = []

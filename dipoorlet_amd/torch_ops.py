@@ -54,7 +54,6 @@ class _Cached:
         if a is None:
             a = self.acc[bins] = ops.CalibAccumulators(self.plan.T, self.device, bins)
             a.ranges = torch.empty(a.n * ctypes.sizeof(_hip.HistRange), dtype=torch.uint8, device=self.device)
-            a.clip = torch.empty(a.n, 2, dtype=torch.float32, device=self.device)
         return a
 
     def pipeline(self, dynamic_sym):

@@ -533,13 +533,15 @@ class OctavPipeline:
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         n_lanes = int(os.environ.get("DPL_OCTAV_LANES", "0")) or (2 if lanes is None else int(lanes))
-        # The side stream's priority.  ONE stream (the caller's carries the streaming kernels): normal — a high-priority side stream
-        # (rounds 4 - 5) takes the workgroup slots the streaming kernel's next workgroups are waiting for: same-box A/B on the
-        # ResNet-50 sweep (scripts/lanes1_after_lanes2.py, profiles/r06/ab_side_prio.txt) 0.75 -> 0.60 ms per batch, bench.py's
-        # mse_lanes1 0.67 -> 0.62.  Two lanes: high, as before — the rescue of batch i then ends before batch i + 3 asks for its set
-        # (five runs each: 0.5765 ms mean at high, 0.5814 - 0.5888 at normal priority).  DPL_OCTAV_SIDE_PRIO overrides both.
-        prio = os.environ.get("DPL_OCTAV_SIDE_PRIO")
-        self.side = torch.cuda.Stream(self.device, priority=int(prio) if prio not in (None, "") else (-1 if n_lanes >= 2 else 0))
+        # The side stream runs at NORMAL priority.  A high-priority side stream (rounds 4 - 5) takes the workgroup slots the streaming
+        # kernel's next workgroups are waiting for — and whether it does depends on which hardware queues the process' streams
+        # land on: on ONE stream (the caller's carries the streaming kernels) 0.75 -> 0.60 ms per batch on the ResNet-50 sweep
+        # (scripts/lanes1_after_lanes2.py, profiles/r06/ab_side_prio.txt), bench.py's mse_lanes1 0.67 -> 0.59 - 0.62; two lanes
+        # within the runs' spread either way (0.565 - 0.587 against 0.570 - 0.588).  A MIX — a two-lane pipeline at high priority
+        # created first, a one-stream pipeline at normal priority after it — put the second one's side stream where it serialised
+        # with the caller's stream on one box (0.71 ms): every pipeline of a process gets the same.  DPL_OCTAV_SIDE_PRIO=-1: the
+        # old setting.
+        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "0")))
         # The streaming kernels of consecutive batches go to two streams of the pipeline's own in rotation (each behind the
         # caller's stream as of its submit), so that batch i + 1 starts while batch i drains: the last workgroups of a batch are
         # the pairs whose walks took longest (raised thresholds, long lists) and hold a few slots while the rest of the chip idles

@@ -397,8 +397,6 @@ def main():
 
         if len(pool) < min_pool and rank == 0:
             print(f"bench.py: --pool {len(pool)} < {min_pool}: batches repeat inside the prediction's memory", file=sys.stderr)
-        if os.environ.get("DPL_BENCH_L1_FIRST") and world == 1:     # (A/B aid: does the order of the two objects matter?)
-            mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
         mse = run_mse(pool, a.mse_steps, jitter)
         # Everything below characterises ONE GPU (other schedules, other activations, other shapes, the fake-quant kernels, the CLI end
         # to end, the CPU baseline) and is reported by the N = 1 run.  A run over several ranks measures the sharded path — the hist
@@ -407,8 +405,7 @@ def main():
         side = world == 1
         if not side:
             a.mse_jitter, a.real_images, a.vit_images, a.big_images, a.fq_reps, pipe1 = "", 0, 0, 0, 0, None
-        if not os.environ.get("DPL_BENCH_L1_FIRST"):
-            mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
+        mse_lanes1 = run_mse(pool, max(1, a.mse_steps // 2), jitter, pipe=pipe1) if pipe1 is not None else None
         # the same sweep over images that differ in contrast (one sweep each): what a prediction from other images costs
         for jit in ([float(x) for x in a.mse_jitter.split(",") if x] if jitter == 0.0 else []):
             jp = [synth_activations(spec, B, dev, seed=99 + 1000 * rank + j, image_jitter=jit) for j in range(len(pool))]

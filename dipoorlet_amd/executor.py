@@ -28,6 +28,16 @@ torch.backends.cuda.matmul.allow_tf32 = False
 # section 4; scripts/conv_repro_probe.py)
 if os.environ.get("DPL_DETERMINISTIC") == "1":
     torch.backends.cudnn.deterministic = True
+# MIOpen's find mode, unless the caller has chosen one.  The library's default (DYNAMIC_HYBRID) answers a convolution configuration
+# its find-db does not hold by BENCHMARKING every applicable solver — 8 launches of its naive kernel among them — and remembers the
+# result in the user find-db (~/.config/miopen): on a fresh account or container that is 0.7 - 4.8 s of a process' first forward
+# (ResNet-50 at batch 16 / 64; ResNet-18 3.8 s, ViT-B/16 0.2 s; profiles/r06/conv_repro.md section 3, scripts/find_mode_probe.sh),
+# where a calibration run over 1 024 images takes 0.35 s.  FAST takes the library's heuristic choice on a miss and benchmarks
+# nothing: 0.06 - 0.07 s on the same cold boxes, the steady forward within 0 - 3 % (the convolutions' own GPU time + 1 - 5 %), a
+# process on a warm find-db unchanged.  DPL_MIOPEN_FIND_MODE=library leaves the library's default; any other value is passed on.
+_find_mode = os.environ.get("DPL_MIOPEN_FIND_MODE", "FAST")
+if _find_mode != "library":
+    os.environ.setdefault("MIOPEN_FIND_MODE", _find_mode)
 
 from .forward_net import ActivationSession
 from .forward_net import wall as _wall

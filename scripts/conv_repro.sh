@@ -1,5 +1,7 @@
 #!/bin/bash
 # VERDICT r05 item 2 on one fresh box: what differs between two forwards, and does the naive convolution run?
+# (the library's own find mode: this package defaults to FAST, which never benchmarks and never launches the naive kernel)
+export DPL_MIOPEN_FIND_MODE=library
 out=gpurun_out/conv_repro; mkdir -p $out
 { echo "== MIOpen user db / cache before"; ls -la ~/.cache/miopen ~/.config/miopen 2>&1 | head; } > $out/cache.txt
 python3 scripts/conv_repro_probe.py --net resnet50 --batch 32 --quant --out $out/default_b32.json > $out/default_b32.log 2>&1

@@ -2,6 +2,8 @@
 # Does MIOpen's naive convolution ever run in a user's process?  A kernel trace of scripts/conv_repro_probe.py with an EMPTY user
 # find-db (MIOPEN_USER_DB_PATH -> a fresh directory; what every new account / box starts with), then the same command again with
 # the db the first run wrote.  scripts/conv_repro_kernels.py prints the kernels per (configuration, call).
+# (the library's own find mode: this package defaults to FAST, which never benchmarks and never launches the naive kernel)
+export DPL_MIOPEN_FIND_MODE=library
 out=$PWD/gpurun_out/conv_repro; mkdir -p $out
 R=$PWD
 export TMPDIR=/tmp

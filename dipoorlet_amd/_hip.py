@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # DPL_LIB: another build of the same sources (kernel-tuning variants, scripts/variant_*.sh); never a different code path
 LIB_PATH = os.environ.get("DPL_LIB") or os.path.join(_HERE, "csrc", "libdipoorlet_hip.so")
 
-ABI_VERSION = 20
+ABI_VERSION = 21
 MAX_BINS = 16384
 
 
@@ -83,6 +83,9 @@ SIGNATURES = {
     "dpl_abi_version": (C.c_int, []),
     "dpl_last_error": (C.c_char_p, []),
     "dpl_device_info": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "dpl_stream_priority_range": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "dpl_stream_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "dpl_stream_destroy": (C.c_int, [_P]),
     "dpl_build_work_items": (_I64, [_P, _I64, _U64, _P, _I64]),
     "dpl_build_balanced_items": (_I64, [_P, _I64, _I64, _P, _I64, _P]),
     "dpl_minmax_init": (C.c_int, [_P, _P, _P, _I64, _P]),

@@ -746,6 +746,35 @@ int dpl_device_info(char* name, int name_cap, int* compute_units, uint64_t* hbm_
     return 0;
 }
 
+int dpl_stream_priority_range(int* least, int* greatest) {
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (e != hipSuccess) return fail("hipDeviceGetStreamPriorityRange", e);
+    if (least) *least = lo;
+    if (greatest) *greatest = hi;
+    return 0;
+}
+
+int dpl_stream_create(int priority, dpl_stream_t* out) {
+    if (!out) return fail_msg("dpl_stream_create: null out");
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // (lo: the numerically largest = least urgent)
+    if (e != hipSuccess) return fail("hipDeviceGetStreamPriorityRange", e);
+    if (priority > lo) priority = lo;
+    if (priority < hi) priority = hi;
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+    if (e != hipSuccess) return fail("hipStreamCreateWithPriority", e);
+    *out = (dpl_stream_t)s;
+    return 0;
+}
+
+int dpl_stream_destroy(dpl_stream_t s) {
+    if (!s) return 0;
+    hipError_t e = hipStreamDestroy((hipStream_t)s);
+    return e == hipSuccess ? 0 : fail("hipStreamDestroy", e);
+}
+
 int64_t dpl_build_work_items(const dpl_span* spans, int64_t n_spans, uint64_t chunk_elems, dpl_work_item* out,
                              int64_t cap) {
     if (!spans || n_spans < 0 || chunk_elems == 0 || (chunk_elems % 1024) != 0 || chunk_elems > 0xFFFFFC00ull)

@@ -508,6 +508,35 @@ def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
 _PIPE_SETS = max(2, int(os.environ.get("DPL_OCTAV_PIPE_SETS", "3")))   # batches the host may run ahead of the device (OctavPipeline)
 
 
+def _runs_beside(device, stream, others, cycles=1500000):
+    """Does work on `stream` run BESIDE work on each of `others` (separate hardware queues) rather than behind it (one queue)?
+    Asked of the device: a spin of about a millisecond on the other stream, then a marker on `stream` — if the marker has passed
+    while the spin is still running, the two do not share a queue.  HOST (synchronises on the marker; once per pipeline)."""
+    for o in others:
+        with torch.cuda.stream(o):
+            torch.cuda._sleep(cycles)
+            spun = torch.cuda.Event()
+            spun.record(o)
+        marker = torch.cuda.Event()
+        marker.record(stream)
+        marker.synchronize()
+        beside = not spun.query()
+        spun.synchronize()
+        if not beside:
+            return False
+    return True
+
+
+def _separate_stream(device, others, tries=8):
+    """A normal-priority stream whose work runs beside that of `others` (_runs_beside); after `tries` candidates, the last one."""
+    s = None
+    for _ in range(tries):
+        s = torch.cuda.Stream(device)
+        if _runs_beside(device, s, others):
+            break
+    return s
+
+
 class OctavPipeline:
     """OCTAV over a RUN of batches in the exact-tail form on streams of its own.  Same kernels, same results as octav_batch.
 
@@ -533,15 +562,26 @@ class OctavPipeline:
         self.dyn = 1 if dynamic_sym else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         n_lanes = int(os.environ.get("DPL_OCTAV_LANES", "0")) or (2 if lanes is None else int(lanes))
-        # The side stream runs at NORMAL priority.  A high-priority side stream (rounds 4 - 5) takes the workgroup slots the streaming
-        # kernel's next workgroups are waiting for — and whether it does depends on which hardware queues the process' streams
-        # land on: on ONE stream (the caller's carries the streaming kernels) 0.75 -> 0.60 ms per batch on the ResNet-50 sweep
-        # (scripts/lanes1_after_lanes2.py, profiles/r06/ab_side_prio.txt), bench.py's mse_lanes1 0.67 -> 0.59 - 0.62; two lanes
-        # within the runs' spread either way (0.565 - 0.587 against 0.570 - 0.588).  A MIX — a two-lane pipeline at high priority
-        # created first, a one-stream pipeline at normal priority after it — put the second one's side stream where it serialised
-        # with the caller's stream on one box (0.71 ms): every pipeline of a process gets the same.  DPL_OCTAV_SIDE_PRIO=-1: the
-        # old setting.
-        self.side = torch.cuda.Stream(self.device, priority=int(os.environ.get("DPL_OCTAV_SIDE_PRIO", "0")))
+        # The side stream: NORMAL priority, on a hardware queue of its own.  High priority (rounds 4 - 5) lets its kernels take over
+        # from the streaming kernel's waves whenever the process' streams land on the queues that way (one stream 0.75 ms per batch
+        # on the ResNet-50 sweep against 0.60; scripts/lanes1_after_lanes2.py, profiles/r06/ab_side_prio.txt); low priority (a stream
+        # of the library's own making, dpl_stream_create) starves the rescue and with it the set the host waits for (0.77).  But a
+        # normal-priority stream may SHARE its hardware queue with the caller's stream — four queues per priority class, handed out
+        # in creation order — and then the rescue of batch i and the streaming kernel of batch i + 1 run one after the other (1.17 ms
+        # under the profiler on one box, 0.71 on another after a two-lane pipeline had been created first): _separate_stream asks
+        # the device.  DPL_OCTAV_SIDE_PRIO = -1 / 0 / 1 (high / normal / low): a fixed priority, no questions asked.
+        self._side_handle = None
+        prio = os.environ.get("DPL_OCTAV_SIDE_PRIO")
+        if prio in (None, ""):
+            self.side = _separate_stream(self.device, [torch.cuda.current_stream(self.device)])
+        elif int(prio) > 0:
+            h = C.c_void_p()
+            with torch.cuda.device(self.device):
+                _hip.check(_hip.lib().dpl_stream_create(int(prio), C.byref(h)), "dpl_stream_create")
+            self._side_handle = h.value
+            self.side = torch.cuda.ExternalStream(h.value, self.device)
+        else:
+            self.side = torch.cuda.Stream(self.device, priority=int(prio))
         # The streaming kernels of consecutive batches go to two streams of the pipeline's own in rotation (each behind the
         # caller's stream as of its submit), so that batch i + 1 starts while batch i drains: the last workgroups of a batch are
         # the pairs whose walks took longest (raised thresholds, long lists) and hold a few slots while the rest of the chip idles
@@ -549,9 +589,10 @@ class OctavPipeline:
         # ViT-B/16 - 0.7 %; three streams: + 3 ... 6 % (three kernels share the slots).  lanes = 1 (or DPL_OCTAV_LANES=1): the
         # caller's stream — what a caller that runs a network forward between two submits wants (forward_net_octav: beside the
         # next forward's convolutions the streaming kernel costs the forward 10 % and the loop 6 %, scripts/e2e_lanes_ab.sh).
-        self.lanes = [torch.cuda.Stream(self.device) for _ in range(n_lanes)]
-        if len(self.lanes) < 2:
-            self.lanes = []
+        self.lanes = []
+        if n_lanes >= 2:       # (each on a queue of its own too: two lanes on one queue would not overlap)
+            for _ in range(n_lanes):
+                self.lanes.append(_separate_stream(self.device, [torch.cuda.current_stream(self.device), self.side] + self.lanes))
         self._plans = {}          # id(plan) -> this pipeline's rotation state for the plan
         self._touched = []
         # record_events = True: per submit a (start, end) pair of timing events around the streaming kernel ON ITS LANE, kept in
@@ -560,6 +601,15 @@ class OctavPipeline:
         self.events = []
         # statistics: batches settled, batches / (image, tensor) pairs whose walk was refused (rescued or compaction route)
         self.reset_stats()
+
+    def __del__(self):
+        h = getattr(self, "_side_handle", None)
+        if h:
+            try:
+                self.side.synchronize()
+                _hip.lib().dpl_stream_destroy(C.c_void_p(h))
+            except Exception:   # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def reset_stats(self):
         self.batches = self.fallback_batches = self.fallback_pairs = self.compaction_pairs = 0

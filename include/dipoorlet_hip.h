@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DPL_ABI_VERSION 20 /* 20: dpl_fake_quant_pre (the producer's ReLU / Add + ReLU inside the Q/DQ kernel) */
+#define DPL_ABI_VERSION 21 /* 20: dpl_fake_quant_pre (the producer's ReLU / Add + ReLU inside the Q/DQ kernel); 21: dpl_stream_* */
 #define DPL_MAX_BINS 16384 /* LDS-privatised histogram: bins * 4 B per workgroup */
 
 typedef void* dpl_stream_t; /* hipStream_t */
@@ -78,6 +78,15 @@ int dpl_abi_version(void);
 const char* dpl_last_error(void);
 /* 0 when the current HIP device is a gfx950 part; fills name (HOST buffer) when non-null. */
 int dpl_device_info(char* name, int name_cap, int* compute_units, uint64_t* hbm_bytes);
+/* A HIP stream of a given priority on the current device (hipStreamNonBlocking), for work that runs BESIDE a caller's stream: the
+ * OCTAV pipeline's rescue / result kernels.  priority: what hipDeviceGetStreamPriorityRange reports — *greatest (-1: high) ...
+ * *least (1: low) on gfx950; values outside the range are clamped.  A LOW-priority stream lives on a hardware queue of its own class:
+ * it neither takes the workgroup slots the caller's streaming kernel is waiting for (a high-priority one does) nor shares a queue
+ * with the caller's stream (a normal-priority one may, depending on the order the process created its streams: the two then run one
+ * after the other).  torch cannot create one (it clamps priorities above 0 to 0): wrap the handle in torch.cuda.ExternalStream. */
+int dpl_stream_priority_range(int* least, int* greatest);
+int dpl_stream_create(int priority, dpl_stream_t* out);
+int dpl_stream_destroy(dpl_stream_t s);
 
 /* HOST-only: cut spans into work items of at most `chunk_elems` (multiple of 1024) elements.
  * Returns the number of items (may exceed cap: call again with a larger buffer), <0 on error. */

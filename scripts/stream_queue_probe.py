@@ -1,0 +1,16 @@
+import sys, time, torch
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dipoorlet_amd import ops
+dev = torch.device("cuda")
+torch.zeros(1, device=dev); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); torch.cuda._sleep(1500000); e1.record(); torch.cuda.synchronize()
+print("_sleep(1.5e6) takes %.3f ms" % e0.elapsed_time(e1))
+main = torch.cuda.current_stream()
+# which of 12 consecutive pool streams run beside the default stream, and beside each other?
+ss = [torch.cuda.Stream(dev) for _ in range(12)]
+print("beside the default stream:", [int(ops._runs_beside(dev, s, [main])) for s in ss])
+print("beside stream 0:          ", [int(ops._runs_beside(dev, s, [ss[0]])) for s in ss])
+t = time.perf_counter(); p = ops.OctavPipeline(False, dev, lanes=1); t1 = time.perf_counter() - t
+t = time.perf_counter(); p2 = ops.OctavPipeline(False, dev, lanes=2); t2 = time.perf_counter() - t
+print("pipeline creation: one stream %.1f ms, two lanes %.1f ms" % (1e3 * t1, 1e3 * t2))

@@ -1159,3 +1159,33 @@ def test_seg_table_checks_every_unbound_call(dev):
     acc.minmax_accumulate(plan, bound)
     with pytest.raises(_hip.DipoorletHipError, match="another plan"):
         acc.minmax_accumulate(ops.TensorSetPlan(sizes, B, dev), bound)
+
+
+def test_pipeline_streams_run_beside_the_callers_stream(dev):
+    """OctavPipeline's side stream (and lanes) must run BESIDE the caller's stream: a normal-priority stream that shares its
+    hardware queue runs behind it instead (ops._separate_stream asks the device; ops._runs_beside is the question).  A stream
+    is never beside itself; the pipeline's choices are beside the caller's stream and beside each other.  dpl_stream_create makes
+    the stream torch cannot (a low-priority one) and the range is gfx950's."""
+    import ctypes as C
+
+    from dipoorlet_amd import _hip, ops
+    main = torch.cuda.current_stream(dev)
+    s = torch.cuda.Stream(dev)
+    assert ops._runs_beside(dev, s, [s]) is False
+    for lanes in (1, 2):
+        p = ops.OctavPipeline(False, dev, lanes=lanes)
+        streams = [p.side] + p.lanes
+        assert len(p.lanes) == (2 if lanes == 2 else 0)
+        ok = sum(ops._runs_beside(dev, x, [main] + [y for y in streams if y is not x]) for x in streams)
+        assert ok == len(streams), (lanes, ok)
+    lo, hi = C.c_int(), C.c_int()
+    _hip.check(_hip.lib().dpl_stream_priority_range(C.byref(lo), C.byref(hi)), "dpl_stream_priority_range")
+    assert (lo.value, hi.value) == (1, -1)
+    h = C.c_void_p()
+    _hip.check(_hip.lib().dpl_stream_create(5, C.byref(h)), "dpl_stream_create")       # (clamped to the least urgent)
+    ext = torch.cuda.ExternalStream(h.value, dev)
+    with torch.cuda.stream(ext):
+        y = torch.arange(8, device=dev).float().sum()
+    ext.synchronize()
+    assert float(y) == 28.0
+    _hip.check(_hip.lib().dpl_stream_destroy(h), "dpl_stream_destroy")

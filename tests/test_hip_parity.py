@@ -1176,7 +1176,9 @@ def test_pipeline_streams_run_beside_the_callers_stream(dev):
         p = ops.OctavPipeline(False, dev, lanes=lanes)
         streams = [p.side] + p.lanes
         assert len(p.lanes) == (2 if lanes == 2 else 0)
-        ok = sum(ops._runs_beside(dev, x, [main] + [y for y in streams if y is not x]) for x in streams)
+        # (the question is answered by timing on the device: a stream that shares a queue is behind EVERY time, one that does not
+        # may look so once when something else delays its marker — asked up to three times)
+        ok = sum(any(ops._runs_beside(dev, x, [main] + [y for y in streams if y is not x]) for _ in range(3)) for x in streams)
         assert ok == len(streams), (lanes, ok)
     lo, hi = C.c_int(), C.c_int()
     _hip.check(_hip.lib().dpl_stream_priority_range(C.byref(lo), C.byref(hi)), "dpl_stream_priority_range")

@@ -322,7 +322,7 @@ def forward_get_minmax(onnx_graph, args, per_image=False, run=None, keep_residen
     # the range kernel of batch i runs on a side stream beside the network forward of batch i + 1 (one is HBM-bound, the
     # other mostly compute-bound library work); a batch's tensors stay referenced until its kernel has run
     main = torch.cuda.current_stream(run.device)
-    side = torch.cuda.Stream(run.device)
+    side = ops._separate_stream(run.device, [main])      # (on a hardware queue of its own: one that shares the forward's runs behind it)
     side.wait_stream(main)                      # the accumulators' initialisation
     in_flight = []
     t_loop = __import__("time").perf_counter()

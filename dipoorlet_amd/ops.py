@@ -508,33 +508,48 @@ def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
 _PIPE_SETS = max(2, int(os.environ.get("DPL_OCTAV_PIPE_SETS", "3")))   # batches the host may run ahead of the device (OctavPipeline)
 
 
-def _runs_beside(device, stream, others, cycles=1500000):
-    """Does work on `stream` run BESIDE work on each of `others` (separate hardware queues) rather than behind it (one queue)?
-    Asked of the device: a spin of about a millisecond on the other stream, then a marker on `stream` — if the marker has passed
-    while the spin is still running, the two do not share a queue.  HOST (synchronises on the marker; once per pipeline)."""
+_BESIDE = 0.75
+
+
+def _behind(device, stream, others, cycles=1500000):
+    """How far BEHIND work on `others` does work on `stream` run: 0 .. 1 per other stream, the largest.  Asked of the device, in
+    its own timestamps: a spin of about a millisecond on the other stream between two timing events, a marker event on `stream`
+    issued right after — a marker stamped at the spin's start ran beside it (separate hardware queues: ~0), one stamped at its
+    end waited for it (one queue: ~1).  HOST (synchronises; a few milliseconds, once per pipeline)."""
+    worst = 0.0
     for o in others:
+        s0, s1, m = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         with torch.cuda.stream(o):
+            s0.record(o)
             torch.cuda._sleep(cycles)
-            spun = torch.cuda.Event()
-            spun.record(o)
-        marker = torch.cuda.Event()
-        marker.record(stream)
-        marker.synchronize()
-        beside = not spun.query()
-        spun.synchronize()
-        if not beside:
-            return False
-    return True
+            s1.record(o)
+        m.record(stream)
+        s1.synchronize()
+        m.synchronize()
+        spin = max(s0.elapsed_time(s1), 1e-6)
+        worst = max(worst, min(1.0, max(0.0, s0.elapsed_time(m) / spin)))
+    return worst
 
 
-def _separate_stream(device, others, tries=8):
-    """A normal-priority stream whose work runs beside that of `others` (_runs_beside); after `tries` candidates, the last one."""
-    s = None
+def _runs_beside(device, stream, others):
+    """Does work on `stream` run beside work on each of `others`?  (_behind reads 0.01 - 0.03 for two pool streams on separate
+    queues and 1.0 on a shared one; against the DEFAULT stream 0.5 - 0.6 and 1.0 — its events are stamped differently —, and 1.0
+    throughout under rocprofv3: scripts/stream_queue_probe.py)"""
+    return _behind(device, stream, others) < _BESIDE
+
+
+def _separate_stream(device, others, tries=6):
+    """A normal-priority stream whose work runs beside that of `others`: the first of `tries` pool streams that does — or, should
+    none be clearly beside (a profiler in the way of the timestamps), the one that was least behind."""
+    best, best_b = None, 2.0
     for _ in range(tries):
         s = torch.cuda.Stream(device)
-        if _runs_beside(device, s, others):
+        b = _behind(device, s, others)
+        if b < best_b:
+            best, best_b = s, b
+        if b < _BESIDE:
             break
-    return s
+    return best
 
 
 class OctavPipeline:

@@ -9,8 +9,8 @@ print("_sleep(1.5e6) takes %.3f ms" % e0.elapsed_time(e1))
 main = torch.cuda.current_stream()
 # which of 12 consecutive pool streams run beside the default stream, and beside each other?
 ss = [torch.cuda.Stream(dev) for _ in range(12)]
-print("beside the default stream:", [int(ops._runs_beside(dev, s, [main])) for s in ss])
-print("beside stream 0:          ", [int(ops._runs_beside(dev, s, [ss[0]])) for s in ss])
+print("behind the default stream:", [round(ops._behind(dev, s, [main]), 2) for s in ss])
+print("behind stream 0:          ", [round(ops._behind(dev, s, [ss[0]]), 2) for s in ss])
 t = time.perf_counter(); p = ops.OctavPipeline(False, dev, lanes=1); t1 = time.perf_counter() - t
 t = time.perf_counter(); p2 = ops.OctavPipeline(False, dev, lanes=2); t2 = time.perf_counter() - t
 print("pipeline creation: one stream %.1f ms, two lanes %.1f ms" % (1e3 * t1, 1e3 * t2))

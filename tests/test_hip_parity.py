@@ -1171,15 +1171,20 @@ def test_pipeline_streams_run_beside_the_callers_stream(dev):
     from dipoorlet_amd import _hip, ops
     main = torch.cuda.current_stream(dev)
     s = torch.cuda.Stream(dev)
-    assert ops._runs_beside(dev, s, [s]) is False
-    for lanes in (1, 2):
+    assert ops._behind(dev, s, [s]) > 0.9 and ops._runs_beside(dev, s, [s]) is False
+    pool = [torch.cuda.Stream(dev) for _ in range(8)]
+    floor = min(ops._behind(dev, x, [main]) for x in pool)      # what "beside the caller's stream" reads on this box (0.5 - 0.6;
+    for lanes in (1, 2):                                          # two pool streams on separate queues: 0.01 - 0.03; shared: 1.0)
         p = ops.OctavPipeline(False, dev, lanes=lanes)
         streams = [p.side] + p.lanes
         assert len(p.lanes) == (2 if lanes == 2 else 0)
-        # (the question is answered by timing on the device: a stream that shares a queue is behind EVERY time, one that does not
-        # may look so once when something else delays its marker — asked up to three times)
-        ok = sum(any(ops._runs_beside(dev, x, [main] + [y for y in streams if y is not x]) for _ in range(3)) for x in streams)
-        assert ok == len(streams), (lanes, ok)
+        for x in streams:
+            # (the answer is a timing on the device: a stream that shares a queue is behind EVERY time, one that does not may look
+            # so once when something else delays its marker — asked up to three times)
+            assert min(ops._behind(dev, x, [main]) for _ in range(3)) <= floor + 0.2, (lanes, floor)
+            for y in streams:
+                if y is not x:
+                    assert min(ops._behind(dev, x, [y]) for _ in range(3)) < 0.5, lanes
     lo, hi = C.c_int(), C.c_int()
     _hip.check(_hip.lib().dpl_stream_priority_range(C.byref(lo), C.byref(hi)), "dpl_stream_priority_range")
     assert (lo.value, hi.value) == (1, -1)

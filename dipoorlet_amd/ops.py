@@ -508,22 +508,25 @@ def _octav_batch_tail(plan, tp, tensors, dynamic_sym, states_out=None):
 _PIPE_SETS = max(2, int(os.environ.get("DPL_OCTAV_PIPE_SETS", "3")))   # batches the host may run ahead of the device (OctavPipeline)
 
 
-_BESIDE = 0.75
+_BESIDE = 0.5
 
 
 def _behind(device, stream, others, cycles=1500000):
-    """How far BEHIND work on `others` does work on `stream` run: 0 .. 1 per other stream, the largest.  Asked of the device, in
-    its own timestamps: a spin of about a millisecond on the other stream between two timing events, a marker event on `stream`
-    issued right after — a marker stamped at the spin's start ran beside it (separate hardware queues: ~0), one stamped at its
-    end waited for it (one queue: ~1).  HOST (synchronises; a few milliseconds, once per pipeline)."""
+    """How far BEHIND work on `stream` does work on each of `others` run — i.e. do they share a hardware queue: 0 .. 1, the largest
+    over `others`.  Asked of the device, in its own timestamps: a spin of under two milliseconds on `stream` between two timing
+    events, a marker event on the other stream issued right after — a marker stamped at the spin's start ran beside it (separate
+    queues: 0.01 - 0.03), one stamped at its end waited for it (one queue: 1.0).  The spin goes on the CANDIDATE and the marker on
+    the other stream because `others` is usually the default stream: a marker on a pool stream beside a spin on the default stream
+    is stamped at 0.5 - 0.6 of the spin, and at 1.0 under rocprofv3 whatever the queues; this way round the readings are 0.01 or
+    1.0 with and without the profiler (scripts/stream_queue_probe.py).  HOST (synchronises; a few milliseconds, once per pipeline)."""
     worst = 0.0
     for o in others:
         s0, s1, m = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        with torch.cuda.stream(o):
-            s0.record(o)
+        with torch.cuda.stream(stream):
+            s0.record(stream)
             torch.cuda._sleep(cycles)
-            s1.record(o)
-        m.record(stream)
+            s1.record(stream)
+        m.record(o)
         s1.synchronize()
         m.synchronize()
         spin = max(s0.elapsed_time(s1), 1e-6)
@@ -532,15 +535,13 @@ def _behind(device, stream, others, cycles=1500000):
 
 
 def _runs_beside(device, stream, others):
-    """Does work on `stream` run beside work on each of `others`?  (_behind reads 0.01 - 0.03 for two pool streams on separate
-    queues and 1.0 on a shared one; against the DEFAULT stream 0.5 - 0.6 and 1.0 — its events are stamped differently —, and 1.0
-    throughout under rocprofv3: scripts/stream_queue_probe.py)"""
+    """Does work on `stream` run beside work on each of `others` (separate hardware queues)?"""
     return _behind(device, stream, others) < _BESIDE
 
 
 def _separate_stream(device, others, tries=6):
     """A normal-priority stream whose work runs beside that of `others`: the first of `tries` pool streams that does — or, should
-    none be clearly beside (a profiler in the way of the timestamps), the one that was least behind."""
+    none be clearly beside, the one that was least behind."""
     best, best_b = None, 2.0
     for _ in range(tries):
         s = torch.cuda.Stream(device)

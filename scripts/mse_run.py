@@ -59,10 +59,5 @@ def main():
 
 
 if __name__ == "__main__":
-    # (the caller's stream is a pool stream, not the default one: OctavPipeline asks the device which of its candidate streams run
-    # beside the caller's — ops._separate_stream — and under rocprofv3 that question cannot be answered against the DEFAULT stream,
-    # every candidate reads "behind": a profiled run would then take the first pool stream, which shares the default stream's
-    # hardware queue one time in four and serialises the rescue with the streaming kernel — 1.16 ms per batch)
-    with torch.cuda.stream(torch.cuda.Stream(torch.device("cuda"))):
-        main()
+    main()
     torch.cuda.synchronize()

@@ -1173,8 +1173,8 @@ def test_pipeline_streams_run_beside_the_callers_stream(dev):
     s = torch.cuda.Stream(dev)
     assert ops._behind(dev, s, [s]) > 0.9 and ops._runs_beside(dev, s, [s]) is False
     pool = [torch.cuda.Stream(dev) for _ in range(8)]
-    floor = min(ops._behind(dev, x, [main]) for x in pool)      # what "beside the caller's stream" reads on this box (0.5 - 0.6;
-    for lanes in (1, 2):                                          # two pool streams on separate queues: 0.01 - 0.03; shared: 1.0)
+    floor = min(ops._behind(dev, x, [main]) for x in pool)      # what "beside the caller's stream" reads on this box (separate
+    for lanes in (1, 2):                                          # queues: 0.01 - 0.03; a shared one: 1.0)
         p = ops.OctavPipeline(False, dev, lanes=lanes)
         streams = [p.side] + p.lanes
         assert len(p.lanes) == (2 if lanes == 2 else 0)

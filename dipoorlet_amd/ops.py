@@ -516,9 +516,10 @@ def _behind(device, stream, others, cycles=1500000):
     over `others`.  Asked of the device, in its own timestamps: a spin of under two milliseconds on `stream` between two timing
     events, a marker event on the other stream issued right after — a marker stamped at the spin's start ran beside it (separate
     queues: 0.01 - 0.03), one stamped at its end waited for it (one queue: 1.0).  The spin goes on the CANDIDATE and the marker on
-    the other stream because `others` is usually the default stream: a marker on a pool stream beside a spin on the default stream
-    is stamped at 0.5 - 0.6 of the spin, and at 1.0 under rocprofv3 whatever the queues; this way round the readings are 0.01 or
-    1.0 with and without the profiler (scripts/stream_queue_probe.py).  HOST (synchronises; a few milliseconds, once per pipeline)."""
+    the other stream because `others` is usually the default stream: the other way round — the spin on the default stream of a
+    process that has not used it for timing before — the marker was stamped at 0.5 - 0.6 of the spin beside it, and at 1.0 under
+    rocprofv3 whatever the queues; this way round the readings are 0.01 or 1.0 with and without the profiler
+    (scripts/stream_queue_probe.py).  HOST (synchronises; a few milliseconds, once per pipeline)."""
     worst = 0.0
     for o in others:
         s0, s1, m = (torch.cuda.Event(enable_timing=True) for _ in range(3))

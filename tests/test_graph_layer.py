@@ -405,3 +405,55 @@ def test_negative_step_slice_follows_onnx_for_empty_ranges():
     assert run(None, node, x, t([4]), t([-100]), t([1]), t([-2])).tolist() == [[4.0, 2.0, 0.0], [9.0, 7.0, 5.0]]
     assert tuple(run(None, node, x, t([1]), t([3]), t([1]), t([-1])).shape) == (2, 0)
     assert tuple(run(None, node, x, t([2]), t([2]), t([1]), t([-1])).shape) == (2, 0)
+
+
+def test_relu_fusion_plan_follows_the_merge_relu_rule(monkeypatch):
+    """executor.relu_fusion on a fake-quantised ResNet-18 (-D trt; host only: the plan is graph logic).  The reference leaves a ReLU
+    behind Conv / Gemm / Add unquantised at its input (quantize.py:50-55), so the next layer's Q/DQ pair sits behind that ReLU
+    (:74-93): such a ReLU — and the residual Add in front of it — is fused into the pair's kernel when NOTHING else reads it: not
+    when it is a network output, asked for by name, or has a second consumer; a session that exposes every tensor fuses nothing;
+    DPL_FUSE_RELU=0 switches the plan off."""
+    import types
+
+    from dipoorlet_amd import executor, models
+    from dipoorlet_amd.quantize import quant_graph
+    g = models.resnet18(seed=1, image=32)
+    s = executor.GraphSession(g, device="cpu")
+    clip = {n: [-3.0, 3.0] for n in s.tensor_names}
+    for node in g.graph.node:
+        for i in node.input[1:]:
+            if i in g.initializer:
+                a = np.asarray(g.initializer[i])
+                a2 = a.reshape(a.shape[0], -1)
+                clip[i] = [a2.min(-1), a2.max(-1)]
+    gq, _ = quant_graph(g, clip, types.SimpleNamespace(deploy="trt", skip_layers=[]))
+    sq = executor.GraphSession(gq, device="cpu")
+    out = gq.network_outputs[0]
+    nodes = {n.name: n for n in gq.graph.node}
+    producer = {o: n for n in gq.graph.node for o in n.output}
+    fused, skipped = executor.relu_fusion(gq, sq._folded, sq.consts, [out], sq.shape1)
+    kinds = [p for p, _ in fused.values()]
+    assert kinds.count("relu") == 9 and kinds.count("add_relu") == 7 and len(skipped) == 9 + 2 * 7
+    for name, (pre, ins) in fused.items():
+        q = nodes[name]
+        relu = producer[q.input[0]]
+        assert q.op_type == "FakeQuant" and relu.op_type == "Relu" and relu.name in skipped
+        if pre == "relu":
+            assert ins == [relu.input[0]]
+        else:
+            add = producer[relu.input[0]]
+            assert add.op_type == "Add" and add.name in skipped and ins == list(add.input)
+            assert sq.shape1[add.output[0]] is not None
+    # (the first ReLU too: -D trt quantises the max pool's input, so the pair behind relu1 is its only reader)
+    assert next(n for n in gq.graph.node if n.op_type == "Relu").name in skipped
+    # asked for by name: that chain is not fused (neither its ReLU nor its Add), the others are
+    one = next(nodes[k] for k, (p, _) in fused.items() if p == "add_relu")
+    kept = one.input[0]
+    f2, s2 = executor.relu_fusion(gq, sq._folded, sq.consts, [out, kept], sq.shape1)
+    assert one.name not in f2 and len(f2) == len(fused) - 1 and len(s2) == len(skipped) - 2
+    # every tensor exposed (run()): nothing can be fused; and the switch
+    f3, s3 = executor.relu_fusion(gq, sq._folded, sq.consts, sq.tensor_names, sq.shape1)
+    assert not f3 and not s3
+    assert sq.fusion([out])[0].keys() == fused.keys()
+    monkeypatch.setenv("DPL_FUSE_RELU", "0")
+    assert executor.relu_fusion(gq, sq._folded, sq.consts, [out], sq.shape1) == ({}, set())
